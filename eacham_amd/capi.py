@@ -1,0 +1,65 @@
+"""ctypes binding of the C-ABI in include/eacham_hip.h (libeacham_hip.so, built by csrc/Makefile).
+
+There is no CPU fallback: if the HIP library is missing or no device is present every entry point
+raises. PyTorch is not involved here; device buffers are passed as raw pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeacham_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NOT_INTEGER, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+
+KERNEL_MATCH_TILE = 0
+KERNEL_MATCH_FINALIZE = 1
+KERNEL_BA_LINEARIZE = 2
+KERNEL_BA_SCHUR = 3
+KERNEL_BA_SOLVE = 4
+KERNEL_BA_ERROR = 5
+
+
+class EachamError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"eacham_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libeacham_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C eacham_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    L.eacham_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.eacham_ctx_destroy.argtypes = [vp]
+    L.eacham_ctx_destroy.restype = None
+    L.eacham_last_error.argtypes = [vp]
+    L.eacham_last_error.restype = C.c_char_p
+    L.eacham_ctx_sync.argtypes = [vp]
+    L.eacham_ctx_stream.argtypes = [vp]
+    L.eacham_ctx_stream.restype = vp
+    L.eacham_version.restype = C.c_char_p
+    L.eacham_upload_descriptors.argtypes = [vp, i32, vp, i32, i32]
+    L.eacham_upload_descriptors_dev.argtypes = [vp, i32, vp, i32, i32]
+    L.eacham_frame_rows.argtypes = [vp, i32]
+    L.eacham_clear_descriptors.argtypes = [vp]
+    L.eacham_match_pair.argtypes = [vp, i32, i32, dbl, vp, vp, i32, C.POINTER(i32)]
+    L.eacham_match_all_pairs.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64), vp]
+    L.eacham_match_all_pairs_dev.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, i64, vp, vp]
+    L.eacham_profile_enable.argtypes = [vp, i32]
+    L.eacham_profile_reset.argtypes = [vp]
+    L.eacham_profile_get.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(dbl)]
+    _lib = L
+    return L

@@ -1,0 +1,207 @@
+// context.hip — context lifetime, workspace, profiling: the non-kernel part of the C-ABI
+// declared in include/eacham_hip.h.
+#include "context.hpp"
+
+#include <cstring>
+#include <new>
+
+namespace eacham {
+
+int ensure_workspace(eacham_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return EACHAM_OK;
+    if (ctx->ws) {
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    EACHAM_HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return EACHAM_OK;
+}
+
+int ensure_io(eacham_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->io_bytes) return EACHAM_OK;
+    if (ctx->io) {
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipFree(ctx->io));
+        ctx->io = nullptr;
+        ctx->io_bytes = 0;
+    }
+    EACHAM_HIP_TRY(ctx, hipMalloc(&ctx->io, bytes));
+    ctx->io_bytes = bytes;
+    return EACHAM_OK;
+}
+
+int sync_frame_table(eacham_ctx* ctx) {
+    if (!ctx->frame_table_dirty) return EACHAM_OK;
+    int need = (int)ctx->frames.size();
+    if (need > ctx->frame_table_cap) {
+        if (ctx->frame_table_dev) {
+            EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            EACHAM_HIP_TRY(ctx, hipFree(ctx->frame_table_dev));
+            ctx->frame_table_dev = nullptr;
+        }
+        int cap = need < 64 ? 64 : need * 2;
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&ctx->frame_table_dev, sizeof(FrameDev) * cap));
+        ctx->frame_table_cap = cap;
+    }
+    std::vector<FrameDev> tab(need);
+    for (int i = 0; i < need; ++i) {
+        const FrameHost& f = ctx->frames[i];
+        tab[i].frag = f.frag;
+        tab[i].norm = f.norm;
+        tab[i].n = f.n < 0 ? 0 : f.n;
+        tab[i].ntiles = f.n < 0 ? 0 : f.ntiles;
+    }
+    if (need > 0) {
+        // pageable source: hipMemcpyAsync stages it before returning, so `tab` may die here
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_table_dev, tab.data(), sizeof(FrameDev) * need,
+                                           hipMemcpyHostToDevice, ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->frame_table_dirty = false;
+    return EACHAM_OK;
+}
+
+ProfileScope::ProfileScope(eacham_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
+    if (!ctx->profile) return;
+    ProfileSlot& s = ctx->prof[id];
+    if (s.used == s.events.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        s.events.emplace_back(a, b);
+    }
+    auto& ev = s.events[s.used++];
+    (void)hipEventRecord(ev.first, ctx->stream);
+    stop = ev.second;
+}
+
+ProfileScope::~ProfileScope() {
+    if (stop) (void)hipEventRecord(stop, ctx->stream);
+}
+
+static void profile_drain(eacham_ctx* ctx) {
+    for (int k = 0; k < EACHAM_KERNEL_COUNT; ++k) {
+        ProfileSlot& s = ctx->prof[k];
+        for (size_t i = 0; i < s.used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.events[i].first, s.events[i].second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches += 1;
+            }
+        }
+        s.used = 0;
+    }
+}
+
+}  // namespace eacham
+
+using namespace eacham;
+
+extern "C" {
+
+const char* eacham_version(void) { return "eacham_hip 0.1 gfx950"; }
+
+int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
+    if (!out_ctx) return EACHAM_ERR_INVALID;
+    *out_ctx = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EACHAM_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return EACHAM_ERR_INVALID;
+    eacham_ctx* ctx = new (std::nothrow) eacham_ctx();
+    if (!ctx) return EACHAM_ERR_INVALID;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->flag_dev, 64 * sizeof(int)) != hipSuccess ||
+        hipMemsetAsync(ctx->flag_dev, 0, 64 * sizeof(int), ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        delete ctx;
+        return EACHAM_ERR_HIP;
+    }
+    *out_ctx = ctx;
+    return EACHAM_OK;
+}
+
+int eacham_clear_descriptors(eacham_ctx* ctx) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& f : ctx->frames) {
+        if (f.frag) (void)hipFree(f.frag);
+        if (f.norm) (void)hipFree(f.norm);
+        f = FrameHost();
+    }
+    ctx->frames.clear();
+    ctx->ks_common = 0;
+    ctx->frame_table_dirty = true;
+    return EACHAM_OK;
+}
+
+void eacham_ctx_destroy(eacham_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& f : ctx->frames) {
+        if (f.frag) (void)hipFree(f.frag);
+        if (f.norm) (void)hipFree(f.norm);
+    }
+    if (ctx->frame_table_dev) (void)hipFree(ctx->frame_table_dev);
+    if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->io) (void)hipFree(ctx->io);
+    for (auto& s : ctx->prof)
+        for (auto& ev : s.events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* eacham_last_error(const eacham_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int eacham_ctx_sync(eacham_ctx* ctx) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EACHAM_OK;
+}
+
+void* eacham_ctx_stream(eacham_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int eacham_profile_enable(eacham_ctx* ctx, int on) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->profile = on != 0;
+    return EACHAM_OK;
+}
+
+int eacham_profile_reset(eacham_ctx* ctx) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& s : ctx->prof) {
+        s.used = 0;
+        s.launches = 0;
+        s.total_ms = 0.0;
+    }
+    return EACHAM_OK;
+}
+
+int eacham_profile_get(eacham_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms) {
+    if (!ctx || kernel_id < 0 || kernel_id >= EACHAM_KERNEL_COUNT) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    profile_drain(ctx);
+    if (launches) *launches = ctx->prof[kernel_id].launches;
+    if (total_ms) *total_ms = ctx->prof[kernel_id].total_ms;
+    return EACHAM_OK;
+}
+
+}  // extern "C"

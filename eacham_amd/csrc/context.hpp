@@ -1,0 +1,105 @@
+// context.hpp — per-device context shared by the matcher and the bundle adjuster.
+// One context = one HIP device + one stream; the C-ABI in include/eacham_hip.h serialises calls on
+// a context with `mu` so the reference's concurrent Match() pattern (apps/sfm/main.cpp:98-109)
+// stays legal.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/eacham_hip.h"
+
+namespace eacham {
+
+// Descriptor of one resident frame as the kernels see it (device-side table entry).
+struct FrameDev {
+    const int4* frag;  // [ntiles][KS][64] 16-byte MFMA operand fragments (int8, centred by -128)
+    const int* norm;   // [ntiles*32] squared norm of the centred row; PAD_VALUE for padding rows
+    int n;             // real rows
+    int ntiles;        // 32-row tiles, always even (a wave owns 2 tiles = 64 rows)
+};
+
+struct FrameHost {
+    int4* frag = nullptr;
+    int* norm = nullptr;
+    int n = -1;  // -1 = not resident
+    int dim = 0;
+    int ks = 0;
+    int ntiles = 0;
+};
+
+struct ProfileSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t used = 0;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+}  // namespace eacham
+
+struct eacham_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    // descriptor store
+    std::vector<eacham::FrameHost> frames;
+    eacham::FrameDev* frame_table_dev = nullptr;
+    int frame_table_cap = 0;
+    bool frame_table_dirty = true;
+    int* flag_dev = nullptr;  // [0] = non-integer descriptor seen, [1..] scratch
+    int ks_common = 0;        // KS shared by all resident frames (0 = none yet)
+
+    // matcher workspace (grown on demand, never inside a timed launch sequence after warm-up)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    void* io = nullptr;  // staging for the host-pointer entry points
+    size_t io_bytes = 0;
+
+    // profiling
+    bool profile = false;
+    eacham::ProfileSlot prof[EACHAM_KERNEL_COUNT];
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define EACHAM_HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return (ctx)->fail(EACHAM_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+namespace eacham {
+
+int ensure_workspace(eacham_ctx* ctx, size_t bytes);
+int ensure_io(eacham_ctx* ctx, size_t bytes);
+int sync_frame_table(eacham_ctx* ctx);
+
+// RAII: records a start/stop HIP event pair around a launch sequence when profiling is on.
+struct ProfileScope {
+    eacham_ctx* ctx;
+    int id;
+    hipEvent_t stop = nullptr;
+    ProfileScope(eacham_ctx* c, int kernel_id);
+    ~ProfileScope();
+};
+
+}  // namespace eacham

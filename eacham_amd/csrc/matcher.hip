@@ -1,0 +1,652 @@
+// matcher.hip — exact all-pairs descriptor matching for gfx950 (MI355X).
+//
+// Replaces   FeatureMatcherFlann::Match   modules/base/features/FeatureMatcherFlann.cpp:14-30
+//            pair loop + mutual check     apps/sfm/main.cpp:84-147
+//
+// Data layout in HBM ("fragment-major int8"): descriptors are integers in [0,255] (OpenCV SIFT),
+// stored centred (x-128) as int8 in the exact register image of v_mfma_i32_32x32x32_i8 operands:
+//     frag[tile = row/32][ks = k/32][lane = 32*((k%32)/16) + row%32] = 16 bytes  (k%16 ascending)
+// so one wave-wide 16-byte load is 1 KiB contiguous and needs no LDS swizzle. The same image
+// serves as the A operand (queries, rows of the distance tile) and the B operand (train, columns).
+//
+// Arithmetic (all integer, hence independent of summation order => bit-exact vs the CPU oracle):
+//     d2(q,t) = |a_q|^2 + |b_t|^2 - 2 a_q.b_t         a.b from the int8 MFMA, int32 accumulate
+// Row direction (q -> best t) ranks by  |b_t|^2 - 2 a.b  (|a_q|^2 is constant per row),
+// column direction (t -> best q) by     |a_q|^2 - 2 a.b.
+// Both rank values fit 25 signed bits for D <= 256, so a candidate is one int32 key
+//     key = (rank << 7) | code        code = column-tile index (row dir) / local row (col dir)
+// and a running top-2 costs two VALU ops:  m2 = med3(m1, m2, key); m1 = min(m1, key).
+// Ties resolve to the lower index because `code` is monotone in the index within a lane.
+#include "context.hpp"
+
+#include <algorithm>
+#include <climits>
+
+namespace eacham {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int PAD_VALUE = (1 << 24) - 1;  // rank value of padding rows/columns; > any real d2
+constexpr int KEY_SHIFT = 7;
+constexpr int KEY_MASK = (1 << KEY_SHIFT) - 1;
+constexpr int MAX_TILES = 1 << KEY_SHIFT;  // 128 tiles * 32 = 4096 rows per frame
+constexpr int WG_THREADS = 512;            // 8 waves: 2 per SIMD so MFMA and VALU phases overlap
+constexpr int WAVES = WG_THREADS / 64;
+constexpr int ROWS_PER_WAVE = 64;          // 2 MFMA tiles of 32 rows, A fragments live in VGPRs
+constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
+
+__device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+
+// ------------------------------------------------------------------------------------------------
+// upload: fp32 row-major -> fragment-major int8 + squared norms
+// ------------------------------------------------------------------------------------------------
+
+__global__ void init_norm_kernel(int* __restrict__ norm, int n, int npad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) norm[i] = i < n ? 0 : PAD_VALUE;
+}
+
+__global__ void quantize_kernel(const float* __restrict__ src, int n, int dim, int KS, int npad,
+                                v4i* __restrict__ frag, int* __restrict__ norm,
+                                int* __restrict__ bad_flag) {
+    const int chunks = KS * 2;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)npad * chunks) return;
+    int row = (int)(idx / chunks), ch = (int)(idx % chunks);
+    int ks = ch >> 1, h = ch & 1, tile = row >> 5, r = row & 31;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    int part = 0;
+    bool bad = false;
+    if (row < n) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int k = ks * 32 + h * 16 + j;
+            int c = 0;  // centred value of a padded dimension
+            if (k < dim) {
+                float v = src[(size_t)row * dim + k];
+                if (!(v >= 0.0f && v <= 255.0f) || v != floorf(v)) bad = true;
+                c = (int)v - 128;
+            }
+            part += c * c;
+            w[j >> 2] |= (unsigned)(c & 0xff) << (8 * (j & 3));
+        }
+    }
+    v4i out = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    frag[((size_t)tile * KS + ks) * 64 + h * 32 + r] = out;
+    if (part) atomicAdd(&norm[row], part);
+    if (bad) atomicOr(bad_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: distance tiles + fused row/column top-2
+// ------------------------------------------------------------------------------------------------
+//
+// grid  = npairs * wgs_per_pair workgroups of 512 threads; workgroup (p, rb) owns rows
+//         [512*rb, 512*rb+512) of frame A = pairs[p].x against ALL rows of frame B = pairs[p].y.
+// wave  = 64 rows (two 32-row MFMA tiles): A fragments stay in VGPRs for the whole sweep
+//         (A-stationary), B tiles (32 train rows = KS KiB) stream through LDS once per workgroup.
+// out   rowres[p][q]      = {rank1, col1, rank2, 0}   final over all columns (rank = d2 - |a_q|^2)
+//       colpart[p][wb][c] = {key1, key2}              top-2 over the 64 rows of wave-block wb;
+//                                                     key = (d2 - |b_c|^2) << 7 | local row
+template <int KS>
+__global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair,
+    int4* __restrict__ rowres, int2* __restrict__ colpart, int wb_stride, int row_stride) {
+    __shared__ v4i sB[2][KS * 64];
+    __shared__ int2 sR[WAVES][32 * 32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 31, h = lane >> 5;
+    const int p = blockIdx.x / wgs_per_pair, rb = blockIdx.x % wgs_per_pair;
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    if (rb * (ROWS_PER_WG / 32) >= A.ntiles) return;  // workgroup-uniform
+    const int wb = rb * WAVES + wave;                  // 64-row wave-block of frame A
+    const bool active = 2 * wb < A.ntiles;             // wave-uniform (ntiles is even)
+    const int T = B.ntiles;
+
+    v4i a[2][KS];
+    int base_r[2][16], rm1[2][16], rm2[2][16];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            a[s][ks] = active ? ((const v4i*)A.frag)[((size_t)(2 * wb + s) * KS + ks) * 64 + lane]
+                              : v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int lrow = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
+            int na = active ? A.norm[64 * wb + lrow] : PAD_VALUE;
+            base_r[s][r] = (na << KEY_SHIFT) | lrow;
+            rm1[s][r] = INT_MAX;
+            rm2[s][r] = INT_MAX;
+        }
+    }
+
+    const bool loader = tid < KS * 64;
+    v4i stage = {0, 0, 0, 0};
+    if (T > 0 && loader) stage = ((const v4i*)B.frag)[tid];
+    if (loader) sB[0][tid] = stage;
+    __syncthreads();
+
+    int2* cp = colpart + ((size_t)p * wb_stride + wb) * row_stride;
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < T && loader) stage = ((const v4i*)B.frag)[(size_t)(t + 1) * KS * 64 + tid];
+        if (active) {
+            const int nb = B.norm[32 * t + cl];
+            v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            v16i acc1 = acc0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                v4i b = sB[cur][ks * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][ks], b, acc1, 0, 0, 0);
+            }
+            const int base_c = (nb << KEY_SHIFT) | t;
+            int cm1 = INT_MAX, cm2 = INT_MAX;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int d8 = acc0[r] << (KEY_SHIFT + 1);  // 2*dot << 7
+                int kr = base_c - d8, kc = base_r[0][r] - d8;
+                rm2[0][r] = med3(rm1[0][r], rm2[0][r], kr);
+                rm1[0][r] = min(rm1[0][r], kr);
+                cm2 = med3(cm1, cm2, kc);
+                cm1 = min(cm1, kc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int d8 = acc1[r] << (KEY_SHIFT + 1);
+                int kr = base_c - d8, kc = base_r[1][r] - d8;
+                rm2[1][r] = med3(rm1[1][r], rm2[1][r], kr);
+                rm1[1][r] = min(rm1[1][r], kr);
+                cm2 = med3(cm1, cm2, kc);
+                cm1 = min(cm1, kc);
+            }
+            // lanes l and l+32 hold the same column, rows 4h.. of each 8-row group: merge halves
+            int o1 = __shfl_xor(cm1, 32), o2 = __shfl_xor(cm2, 32);
+            int n1 = min(cm1, o1);
+            int n2 = min(max(cm1, o1), min(cm2, o2));
+            if (h == 0) cp[32 * t + cl] = make_int2(n1, n2);
+        }
+        if (t + 1 < T && loader) sB[cur ^ 1][tid] = stage;
+        __syncthreads();
+    }
+    if (!active) return;
+
+    // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
+    // through this wave's private LDS slab so that lane i owns row i and scans the 32 partials.
+    int2* slab = sR[wave];
+    int4* rr = rowres + (size_t)p * row_stride + 64 * wb;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            slab[row * 32 + cl] = make_int2(rm1[s][r], rm2[s][r]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // candidate order: (key, lane-column) lexicographic == (rank, column) lexicographic
+        long long b1 = LLONG_MAX, b2 = LLONG_MAX;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int cc = 16 * h + ((j + lane) & 15);
+            int2 e = slab[cl * 32 + cc];
+            long long k1 = ((long long)e.x << 5) | cc, k2 = ((long long)e.y << 5) | cc;
+            b2 = min(b2, max(b1, k1));
+            b1 = min(b1, k1);
+            b2 = min(b2, max(b1, k2));
+            b1 = min(b1, k2);
+        }
+        long long o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+        long long f1 = min(b1, o1);
+        long long f2 = min(max(b1, o1), min(b2, o2));
+        if (h == 0) {
+            int key1 = (int)(f1 >> 5), key2 = (int)(f2 >> 5);
+            int col1 = 32 * (key1 & KEY_MASK) + (int)(f1 & 31);
+            rr[32 * s + cl] = make_int4(key1 >> KEY_SHIFT, col1, key2 >> KEY_SHIFT, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: merge column partials, ratio test, mutual check, thresholds, ordered compaction
+// ------------------------------------------------------------------------------------------------
+
+// FeatureMatcherFlann.cpp:23 — `m[0].distance / m[1].distance < 0.8`: distances are
+// sqrtf(squared L2) in fp32, fp32 quotient, compared as double. d2 values are exact integers.
+__device__ __forceinline__ bool ratio_pass(int d2_best, int d2_second, double ratio) {
+    float q = __fdiv_rn(__fsqrt_rn((float)d2_best), __fsqrt_rn((float)d2_second));
+    return (double)q < ratio;  // 0/0 = NaN -> false
+}
+
+constexpr int FIN_THREADS = 256;
+
+// mode 0: mutual matches + thresholds (apps/sfm/main.cpp:111-146); mode 1: directed list m12.
+// out_matches[p][k] = {q, t} sorted by q; counts[p]; stats[p] = {|m12|, |m21|, |mutual|, edge}.
+__global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
+    const int4* __restrict__ rowres, const int2* __restrict__ colpart, int wb_stride,
+    int row_stride, double ratio, int min_dir, int min_mutual, int mode,
+    uint2* __restrict__ out_matches, int* __restrict__ counts, int4* __restrict__ stats) {
+    extern __shared__ int smem[];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    int* fwd = smem;               // [row_stride]
+    int* bwd = smem + row_stride;  // [row_stride]
+    __shared__ int s_cnt[3];
+    __shared__ int s_scan[FIN_THREADS];
+    if (tid < 3) s_cnt[tid] = 0;
+    __syncthreads();
+
+    int c12 = 0, c21 = 0;
+    for (int q = tid; q < A.n; q += FIN_THREADS) {
+        int4 r = rowres[(size_t)p * row_stride + q];
+        int na = A.norm[q];
+        bool ok = r.z < PAD_VALUE && ratio_pass(r.x + na, r.z + na, ratio);  // r.z pad => < 2 train rows
+        fwd[q] = ok ? r.y : -1;
+        c12 += ok;
+    }
+    const int nwb = A.ntiles / 2;
+    for (int c = tid; c < B.n; c += FIN_THREADS) {
+        int v1 = PAD_VALUE, v2 = PAD_VALUE, r1 = -1;
+        const int2* cp = colpart + (size_t)p * wb_stride * row_stride + c;
+        for (int wb = 0; wb < nwb; ++wb) {  // ascending rows; strict '<' keeps the lower row on ties
+            int2 e = cp[(size_t)wb * row_stride];
+            int va = e.x >> KEY_SHIFT, vb = e.y >> KEY_SHIFT;
+            if (va < v1) {
+                v2 = v1;
+                v1 = va;
+                r1 = 64 * wb + (e.x & KEY_MASK);
+            } else if (va < v2) {
+                v2 = va;
+            }
+            if (vb < v2) v2 = vb;  // e.y >= e.x, it can only become the runner-up
+        }
+        int nb = B.norm[c];
+        bool ok = v2 < PAD_VALUE && ratio_pass(v1 + nb, v2 + nb, ratio);
+        bwd[c] = ok ? r1 : -1;
+        c21 += ok;
+    }
+    atomicAdd(&s_cnt[0], c12);
+    atomicAdd(&s_cnt[1], c21);
+    __syncthreads();
+
+    // ordered compaction over q in chunks of FIN_THREADS
+    uint2* out = out_matches + (size_t)p * row_stride;
+    int base = 0;
+    for (int q0 = 0; q0 < A.n; q0 += FIN_THREADS) {
+        int q = q0 + tid;
+        int t = q < A.n ? fwd[q] : -1;
+        bool keep = t >= 0 && (mode == 1 || bwd[t] == q);  // main.cpp:133-140
+        s_scan[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < FIN_THREADS; off <<= 1) {  // Hillis-Steele inclusive scan
+            int v = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        if (keep) out[base + s_scan[tid] - 1] = make_uint2((unsigned)q, (unsigned)t);
+        base += s_scan[FIN_THREADS - 1];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int n12 = s_cnt[0], n21 = s_cnt[1];
+        bool edge = n12 >= min_dir && n21 >= min_dir && base > min_mutual;  // main.cpp:111,142
+        counts[p] = mode == 1 ? base : (edge ? base : 0);
+        if (stats) stats[p] = make_int4(n12, n21, base, edge ? 1 : 0);
+    }
+}
+
+// offsets[first + i] = running total; single workgroup, sequential over chunks (npairs is small)
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ counts, int n,
+                                                           long long* __restrict__ offsets,
+                                                           long long* __restrict__ total,
+                                                           int first, int is_last) {
+    __shared__ long long s[1024];
+    __shared__ long long carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = first == 0 ? 0 : *total;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        int i = i0 + tid;
+        long long v = i < n ? counts[i] : 0;
+        s[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            long long u = tid >= off ? s[tid - off] : 0;
+            __syncthreads();
+            s[tid] += u;
+            __syncthreads();
+        }
+        if (i < n) offsets[first + i] = carry + s[tid] - v;
+        __syncthreads();
+        if (tid == 0) carry += s[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *total = carry;
+        if (is_last) offsets[first + n] = carry;
+    }
+}
+
+__global__ void compact_edges_kernel(const uint2* __restrict__ matches, const int* __restrict__ counts,
+                                     const long long* __restrict__ offsets, int row_stride,
+                                     uint2* __restrict__ edges, long long edge_cap) {
+    const int p = blockIdx.x;
+    const int n = counts[p];
+    const long long off = offsets[p];
+    for (int k = threadIdx.x; k < n; k += blockDim.x)
+        if (off + k < edge_cap) edges[off + k] = matches[(size_t)p * row_stride + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+static int ks_for_dim(int dim) {
+    if (dim <= 0 || dim > 256 || dim % 16) return 0;
+    if (dim <= 64) return 2;
+    if (dim <= 128) return 4;
+    return 8;
+}
+
+static int upload_frame(eacham_ctx* ctx, int frame_id, const float* src_dev, int n, int dim) {
+    if (frame_id < 0 || frame_id >= (1 << 20)) return ctx->fail(EACHAM_ERR_INVALID, "frame_id %d out of range", frame_id);
+    if (n < 0) return ctx->fail(EACHAM_ERR_INVALID, "negative row count");
+    int ks = ks_for_dim(dim);
+    if (!ks) return ctx->fail(EACHAM_ERR_UNSUPPORTED, "descriptor dim %d: need a multiple of 16, <= 256", dim);
+    if (ctx->ks_common && ctx->ks_common != ks)
+        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "all resident frames must share one descriptor dim class");
+    int ntiles = (n + 31) / 32;
+    ntiles += ntiles & 1;
+    if (ntiles > MAX_TILES)
+        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "frame has %d rows; this build supports <= %d", n, MAX_TILES * 32);
+    if ((size_t)frame_id >= ctx->frames.size()) ctx->frames.resize(frame_id + 1);
+    FrameHost& f = ctx->frames[frame_id];
+    if (f.frag || f.norm) {
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (f.frag) (void)hipFree(f.frag);
+        if (f.norm) (void)hipFree(f.norm);
+        f = FrameHost();
+    }
+    const int npad = ntiles * 32;
+    if (npad > 0) {
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.frag, (size_t)ntiles * ks * 64 * sizeof(int4)));
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.norm, (size_t)npad * sizeof(int)));
+        init_norm_kernel<<<(npad + 255) / 256, 256, 0, ctx->stream>>>(f.norm, n, npad);
+        long long work = (long long)npad * ks * 2;
+        quantize_kernel<<<(unsigned)((work + 255) / 256), 256, 0, ctx->stream>>>(
+            src_dev, n, dim, ks, npad, (v4i*)f.frag, f.norm, ctx->flag_dev);
+        EACHAM_HIP_TRY(ctx, hipGetLastError());
+    }
+    f.n = n;
+    f.dim = dim;
+    f.ks = ks;
+    f.ntiles = ntiles;
+    ctx->ks_common = ks;
+    ctx->frame_table_dirty = true;
+    return EACHAM_OK;
+}
+
+static int check_integer_flag(eacham_ctx* ctx) {
+    int flag = 0;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));
+        return ctx->fail(EACHAM_ERR_NOT_INTEGER,
+                         "descriptors must be integer-valued in [0,255] for the exact int8 path");
+    }
+    return EACHAM_OK;
+}
+
+struct MatchPlan {
+    int batch;       // pairs per launch
+    int wb_stride;   // wave-blocks per frame (max over resident frames)
+    int row_stride;  // padded rows per frame (max)
+    int wgs_per_pair;
+    size_t off_rowres, off_colpart, off_matches, off_counts, total;
+};
+
+static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
+    int max_tiles = 2;
+    for (const auto& f : ctx->frames)
+        if (f.n >= 0) max_tiles = std::max(max_tiles, f.ntiles);
+    MatchPlan pl;
+    pl.row_stride = max_tiles * 32;
+    pl.wb_stride = max_tiles / 2;
+    pl.wgs_per_pair = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32);
+    size_t per_pair = (size_t)pl.row_stride * sizeof(int4) + (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) +
+                      (size_t)pl.row_stride * sizeof(uint2) + sizeof(int);
+    // bound the workspace near 1 GiB so the column partials of one batch stay cache-friendly
+    size_t budget = (size_t)1 << 30;
+    int batch = (int)std::min<size_t>(std::max<size_t>(budget / per_pair, 1), (size_t)npairs);
+    pl.batch = std::max(batch, 1);
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    pl.off_rowres = 0;
+    pl.off_colpart = align(pl.off_rowres + (size_t)pl.batch * pl.row_stride * sizeof(int4));
+    pl.off_matches = align(pl.off_colpart + (size_t)pl.batch * pl.wb_stride * pl.row_stride * sizeof(int2));
+    pl.off_counts = align(pl.off_matches + (size_t)pl.batch * pl.row_stride * sizeof(uint2));
+    pl.total = align(pl.off_counts + (size_t)pl.batch * sizeof(int));
+    return pl;
+}
+
+template <int KS>
+static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws) {
+    match_tile_kernel<KS><<<nb * pl.wgs_per_pair, WG_THREADS, 0, ctx->stream>>>(
+        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, (int4*)(ws + pl.off_rowres),
+        (int2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
+}
+
+// Core driver. mode 0 = mutual (CSR out), mode 1 = directed single pair (fixed-stride out in ws).
+static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double ratio, int min_dir,
+                     int min_mutual, int mode, int* counts_dev, long long* offsets_dev,
+                     uint2* edges_dev, long long edge_cap, long long* total_dev, int4* stats_dev) {
+    int rc = sync_frame_table(ctx);
+    if (rc) return rc;
+    if (npairs <= 0) return EACHAM_OK;
+    MatchPlan pl = make_plan(ctx, npairs);
+    rc = ensure_workspace(ctx, pl.total);
+    if (rc) return rc;
+    char* ws = (char*)ctx->ws;
+    const size_t fin_smem = (size_t)2 * pl.row_stride * sizeof(int);
+    for (int first = 0; first < npairs; first += pl.batch) {
+        int nb = std::min(pl.batch, npairs - first);
+        const int2* pb = pairs_dev + first;
+        {
+            ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_TILE);
+            switch (ctx->ks_common) {
+                case 2: launch_tile<2>(ctx, pl, pb, nb, ws); break;
+                case 4: launch_tile<4>(ctx, pl, pb, nb, ws); break;
+                default: launch_tile<8>(ctx, pl, pb, nb, ws); break;
+            }
+        }
+        int* cnt = mode == 1 ? counts_dev : counts_dev + first;
+        {
+            ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE);
+            match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, ctx->stream>>>(
+                ctx->frame_table_dev, pb, (const int4*)(ws + pl.off_rowres),
+                (const int2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride, ratio, min_dir,
+                min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt,
+                stats_dev ? stats_dev + first : nullptr);
+            if (mode == 0) {
+                scan_counts_kernel<<<1, 1024, 0, ctx->stream>>>(cnt, nb, offsets_dev, total_dev, first,
+                                                                first + nb == npairs);
+                compact_edges_kernel<<<nb, 256, 0, ctx->stream>>>((const uint2*)(ws + pl.off_matches), cnt,
+                                                                  offsets_dev + first, pl.row_stride,
+                                                                  edges_dev, edge_cap);
+            }
+        }
+        EACHAM_HIP_TRY(ctx, hipGetLastError());
+    }
+    return EACHAM_OK;
+}
+
+static int check_pairs_host(eacham_ctx* ctx, const int32_t* pairs, int npairs) {
+    for (int i = 0; i < 2 * npairs; ++i) {
+        int f = pairs[i];
+        if (f < 0 || (size_t)f >= ctx->frames.size() || ctx->frames[f].n < 0)
+            return ctx->fail(EACHAM_ERR_INVALID, "pair %d references frame %d which is not resident", i / 2, f);
+    }
+    return EACHAM_OK;
+}
+
+}  // namespace eacham
+
+using namespace eacham;
+
+extern "C" {
+
+int eacham_upload_descriptors_dev(eacham_ctx* ctx, int frame_id, const float* rowmajor_dev, int n, int dim) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (n > 0 && !rowmajor_dev) return ctx->fail(EACHAM_ERR_INVALID, "null descriptor pointer");
+    return upload_frame(ctx, frame_id, rowmajor_dev, n, dim);
+}
+
+int eacham_upload_descriptors(eacham_ctx* ctx, int frame_id, const float* rowmajor, int n, int dim) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (n > 0 && !rowmajor) return ctx->fail(EACHAM_ERR_INVALID, "null descriptor pointer");
+    if (n < 0 || dim <= 0) return ctx->fail(EACHAM_ERR_INVALID, "bad descriptor shape %d x %d", n, dim);
+    size_t bytes = (size_t)n * dim * sizeof(float);
+    int rc = ensure_io(ctx, std::max<size_t>(bytes, 256));
+    if (rc) return rc;
+    if (bytes) {
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->io, rowmajor, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = upload_frame(ctx, frame_id, (const float*)ctx->io, n, dim);
+    if (rc) return rc;
+    return check_integer_flag(ctx);  // also orders reuse of the staging buffer
+}
+
+int eacham_frame_rows(eacham_ctx* ctx, int frame_id) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (frame_id < 0 || (size_t)frame_id >= ctx->frames.size() || ctx->frames[frame_id].n < 0)
+        return ctx->fail(EACHAM_ERR_INVALID, "frame %d is not resident", frame_id);
+    return ctx->frames[frame_id].n;
+}
+
+int eacham_match_pair(eacham_ctx* ctx, int f1, int f2, double ratio, uint32_t* out_q, uint32_t* out_t,
+                      int cap, int* out_count) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (!out_count || cap < 0 || (cap > 0 && (!out_q || !out_t))) return ctx->fail(EACHAM_ERR_INVALID, "null output");
+    int32_t pr[2] = {f1, f2};
+    int rc = check_pairs_host(ctx, pr, 1);
+    if (rc) return rc;
+    rc = check_integer_flag(ctx);
+    if (rc) return rc;
+    rc = ensure_io(ctx, 256);
+    if (rc) return rc;
+    int2* pairs_dev = (int2*)ctx->io;
+    int* count_dev = (int*)((char*)ctx->io + 64);
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(pairs_dev, pr, sizeof(pr), hipMemcpyHostToDevice, ctx->stream));
+    rc = run_match(ctx, pairs_dev, 1, ratio, 0, 0, /*mode=*/1, count_dev, nullptr, nullptr, 0, nullptr, nullptr);
+    if (rc) return rc;
+    int count = 0;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_count = count;
+    if (count > cap) return ctx->fail(EACHAM_ERR_CAPACITY, "%d matches but capacity %d", count, cap);
+    if (count > 0) {
+        MatchPlan pl = make_plan(ctx, 1);
+        std::vector<uint2> tmp(count);
+        EACHAM_HIP_TRY(ctx, hipMemcpy(tmp.data(), (char*)ctx->ws + pl.off_matches, sizeof(uint2) * count,
+                                      hipMemcpyDeviceToHost));
+        for (int k = 0; k < count; ++k) {
+            out_q[k] = tmp[k].x;
+            out_t[k] = tmp[k].y;
+        }
+    }
+    return EACHAM_OK;
+}
+
+int eacham_match_all_pairs_dev(eacham_ctx* ctx, const int32_t* pairs_dev, int npairs, double ratio,
+                               int min_dir, int min_mutual, int32_t* counts_dev, int64_t* offsets_dev,
+                               uint32_t* edges_dev, int64_t edge_cap, int64_t* total_dev,
+                               int32_t* stats_dev) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (npairs < 0 || (npairs > 0 && (!pairs_dev || !counts_dev || !offsets_dev || !total_dev)) ||
+        edge_cap < 0 || (edge_cap > 0 && !edges_dev))
+        return ctx->fail(EACHAM_ERR_INVALID, "bad arguments to match_all_pairs_dev");
+    return run_match(ctx, (const int2*)pairs_dev, npairs, ratio, min_dir, min_mutual, 0, counts_dev,
+                     (long long*)offsets_dev, (uint2*)edges_dev, edge_cap, (long long*)total_dev,
+                     (int4*)stats_dev);
+}
+
+int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio, int min_dir,
+                           int min_mutual, int32_t* counts, int64_t* offsets, uint32_t* out_q,
+                           uint32_t* out_t, int64_t cap, int64_t* out_total, int32_t* stats) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (npairs < 0 || (npairs > 0 && (!pairs || !counts || !offsets)) || !out_total || cap < 0)
+        return ctx->fail(EACHAM_ERR_INVALID, "bad arguments to match_all_pairs");
+    int rc = check_pairs_host(ctx, pairs, npairs);
+    if (rc) return rc;
+    rc = check_integer_flag(ctx);
+    if (rc) return rc;
+    *out_total = 0;
+    if (npairs == 0) {
+        if (offsets) offsets[0] = 0;
+        return EACHAM_OK;
+    }
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_pairs = 0;
+    size_t o_counts = align(o_pairs + (size_t)npairs * 2 * sizeof(int32_t));
+    size_t o_offsets = align(o_counts + (size_t)npairs * sizeof(int32_t));
+    size_t o_total = align(o_offsets + (size_t)(npairs + 1) * sizeof(int64_t));
+    size_t o_stats = align(o_total + sizeof(int64_t));
+    size_t o_edges = align(o_stats + (size_t)npairs * 4 * sizeof(int32_t));
+    size_t bytes = o_edges + (size_t)cap * sizeof(uint2);
+    rc = ensure_io(ctx, bytes);
+    if (rc) return rc;
+    char* io = (char*)ctx->io;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(io + o_pairs, pairs, (size_t)npairs * 2 * sizeof(int32_t),
+                                       hipMemcpyHostToDevice, ctx->stream));
+    rc = run_match(ctx, (const int2*)(io + o_pairs), npairs, ratio, min_dir, min_mutual, 0,
+                   (int*)(io + o_counts), (long long*)(io + o_offsets), (uint2*)(io + o_edges), cap,
+                   (long long*)(io + o_total), (int4*)(io + o_stats));
+    if (rc) return rc;
+    long long total = 0;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(&total, io + o_total, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(counts, io + o_counts, (size_t)npairs * sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(offsets, io + o_offsets, (size_t)(npairs + 1) * sizeof(int64_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    if (stats)
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(stats, io + o_stats, (size_t)npairs * 4 * sizeof(int32_t),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_total = total;
+    if (total > cap) return ctx->fail(EACHAM_ERR_CAPACITY, "%lld matches but capacity %lld", total, (long long)cap);
+    if (total > 0) {
+        std::vector<uint2> tmp((size_t)total);
+        EACHAM_HIP_TRY(ctx, hipMemcpy(tmp.data(), io + o_edges, sizeof(uint2) * (size_t)total, hipMemcpyDeviceToHost));
+        for (long long k = 0; k < total; ++k) {
+            out_q[k] = tmp[k].x;
+            out_t[k] = tmp[k].y;
+        }
+    }
+    return EACHAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+"""Host-side mirror of the reference matcher interface, on top of the C-ABI.
+
+  FeatureMatcherHip.Match(d1, d2)    <->  FeatureMatcherFlann::Match / IFeatureMatcher<T>::Match
+                                          (modules/base/features/FeatureMatcherFlann.h:14-19,
+                                           modules/base/features/IFeatureMatcher.h:8-20)
+  HipContext.match_all_pairs(pairs)  <->  the pair loop + mutual check of apps/sfm/main.cpp:84-147
+
+Python is only the test/bench driver here (the reference is C++; its adapter is
+include/eacham/FeatureMatcherHip.hpp). Same names, argument meaning and error behaviour.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+# literals of the reference
+RATIO = 0.8        # FeatureMatcherFlann.cpp:23 (the ctor's inliersRatio is stored but never used)
+MIN_DIRECTED = 30  # apps/sfm/main.cpp:111  `matches12.size() < 30` -> drop
+MIN_MUTUAL = 30    # apps/sfm/main.cpp:142  `bestMatches12.size() > 30` -> connect
+
+
+class HipContext:
+    """One HIP device + stream + resident descriptor store (eacham_ctx)."""
+
+    def __init__(self, device_id: int = 0):
+        self._L = capi.lib()
+        h = C.c_void_p()
+        rc = self._L.eacham_ctx_create(device_id, C.byref(h))
+        if rc != capi.OK:
+            raise capi.EachamError(rc, "eacham_ctx_create failed (no HIP device? the hot path has no CPU fallback)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.eacham_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != capi.OK:
+            raise capi.EachamError(rc, self._L.eacham_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.eacham_ctx_stream(self._h) or 0)
+
+    def sync(self):
+        self._check(self._L.eacham_ctx_sync(self._h))
+
+    # ---- descriptor store ------------------------------------------------------------------
+    def upload_descriptors(self, frame_id: int, desc: np.ndarray):
+        d = np.ascontiguousarray(desc, dtype=np.float32)
+        if d.ndim != 2:
+            raise ValueError("descriptors must be an N x D matrix")
+        self._check(self._L.eacham_upload_descriptors(self._h, frame_id, d.ctypes.data, d.shape[0], d.shape[1]))
+
+    def upload_descriptors_dev(self, frame_id: int, dev_ptr: int, n: int, dim: int):
+        self._check(self._L.eacham_upload_descriptors_dev(self._h, frame_id, C.c_void_p(dev_ptr), n, dim))
+
+    def frame_rows(self, frame_id: int) -> int:
+        n = self._L.eacham_frame_rows(self._h, frame_id)
+        if n < 0:
+            self._check(n)
+        return n
+
+    def clear_descriptors(self):
+        self._check(self._L.eacham_clear_descriptors(self._h))
+
+    # ---- matching --------------------------------------------------------------------------
+    def match_pair(self, f1: int, f2: int, ratio: float = RATIO):
+        cap = max(self.frame_rows(f1), 1)
+        q = np.empty(cap, dtype=np.uint32)
+        t = np.empty(cap, dtype=np.uint32)
+        cnt = C.c_int(0)
+        self._check(self._L.eacham_match_pair(self._h, f1, f2, ratio, q.ctypes.data, t.ctypes.data, cap, C.byref(cnt)))
+        return q[:cnt.value].copy(), t[:cnt.value].copy()
+
+    def match_all_pairs(self, pairs: np.ndarray, ratio: float = RATIO, min_dir: int = MIN_DIRECTED,
+                        min_mutual: int = MIN_MUTUAL, cap: int | None = None):
+        """Returns (counts, offsets, q, t, stats): CSR over pairs, see include/eacham_hip.h."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        npairs = pairs.shape[0]
+        if cap is None:
+            cap = int(sum(self.frame_rows(int(p[0])) for p in pairs)) if npairs else 0
+        counts = np.zeros(npairs, dtype=np.int32)
+        offsets = np.zeros(npairs + 1, dtype=np.int64)
+        q = np.empty(max(cap, 1), dtype=np.uint32)
+        t = np.empty(max(cap, 1), dtype=np.uint32)
+        stats = np.zeros((npairs, 4), dtype=np.int32)
+        total = C.c_int64(0)
+        self._check(self._L.eacham_match_all_pairs(
+            self._h, pairs.ctypes.data, npairs, ratio, min_dir, min_mutual, counts.ctypes.data,
+            offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total), stats.ctypes.data))
+        return counts, offsets, q[:total.value].copy(), t[:total.value].copy(), stats
+
+    def match_all_pairs_dev(self, pairs_dev: int, npairs: int, counts_dev: int, offsets_dev: int,
+                            edges_dev: int, edge_cap: int, total_dev: int, stats_dev: int = 0,
+                            ratio: float = RATIO, min_dir: int = MIN_DIRECTED, min_mutual: int = MIN_MUTUAL):
+        vp = C.c_void_p
+        self._check(self._L.eacham_match_all_pairs_dev(
+            self._h, vp(pairs_dev), npairs, ratio, min_dir, min_mutual, vp(counts_dev), vp(offsets_dev),
+            vp(edges_dev), edge_cap, vp(total_dev), vp(stats_dev) if stats_dev else None))
+
+    # ---- profiling -------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self._L.eacham_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._L.eacham_profile_reset(self._h))
+
+    def profile_get(self, kernel_id: int):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        self._check(self._L.eacham_profile_get(self._h, kernel_id, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class FeatureMatcherHip:
+    """Drop-in shape of eacham::FeatureMatcherFlann (FeatureMatcherFlann.h:11-25).
+
+    `Match(descriptor1, descriptor2)` takes two N x D fp32 matrices (cv::Mat CV_32F layout) and
+    returns {queryIdx: trainIdx}. As in the reference, the constructor's `inliersRatio` is kept
+    but the ratio test uses the literal 0.8 unless `ratio` is given explicitly.
+    """
+
+    def __init__(self, inliersRatio: float = 0.8, ratio: float = RATIO, context: HipContext | None = None):
+        self.inliersRatio = inliersRatio
+        self.ratio = ratio
+        self.ctx = context or HipContext()
+        self._scratch = (1 << 16) - 2  # two frame slots reserved for ad-hoc Match() calls
+
+    def Match(self, descriptor1: np.ndarray, descriptor2: np.ndarray) -> dict:
+        a, b = self._scratch, self._scratch + 1
+        self.ctx.upload_descriptors(a, descriptor1)
+        self.ctx.upload_descriptors(b, descriptor2)
+        q, t = self.ctx.match_pair(a, b, self.ratio)
+        return dict(zip(q.tolist(), t.tolist()))

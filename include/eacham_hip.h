@@ -1,0 +1,130 @@
+/*
+ * eacham_hip.h — C-ABI of the MI355X (gfx950) matching + bundle-adjustment hot path.
+ *
+ * This is the drop-in boundary for the two hot spots of fatlipp/eacham:
+ *
+ *   matching : FeatureMatcherFlann::Match        modules/base/features/FeatureMatcherFlann.cpp:14-30
+ *              IFeatureMatcher<T>::Match         modules/base/features/IFeatureMatcher.h:8-20
+ *              pair loop + mutual cross-check    apps/sfm/main.cpp:84-147
+ *   BA       : RefineBA                          modules/sfm/reconstruction/BundleAdjuster.h:13-17
+ *                                                modules/sfm/reconstruction/BundleAdjuster.cpp:40-250
+ *              OptimizerConfig                   modules/sfm/config/SfmConfig.h:15-22
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the ABI.
+ *   - every call returns EACHAM_OK (0) or a negative error code; eacham_last_error(ctx)
+ *     returns the message of the last failure on that context.
+ *   - one context = one HIP device + one HIP stream; calls on one context are serialised by an
+ *     internal mutex, so the reference's pattern of calling Match() concurrently on one shared
+ *     matcher instance (apps/sfm/main.cpp:98-109) stays legal. Distinct contexts are independent.
+ *   - pointers named *_dev are device pointers valid on the context's device; everything else is
+ *     host memory. *_dev entry points enqueue on the context stream and do not synchronise;
+ *     use eacham_ctx_sync().
+ *   - match lists are emitted SORTED BY QUERY INDEX: the reference returns an unordered_map whose
+ *     iteration order is unspecified; sorted is the canonical form used for bit-exact parity.
+ */
+#ifndef EACHAM_HIP_H
+#define EACHAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EACHAM_OK 0
+#define EACHAM_ERR_INVALID (-1)      /* bad argument */
+#define EACHAM_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define EACHAM_ERR_CAPACITY (-3)     /* caller-provided output buffer too small */
+#define EACHAM_ERR_UNSUPPORTED (-4)  /* e.g. descriptor dimension not supported by the kernel */
+#define EACHAM_ERR_NOT_INTEGER (-5)  /* descriptors are not integer-valued in [0,255] (exact i8 path) */
+#define EACHAM_ERR_NO_DEVICE (-6)    /* no HIP device / extension unusable: the product path never falls back to CPU */
+
+typedef struct eacham_ctx eacham_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device_id`. Fails (no CPU fallback) if no device exists. */
+int eacham_ctx_create(int device_id, eacham_ctx** out_ctx);
+void eacham_ctx_destroy(eacham_ctx* ctx);
+const char* eacham_last_error(const eacham_ctx* ctx);
+/* Blocks until everything enqueued on the context stream has finished. */
+int eacham_ctx_sync(eacham_ctx* ctx);
+/* Returns the hipStream_t of the context (as void*), so callers can order their own work. */
+void* eacham_ctx_stream(eacham_ctx* ctx);
+/* Library / build identification ("eacham_hip <version> gfx950"). */
+const char* eacham_version(void);
+
+/* ---- descriptor store (input of Match: Node::GetDescriptors(), modules/sfm/data/Node.h:136-139) */
+
+/* Uploads the N x dim row-major fp32 descriptor matrix of frame `frame_id` (the layout of the
+ * cv::Mat returned by FeatureExtractorSift::Extract, modules/base/features/FeatureExtractorSift.cpp:14-26)
+ * and keeps it resident on the device in the kernel's fragment-major int8 layout.
+ * Values must be integers in [0,255] (OpenCV SIFT descriptors are) —
+ * otherwise EACHAM_ERR_NOT_INTEGER. dim must be a multiple of 16 and <= 256. n may be 0.
+ * Re-uploading a frame id replaces it. */
+int eacham_upload_descriptors(eacham_ctx* ctx, int frame_id, const float* rowmajor, int n, int dim);
+/* Same, source already on the device (enqueued on the context stream; the integrality check is
+ * reported by the next synchronising call). */
+int eacham_upload_descriptors_dev(eacham_ctx* ctx, int frame_id, const float* rowmajor_dev, int n, int dim);
+/* Number of rows of a resident frame, or a negative error code. */
+int eacham_frame_rows(eacham_ctx* ctx, int frame_id);
+/* Drops all resident frames. */
+int eacham_clear_descriptors(eacham_ctx* ctx);
+
+/* ---- directed match: FeatureMatcherFlann::Match (FeatureMatcherFlann.cpp:14-30) -------------
+ * For each row q of frame f1: the two nearest rows of frame f2 under L2 (exact; ties -> lower
+ * train index first); keep q -> t0 iff (float)(d0 / d1) < ratio with d = sqrtf(squared L2), the
+ * quotient promoted to double as in the reference (ratio = 0.8 there, FeatureMatcherFlann.cpp:23).
+ * Output sorted by q. If frame f2 has fewer than 2 rows the result is empty (the reference would
+ * read m[1] out of bounds). */
+int eacham_match_pair(eacham_ctx* ctx, int f1, int f2, double ratio,
+                      uint32_t* out_q, uint32_t* out_t, int cap, int* out_count);
+
+/* ---- all-pairs match + mutual check: apps/sfm/main.cpp:84-147 -------------------------------
+ * pairs = npairs x {f1, f2} (unordered pairs; both directions are evaluated from one distance
+ * tile). For each pair: directed matches m12, m21 as above; if |m12| < min_dir or |m21| < min_dir
+ * the pair is dropped (main.cpp:111, literal 30); mutual = {(q,t) in m12 : m21[t] == q}
+ * (main.cpp:133-140); the pair becomes an edge iff |mutual| > min_mutual (main.cpp:142, literal 30).
+ *
+ * Result (CSR over pairs): counts[p] = |mutual| for edges, 0 otherwise; offsets[p] = prefix sum
+ * (npairs+1 entries); (q[k], t[k]) for k in [offsets[p], offsets[p+1]) sorted by q, q indexing
+ * frame pairs[2p], t indexing frame pairs[2p+1]  (= Graph::Connect(n1,n2,best12); the reverse
+ * edge Connect(n2,n1,best21) is its inverse, main.cpp:144-145).
+ * stats (optional, may be NULL): npairs x {|m12|, |m21|, |mutual|, edge?1:0}. */
+int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio,
+                           int min_dir, int min_mutual,
+                           int32_t* counts, int64_t* offsets,
+                           uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total,
+                           int32_t* stats);
+
+/* Device-resident, asynchronous form used by the benchmark and the multi-GPU shard driver.
+ * pairs_dev: npairs x 2 int32. counts_dev: npairs int32. offsets_dev: npairs+1 int64.
+ * edges_dev: edge_cap x {uint32 q, uint32 t}; entries beyond edge_cap are dropped and
+ * *total_dev (int64, device) still holds the uncapped total. stats_dev: npairs x 4 int32 or NULL. */
+int eacham_match_all_pairs_dev(eacham_ctx* ctx, const int32_t* pairs_dev, int npairs, double ratio,
+                               int min_dir, int min_mutual,
+                               int32_t* counts_dev, int64_t* offsets_dev,
+                               uint32_t* edges_dev, int64_t edge_cap, int64_t* total_dev,
+                               int32_t* stats_dev);
+
+/* ---- kernel timing (HIP events on the context stream; used for roofline reporting) ---------- */
+
+#define EACHAM_KERNEL_MATCH_TILE 0     /* all-pairs int8 MFMA distance + fused row/col top-2      */
+#define EACHAM_KERNEL_MATCH_FINALIZE 1 /* partial merge + ratio + mutual check + compaction       */
+#define EACHAM_KERNEL_BA_LINEARIZE 2
+#define EACHAM_KERNEL_BA_SCHUR 3
+#define EACHAM_KERNEL_BA_SOLVE 4
+#define EACHAM_KERNEL_BA_ERROR 5
+#define EACHAM_KERNEL_COUNT 8
+
+/* Enables (1) / disables (0) per-launch HIP-event timing of the kernels above. */
+int eacham_profile_enable(eacham_ctx* ctx, int on);
+int eacham_profile_reset(eacham_ctx* ctx);
+/* Synchronises, then returns launches and total milliseconds recorded for `kernel_id`. */
+int eacham_profile_get(eacham_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EACHAM_HIP_H */

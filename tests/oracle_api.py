@@ -1,0 +1,80 @@
+"""numpy front-end of the C oracle (oracle/*.c). Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+import oracle
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def match_directed(A, B, ratio=0.8, force_f32=False):
+    L = oracle.lib()
+    A, B = _f32(A), _f32(B)
+    n1, n2 = A.shape[0], B.shape[0]
+    dim = A.shape[1] if A.ndim == 2 and A.shape[1] else (B.shape[1] if B.ndim == 2 else 0)
+    q = np.empty(max(n1, 1), dtype=np.uint32)
+    t = np.empty(max(n1, 1), dtype=np.uint32)
+    L.oracle_match_directed.restype = C.c_int
+    cnt = L.oracle_match_directed(C.c_void_p(A.ctypes.data), n1, C.c_void_p(B.ctypes.data), n2, dim,
+                                  C.c_double(ratio), int(force_f32), C.c_void_p(q.ctypes.data),
+                                  C.c_void_p(t.ctypes.data))
+    return q[:cnt].copy(), t[:cnt].copy()
+
+
+def knn2(A, B, force_f32=False):
+    L = oracle.lib()
+    A, B = _f32(A), _f32(B)
+    n1, n2, dim = A.shape[0], B.shape[0], A.shape[1]
+    idx = np.empty(max(n1, 1), dtype=np.int32)
+    d0 = np.empty(max(n1, 1), dtype=np.float32)
+    d1 = np.empty(max(n1, 1), dtype=np.float32)
+    L.oracle_knn2.restype = None
+    L.oracle_knn2(C.c_void_p(A.ctypes.data), n1, C.c_void_p(B.ctypes.data), n2, dim, int(force_f32),
+                  C.c_void_p(idx.ctypes.data), C.c_void_p(d0.ctypes.data), C.c_void_p(d1.ctypes.data))
+    return idx[:n1], d0[:n1], d1[:n1]
+
+
+def match_mutual(A, B, ratio=0.8, min_dir=30, min_mutual=30, force_f32=False):
+    L = oracle.lib()
+    A, B = _f32(A), _f32(B)
+    n1, n2 = A.shape[0], B.shape[0]
+    dim = A.shape[1] if A.shape[1] else B.shape[1]
+    q = np.empty(max(n1, 1), dtype=np.uint32)
+    t = np.empty(max(n1, 1), dtype=np.uint32)
+    stats = np.zeros(4, dtype=np.int32)
+    L.oracle_match_mutual.restype = C.c_int
+    cnt = L.oracle_match_mutual(C.c_void_p(A.ctypes.data), n1, C.c_void_p(B.ctypes.data), n2, dim,
+                                C.c_double(ratio), min_dir, min_mutual, int(force_f32),
+                                C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data),
+                                C.c_void_p(stats.ctypes.data))
+    return q[:cnt].copy(), t[:cnt].copy(), stats
+
+
+def match_all_pairs(descs, pairs, ratio=0.8, min_dir=30, min_mutual=30, nthreads=0):
+    """Returns (counts, offsets, q, t, stats, threads_used) in the CSR form of the C-ABI."""
+    L = oracle.lib()
+    descs = [_f32(d) for d in descs]
+    dim = max((d.shape[1] for d in descs if d.ndim == 2), default=0)
+    n = np.array([d.shape[0] for d in descs], dtype=np.int32)
+    ptrs = (C.c_void_p * len(descs))(*[d.ctypes.data for d in descs])
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    npairs = pairs.shape[0]
+    stride = int(max(n.max() if len(n) else 1, 1))
+    counts = np.zeros(npairs, dtype=np.int32)
+    matches = np.zeros((npairs, stride, 2), dtype=np.uint32)
+    stats = np.zeros((npairs, 4), dtype=np.int32)
+    L.oracle_match_all_pairs.restype = C.c_int
+    used = L.oracle_match_all_pairs(ptrs, C.c_void_p(n.ctypes.data), dim, C.c_void_p(pairs.ctypes.data),
+                                    npairs, C.c_double(ratio), min_dir, min_mutual, nthreads,
+                                    C.c_void_p(counts.ctypes.data), C.c_void_p(matches.ctypes.data),
+                                    stride, C.c_void_p(stats.ctypes.data))
+    offsets = np.zeros(npairs + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    q = np.concatenate([matches[p, :counts[p], 0] for p in range(npairs)]) if npairs else np.zeros(0, np.uint32)
+    t = np.concatenate([matches[p, :counts[p], 1] for p in range(npairs)]) if npairs else np.zeros(0, np.uint32)
+    return counts, offsets, q.astype(np.uint32), t.astype(np.uint32), stats, used

@@ -1,0 +1,170 @@
+"""GPU: the HIP matcher (through the C-ABI) against the CPU oracle — indices must be bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from eacham_amd import EachamError, FeatureMatcherHip, synth
+from eacham_amd import capi
+import np_reference as R
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz")
+
+
+def _upload(ctx, descs):
+    ctx.clear_descriptors()
+    for f, d in enumerate(descs):
+        ctx.upload_descriptors(f, d)
+
+
+def _assert_csr_equal(got, want):
+    names = ["counts", "offsets", "q", "t", "stats"]
+    for n, g, w in zip(names, got[:5], want[:5]):
+        assert np.array_equal(g, w), f"{n} differs"
+
+
+def test_golden_fixture(hip_ctx):
+    g = np.load(GOLD)
+    descs = [g[f"desc{f}"].astype(np.float32) for f in range(4)]
+    _upload(hip_ctx, descs)
+    for tag, (md, mm) in {"ref": (30, 30), "low": (5, 5)}.items():
+        c, o, q, t, st = hip_ctx.match_all_pairs(g["pairs"], float(g["ratio"]), md, mm)
+        assert np.array_equal(c, g[f"counts_{tag}"]) and np.array_equal(o, g[f"offsets_{tag}"])
+        assert np.array_equal(q, g[f"q_{tag}"]) and np.array_equal(t, g[f"t_{tag}"])
+        assert np.array_equal(st, g[f"stats_{tag}"])
+    for a, b in [(0, 1), (1, 0), (2, 3), (3, 2)]:
+        q, t = hip_ctx.match_pair(a, b)
+        assert np.array_equal(q, g[f"dir_{a}_{b}_q"]) and np.array_equal(t, g[f"dir_{a}_{b}_t"])
+
+
+@pytest.mark.parametrize("n1,n2,dim", [(1, 2, 16), (31, 33, 64), (64, 64, 128), (200, 150, 128),
+                                       (97, 203, 256), (513, 700, 256), (1100, 520, 128), (300, 280, 48)])
+def test_directed_parity(hip_ctx, n1, n2, dim):
+    A = synth.random_u8_descriptors(n1, dim, 21, 0)
+    B = synth.random_u8_descriptors(n2, dim, 21, 1)
+    m = min(n1, n2) // 2
+    B[:m] = np.clip(A[:m] + np.rint(6 * synth.rng_normal(5, 3, (m, dim))), 0, 255)
+    _upload(hip_ctx, [A, B])
+    for a, b, X, Y in [(0, 1, A, B), (1, 0, B, A)]:
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(X, Y)
+        assert np.array_equal(q, qo) and np.array_equal(t, to)
+    assert len(O.match_directed(A, B)[0]) >= m // 2 or m < 4
+
+
+def test_extreme_values_and_ties(hip_ctx):
+    """0/255 saturated rows exercise the full 25-bit rank range; duplicates exercise tie-breaks."""
+    dim = 256
+    A = synth.random_u8_descriptors(130, dim, 8, 0)
+    B = synth.random_u8_descriptors(190, dim, 8, 1)
+    A[0], A[1], A[2] = 0, 255, 0
+    A[2, ::2] = 255
+    B[0], B[1], B[3] = 255, 0, 255
+    B[3, ::2] = 0
+    B[100:110] = A[20:30]          # exact duplicates (distance 0 -> 0/0 never passes)
+    B[110:120] = A[20:30]          # and a second copy: tie between 100.. and 110..
+    B[120:125] = np.clip(A[40:45] + 1, 0, 255)
+    B[125:130] = np.clip(A[40:45] + 1, 0, 255)  # equal non-zero distances: lower index must win
+    _upload(hip_ctx, [A, B])
+    for a, b, X, Y in [(0, 1, A, B), (1, 0, B, A)]:
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(X, Y)
+        qr, tr = R.directed(X, Y)
+        assert np.array_equal(q, qo) and np.array_equal(t, to)
+        assert np.array_equal(q, qr) and np.array_equal(t, tr)
+    c, o, q, t, st = hip_ctx.match_all_pairs(np.array([[0, 1], [1, 0]]), min_dir=1, min_mutual=0)
+    want = O.match_all_pairs([A, B], np.array([[0, 1], [1, 0]]), min_dir=1, min_mutual=0)
+    _assert_csr_equal((c, o, q, t, st), want)
+
+
+def test_ragged_and_empty_frames(hip_ctx):
+    sc = synth.make_scene(6, 500, 4, seed=31)
+    descs, _ = synth.make_frame_descriptors(sc, 300, 128, seed=31)
+    descs[1] = descs[1][:37]
+    descs[2] = descs[2][:0]            # empty frame
+    descs[3] = descs[3][:1]            # single row: nothing can pass the ratio test against it
+    descs[4] = descs[4][:64]
+    pairs = np.concatenate([synth.all_pairs(6), np.array([[5, 0], [4, 1]], dtype=np.int32)])
+    _upload(hip_ctx, descs)
+    got = hip_ctx.match_all_pairs(pairs, min_dir=3, min_mutual=2)
+    want = O.match_all_pairs(descs, pairs, min_dir=3, min_mutual=2)
+    _assert_csr_equal(got, want)
+    assert got[0].sum() > 0
+    assert len(hip_ctx.match_pair(0, 2)[0]) == 0 and len(hip_ctx.match_pair(2, 0)[0]) == 0
+    assert len(hip_ctx.match_pair(0, 3)[0]) == 0
+
+
+def test_scene_parity_reference_thresholds(hip_ctx):
+    """config[0]-like: 10 frames, SIFT-sized 128-D, literal thresholds 0.8 / 30 / 30."""
+    sc = synth.make_scene(10, 3000, 5, seed=synth.MASTER_SEED)
+    descs, _ = synth.make_frame_descriptors(sc, 1500, 128)
+    pairs = synth.all_pairs(10)
+    _upload(hip_ctx, descs)
+    got = hip_ctx.match_all_pairs(pairs)
+    want = O.match_all_pairs(descs, pairs)
+    _assert_csr_equal(got, want)
+    assert (got[0] > 30).sum() >= 5
+
+
+def test_feature_matcher_interface(hip_ctx):
+    """FeatureMatcherFlann-shaped adapter: Match(d1, d2) -> {query: train}."""
+    A = synth.random_u8_descriptors(150, 128, 3, 0)
+    B = np.clip(A[::-1] + np.rint(4 * synth.rng_normal(5, 4, A.shape)), 0, 255).astype(np.float32)
+    m = FeatureMatcherHip(0.8, context=hip_ctx)
+    got = m.Match(A, B)
+    q, t = O.match_directed(A, B)
+    assert got == dict(zip(q.tolist(), t.tolist())) and len(got) > 100
+    hip_ctx.clear_descriptors()
+
+
+def test_errors(hip_ctx):
+    hip_ctx.clear_descriptors()
+    with pytest.raises(EachamError) as e:
+        hip_ctx.upload_descriptors(0, np.full((4, 32), 0.5, np.float32))
+    assert e.value.code == capi.ERR_NOT_INTEGER
+    with pytest.raises(EachamError) as e:
+        hip_ctx.upload_descriptors(0, np.zeros((4, 24), np.float32))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    hip_ctx.clear_descriptors()
+    hip_ctx.upload_descriptors(0, np.zeros((4, 32), np.float32))
+    with pytest.raises(EachamError) as e:
+        hip_ctx.match_pair(0, 7)
+    assert e.value.code == capi.ERR_INVALID
+    hip_ctx.clear_descriptors()
+
+
+def test_full_size_properties(hip_ctx):
+    """BASELINE config[1] frame size (2000 x 256): properties that need no oracle at this size,
+    plus an oracle check on one pair."""
+    sc = synth.make_scene(6, 6000, 4, seed=77)
+    descs, ids = synth.make_frame_descriptors(sc, 2000, 256, seed=77)
+    pairs = synth.all_pairs(6)
+    _upload(hip_ctx, descs)
+    c, o, q, t, st = hip_ctx.match_all_pairs(pairs)
+    # symmetry: matching (j,i) yields the inverse edge list (Connect(n2,n1,best21), main.cpp:145)
+    c2, o2, q2, t2, st2 = hip_ctx.match_all_pairs(pairs[:, ::-1].copy())
+    assert np.array_equal(c, c2)
+    for p in range(len(pairs)):
+        a = sorted(zip(q[o[p]:o[p + 1]].tolist(), t[o[p]:o[p + 1]].tolist()))
+        b = sorted(zip(t2[o2[p]:o2[p + 1]].tolist(), q2[o2[p]:o2[p + 1]].tolist()))
+        assert a == b
+        # sortedness and injectivity
+        qq = q[o[p]:o[p + 1]]
+        assert np.all(np.diff(qq.astype(np.int64)) > 0) and len(set(t[o[p]:o[p + 1]].tolist())) == len(qq)
+        # every mutual match joins two observations of the same landmark in this synthetic scene
+        i, j = pairs[p]
+        la, lb = ids[i][qq], ids[j][t[o[p]:o[p + 1]]]
+        assert np.array_equal(la, lb) and np.all(la >= 0)
+    assert c.sum() > 1000
+    # self-match: identical frames -> every distance-0 best is rejected by the ratio test (0/x or 0/0)
+    hip_ctx.upload_descriptors(6, descs[0])
+    qs, ts = hip_ctx.match_pair(0, 6)
+    assert np.array_equal(qs, ts)  # each row's nearest is its copy; d0 = 0 passes 0/d1 < 0.8
+    qo, to = O.match_directed(descs[0], descs[0])
+    assert np.array_equal(qs, qo) and np.array_equal(ts, to)
+    want = O.match_all_pairs(descs, pairs[:2])
+    got = hip_ctx.match_all_pairs(pairs[:2])
+    _assert_csr_equal(got, want)
+    hip_ctx.clear_descriptors()
