@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeacham_hip.so")
+# EACHAM_HIP_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("EACHAM_HIP_LIB") or os.path.join(_HERE, "lib", "libeacham_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NOT_INTEGER, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6

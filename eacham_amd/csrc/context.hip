@@ -51,6 +51,7 @@ int sync_frame_table(eacham_ctx* ctx) {
         const FrameHost& f = ctx->frames[i];
         tab[i].frag = f.frag;
         tab[i].norm = f.norm;
+        tab[i].normb = f.normb;
         tab[i].n = f.n < 0 ? 0 : f.n;
         tab[i].ntiles = f.n < 0 ? 0 : f.ntiles;
     }

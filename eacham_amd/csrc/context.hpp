@@ -22,6 +22,7 @@ namespace eacham {
 struct FrameDev {
     const int4* frag;  // [ntiles][KS][64] 16-byte MFMA operand fragments (int8, centred by -128)
     const int* norm;   // [ntiles*32] squared norm of the centred row; PAD_VALUE for padding rows
+    const int* normb;  // [ntiles*32] norm + 2*sum of the centred row (train-role norm, see matcher.hip K1)
     int n;             // real rows
     int ntiles;        // 32-row tiles, always even (a wave owns 2 tiles = 64 rows)
 };
@@ -29,6 +30,7 @@ struct FrameDev {
 struct FrameHost {
     int4* frag = nullptr;
     int* norm = nullptr;
+    int* normb = nullptr;  // second half of the `norm` allocation
     int n = -1;  // -1 = not resident
     int dim = 0;
     int ks = 0;

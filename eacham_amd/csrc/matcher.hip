@@ -26,12 +26,18 @@ namespace eacham {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+// Pointers read out of the device-side frame table are generic to the compiler; casting them to the
+// global address space turns flat_load (which ties vmcnt to lgkmcnt) into global_load.
+typedef const v4i __attribute__((address_space(1)))* gfrag_t;
+typedef const int __attribute__((address_space(1)))* gint_t;
 
-constexpr int PAD_VALUE = (1 << 24) - 1;  // rank value of padding rows/columns; > any real d2
+// norm of padding rows/columns: above any real d2 (<= 256*255^2 = 16,646,400) and low enough that
+// PAD_VALUE + 2^16 still fits the 25-bit signed rank field of a key
+constexpr int PAD_VALUE = 16700000;
 constexpr int KEY_SHIFT = 7;
 constexpr int KEY_MASK = (1 << KEY_SHIFT) - 1;
 constexpr int MAX_TILES = 1 << KEY_SHIFT;  // 128 tiles * 32 = 4096 rows per frame
-constexpr int WG_THREADS = 512;            // 8 waves: 2 per SIMD so MFMA and VALU phases overlap
+constexpr int WG_THREADS = 256;            // 4 waves (1 per SIMD); 2 workgroups per CU drift out of phase so MFMA and VALU overlap
 constexpr int WAVES = WG_THREADS / 64;
 constexpr int ROWS_PER_WAVE = 64;          // 2 MFMA tiles of 32 rows, A fragments live in VGPRs
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
@@ -42,21 +48,26 @@ __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b),
 // upload: fp32 row-major -> fragment-major int8 + squared norms
 // ------------------------------------------------------------------------------------------------
 
-__global__ void init_norm_kernel(int* __restrict__ norm, int n, int npad) {
+__global__ void init_norm_kernel(int* __restrict__ norm, int* __restrict__ normb, int n, int npad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npad) norm[i] = i < n ? 0 : PAD_VALUE;
+    if (i < npad) {
+        norm[i] = i < n ? 0 : PAD_VALUE;
+        normb[i] = i < n ? 0 : PAD_VALUE;
+    }
 }
 
+// norm[row]  = sum c^2             (c = x - 128, the stored int8)            -> query role
+// normb[row] = sum c^2 + 2 sum c   (absorbs the -1 of the ~a trick, see K1)  -> train role
 __global__ void quantize_kernel(const float* __restrict__ src, int n, int dim, int KS, int npad,
                                 v4i* __restrict__ frag, int* __restrict__ norm,
-                                int* __restrict__ bad_flag) {
+                                int* __restrict__ normb, int* __restrict__ bad_flag) {
     const int chunks = KS * 2;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)npad * chunks) return;
     int row = (int)(idx / chunks), ch = (int)(idx % chunks);
     int ks = ch >> 1, h = ch & 1, tile = row >> 5, r = row & 31;
     unsigned w[4] = {0u, 0u, 0u, 0u};
-    int part = 0;
+    int sq = 0, sum = 0;
     bool bad = false;
     if (row < n) {
 #pragma unroll
@@ -68,13 +79,15 @@ __global__ void quantize_kernel(const float* __restrict__ src, int n, int dim, i
                 if (!(v >= 0.0f && v <= 255.0f) || v != floorf(v)) bad = true;
                 c = (int)v - 128;
             }
-            part += c * c;
+            sq += c * c;
+            sum += c;
             w[j >> 2] |= (unsigned)(c & 0xff) << (8 * (j & 3));
         }
     }
     v4i out = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
     frag[((size_t)tile * KS + ks) * 64 + h * 32 + r] = out;
-    if (part) atomicAdd(&norm[row], part);
+    if (sq) atomicAdd(&norm[row], sq);
+    if (sq + 2 * sum) atomicAdd(&normb[row], sq + 2 * sum);
     if (bad) atomicOr(bad_flag, 1);
 }
 
@@ -82,22 +95,59 @@ __global__ void quantize_kernel(const float* __restrict__ src, int n, int dim, i
 // K1: distance tiles + fused row/column top-2
 // ------------------------------------------------------------------------------------------------
 //
-// grid  = npairs * wgs_per_pair workgroups of 512 threads; workgroup (p, rb) owns rows
-//         [512*rb, 512*rb+512) of frame A = pairs[p].x against ALL rows of frame B = pairs[p].y.
+// grid  = npairs * wgs_per_pair workgroups of 256 threads; workgroup (p, rb) owns rows
+//         [256*rb, 256*rb+256) of frame A = pairs[p].x against ALL rows of frame B = pairs[p].y.
 // wave  = 64 rows (two 32-row MFMA tiles): A fragments stay in VGPRs for the whole sweep
 //         (A-stationary), B tiles (32 train rows = KS KiB) stream through LDS once per workgroup.
-// out   rowres[p][q]      = {rank1, col1, rank2, 0}   final over all columns (rank = d2 - |a_q|^2)
-//       colpart[p][wb][c] = {key1, key2}              top-2 over the 64 rows of wave-block wb;
-//                                                     key = (d2 - |b_c|^2) << 7 | local row
+//
+// The kernel is VALU-bound (each wave64 integer op costs 4 cycles per SIMD, the int8 MFMAs of a
+// tile only 16 x 32), so the epilogue is cut to 6 ops per distance:
+//   * the query fragments are complemented once (a' = ~a = -a-1 per byte), so the MFMA returns
+//     acc = -a.b - sum(b) and each key is ONE v_lshl_add_u32:
+//         row key  = (acc << 8) + ((normb_c << 7) | t)        rank = |b|^2 - 2 a.b
+//         col key  = (acc << 8) + ((norm_r  << 7) | lrow)     rank = |a|^2 - 2 a.b - 2 sum(b)
+//     (normb = |b|^2 + 2 sum(b) is precomputed at upload; the -2 sum(b) offset of the column
+//     rank is constant per column and is added back by K2);
+//   * each running top-2 update is v_med3_i32 + v_min_i32.
+// Measured on MI355X (tools/valu_ubench.hip, tools/mfma_ubench.hip): a wave64 integer VALU op costs
+// ~4 cycles of its SIMD whatever the number of resident waves, the int8 32x32x32 MFMA 32 cycles.
+// With 6 ops per distance the VALU floor is 192 ops = 768 cycles per 64x32 wave-tile against 512
+// MFMA cycles, so the MFMA chains are software-pipelined UNDER the epilogue (see the main loop).
+// out   rowres[p][q]      = {rank1, col1, rank2, 0}   final over all columns (d2 = rank + norm_q)
+//       colpart[p][wb][c] = {key1, key2}              top-2 over the 64 rows of wave-block wb
+//                                                     (d2 = (key >> 7) + normb_c, row = key & 127)
+__device__ __forceinline__ int vmed3(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Two keys from one accumulator, each ONE v_lshl_add_u32. The empty asm hides the second use of
+// `acc` from CSE (hipcc would otherwise share the shift: 3 ops); it emits no instruction, so the
+// MFMA->VALU wait states stay under the compiler's control (an asm that READS an MFMA result
+// directly gets no hazard padding and returned stale data).
+__device__ __forceinline__ void vkeys(int acc, int base_row_dir, int base_col_dir, int& kr, int& kc) {
+    kr = (acc << (KEY_SHIFT + 1)) + base_row_dir;
+    int again = acc;
+    asm("" : "+v"(again));
+    kc = (again << (KEY_SHIFT + 1)) + base_col_dir;
+}
+
+#ifdef EXP_STAMPS
+__device__ unsigned long long g_dbg[16];
+#endif
+
 template <int KS>
 __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair,
     int4* __restrict__ rowres, int2* __restrict__ colpart, int wb_stride, int row_stride) {
-    __shared__ v4i sB[2][KS * 64];
+    constexpr int TILE_V4 = KS * 64;                                   // int4 per B tile
+    __shared__ v4i sB[3][TILE_V4];
     __shared__ int2 sR[WAVES][32 * 32];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 31, h = lane >> 5;
     const int p = blockIdx.x / wgs_per_pair, rb = blockIdx.x % wgs_per_pair;
     const int2 pr = pairs[p];
@@ -106,74 +156,163 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     const int wb = rb * WAVES + wave;                  // 64-row wave-block of frame A
     const bool active = 2 * wb < A.ntiles;             // wave-uniform (ntiles is even)
     const int T = B.ntiles;
+    const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag;
+    const gint_t Anorm = (gint_t)A.norm, Bnormb = (gint_t)B.normb;
 
     v4i a[2][KS];
     int base_r[2][16], rm1[2][16], rm2[2][16];
+    const int wbc = active ? wb : 0;  // inactive waves load a valid block and never use it
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            a[s][ks] = active ? ((const v4i*)A.frag)[((size_t)(2 * wb + s) * KS + ks) * 64 + lane]
-                              : v4i{0, 0, 0, 0};
+        for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(2 * wbc + s) * KS + ks) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int lrow = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
-            int na = active ? A.norm[64 * wb + lrow] : PAD_VALUE;
-            base_r[s][r] = (na << KEY_SHIFT) | lrow;
+            base_r[s][r] = (Anorm[64 * wbc + lrow] << KEY_SHIFT) | lrow;
             rm1[s][r] = INT_MAX;
             rm2[s][r] = INT_MAX;
         }
     }
 
-    const bool loader = tid < KS * 64;
-    v4i stage = {0, 0, 0, 0};
-    if (T > 0 && loader) stage = ((const v4i*)B.frag)[tid];
-    if (loader) sB[0][tid] = stage;
+    // Software pipeline (no extra registers): the two accumulators of a wave are half a tile apart.
+    //   phase A(t): issue the 8 MFMAs of acc1(t)   while the VALU runs the epilogue of acc0(t)
+    //   phase B(t): issue the 8 MFMAs of acc0(t+1) while the VALU runs the epilogue of acc1(t)
+    // so an MFMA chain (8 x 32 cycles) always hides under ~100 VALU ops (4 cycles each). Waves issue
+    // in order, hence the source interleaves one MFMA with two epilogue elements and pins that order
+    // with sched_barrier. B fragments are read from LDS just in time through a 3-deep register ring
+    // (each tile is read twice, once per accumulator) instead of holding a whole tile in VGPRs.
+    // LDS ring of 3 tiles: sB[t % 3] holds tile t. Tile t+2 is DMA-ed into sB[(t+2) % 3] from the
+    // top of iteration t (that slot held tile t-1, last read in phase A(t-1), i.e. before the
+    // previous barrier); the barrier at the end of the iteration (vmcnt(0) + s_barrier) publishes it.
+    // Staging is LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 1 KiB = one k-step of
+    // the fragment-major tile straight into LDS (destination = wave-uniform base + lane*16, which
+    // is exactly the linear tile image), no VGPR round trip and no ds_write pass.
+    static_assert(TILE_V4 % 64 == 0, "a tile is a whole number of 1 KiB pieces");
+    constexpr int PIECES = TILE_V4 / 64;                 // 1 KiB pieces per tile (= KS)
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;    // pieces per wave
+    auto stage_tile = [&](int tile, int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + i * WAVES;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(Bfrag + (size_t)tile * TILE_V4 + piece * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(&sB[slot][piece * 64]), 16, 0, 0);
+        }
+    };
+    if (T > 0) {
+        stage_tile(0, 0);
+        stage_tile(min(1, T - 1), 1);
+    }
+    int nb_cur = T > 0 ? Bnormb[cl] : 0;
+    __builtin_amdgcn_s_waitcnt(0);  // every prologue load has landed (keeps vmcnt(0) out of the loop)
     __syncthreads();
 
+    v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v16i acc1 = acc0;
+    const v16i zero16 = acc0;
+    v4i bq[3];  // fragment ring: step i of the (phase, ks) sequence lives in bq[i % 3]
+    if (T > 0 && active) {
+        v4i b0[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b0[ks] = sB[0][ks * 64 + lane];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b0[ks], ks ? acc0 : zero16, 0, 0, 0);
+        bq[0] = sB[0][lane];       // steps 0 and 1 of iteration 0 (phase A re-reads tile 0)
+        bq[1] = sB[0][64 + lane];
+    }
+
     int2* cp = colpart + ((size_t)p * wb_stride + wb) * row_stride;
+#ifdef EXP_STAMPS
+    // diagnostic build: where does a wave's time go? (sums of s_memtime deltas per segment)
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0);} while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+    constexpr int EPK = 16 / KS;         // epilogue elements interleaved per MFMA (KS = 8 -> 2)
+    int slot_cur = 0, slot_nxt = 1, slot_new = 2;  // t % 3, (t+1) % 3, (t+2) % 3
     for (int t = 0; t < T; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < T && loader) stage = ((const v4i*)B.frag)[(size_t)(t + 1) * KS * 64 + tid];
+        const int base_c = (nb_cur << KEY_SHIFT) | t;
+        const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
+        nb_cur = Bnormb[32 * t1 + cl];
+        stage_tile(t2, slot_new);  // lands during this iteration; the barrier below publishes it
+        int cm1 = INT_MAX, cm2 = INT_MAX;
+        STAMP(0);
         if (active) {
-            const int nb = B.norm[32 * t + cl];
-            v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            v16i acc1 = acc0;
+            const v4i* curB = sB[slot_cur];
+            const v4i* nxtB = sB[slot_nxt];
+            // 2*KS steps per iteration; 2*KS = 16 steps -> ring phase advances by 16 % 3 = 1 per
+            // iteration, so the loop body is written for a fixed phase and the ring is rotated at
+            // the end (three register moves) to keep every index a compile-time constant.
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                v4i b = sB[cur][ks * 64 + lane];
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][ks], b, acc1, 0, 0, 0);
+            for (int i = 0; i < 2 * KS; ++i) {
+                const int ks = i % KS;
+                const bool phaseA = i < KS;
+                // prefetch the fragment of step i+2 (wrapping into the next iteration's phase A,
+                // which re-reads tile t+1)
+                const int j = i + 2;
+                const v4i* src = (j < KS) ? curB : nxtB;
+                bq[j % 3] = src[(j % KS) * 64 + lane];
+                if (phaseA) {
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][ks], bq[i % 3], ks ? acc1 : zero16, 0, 0, 0);
+                } else {
+                    // (the last iteration recomputes tile T-1 into acc0; it is never read)
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], bq[i % 3], ks ? acc0 : zero16, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < EPK; ++e) {
+                    const int r = ks * EPK + e;
+                    int kr, kc;
+                    if (phaseA) {
+                        vkeys(acc0[r], base_c, base_r[0][r], kr, kc);
+                        rm2[0][r] = vmed3(rm1[0][r], rm2[0][r], kr);
+                        rm1[0][r] = min(rm1[0][r], kr);
+                    } else {
+                        vkeys(acc1[r], base_c, base_r[1][r], kr, kc);
+                        rm2[1][r] = vmed3(rm1[1][r], rm2[1][r], kr);
+                        rm1[1][r] = min(rm1[1][r], kr);
+                    }
+                    cm2 = vmed3(cm1, cm2, kc);
+                    cm1 = min(cm1, kc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == KS - 1) STAMP(1);
             }
-            const int base_c = (nb << KEY_SHIFT) | t;
-            int cm1 = INT_MAX, cm2 = INT_MAX;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int d8 = acc0[r] << (KEY_SHIFT + 1);  // 2*dot << 7
-                int kr = base_c - d8, kc = base_r[0][r] - d8;
-                rm2[0][r] = med3(rm1[0][r], rm2[0][r], kr);
-                rm1[0][r] = min(rm1[0][r], kr);
-                cm2 = med3(cm1, cm2, kc);
-                cm1 = min(cm1, kc);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int d8 = acc1[r] << (KEY_SHIFT + 1);
-                int kr = base_c - d8, kc = base_r[1][r] - d8;
-                rm2[1][r] = med3(rm1[1][r], rm2[1][r], kr);
-                rm1[1][r] = min(rm1[1][r], kr);
-                cm2 = med3(cm1, cm2, kc);
-                cm1 = min(cm1, kc);
+            STAMP(2);
+            // steps 16 and 17 (= steps 0, 1 of the next iteration) sit in bq[16 % 3], bq[17 % 3]
+            {
+                v4i s0 = bq[(2 * KS) % 3], s1 = bq[(2 * KS + 1) % 3];
+                bq[0] = s0;
+                bq[1] = s1;
             }
             // lanes l and l+32 hold the same column, rows 4h.. of each 8-row group: merge halves
-            int o1 = __shfl_xor(cm1, 32), o2 = __shfl_xor(cm2, 32);
-            int n1 = min(cm1, o1);
-            int n2 = min(max(cm1, o1), min(cm2, o2));
+            // (v_permlane32_swap: lanes 0-31 of the 2nd operand <-> lanes 32-63 of the 1st, pure VALU)
+            auto w1 = __builtin_amdgcn_permlane32_swap(cm1, cm1, false, false);
+            auto w2 = __builtin_amdgcn_permlane32_swap(cm2, cm2, false, false);
+            int n1 = min((int)w1[0], (int)w1[1]);
+            int n2 = min(max((int)w1[0], (int)w1[1]), min((int)w2[0], (int)w2[1]));
             if (h == 0) cp[32 * t + cl] = make_int2(n1, n2);
         }
-        if (t + 1 < T && loader) sB[cur ^ 1][tid] = stage;
+        STAMP(3);
+        STAMP(4);
+        const int tmp = slot_cur;
+        slot_cur = slot_nxt;
+        slot_nxt = slot_new;
+        slot_new = tmp;
         __syncthreads();
+        STAMP(5);
     }
+#ifdef EXP_STAMPS
+    if (lane == 0 && blockIdx.x % 97 == 0) {
+        unsigned long long* dbg = g_dbg;
+        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[i], st_acc[i]);
+        atomicAdd(&dbg[6], 1ull);
+        atomicAdd(&dbg[7], (unsigned long long)T);
+    }
+#endif
     if (!active) return;
 
     // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
@@ -252,13 +391,13 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
     for (int q = tid; q < A.n; q += FIN_THREADS) {
         int4 r = rowres[(size_t)p * row_stride + q];
         int na = A.norm[q];
-        bool ok = r.z < PAD_VALUE && ratio_pass(r.x + na, r.z + na, ratio);  // r.z pad => < 2 train rows
+        bool ok = r.z + na < PAD_VALUE && ratio_pass(r.x + na, r.z + na, ratio);  // pad second => < 2 train rows
         fwd[q] = ok ? r.y : -1;
         c12 += ok;
     }
     const int nwb = A.ntiles / 2;
     for (int c = tid; c < B.n; c += FIN_THREADS) {
-        int v1 = PAD_VALUE, v2 = PAD_VALUE, r1 = -1;
+        int v1 = INT_MAX >> KEY_SHIFT, v2 = INT_MAX >> KEY_SHIFT, r1 = -1;
         const int2* cp = colpart + (size_t)p * wb_stride * row_stride + c;
         for (int wb = 0; wb < nwb; ++wb) {  // ascending rows; strict '<' keeps the lower row on ties
             int2 e = cp[(size_t)wb * row_stride];
@@ -272,8 +411,8 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
             }
             if (vb < v2) v2 = vb;  // e.y >= e.x, it can only become the runner-up
         }
-        int nb = B.norm[c];
-        bool ok = v2 < PAD_VALUE && ratio_pass(v1 + nb, v2 + nb, ratio);
+        int nb = B.normb[c];  // column ranks are d2 - normb_c
+        bool ok = v2 + nb < PAD_VALUE && ratio_pass(v1 + nb, v2 + nb, ratio);
         bwd[c] = ok ? r1 : -1;
         c21 += ok;
     }
@@ -377,17 +516,18 @@ static int upload_frame(eacham_ctx* ctx, int frame_id, const float* src_dev, int
     if (f.frag || f.norm) {
         EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (f.frag) (void)hipFree(f.frag);
-        if (f.norm) (void)hipFree(f.norm);
+        if (f.norm) (void)hipFree(f.norm);  // normb shares the allocation
         f = FrameHost();
     }
     const int npad = ntiles * 32;
     if (npad > 0) {
         EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.frag, (size_t)ntiles * ks * 64 * sizeof(int4)));
-        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.norm, (size_t)npad * sizeof(int)));
-        init_norm_kernel<<<(npad + 255) / 256, 256, 0, ctx->stream>>>(f.norm, n, npad);
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.norm, (size_t)2 * npad * sizeof(int)));
+        f.normb = f.norm + npad;
+        init_norm_kernel<<<(npad + 255) / 256, 256, 0, ctx->stream>>>(f.norm, f.normb, n, npad);
         long long work = (long long)npad * ks * 2;
         quantize_kernel<<<(unsigned)((work + 255) / 256), 256, 0, ctx->stream>>>(
-            src_dev, n, dim, ks, npad, (v4i*)f.frag, f.norm, ctx->flag_dev);
+            src_dev, n, dim, ks, npad, (v4i*)f.frag, f.norm, f.normb, ctx->flag_dev);
         EACHAM_HIP_TRY(ctx, hipGetLastError());
     }
     f.n = n;
@@ -507,6 +647,17 @@ static int check_pairs_host(eacham_ctx* ctx, const int32_t* pairs, int npairs) {
 using namespace eacham;
 
 extern "C" {
+
+#ifdef EXP_STAMPS
+int eacham_debug_read(unsigned long long* out, int n, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 int eacham_upload_descriptors_dev(eacham_ctx* ctx, int frame_id, const float* rowmajor_dev, int n, int dim) {
     if (!ctx) return EACHAM_ERR_INVALID;
