@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference bundle-adjustment interface, on top of the C-ABI.
+
+  RefineBA(currentFrameId, graph, map, K, config)   modules/sfm/reconstruction/BundleAdjuster.h:13-17
+  OptimizerConfig                                    modules/sfm/config/SfmConfig.h:15-22
+
+The reference walks its Graph/Map objects; this driver takes the same information as arrays
+(`BaArrays`) — what include/eacham/BundleAdjusterHip.hpp extracts from graph_t / Map.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class OptimizerConfig:
+    """modules/sfm/config/SfmConfig.h:15-22, fields verbatim."""
+    method: str = "LM"
+    maxIter: int = 100
+    maxTolerance: float = 1e-5
+    delta: float = 10.0
+    usePreconditioner: bool = False
+
+    # config/SfmConfigNerf.json:29-42
+    @staticmethod
+    def refine_ba():
+        return OptimizerConfig("LM", 100, 1e-5, 10.0, False)
+
+    @staticmethod
+    def global_ba():
+        return OptimizerConfig("LM", 50, 1e-4, 10.0, False)
+
+
+@dataclass
+class BaArrays:
+    """The BA window as plain arrays (see eacham_ba_problem in include/eacham_hip.h)."""
+    cam_T_wc: np.ndarray          # n_cams x 4 x 4 world->camera (Node::transform)
+    cam_fixed: np.ndarray         # n_cams int32
+    points: np.ndarray            # n_points x 3
+    point_observers: np.ndarray   # n_points int32 (global observer counts)
+    obs_cam: np.ndarray           # n_obs uint32
+    obs_point: np.ndarray         # n_obs uint32
+    obs_uv: np.ndarray            # n_obs x 2
+    K: np.ndarray                 # fx, fy, cx, cy
+    _keep: list = field(default_factory=list, repr=False)
+
+    @staticmethod
+    def from_scene(scene, initial=True):
+        """Arrays of a eacham_amd.synth scene (initial guess or ground truth)."""
+        return BaArrays(
+            cam_T_wc=np.ascontiguousarray(scene["T_init" if initial else "T_true"], dtype=np.float64),
+            cam_fixed=np.ascontiguousarray(scene["fixed"], dtype=np.int32),
+            points=np.ascontiguousarray(scene["points_init" if initial else "points_true"], dtype=np.float64),
+            point_observers=np.ascontiguousarray(scene["observers"], dtype=np.int32),
+            obs_cam=np.ascontiguousarray(scene["obs_cam"], dtype=np.uint32),
+            obs_point=np.ascontiguousarray(scene["obs_lm"], dtype=np.uint32),
+            # keypoints are cv::Point2f in the reference: pixel coordinates carry fp32 precision
+            obs_uv=np.ascontiguousarray(scene["obs_uv"].astype(np.float32), dtype=np.float64),
+            K=np.ascontiguousarray(scene["K"], dtype=np.float64))
+
+    def c_problem(self) -> capi.BaProblem:
+        arrs = [np.ascontiguousarray(self.cam_T_wc, np.float64).reshape(-1, 16),
+                np.ascontiguousarray(self.cam_fixed, np.int32),
+                np.ascontiguousarray(self.points, np.float64).reshape(-1, 3),
+                np.ascontiguousarray(self.point_observers, np.int32),
+                np.ascontiguousarray(self.obs_cam, np.uint32),
+                np.ascontiguousarray(self.obs_point, np.uint32),
+                np.ascontiguousarray(self.obs_uv, np.float64).reshape(-1, 2)]
+        self._keep = arrs
+        p = capi.BaProblem()
+        p.n_cams, p.n_points, p.n_obs = arrs[0].shape[0], arrs[2].shape[0], arrs[4].shape[0]
+        (p.cam_T_wc, p.cam_fixed, p.points, p.point_observers, p.obs_cam, p.obs_point, p.obs_uv) = [a.ctypes.data for a in arrs]
+        for i in range(4):
+            p.K[i] = float(self.K[i])
+        return p
+
+
+@dataclass
+class BaOutcome:
+    cam_T_wc: np.ndarray
+    points: np.ndarray
+    K: np.ndarray
+    initial_error: float
+    final_error: float
+    final_lambda: float
+    status: int
+    outer_iterations: int
+    inner_iterations: int
+    trace: np.ndarray  # rows: lambda, new_error, lin_change, accepted, outer
+
+
+def c_options(cfg: OptimizerConfig, min_landmarks: int = 50) -> capi.BaOptions:
+    o = capi.BaOptions()
+    o.method = {"LM": capi.BA_LM, "DogLeg": capi.BA_DOGLEG}[cfg.method]
+    o.max_iter, o.max_tolerance, o.delta = int(cfg.maxIter), float(cfg.maxTolerance), float(cfg.delta)
+    o.use_preconditioner, o.min_landmarks = int(bool(cfg.usePreconditioner)), int(min_landmarks)
+    return o
+
+
+def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024, extra=()):
+    """Shared marshalling for any function with the eacham_ba_solve result contract."""
+    prob, opt = arrays.c_problem(), c_options(cfg, min_landmarks)
+    T = np.zeros((prob.n_cams, 16), np.float64)
+    pts = np.zeros((prob.n_points, 3), np.float64)
+    trace = (capi.BaTraceRow * max(trace_cap, 1))()
+    res = capi.BaResult()
+    res.cam_T_wc, res.points = T.ctypes.data, pts.ctypes.data
+    res.trace_cap, res.trace = trace_cap, C.cast(trace, C.POINTER(capi.BaTraceRow))
+    rc = fn(C.byref(prob), C.byref(opt), C.byref(res), *extra)
+    tr = np.array([[r.lambda_, r.new_error, r.lin_change, r.accepted, r.outer] for r in trace[:res.trace_len]],
+                  dtype=np.float64).reshape(-1, 5)
+    out = BaOutcome(T.reshape(-1, 4, 4), pts, np.array(list(res.K)), res.initial_error, res.final_error,
+                    res.final_lambda, res.status, res.outer_iterations, res.inner_iterations, tr)
+    return rc, out
+
+
+def RefineBA(ctx, arrays: BaArrays, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024) -> BaOutcome:
+    """RefineBA on the device (eacham_ba_solve). `ctx` is a HipContext."""
+    L = capi.lib()
+    L.eacham_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc, out = run_solver(lambda p, o, r: L.eacham_ba_solve(ctx.handle, p, o, r), arrays, config, min_landmarks, trace_cap)
+    ctx._check(rc)
+    return out
+
+
+def debug_step(ctx, arrays: BaArrays, lam: float):
+    """eacham_ba_debug_step: reduced system, step and errors of one damped step at the initial values."""
+    L = capi.lib()
+    L.eacham_ba_debug_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 6
+    prob = arrays.c_problem()
+    n = 6 * prob.n_cams + 5
+    S = np.zeros((n, n)); g = np.zeros(n); dc = np.zeros(n); dl = np.zeros((prob.n_points, 3))
+    err = C.c_double(0); lin = C.c_double(0)
+    ctx._check(L.eacham_ba_debug_step(ctx.handle, C.byref(prob), lam, S.ctypes.data, g.ctypes.data, dc.ctypes.data,
+                                      dl.ctypes.data, C.addressof(err), C.addressof(lin)))
+    return S, g, dc, dl, err.value, lin.value

@@ -64,3 +64,33 @@ def lib() -> C.CDLL:
     L.eacham_profile_get.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(dbl)]
     _lib = L
     return L
+
+
+# ---- bundle adjustment structs (include/eacham_hip.h) ---------------------------------------------
+BA_LM, BA_DOGLEG = 0, 1
+BA_DONE, BA_SKIPPED = 0, 1
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32), ("reserved", C.c_int32),
+                ("cam_T_wc", C.c_void_p), ("cam_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("point_observers", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_point", C.c_void_p),
+                ("obs_uv", C.c_void_p), ("K", C.c_double * 4)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("method", C.c_int32), ("max_iter", C.c_int32), ("max_tolerance", C.c_float),
+                ("delta", C.c_float), ("use_preconditioner", C.c_int32), ("min_landmarks", C.c_int32)]
+
+
+class BaTraceRow(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("new_error", C.c_double), ("lin_change", C.c_double),
+                ("accepted", C.c_int32), ("outer", C.c_int32)]
+
+
+class BaResult(C.Structure):
+    _fields_ = [("cam_T_wc", C.c_void_p), ("points", C.c_void_p), ("K", C.c_double * 4),
+                ("initial_error", C.c_double), ("final_error", C.c_double), ("final_lambda", C.c_double),
+                ("status", C.c_int32), ("outer_iterations", C.c_int32), ("inner_iterations", C.c_int32),
+                ("trace_cap", C.c_int32), ("trace_len", C.c_int32), ("reserved", C.c_int32),
+                ("trace", C.POINTER(BaTraceRow))]

@@ -108,6 +108,90 @@ int eacham_match_all_pairs_dev(eacham_ctx* ctx, const int32_t* pairs_dev, int np
                                uint32_t* edges_dev, int64_t edge_cap, int64_t* total_dev,
                                int32_t* stats_dev);
 
+/* ---- bundle adjustment: RefineBA (modules/sfm/reconstruction/BundleAdjuster.cpp:40-250) --------
+ *
+ * The caller (the C++ adapter in include/eacham/BundleAdjusterHip.hpp) performs the reference's
+ * graph walk (window selection :123-162, landmark filter `status && observers >= 2` :84) and
+ * hands over plain arrays; the library restates everything from the factor graph on: factors and
+ * noise models (:57-121, :171-178), Levenberg-Marquardt with GTSAM's Ceres defaults (:182-216),
+ * error evaluation (:218-219). Write-back (:221-249) is the inverse mapping done by the adapter.
+ *
+ * Variable blocks: camera i -> Pose3 camera->world (the inverse of cam_T_wc, :65), tangent
+ * [omega, v]; landmark j -> Point3; one shared Cal3_S2 (fx, fy, s = 0, u0, v0) (:47-49).
+ * All arithmetic is fp64.
+ */
+typedef struct eacham_ba_problem {
+    int32_t n_cams;
+    int32_t n_points;
+    int32_t n_obs;
+    int32_t reserved;
+    const double* cam_T_wc;          /* n_cams x 16, row-major world->camera (Node::GetTransform())   */
+    const int32_t* cam_fixed;        /* n_cams, Graph::IsFixed(id) (:69)                              */
+    const double* points;            /* n_points x 3 (Map::Get(id3d), :102)                          */
+    const int32_t* point_observers;  /* n_points, Map::GetObservers(id3d).size(): the GLOBAL count,  */
+                                     /* also inside a local window (:109) -> prior sigma 1/obs       */
+    const uint32_t* obs_cam;         /* n_obs, index into cams                                       */
+    const uint32_t* obs_point;       /* n_obs, index into points                                     */
+    const double* obs_uv;            /* n_obs x 2, keypoint in pixels (cv::Point2f widened, :93)     */
+    double K[4];                     /* fx, fy, cx, cy = K(0,0), K(1,1), K(0,2), K(1,2) (:47-49)     */
+} eacham_ba_problem;
+
+#define EACHAM_BA_LM 0
+#define EACHAM_BA_DOGLEG 1
+
+/* OptimizerConfig (modules/sfm/config/SfmConfig.h:15-22), fields verbatim + the reference's literal. */
+typedef struct eacham_ba_options {
+    int32_t method;             /* "LM" -> EACHAM_BA_LM, "DogLeg" -> EACHAM_BA_DOGLEG               */
+    int32_t max_iter;           /* maxIter                                                           */
+    float max_tolerance;        /* maxTolerance: absoluteErrorTol = relativeErrorTol (:187-188)      */
+    float delta;                /* DogLeg deltaInitial (:211)                                        */
+    int32_t use_preconditioner; /* usePreconditioner: PCG + block-Jacobi at 1e-10 (:192-200)         */
+    int32_t min_landmarks;      /* literal 50 (:166): fewer landmarks -> silently do nothing         */
+} eacham_ba_options;
+
+#define EACHAM_BA_DONE 0     /* optimised                                                            */
+#define EACHAM_BA_SKIPPED 1  /* fewer than min_landmarks landmarks: inputs copied through (:166-169) */
+
+/* One row per tryLambda() call of the LM loop (for parity tests and reporting). */
+typedef struct eacham_ba_trace_row {
+    double lambda;          /* lambda used for this try                                              */
+    double new_error;       /* nonlinear error at the tentative values (inf if not evaluated)        */
+    double lin_change;      /* oldLinearizedError - newLinearizedError                               */
+    int32_t accepted;       /* 1 = step taken                                                        */
+    int32_t outer;          /* outer iteration index (iterate() call)                                */
+} eacham_ba_trace_row;
+
+typedef struct eacham_ba_result {
+    double* cam_T_wc;        /* out: n_cams x 16 world->camera (Node::SetTransform, :247)            */
+    double* points;          /* out: n_points x 3 (Map::UpdatePoint, :239)                           */
+    double K[4];             /* out: fx, fy, cx, cy (:224-227)                                       */
+    double initial_error;    /* graph.error(initial)   (:218)                                        */
+    double final_error;      /* graph.error(result)    (:219)                                        */
+    double final_lambda;
+    int32_t status;          /* EACHAM_BA_DONE / EACHAM_BA_SKIPPED                                   */
+    int32_t outer_iterations; /* successful LM iterations (NonlinearOptimizer::iterations())         */
+    int32_t inner_iterations; /* tryLambda() calls = linear solves                                   */
+    int32_t trace_cap;       /* in: capacity of `trace` (may be 0)                                   */
+    int32_t trace_len;       /* out: rows written                                                    */
+    int32_t reserved;
+    eacham_ba_trace_row* trace; /* optional                                                          */
+} eacham_ba_result;
+
+/* Runs RefineBA's optimisation on the device. Host pointers in, host pointers out; all state stays
+ * resident on the device during the LM loop, only scalars (errors, lambda decisions) cross PCIe
+ * per inner iteration. Returns EACHAM_OK also when the problem is skipped (see result->status).
+ * EACHAM_ERR_UNSUPPORTED for method DogLeg. */
+int eacham_ba_solve(eacham_ctx* ctx, const eacham_ba_problem* problem, const eacham_ba_options* options,
+                    eacham_ba_result* result);
+
+/* Test/diagnostic entry point: linearises at the problem's initial values and returns the reduced
+ * camera system of one damped Gauss-Newton step: S (n x n, row-major, n = 6*n_cams + 5, cameras
+ * first, then K), its right-hand side g (n), the step delta for cameras+K (n) and for the points
+ * (3*n_points), the nonlinear error at the linearisation point, and the linearised cost change. */
+int eacham_ba_debug_step(eacham_ctx* ctx, const eacham_ba_problem* problem, double lambda,
+                         double* S, double* g, double* delta_cams, double* delta_points,
+                         double* error, double* lin_change);
+
 /* ---- kernel timing (HIP events on the context stream; used for roofline reporting) ---------- */
 
 #define EACHAM_KERNEL_MATCH_TILE 0     /* all-pairs int8 MFMA distance + fused row/col top-2      */

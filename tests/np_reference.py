@@ -36,3 +36,56 @@ def mutual(A, B, ratio=0.8, min_dir=30, min_mutual=30):
     q = np.array([k[0] for k in keep], dtype=np.uint32)
     t = np.array([k[1] for k in keep], dtype=np.uint32)
     return q, t, stats
+
+
+# ---- bundle adjustment: independent numpy statement of graph.error --------
+def _huber(n, k):
+    return np.where(n <= k, 0.5 * n * n, k * (n - 0.5 * k))
+
+
+def _cayley_local(R):
+    return 2.0 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (1.0 + np.trace(R))
+
+
+def ba_error_np(arrays, T_wc=None, points=None, K=None):
+    """Sum of factor errors of RefineBA's graph at the given values (priors centred on `arrays`)."""
+    T0 = np.asarray(arrays.cam_T_wc, np.float64).reshape(-1, 4, 4)
+    P0 = np.asarray(arrays.points, np.float64).reshape(-1, 3)
+    K0 = np.array([arrays.K[0], arrays.K[1], 0.0, arrays.K[2], arrays.K[3]])
+    T = T0 if T_wc is None else np.asarray(T_wc, np.float64).reshape(-1, 4, 4)
+    P = P0 if points is None else np.asarray(points, np.float64).reshape(-1, 3)
+    Kv = K0 if K is None else np.array([K[0], K[1], 0.0, K[2], K[3]])
+    f32 = np.float32
+    err = 0.0
+    # reprojection factors: sigma 1.5 px, Huber 3.0 on the whitened 2-vector norm
+    c, j = arrays.obs_cam.astype(int), arrays.obs_point.astype(int)
+    pc = np.einsum("nij,nj->ni", T[c, :3, :3], P[j]) + T[c, :3, 3]
+    ok = pc[:, 2] > 0
+    u, v = pc[:, 0] / pc[:, 2], pc[:, 1] / pc[:, 2]
+    r = np.stack([Kv[0] * u + Kv[2] * v + Kv[3], Kv[1] * v + Kv[4]], 1) - arrays.obs_uv
+    n = np.where(ok, np.linalg.norm(r, axis=1) / 1.5, 0.0)
+    err += _huber(n, 3.0).sum()
+    # pose priors
+    rot_sig = float(f32(45.0) * f32(3.141592) / f32(180.0))
+    fix_rot = float(f32(0.0001) * f32(3.141592) / f32(180.0))
+    for i in range(len(T)):
+        Rx, tx = T[i, :3, :3].T, -T[i, :3, :3].T @ T[i, :3, 3]      # camera->world
+        Rp, tp = T0[i, :3, :3].T, -T0[i, :3, :3].T @ T0[i, :3, 3]
+        xi = np.concatenate([_cayley_local(Rx.T @ Rp), Rx.T @ (tp - tx)])
+        if arrays.cam_fixed[i]:
+            sg = np.array([fix_rot] * 3 + [float(f32(0.0001))] * 3)
+            err += 0.5 * np.sum((xi / sg) ** 2)
+        else:
+            sg = np.array([rot_sig] * 3 + [float(f32(0.35))] * 3)
+            err += float(_huber(np.linalg.norm(xi / sg), 2.5))
+    # landmark priors (only landmarks that appear in the graph)
+    used = np.zeros(len(P), bool)
+    used[j] = True
+    obs = np.maximum(arrays.point_observers.astype(np.float32), 1)
+    sg = (f32(1.0) / obs).astype(np.float64)
+    kh = (f32(3.0) / obs).astype(np.float64)
+    n = np.linalg.norm(P - P0, axis=1) / sg
+    err += _huber(n, kh)[used].sum()
+    # calibration prior
+    err += 0.5 * np.sum(((Kv - K0) / np.array([25, 25, 1e-5, 1e-4, 1e-4])) ** 2)
+    return float(err)

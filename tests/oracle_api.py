@@ -78,3 +78,66 @@ def match_all_pairs(descs, pairs, ratio=0.8, min_dir=30, min_mutual=30, nthreads
     q = np.concatenate([matches[p, :counts[p], 0] for p in range(npairs)]) if npairs else np.zeros(0, np.uint32)
     t = np.concatenate([matches[p, :counts[p], 1] for p in range(npairs)]) if npairs else np.zeros(0, np.uint32)
     return counts, offsets, q.astype(np.uint32), t.astype(np.uint32), stats, used
+
+
+# ---- bundle adjustment --------------------------------------------------------------------------
+def ba_project(T_wc, point, K5, uv):
+    L = oracle.lib()
+    T = np.ascontiguousarray(T_wc, np.float64).reshape(16)
+    pt = np.ascontiguousarray(point, np.float64)
+    K = np.ascontiguousarray(K5, np.float64)
+    m = np.ascontiguousarray(uv, np.float64)
+    r = np.zeros(2); Jp = np.zeros((2, 6)); Jl = np.zeros((2, 3)); Jk = np.zeros((2, 5))
+    L.oracle_ba_project.restype = C.c_int
+    ok = L.oracle_ba_project(*[C.c_void_p(a.ctypes.data) for a in (T, pt, K, m, r, Jp, Jl, Jk)])
+    return ok, r, Jp, Jl, Jk
+
+
+def ba_pose_retract(T_wc, xi):
+    L = oracle.lib()
+    T = np.ascontiguousarray(T_wc, np.float64).reshape(16)
+    x = np.ascontiguousarray(xi, np.float64)
+    out = np.zeros(16)
+    L.oracle_ba_pose_retract.restype = None
+    L.oracle_ba_pose_retract(C.c_void_p(T.ctypes.data), C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out.reshape(4, 4)
+
+
+def ba_pose_local(T_wc, T_prior_wc):
+    L = oracle.lib()
+    a = np.ascontiguousarray(T_wc, np.float64).reshape(16)
+    b = np.ascontiguousarray(T_prior_wc, np.float64).reshape(16)
+    out = np.zeros(6)
+    L.oracle_ba_pose_local.restype = None
+    L.oracle_ba_pose_local(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def ba_error(arrays):
+    L = oracle.lib()
+    L.oracle_ba_error.restype = C.c_double
+    prob = arrays.c_problem()
+    return L.oracle_ba_error(C.byref(prob))
+
+
+def ba_step(arrays, lam, mode=0):
+    """(S, g, delta_cams, delta_points, error, lin_change, ok) of one damped step (mode 1 = dense solve)."""
+    L = oracle.lib()
+    prob = arrays.c_problem()
+    n = 6 * prob.n_cams + 5
+    S = np.zeros((n, n)); g = np.zeros(n); dc = np.zeros(n); dl = np.zeros((prob.n_points, 3))
+    err = C.c_double(0); lin = C.c_double(0)
+    L.oracle_ba_step.restype = C.c_int
+    rc = L.oracle_ba_step(C.byref(prob), C.c_double(lam), int(mode), C.c_void_p(S.ctypes.data), C.c_void_p(g.ctypes.data),
+                          C.c_void_p(dc.ctypes.data), C.c_void_p(dl.ctypes.data), C.byref(err), C.byref(lin))
+    return S, g, dc, dl, err.value, lin.value, rc == 0
+
+
+def ba_solve(arrays, cfg, min_landmarks=50, trace_cap=1024, nthreads=0):
+    from eacham_amd import ba
+    L = oracle.lib()
+    L.oracle_ba_solve.restype = C.c_int
+    rc, out = ba.run_solver(lambda p, o, r, nt: L.oracle_ba_solve(p, o, r, nt), arrays, cfg, min_landmarks, trace_cap,
+                            extra=(C.c_int(nthreads),))
+    assert rc == 0, rc
+    return out
