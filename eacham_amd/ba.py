@@ -121,7 +121,6 @@ def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 
 def RefineBA(ctx, arrays: BaArrays, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024) -> BaOutcome:
     """RefineBA on the device (eacham_ba_solve). `ctx` is a HipContext."""
     L = capi.lib()
-    L.eacham_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     rc, out = run_solver(lambda p, o, r: L.eacham_ba_solve(ctx.handle, p, o, r), arrays, config, min_landmarks, trace_cap)
     ctx._check(rc)
     return out
@@ -130,7 +129,6 @@ def RefineBA(ctx, arrays: BaArrays, config: OptimizerConfig, min_landmarks: int 
 def debug_step(ctx, arrays: BaArrays, lam: float):
     """eacham_ba_debug_step: reduced system, step and errors of one damped step at the initial values."""
     L = capi.lib()
-    L.eacham_ba_debug_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 6
     prob = arrays.c_problem()
     n = 6 * prob.n_cams + 5
     S = np.zeros((n, n)); g = np.zeros(n); dc = np.zeros(n); dl = np.zeros((prob.n_points, 3))
@@ -138,3 +136,25 @@ def debug_step(ctx, arrays: BaArrays, lam: float):
     ctx._check(L.eacham_ba_debug_step(ctx.handle, C.byref(prob), lam, S.ctypes.data, g.ctypes.data, dc.ctypes.data,
                                       dl.ctypes.data, C.addressof(err), C.addressof(lin)))
     return S, g, dc, dl, err.value, lin.value
+
+
+class PreparedBA:
+    """eacham_ba_prepare / eacham_ba_run / eacham_ba_release: solve one window repeatedly (benchmark)."""
+
+    def __init__(self, ctx, arrays: BaArrays):
+        self.ctx, self.arrays, self._L = ctx, arrays, capi.lib()
+        self._prob = arrays.c_problem()
+        h = C.c_void_p()
+        ctx._check(self._L.eacham_ba_prepare(ctx.handle, C.byref(self._prob), C.byref(h)))
+        self._h = h
+
+    def run(self, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024) -> BaOutcome:
+        rc, out = run_solver(lambda p, o, r: self._L.eacham_ba_run(self.ctx.handle, self._h, o, r), self.arrays,
+                             config, min_landmarks, trace_cap)
+        self.ctx._check(rc)
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.eacham_ba_release(self.ctx.handle, self._h)
+            self._h = None

@@ -59,6 +59,12 @@ def lib() -> C.CDLL:
     L.eacham_match_pair.argtypes = [vp, i32, i32, dbl, vp, vp, i32, C.POINTER(i32)]
     L.eacham_match_all_pairs.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64), vp]
     L.eacham_match_all_pairs_dev.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, i64, vp, vp]
+    L.eacham_ba_solve.argtypes = [vp, vp, vp, vp]
+    L.eacham_ba_prepare.argtypes = [vp, vp, C.POINTER(vp)]
+    L.eacham_ba_run.argtypes = [vp, vp, vp, vp]
+    L.eacham_ba_release.argtypes = [vp, vp]
+    L.eacham_ba_release.restype = None
+    L.eacham_ba_debug_step.argtypes = [vp, vp, dbl, vp, vp, vp, vp, vp, vp]
     L.eacham_profile_enable.argtypes = [vp, i32]
     L.eacham_profile_reset.argtypes = [vp]
     L.eacham_profile_get.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(dbl)]

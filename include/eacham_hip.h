@@ -184,6 +184,16 @@ typedef struct eacham_ba_result {
 int eacham_ba_solve(eacham_ctx* ctx, const eacham_ba_problem* problem, const eacham_ba_options* options,
                     eacham_ba_result* result);
 
+/* Split form for callers that solve the same window repeatedly (the benchmark): prepare uploads the
+ * problem and builds the device-side structure (observations grouped by landmark and by camera,
+ * the camera-pair lists of the Schur complement); run restarts from the uploaded initial values,
+ * so the timed region holds only device work and the per-try scalar read-backs. */
+typedef struct eacham_ba_handle eacham_ba_handle;
+int eacham_ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* problem, eacham_ba_handle** out_handle);
+int eacham_ba_run(eacham_ctx* ctx, eacham_ba_handle* handle, const eacham_ba_options* options,
+                  eacham_ba_result* result);
+void eacham_ba_release(eacham_ctx* ctx, eacham_ba_handle* handle);
+
 /* Test/diagnostic entry point: linearises at the problem's initial values and returns the reduced
  * camera system of one damped Gauss-Newton step: S (n x n, row-major, n = 6*n_cams + 5, cameras
  * first, then K), its right-hand side g (n), the step delta for cameras+K (n) and for the points

@@ -1,0 +1,138 @@
+"""GPU: the HIP bundle adjuster (through the C-ABI) against the CPU oracle.
+Tolerance (north_star): camera poses / landmark positions within 1e-5 relative; the tests ask for
+far tighter agreement wherever fp64 + identical algorithm allow it."""
+import os
+
+import numpy as np
+import pytest
+
+from eacham_amd import ba, synth
+from eacham_amd import capi, EachamError
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
+POSE_POINT_RTOL = 1e-5  # north_star tolerance
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def scene_arrays(seed=3, n_cams=6, n_lm=200, k=4, outliers=True, **kw):
+    sc = synth.make_scene(n_cams, n_lm, k, seed=seed, **kw)
+    A = ba.BaArrays.from_scene(sc)
+    if outliers:
+        A.obs_uv[::13] += 30.0
+    return sc, A
+
+
+@pytest.mark.parametrize("lam", [0.0, 1e-4, 10.0])
+def test_damped_step_matches_oracle(hip_ctx, lam):
+    """K3-K7 in one shot: reduced system, its rhs, both parts of the step, error, linear cost change."""
+    sc, A = scene_arrays(seed=9, n_cams=7, n_lm=150, k=4, pixel_noise=2.0)
+    S, g, dc, dl, err, lin = ba.debug_step(hip_ctx, A, lam)
+    So, go, dco, dlo, erro, lino, ok = O.ba_step(A, lam, 0)
+    assert ok
+    assert rel(S, So) < 1e-11 and rel(g, go) < 1e-11
+    assert rel(dc, dco) < 1e-8 and rel(dl, dlo) < 1e-8
+    assert np.isclose(err, erro, rtol=1e-12) and np.isclose(lin, lino, rtol=1e-9)
+
+
+def test_step_with_repeated_camera_and_cheirality(hip_ctx):
+    sc, A = scene_arrays(seed=4, n_cams=5, n_lm=80, k=3)
+    # the same camera observes one landmark twice (two keypoints -> one map point)
+    A.obs_cam = np.concatenate([A.obs_cam, A.obs_cam[:3]]).astype(np.uint32)
+    A.obs_point = np.concatenate([A.obs_point, A.obs_point[:3]]).astype(np.uint32)
+    A.obs_uv = np.concatenate([A.obs_uv, A.obs_uv[:3] + 0.7])
+    # a landmark behind its cameras: zero residual / Jacobians for those factors
+    A.points[5] = A.points[5] + 50.0 * (np.linalg.inv(A.cam_T_wc[int(A.obs_cam[15])])[:3, 3] - A.points[5])
+    # and an unobserved landmark
+    A.points = np.concatenate([A.points, [[0.1, 0.2, 0.3]]])
+    A.point_observers = np.concatenate([A.point_observers, [2]]).astype(np.int32)
+    S, g, dc, dl, err, lin = ba.debug_step(hip_ctx, A, 1e-3)
+    So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
+    assert ok and rel(S, So) < 1e-11 and rel(dc, dco) < 1e-8 and rel(dl, dlo) < 1e-8
+    assert np.isclose(err, erro, rtol=1e-12) and not dl[-1].any()
+
+
+@pytest.mark.parametrize("name", ["ba_golden.npz", "ba_golden_hard.npz"])
+def test_golden_fixture(hip_ctx, name):
+    g = np.load(os.path.join(GOLD_DIR, name))
+    A = ba.BaArrays(g["cam_T_wc"], g["cam_fixed"], g["points"], g["point_observers"], g["obs_cam"], g["obs_point"],
+                    g["obs_uv"], g["K"])
+    out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("LM", int(g["max_iter"]), float(g["max_toler"]), 10.0, False))
+    assert out.outer_iterations == int(g["outer_iterations"]) and out.inner_iterations == int(g["inner_iterations"])
+    assert np.array_equal(out.trace[:, 3:], g["trace"][:, 3:])                     # accept/reject decisions
+    assert np.allclose(out.trace[:, 0], g["trace"][:, 0], rtol=1e-6)               # lambda schedule
+    assert np.allclose(out.trace[:, 1], g["trace"][:, 1], rtol=1e-8)               # nonlinear errors
+    assert rel(out.cam_T_wc, g["out_T_wc"]) < POSE_POINT_RTOL and rel(out.points, g["out_points"]) < POSE_POINT_RTOL
+    assert rel(out.cam_T_wc, g["out_T_wc"]) < 1e-7 and rel(out.points, g["out_points"]) < 1e-7
+    assert np.allclose(out.K, g["out_K"], rtol=1e-8) and np.isclose(out.final_error, float(g["final_error"]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("cfg", [ba.OptimizerConfig.refine_ba(), ba.OptimizerConfig.global_ba(),
+                                 ba.OptimizerConfig("LM", 2, 1e-5, 10.0, True)])
+def test_refine_ba_parity(hip_ctx, cfg):
+    sc, A = scene_arrays(seed=21, n_cams=12, n_lm=900, k=5)
+    out = ba.RefineBA(hip_ctx, A, cfg)
+    ref = O.ba_solve(A, cfg)
+    assert out.status == ref.status == 0
+    assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+    assert out.outer_iterations <= cfg.maxIter
+    assert np.allclose(out.trace, ref.trace, rtol=1e-6)
+    assert rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL and rel(out.points, ref.points) < POSE_POINT_RTOL
+    assert rel(out.cam_T_wc, ref.cam_T_wc) < 1e-7 and rel(out.points, ref.points) < 1e-7
+    assert np.allclose(out.K, ref.K, rtol=1e-9)
+    assert np.isclose(out.initial_error, ref.initial_error, rtol=1e-12)
+    assert np.isclose(out.final_error, ref.final_error, rtol=1e-9)
+    # camera 0 is the fixed node: it must not move (prior sigma 1e-4)
+    assert np.abs(out.cam_T_wc[0] - A.cam_T_wc.reshape(-1, 4, 4)[0]).max() < 1e-5
+
+
+def test_hard_start_with_rejected_steps(hip_ctx):
+    sc = synth.make_scene(6, 90, 2, seed=1, rot_noise=0.5, trans_noise=0.5, point_noise=0.8)
+    A = ba.BaArrays.from_scene(sc)
+    out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
+    ref = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
+    assert (ref.trace[:, 3] == 0).sum() >= 1  # the case does exercise increaseLambda
+    assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :2], ref.trace[:, :2], rtol=1e-6)
+    assert rel(out.points, ref.points) < POSE_POINT_RTOL and rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL
+
+
+def test_fewer_than_50_landmarks_is_a_silent_no_op(hip_ctx):
+    sc, A = scene_arrays(n_cams=4, n_lm=49, k=3, outliers=False)
+    out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
+    assert out.status == capi.BA_SKIPPED and out.outer_iterations == 0
+    assert np.allclose(out.points, A.points, atol=0) and rel(out.cam_T_wc.reshape(-1, 16), A.cam_T_wc.reshape(-1, 16)) < 1e-15
+
+
+def test_errors(hip_ctx):
+    sc, A = scene_arrays(n_cams=4, n_lm=60, k=3)
+    with pytest.raises(EachamError) as e:
+        ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("DogLeg", 10, 1e-5, 10.0, False))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    A.obs_cam = A.obs_cam.copy()
+    A.obs_cam[0] = 99
+    with pytest.raises(EachamError) as e:
+        ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
+    assert e.value.code == capi.ERR_INVALID
+
+
+def test_metric_scene_s200(hip_ctx):
+    """BASELINE metric scene: 200 cameras / 50k landmarks / 500k observations, refine_ba options."""
+    sc = synth.make_scene(200, 50_000, 10)
+    A = ba.BaArrays.from_scene(sc)
+    solver = ba.PreparedBA(hip_ctx, A)
+    out = solver.run(ba.OptimizerConfig.refine_ba())
+    again = solver.run(ba.OptimizerConfig.refine_ba())     # deterministic: no atomics anywhere
+    solver.close()
+    assert np.array_equal(out.points, again.points) and np.array_equal(out.trace, again.trace)
+    ref = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
+    assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+    assert np.allclose(out.trace, ref.trace, rtol=1e-6)
+    assert rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL and rel(out.points, ref.points) < POSE_POINT_RTOL
+    # size-independent properties: the error drops by orders of magnitude and the truth is recovered
+    assert out.final_error < 0.05 * out.initial_error
+    assert np.abs(out.points - sc["points_true"]).max() < 0.05
+    assert np.abs(out.K - sc["K"]).max() < 5.0
