@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--landmarks", type=int, default=50_000)
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (-1 = 4 per core, 0 = skip)")
+    ap.add_argument("--ba-solves", type=int, default=5, help="timed RefineBA solves of the S200 window (0 = skip BA)")
     return ap.parse_args()
 
 
@@ -134,6 +135,8 @@ def main():
     _, fin_ms = ctx.profile_get(capi.KERNEL_MATCH_FINALIZE)
     n_matches = int(total.item())
 
+    ba_out = bench_ba(ctx, scene, args, rank, world, dev) if args.ba_solves > 0 else None
+
     if rank == 0:
         ops_per_pair = 2.0 * args.kpts * args.kpts * args.dim  # 2*N1*N2*D per unordered pair
         achieved = ops_per_pair * npairs * args.steps / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0
@@ -160,8 +163,12 @@ def main():
                          "avg_launch_ms": tile_ms / max(launches, 1),
                          "finalize_ms_per_step": fin_ms / args.steps},
         }
+        if ba_out is not None:
+            out["ba"] = ba_out
         if world == 1 and args.cpu_pairs != 0:
             out["cpu_baseline"] = cpu_baseline(descs, pairs_all, args)
+            if ba_out is not None:
+                out["ba"]["cpu_baseline"] = cpu_baseline_ba(scene)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -169,12 +176,91 @@ def main():
     ctx.close()
 
 
+def host_cores() -> int:
+    """Usable host cores: the affinity mask capped by the cgroup CPU quota (the GPU box grants a
+    share of a large host)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def bench_ba(ctx, scene, args, rank, world, dev):
+    """BA iters/s: K timed RefineBA solves (config/SfmConfigNerf.json `refine_ba`: LM, 100 it, 1e-5) of
+    the whole S200 window, values resident on the device, each solve restarting from the same
+    perturbed initial guess. BA does not shard at these sizes: with N > 1 every
+    rank runs an independent replica and the rates are summed ("replicas")."""
+    import torch
+    import torch.distributed as dist
+    from eacham_amd import ba, capi
+
+    arrays = ba.BaArrays.from_scene(scene)
+    cfg = ba.OptimizerConfig.refine_ba()
+    solver = ba.PreparedBA(ctx, arrays)
+    first = solver.run(cfg)  # warm-up (allocations, code objects)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outer = inner = 0
+    for _ in range(args.ba_solves):
+        o = solver.run(cfg)
+        outer += o.outer_iterations
+        inner += o.inner_iterations
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    stage = {}
+    for name, kid in [("linearize", capi.KERNEL_BA_LINEARIZE), ("schur", capi.KERNEL_BA_SCHUR),
+                      ("solve", capi.KERNEL_BA_SOLVE), ("error", capi.KERNEL_BA_ERROR)]:
+        n, ms = ctx.profile_get(kid)
+        stage[name + "_ms_per_inner_iter"] = ms / max(inner, 1)
+    solver.close()
+    rate = torch.tensor([outer / dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rate, op=dist.ReduceOp.SUM)
+    nc, nl, no = arrays.cam_T_wc.shape[0], arrays.points.shape[0], arrays.obs_cam.shape[0]
+    n = 6 * nc + 5
+    bytes_iter = 48 * no + 3 * (96 * nc + 24 * nl + 40) + 144 * nl + 8 * n * (n + 1)  # SURVEY.md §8(d)
+    dev_ms = sum(stage.values())
+    achieved = bytes_iter / (dev_ms * 1e-3) / 1e9 if dev_ms > 0 else 0.0
+    return {"value": float(rate.item()), "unit": "LM outer iters/s", "replicas": world, "solves": args.ba_solves,
+            "outer_iters_per_solve": outer / args.ba_solves, "inner_iters_per_solve": inner / args.ba_solves,
+            "ms_per_inner_iter": dt / max(inner, 1) * 1e3, "dtype": "f64",
+            "workload": f"S200 RefineBA: {nc} cams / {nl} landmarks / {no} obs, refine_ba (LM, 100, 1e-5)",
+            "final_error": first.final_error, "initial_error": first.initial_error, **stage,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "note": "algorithmic bytes of one inner iteration (SURVEY.md §8(d)) / summed kernel time"}}
+
+
+def cpu_baseline_ba(scene):
+    """oracle/ba_oracle.c (kind "port"): two LM iterations of the same S200 window on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    from eacham_amd import ba
+    cores = host_cores()
+    arrays = ba.BaArrays.from_scene(scene)
+    O.ba_solve(arrays, ba.OptimizerConfig("LM", 1, 1e-5, 10.0, False), nthreads=cores)  # warm-up
+    t0 = time.perf_counter()
+    out = O.ba_solve(arrays, ba.OptimizerConfig("LM", 3, 1e-5, 10.0, False), nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": out.outer_iterations / dt, "unit": "LM outer iters/s", "cores": cores, "kind": "port",
+            "sample": f"{out.outer_iterations} LM iterations of the same window (Schur + dense Cholesky, OpenMP), {dt:.1f} s"}
+
+
 def cpu_baseline(descs, pairs_all, args):
     """The CPU restatement (oracle/match_oracle.c, kind "port") on a bounded sample of the same
     workload, threaded over pairs like apps/sfm/main.cpp:98, on the GPU box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as O
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     n = args.cpu_pairs if args.cpu_pairs > 0 else 4 * cores
     n = min(n, len(pairs_all))
     sel = pairs_all[np.linspace(0, len(pairs_all) - 1, n).astype(np.int64)]

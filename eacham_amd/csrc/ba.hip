@@ -53,7 +53,7 @@ static Noise make_noise() {
 }
 
 constexpr int TPB = 256;           // threads per block of the streaming kernels
-constexpr int PAIR_CHUNK = 128;    // pair-list entries summed by one wave
+constexpr int PAIR_CHUNK = 64;     // pair-list entries summed by one wave (one per lane)
 constexpr int NB = 32;             // Cholesky block size
 constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) ElK(15)
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
@@ -176,7 +176,8 @@ __device__ __forceinline__ void pose_local(const double* x, const double* p, dou
 
 // ---- device-side view of a prepared problem --------------------------------------------------------
 struct BaDev {
-    int nc, nl, no, n, ld;  // n = 6 nc + 5, S is (n+1) x ld (row n = right-hand side)
+    int nc, nl, no, n, ld, nr;  // n = 6 nc + 5; S is (nr+1) x ld, nr = n rounded up to the Cholesky
+                                // block size; rows n..nr-1 are padding, row nr is the right-hand side
     // values
     double *pose, *pose0, *pose_new, *pt, *pt0, *pt_new, *Kc, *K0, *K_new;  // Kc: fx fy s u0 v0
     const int* fixed;
@@ -192,7 +193,7 @@ struct BaDev {
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
-    double *Et, *lmtry, *S, *Ldiag, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
+    double *Et, *lmtry, *S, *Lm, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     int* flags;
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
@@ -351,19 +352,23 @@ __global__ __launch_bounds__(TPB) void ba_linearize_cameras(BaDev D, double* __r
     }
 }
 
-// sums the per-camera K parts in camera order and adds the Cal3_S2 prior -> klin
-__global__ void ba_finish_klin(BaDev D, const double* __restrict__ kpart) {
-    const int i = threadIdx.x;
-    if (i >= KLIN) return;
+// sums the per-camera K parts (fixed order: strided partial sums, then a shuffle tree) and adds the
+// Cal3_S2 prior -> klin. One wave per entry of [HKK | gK].
+__global__ __launch_bounds__(64) void ba_finish_klin(BaDev D, const double* __restrict__ kpart) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     double s = 0.0;
-    for (int c = 0; c < D.nc; ++c) s += kpart[(size_t)KLIN * c + i];
-    if (i < 25) {
-        if (i / 5 == i % 5) s += 1.0 / (D.nz.k_sigma[i / 5] * D.nz.k_sigma[i / 5]);
-    } else {
-        const int a = i - 25;
-        s += (1.0 / D.nz.k_sigma[a]) * (-(D.Kc[a] - D.K0[a]) / D.nz.k_sigma[a]);
+    for (int c = lane; c < D.nc; c += 64) s += kpart[(size_t)KLIN * c + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) {
+        if (i < 25) {
+            if (i / 5 == i % 5) s += 1.0 / (D.nz.k_sigma[i / 5] * D.nz.k_sigma[i / 5]);
+        } else {
+            const int a = i - 25;
+            s += (1.0 / D.nz.k_sigma[a]) * (-(D.Kc[a] - D.K0[a]) / D.nz.k_sigma[a]);
+        }
+        D.klin[i] = s;
     }
-    D.klin[i] = s;
 }
 
 // ---- K-C: per-landmark elimination for one lambda (thread = landmark) -------------------------------
@@ -442,24 +447,44 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
         for (int k = 0; k < 30; ++k) D.kk_part[(size_t)30 * blockIdx.x + k] = kk[k];
 }
 
-// ---- K-D1: Schur pair products (wave = chunk of one camera block's pair list) -----------------------
-// lane (a, b) of the 6x6 block accumulates sum_e Et[o_e][a] . Et[o'_e][b] sequentially: deterministic.
+// ---- K-D1: Schur pair products (wave = chunk of <= 64 entries of one camera block's pair list) ------
+// lane e computes the 6x6 product Et[o_e] Et[o'_e]^T of its entry (all loads independent: the
+// gathers of a whole chunk are in flight together), then the 36 sums are reduced over the wave by
+// a fixed shuffle tree: deterministic, no atomics.
 __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
     const int chunk = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (chunk >= D.n_chunks) return;
     const int lane = threadIdx.x & 63;
     const int4 ch = D.pair_chunks[chunk];
-    const int a = lane / 6, b = lane % 6;
-    double acc = 0.0;
-    if (lane < 36) {
-        const int2* ent = D.pair_entries + ch.y;
-        for (int e = 0; e < ch.z; ++e) {
-            const int2 pr = ent[e];
-            const double* x = D.Et + 18 * (size_t)pr.x + 3 * a;
-            const double* y = D.Et + 18 * (size_t)pr.y + 3 * b;
-            acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    if (lane < ch.z) {
+        const int2 pr = D.pair_entries[ch.y + lane];
+        const double* xp = D.Et + 18 * (size_t)pr.x;
+        const double* yp = D.Et + 18 * (size_t)pr.y;
+        double x[18], y[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            x[k] = xp[k];
+            y[k] = yp[k];
         }
-        D.partial[(size_t)36 * chunk + lane] = acc;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[6 * a + b] = x[3 * a] * y[3 * b] + x[3 * a + 1] * y[3 * b + 1] + x[3 * a + 2] * y[3 * b + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        acc[k] = v;
+    }
+    if (lane == 0) {
+        double* out = D.partial + (size_t)36 * chunk;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) out[k] = acc[k];
     }
 }
 
@@ -486,7 +511,6 @@ __global__ __launch_bounds__(TPB) void ba_assemble_blocks(BaDev D, double lambda
 __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda) {
     __shared__ double sm[(TPB / 64) * 36];
     const int c = blockIdx.x;
-    const int n = D.n;
     if (c < D.nc) {
         const int p0 = D.cam_ptr[c], p1 = D.cam_ptr[c + 1];
         double acc[36];
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
                     D.S[(size_t)(6 * c + a) * D.ld + 6 * D.nc + bb] = v;
                     D.S[(size_t)(6 * D.nc + bb) * D.ld + 6 * c + a] = v;
                 }
-                D.S[(size_t)n * D.ld + 6 * c + a] = cl[66 + a] - acc[30 + a];  // rhs row
+                D.S[(size_t)D.nr * D.ld + 6 * c + a] = cl[66 + a] - acc[30 + a];  // rhs row
             }
         }
     } else if (threadIdx.x < 30) {
@@ -526,82 +550,114 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
             if (a == bb) v += lambda * clampd(D.klin[i], 1e-6, 1e32);
             D.S[(size_t)(6 * D.nc + a) * D.ld + 6 * D.nc + bb] = v;
         } else {
-            D.S[(size_t)n * D.ld + 6 * D.nc + (i - 25)] = D.klin[i] - s;
+            D.S[(size_t)D.nr * D.ld + 6 * D.nc + (i - 25)] = D.klin[i] - s;
         }
     }
 }
 
-// ---- K-E: blocked right-looking Cholesky of S (lower triangle, in place), rhs carried as row n --------
-// panel: every workgroup factorises the NB x NB diagonal block in LDS (redundantly: saves a launch
-// per step) and solves its own strip of rows of the panel, one thread per row.
-// The factorised diagonal block goes to Ldiag[k0/NB] (not back into A): other workgroups of the same
-// launch may still be loading the unfactorised block.
-__global__ __launch_bounds__(TPB) void chol_panel(double* __restrict__ A, int ld, int n, int k0, double* __restrict__ Ldiag,
+// ---- K-E: blocked right-looking Cholesky of S (lower triangle), rhs carried as row n ------------------
+// One launch per block column k (NB = 32 wide), every launch is a grid of 64x64 tiles of the
+// trailing matrix. A workgroup
+//   * loads W_k = L_kk^-1 (computed by the previous launch) and the RAW panel strips A[i.., k] of its
+//     tile, and forms the factor strips L_ik = A_ik W_k^T itself (a 32-wide GEMM instead of a
+//     triangular solve; the tiles of the first tile column also store L_ik into Lm for the
+//     back-substitution) — so panel solve and trailing update share one launch;
+//   * updates its tile A_ij -= L_ik L_jk^T;
+//   * tile (0,0), which holds the next diagonal block, factorises it in LDS and stores W_{k+1}.
+// The raw matrix A is never overwritten inside the columns a concurrent workgroup may still read.
+// Factor + invert one 32x32 SPD block: this is the serial chain of the whole factorisation (one per
+// launch), so it runs on ONE wave with the block in registers — lane i holds row i, pivots and
+// multipliers are broadcast with v_readlane (compile-time lane ids after full unrolling), no LDS
+// traffic and no workgroup barriers. Called by the first wave only; Dn must be complete.
+__device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane is a compile-time constant
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ void factor_invert_32(double (*Dn)[NB + 1], double* __restrict__ Wout, int* __restrict__ flags) {
+    const int i = threadIdx.x & 31;  // lanes 32..63 mirror lanes 0..31
+    double row[NB], dinv[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) row[m] = Dn[i][m];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {  // right-looking Cholesky
+        double d = bcast(row[j], j);
+        if (!(d > 0.0)) {
+            bad = true;
+            d = 1.0;
+        }
+        // 1/sqrt(d): hardware estimate + two Newton steps (fp64 sqrt and divide are ~30-instruction
+        // sequences each; this sits on the critical path of every block step)
+        double y = __builtin_amdgcn_rsq(d);
+        y = y * (1.5 - 0.5 * d * y * y);
+        y = y * (1.5 - 0.5 * d * y * y);
+        double rs = d * y;
+        rs = rs + 0.5 * y * (d - rs * rs);
+        dinv[j] = y;
+        const double lij = (i == j) ? rs : row[j] * y;
+        row[j] = lij;
+#pragma unroll
+        for (int l = j + 1; l < NB; ++l) row[l] -= lij * bcast(lij, l);
+    }
+    if (bad && threadIdx.x == 0) atomicOr(flags, 2);
+    double w[NB];  // lane c: column c of W = L^-1
+#pragma unroll
+    for (int ii = 0; ii < NB; ++ii) {
+        double sacc = (ii == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < ii; ++m) sacc -= bcast(row[m], ii) * w[m];
+        w[ii] = sacc * dinv[ii];
+    }
+    if (threadIdx.x < NB) {
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) Wout[ii * NB + i] = w[ii];
+    }
+}
+
+// W_0 of the first diagonal block
+__global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Winv,
                                                   int* __restrict__ flags) {
-    __shared__ double Ld[NB][NB + 1];
-    const int kb = min(NB, n - k0), k1 = k0 + kb;
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += TPB) {
+    __shared__ double Dn[NB][NB + 1];
+    for (int idx = threadIdx.x; idx < NB * NB; idx += TPB) {
         const int i = idx / NB, j = idx % NB;
-        Ld[i][j] = (i < kb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
+        Dn[i][j] = (i < n && j < n) ? (j <= i ? A[(size_t)i * ld + j] : 0.0) : (i == j ? 1.0 : 0.0);
     }
     __syncthreads();
-    for (int j = 0; j < kb; ++j) {
-        if (tid == 0) {
-            double d = Ld[j][j];
-            if (!(d > 0.0)) {
-                if (blockIdx.x == 0) atomicOr(flags, 2);
-                d = 1.0;
-            }
-            Ld[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        if (tid > j && tid < kb) Ld[tid][j] /= Ld[j][j];
-        __syncthreads();
-        for (int idx = tid; idx < kb * kb; idx += TPB) {
-            const int i = idx / kb, l = idx % kb;
-            if (l > j && i >= l) Ld[i][l] -= Ld[i][j] * Ld[l][j];
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0)
-        for (int idx = tid; idx < NB * NB; idx += TPB) Ldiag[(size_t)(k0 / NB) * NB * NB + idx] = Ld[idx / NB][idx % NB];
-    const int row = k1 + blockIdx.x * TPB + tid;  // rows k1 .. n (row n = rhs)
-    if (row <= n) {
-        double* ar = A + (size_t)row * ld + k0;
-        double x[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) x[j] = j < kb ? ar[j] : 0.0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (j < kb) {
-                double s = x[j];
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-                    if (l < j) s -= x[l] * Ld[j][l];
-                x[j] = s / Ld[j][j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (j < kb) ar[j] = x[j];
-    }
+    if (threadIdx.x < 64) factor_invert_32(Dn, Winv, flags);
 }
 
-// trailing update: A[i][j] -= sum_l L[i][k0+l] L[j][k0+l] for i >= j >= k1 (64x64 tiles, lower only)
-__global__ __launch_bounds__(TPB) void chol_update(double* __restrict__ A, int ld, int n, int k0) {
+__global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr,
+                                                 int k0, double* __restrict__ Winv, int* __restrict__ flags) {
+    __shared__ double W[NB][NB + 1];
+    __shared__ double Ri[64][NB + 1], Rj[64][NB + 1];  // raw strips, then reused
     __shared__ double Li[64][NB + 1], Lj[64][NB + 1];
-    const int kb = min(NB, n - k0), k1 = k0 + kb;
-    // triangular tile index -> (ti >= tj)
+    const int k1 = k0 + NB;  // columns >= n inside the block are zero padding, rows are masked below
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
     const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
     const int tid = threadIdx.x;
+    const double* Wk = Winv + (size_t)(k0 / NB) * NB * NB;
+    for (int idx = tid; idx < NB * NB; idx += TPB) W[idx / NB][idx % NB] = Wk[idx];
     for (int idx = tid; idx < 64 * NB; idx += TPB) {
         const int r = idx / NB, l = idx % NB;
-        Li[r][l] = (i0 + r <= n && l < kb) ? A[(size_t)(i0 + r) * ld + k0 + l] : 0.0;
-        Lj[r][l] = (j0 + r <= n && l < kb) ? A[(size_t)(j0 + r) * ld + k0 + l] : 0.0;
+        const int ri = i0 + r, rj = j0 + r;  // matrix rows < n, plus the rhs row nr
+        Ri[r][l] = ((ri < n || ri == nr) && k0 + l < n) ? A[(size_t)ri * ld + k0 + l] : 0.0;
+        Rj[r][l] = ((rj < n || rj == nr) && k0 + l < n) ? A[(size_t)rj * ld + k0 + l] : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * NB; idx += TPB) {  // L = R W^T  (W lower: L[r][c] = sum_{m<=c} R[r][m] W[c][m])
+        const int r = idx / NB, c = idx % NB;
+        double si = 0.0, sj = 0.0;
+        for (int m = 0; m <= c; ++m) {
+            si += Ri[r][m] * W[c][m];
+            sj += Rj[r][m] * W[c][m];
+        }
+        Li[r][c] = si;
+        Lj[r][c] = sj;
+        if (tj == 0 && (i0 + r < n || i0 + r == nr) && k0 + c < n) Lm[(size_t)(i0 + r) * ld + k0 + c] = si;
     }
     __syncthreads();
     const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;  // 4x4 outputs per thread
@@ -623,38 +679,57 @@ __global__ __launch_bounds__(TPB) void chol_update(double* __restrict__ A, int l
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] += xi[a] * xj[b];
     }
+    const bool next_diag = (t == 0) && (k1 < n);
+    double (*Dn)[NB + 1] = Ri;  // reuse (all reads of Ri are behind the barrier above)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int i = i0 + tr + a, j = j0 + tc + b;
-            if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] -= acc[a][b];
+            double v = 0.0;
+            const bool inside = (i < n || i == nr) && j < n && j <= i;
+            if (inside) {
+                v = A[(size_t)i * ld + j] - acc[a][b];
+                A[(size_t)i * ld + j] = v;
+            }
+            if (next_diag && tr + a < NB && tc + b < NB) {
+                const int ra = tr + a, cb = tc + b;
+                Dn[ra][cb] = (k1 + ra < n && k1 + cb < n) ? (cb <= ra ? v : 0.0) : (ra == cb ? 1.0 : 0.0);
+            }
         }
+    if (next_diag) {
+        __syncthreads();
+        if (tid < 64) factor_invert_32(Dn, Winv + (size_t)(k1 / NB) * NB * NB, flags);
+    }
 }
 
-// back substitution L^T x = y (y = row n of the factor), one workgroup; x -> delta_c
-__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ A, int ld, int n,
-                                                       const double* __restrict__ Ldiag, double* __restrict__ xout) {
-    extern __shared__ double xs[];  // n doubles: running y, becomes x
-    __shared__ double Ld[NB][NB + 1];
+// back substitution L^T x = y (y = row n of Lm) with the explicit block inverses, one workgroup
+__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nr,
+                                                       const double* __restrict__ Winv, double* __restrict__ xout) {
+    extern __shared__ double xs[];  // n (+ padding) doubles: running y, becomes x
+    __shared__ double W[NB][NB + 1];
+    __shared__ double yk[NB];
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 1024) xs[i] = A[(size_t)n * ld + i];
-    __syncthreads();
     const int nblk = (n + NB - 1) / NB;
+    for (int i = tid; i < nblk * NB; i += 1024) xs[i] = i < n ? Lm[(size_t)nr * ld + i] : 0.0;
+    __syncthreads();
     for (int kb_i = nblk - 1; kb_i >= 0; --kb_i) {
-        const int k0 = kb_i * NB, kb = min(NB, n - k0);
-        for (int idx = tid; idx < NB * NB; idx += 1024) Ld[idx / NB][idx % NB] = Ldiag[(size_t)kb_i * NB * NB + idx];
+        const int k0 = kb_i * NB;
+        for (int idx = tid; idx < NB * NB; idx += 1024) W[idx / NB][idx % NB] = Winv[(size_t)kb_i * NB * NB + idx];
+        if (tid < NB) yk[tid] = xs[k0 + tid];
         __syncthreads();
-        for (int j = kb - 1; j >= 0; --j) {  // solve the kb x kb triangle
-            if (tid == 0) xs[k0 + j] /= Ld[j][j];
-            __syncthreads();
-            if (tid < j) xs[k0 + tid] -= Ld[j][tid] * xs[k0 + j];
-            __syncthreads();
+        if (tid < NB) {  // x_k = W^T y_k
+            double sacc = 0.0;
+            for (int m = tid; m < NB; ++m) sacc += W[m][tid] * yk[m];
+            xs[k0 + tid] = sacc;
         }
+        __syncthreads();
         for (int col = tid; col < k0; col += 1024) {  // y[0..k0) -= L[k0.., col]^T x_k
-            double s = 0.0;
-            for (int j = 0; j < kb; ++j) s += A[(size_t)(k0 + j) * ld + col] * xs[k0 + j];
-            xs[col] -= s;
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < NB; ++j)
+                if (k0 + j < n) sacc += Lm[(size_t)(k0 + j) * ld + col] * xs[k0 + j];
+            xs[col] -= sacc;
         }
         __syncthreads();
     }
@@ -874,7 +949,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     BaDev& D = h->D;
     memset(&D, 0, sizeof(D));
     D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
-    D.ld = ((D.n + 1 + 31) / 32) * 32;
+    D.nr = ((D.n + NB - 1) / NB) * NB;
+    D.ld = D.nr + NB;
     D.nz = make_noise();
     D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
 
@@ -995,8 +1071,9 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
     TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
     TRY(dev_alloc(ctx, h, &h->kpart, (size_t)KLIN * nc));
-    TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.n + 1) * D.ld));
-    TRY(dev_alloc(ctx, h, &D.Ldiag, (size_t)((D.n + NB - 1) / NB) * NB * NB));
+    TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 1) * D.ld));
+    TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
+    TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
     TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
     TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
     TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
@@ -1052,7 +1129,7 @@ static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
     ba_linearize_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D);
     if (D.nc > 0) ba_linearize_cameras<<<D.nc, TPB, 0, ctx->stream>>>(D, h->kpart);
-    ba_finish_klin<<<1, 64, 0, ctx->stream>>>(D, h->kpart);
+    ba_finish_klin<<<KLIN, 64, 0, ctx->stream>>>(D, h->kpart);
 }
 
 // one tryLambda(): builds and solves the damped system, writes tentative values and
@@ -1063,7 +1140,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, 4 * sizeof(int), ctx->stream));
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
-        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(n + 1) * D.ld, ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 1) * D.ld, ctx->stream));
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         if (D.n_chunks > 0) ba_schur_pairs<<<(D.n_chunks + TPB / 64 - 1) / (TPB / 64), TPB, 0, ctx->stream>>>(D);
         if (D.n_blocks > 0) ba_assemble_blocks<<<(unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D, lambda);
@@ -1072,20 +1149,20 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     if (S_copy) {
         EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         EACHAM_HIP_TRY(ctx, hipMemcpy2D(S_copy, sizeof(double) * (size_t)n, D.S, sizeof(double) * (size_t)D.ld,
-                                        sizeof(double) * (size_t)n, (size_t)n + 1, hipMemcpyDeviceToHost));
+                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToHost));
+        EACHAM_HIP_TRY(ctx, hipMemcpy(S_copy + (size_t)n * n, D.S + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
+                                      hipMemcpyDeviceToHost));
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
+        chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
         for (int k0 = 0; k0 < n; k0 += NB) {
-            const int kb = std::min(NB, n - k0), k1 = k0 + kb;
-            const int rows = n + 1 - k1;  // rows below the diagonal block, incl. the rhs row
-            chol_panel<<<std::max(1, (rows + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D.S, D.ld, n, k0, D.Ldiag, D.flags);
-            if (rows > 0 && k1 < n) {
-                const int nt = (rows + 63) / 64;
-                chol_update<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.ld, n, k0);
-            }
+            const int k1 = k0 + NB;
+            const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
+            chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
         }
-        chol_backsolve<<<1, 1024, sizeof(double) * (size_t)n, ctx->stream>>>(D.S, D.ld, n, D.Ldiag, D.delta_c);
+        const int nblk = (n + NB - 1) / NB;
+        chol_backsolve<<<1, 1024, sizeof(double) * (size_t)nblk * NB, ctx->stream>>>(D.Lm, D.ld, n, D.nr, D.Winv, D.delta_c);
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
