@@ -1,0 +1,116 @@
+"""GPU: the C++ adapters (include/eacham/*.hpp — the reference-shaped IFeatureMatcher / RefineBA on top
+of the C-ABI) compiled with g++ and checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from eacham_amd import ba, synth
+import oracle_api as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _build(tmp):
+    exe = os.path.join(tmp, "adapter_driver")
+    lib = os.path.join(ROOT, "eacham_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_driver.cpp"),
+           "-o", exe, "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return exe
+
+
+def _vec(f, dtype):
+    n = struct.unpack("q", f.read(8))[0]
+    return np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype).copy()
+
+
+def test_cpp_adapters_against_oracle(tmp_path):
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    # ---- matcher inputs ----
+    sc = synth.make_scene(4, 300, 3, seed=17)
+    descs, _ = synth.make_frame_descriptors(sc, 200, 128, seed=17)
+    descs[2] = descs[2][:150]
+    # ---- a graph/map with the cases RefineBA's walk distinguishes ----
+    bsc = synth.make_scene(7, 400, 4, seed=23)
+    ids = [10, 11, 12, 20, 21, 30, 31]                 # node ids are not dense
+    valid = [1, 1, 1, 1, 0, 1, 1]                      # node 21 is not valid -> skipped as a neighbour
+    fixed = [1, 0, 0, 0, 0, 0, 0]
+    neighbours = {12: [10, 11, 20, 21, 30]}            # local window around node 12 (31 is not a neighbour)
+    current = 12
+    n_lm = 400
+    status = np.ones(n_lm, bool); status[::9] = False  # not-yet-triangulated landmarks are filtered
+    observers = bsc["observers"].copy(); observers[5::11] = 1   # < 2 observers -> filtered
+    cam_of = {i: k for k, i in enumerate(ids)}
+    kp = {i: [] for i in ids}; p3 = {i: [] for i in ids}
+    for o in range(len(bsc["obs_cam"])):
+        node = ids[int(bsc["obs_cam"][o])]
+        p3[node].append((len(kp[node]), int(bsc["obs_lm"][o]) + 100))   # landmark ids offset by 100
+        kp[node].append(bsc["obs_uv"][o].astype(np.float32))
+    K9 = np.array([bsc["K"][0], 0, bsc["K"][2], 0, bsc["K"][1], bsc["K"][3], 0, 0, 1.0])
+
+    fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("ii", len(descs), 128))
+        for d in descs:
+            f.write(struct.pack("i", d.shape[0])); f.write(np.ascontiguousarray(d, np.float32).tobytes())
+        f.write(struct.pack("i", len(ids)))
+        for k, i in enumerate(ids):
+            f.write(struct.pack("Iii", i, valid[k], fixed[k])); f.write(bsc["T_init"][k].astype(np.float64).tobytes())
+            f.write(struct.pack("i", len(kp[i]))); f.write(np.array(kp[i], np.float32).reshape(-1).tobytes())
+            f.write(struct.pack("i", len(p3[i])))
+            for a, b in p3[i]:
+                f.write(struct.pack("II", a, b))
+            nb = neighbours.get(i, [])
+            f.write(struct.pack("i", len(nb))); f.write(np.array(nb, np.uint32).tobytes())
+        f.write(struct.pack("i", n_lm))
+        for j in range(n_lm):
+            f.write(struct.pack("I", j + 100)); f.write(bsc["points_init"][j].astype(np.float64).tobytes())
+            f.write(struct.pack("iI", int(status[j]), int(observers[j])))
+        f.write(K9.tobytes()); f.write(struct.pack("i", current))
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    with open(fout, "rb") as f:
+        for a, b in [(0, 1), (1, 0), (0, 2), (2, 1)]:
+            got = _vec(f, np.uint32).reshape(-1, 2)
+            q, t = O.match_directed(descs[a], descs[b])
+            assert np.array_equal(got[:, 0], q) and np.array_equal(got[:, 1], t)
+        counts, gq, gt = _vec(f, np.int32), _vec(f, np.uint32), _vec(f, np.uint32)
+        want = O.match_all_pairs(descs, synth.all_pairs(4), min_dir=5, min_mutual=5)
+        assert np.array_equal(counts, want[0]) and np.array_equal(gq, want[2]) and np.array_equal(gt, want[3]) and counts.sum() > 0
+        meta, K_out = _vec(f, np.float64), _vec(f, np.float64)
+        Ts, Ps, st_out = _vec(f, np.float64).reshape(-1, 4, 4), _vec(f, np.float64).reshape(-1, 3), _vec(f, np.int32)
+
+    # expected: the same window built here, independently, then solved by the oracle
+    window = [12] + [i for i in neighbours[12] if valid[ids.index(i)]]
+    lm_index, pts, obs_c, obs_p, uv, nobs = {}, [], [], [], [], []
+    for w, node in enumerate(window):
+        for a, lm in sorted(p3[node]):
+            j = lm - 100
+            if not status[j] or observers[j] < 2:
+                continue
+            if lm not in lm_index:
+                lm_index[lm] = len(pts); pts.append(bsc["points_init"][j]); nobs.append(observers[j])
+            obs_c.append(w); obs_p.append(lm_index[lm]); uv.append(kp[node][a].astype(np.float64))
+    A = ba.BaArrays(np.array([bsc["T_init"][ids.index(i)] for i in window]), np.array([fixed[ids.index(i)] for i in window], np.int32),
+                    np.array(pts), np.array(nobs, np.int32), np.array(obs_c, np.uint32), np.array(obs_p, np.uint32),
+                    np.array(uv), bsc["K"])
+    ref = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
+    assert meta[0] == 0 and int(meta[5]) == len(window) and int(meta[6]) == len(pts) and int(meta[7]) == len(obs_c)
+    assert (int(meta[3]), int(meta[4])) == (ref.outer_iterations, ref.inner_iterations)
+    assert np.isclose(meta[2], ref.final_error, rtol=1e-9)
+    assert np.allclose([K_out[0], K_out[4], K_out[2], K_out[5]], ref.K, rtol=1e-9)
+    for w, node in enumerate(window):                     # window poses updated ...
+        assert np.abs(Ts[ids.index(node)] - ref.cam_T_wc[w]).max() < 1e-7
+    for k, i in enumerate(ids):                           # ... everything else untouched
+        if i not in window:
+            assert np.array_equal(Ts[k], bsc["T_init"][k])
+    for lm, idx in lm_index.items():
+        assert np.abs(Ps[lm - 100] - ref.points[idx]).max() < 1e-7 and st_out[lm - 100] == 1
+    untouched = [j for j in range(n_lm) if (j + 100) not in lm_index]
+    assert np.array_equal(Ps[untouched], bsc["points_init"][untouched]) and np.array_equal(st_out[untouched], status[untouched].astype(np.int32))
