@@ -60,7 +60,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from eacham_amd import HipContext, synth, capi
+    from eacham_amd import HipContext, synth, capi, shard
 
     # ---- synthetic S200 inputs, identical on every rank ------------------------------------
     t_gen = time.time()
@@ -68,12 +68,11 @@ def main():
     descs, _ = synth.make_frame_descriptors(scene, args.kpts, args.dim)
     pairs_all = synth.all_pairs(args.frames)
     npairs_total = len(pairs_all)
-    # order pairs by train frame so consecutive workgroups stream the same B frame (L2 reuse)
-    pairs_all = pairs_all[np.lexsort((pairs_all[:, 0], pairs_all[:, 1]))]
-    shard = np.array_split(np.arange(npairs_total), world)[rank]
-    pairs = np.ascontiguousarray(pairs_all[shard])
+    # pairs ordered by train frame (L2 reuse of the B operand), contiguous shard per rank
+    pairs_all = shard.order_pairs(pairs_all)
+    pairs = shard.shard_pairs(pairs_all, world, rank)
     npairs = len(pairs)
-    shard_max = -(-npairs_total // world)
+    shard_max = shard.shard_capacity(npairs_total, world)
     t_gen = time.time() - t_gen
 
     ctx = HipContext(local)
@@ -107,8 +106,7 @@ def main():
             ctx.match_all_pairs_dev(pairs_dev.data_ptr(), npairs, counts.data_ptr(), offsets.data_ptr(),
                                     edges.data_ptr(), edge_cap, total.data_ptr())
             if world > 1:  # RCCL all-gather of the match graph (counts + padded edge lists) over xGMI
-                dist.all_gather_into_tensor(g_counts, counts)
-                dist.all_gather_into_tensor(g_edges, edges)
+                shard.all_gather_match_graph(counts, edges, shard_max, edge_cap, world, g_counts, g_edges)
 
     def fence():
         if world > 1:
@@ -261,7 +259,7 @@ def cpu_baseline(descs, pairs_all, args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as O
     cores = host_cores()
-    n = args.cpu_pairs if args.cpu_pairs > 0 else 4 * cores
+    n = args.cpu_pairs if args.cpu_pairs > 0 else 400 * cores  # ~10 s of CPU work on the GPU box's share
     n = min(n, len(pairs_all))
     sel = pairs_all[np.linspace(0, len(pairs_all) - 1, n).astype(np.int64)]
     O.match_all_pairs(descs, sel[:cores], nthreads=cores)  # warm-up (threads, page faults)

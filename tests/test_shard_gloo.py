@@ -1,0 +1,76 @@
+"""CPU: the N > 1 path — pair sharding + all-gather of the match graph — with world_size 2 on gloo.
+Each rank matches its shard with the CPU oracle (a stand-in for the device matcher, test only);
+the collective and the assembly are the product code of eacham_amd/shard.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from eacham_amd import shard, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in [0, 1, 7, 19900]:
+        for w in [1, 2, 3, 8]:
+            b = shard.shard_bounds(n, w)
+            assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and np.diff(b).max() - np.diff(b).min() <= 1
+            assert shard.shard_capacity(n, w) >= np.diff(b).max()
+    pairs = synth.all_pairs(9)
+    ordered = shard.order_pairs(pairs)
+    assert sorted(map(tuple, ordered.tolist())) == sorted(map(tuple, pairs.tolist()))
+    assert np.all(np.diff(ordered[:, 1]) >= 0)  # grouped by train frame
+    got = np.concatenate([shard.shard_pairs(ordered, 4, r) for r in range(4)])
+    assert np.array_equal(got, ordered)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, descs, pairs, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_pairs(pairs, world, rank)
+    c, o, q, t, st, _ = O.match_all_pairs(descs, mine, min_dir=3, min_mutual=2, nthreads=1)
+    cap = shard.shard_capacity(len(pairs), world)
+    tot = torch.tensor([len(q)], dtype=torch.int64)
+    dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+    edge_cap = max(int(tot.item()), 1)
+    counts = torch.zeros(cap, dtype=torch.int32)
+    counts[: len(c)] = torch.from_numpy(c)
+    edges = torch.zeros(2 * edge_cap, dtype=torch.int32)
+    edges[: 2 * len(q)] = torch.from_numpy(np.stack([q, t], 1).astype(np.int32).reshape(-1))
+    g_counts, g_edges = shard.all_gather_match_graph(counts, edges, cap, edge_cap, world)
+    res = shard.assemble_match_graph(g_counts.numpy(), g_edges.numpy(), len(pairs), world, cap, edge_cap)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), counts=res[0], offsets=res[1], q=res[2], t=res[3])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_all_gather_reproduces_the_single_process_graph(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    sc = synth.make_scene(6, 300, 3, seed=8)
+    descs, _ = synth.make_frame_descriptors(sc, 96, 64, seed=8)
+    descs[4] = descs[4][:50]
+    pairs = shard.order_pairs(synth.all_pairs(6))
+    want = O.match_all_pairs(descs, pairs, min_dir=3, min_mutual=2, nthreads=1)
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), descs, pairs, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):  # every rank ends up with the complete graph
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.array_equal(got["counts"], want[0]) and np.array_equal(got["offsets"], want[1])
+        assert np.array_equal(got["q"], want[2]) and np.array_equal(got["t"], want[3])
+    assert want[0].sum() > 0
