@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir> <counters...> -- runs the reduced bench under rocprofv3 --pmc
+# usage: tools/pmc.sh <outdir> <counters...> -- runs the reduced bench under rocprofv3 --pmc
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --frames 64 --landmarks 16000 --cpu-pairs 0 > gpurun_out/$out.log 2>&1
