@@ -36,7 +36,8 @@ typedef const int __attribute__((address_space(1)))* gint_t;
 constexpr int PAD_VALUE = 16700000;
 constexpr int KEY_SHIFT = 7;
 constexpr int KEY_MASK = (1 << KEY_SHIFT) - 1;
-constexpr int MAX_TILES = 1 << KEY_SHIFT;  // 128 tiles * 32 = 4096 rows per frame
+constexpr int CHUNK_TILES = 1 << KEY_SHIFT;  // column tiles one sweep can tag in a key: 128 * 32 = 4096 train rows
+constexpr int MAX_TILES = 512;               // 16384 rows per frame (K2 keeps two int per row in LDS)
 constexpr int WG_THREADS = 256;            // 4 waves (1 per SIMD); 2 workgroups per CU drift out of phase so MFMA and VALU overlap
 constexpr int WAVES = WG_THREADS / 64;
 constexpr int ROWS_PER_WAVE = 64;          // 2 MFMA tiles of 32 rows, A fragments live in VGPRs
@@ -139,7 +140,7 @@ __device__ unsigned long long g_dbg[16];
 
 template <int KS>
 __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
-    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair,
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair, int col_chunks,
     int4* __restrict__ rowres, int2* __restrict__ colpart, int wb_stride, int row_stride) {
     constexpr int TILE_V4 = KS * 64;                                   // int4 per B tile
     __shared__ v4i sB[3][TILE_V4];
@@ -149,15 +150,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 31, h = lane >> 5;
-    const int p = blockIdx.x / wgs_per_pair, rb = blockIdx.x % wgs_per_pair;
+    // workgroup (pair p, row block rb, column chunk cc): frames with more than 4096 rows are swept in
+    // chunks of CHUNK_TILES column tiles because a key has 7 bits for the tile index; K2 merges the
+    // per-chunk row results (ascending chunks keep the lower column on ties).
+    const int cc = blockIdx.x % col_chunks;
+    const int rb = (blockIdx.x / col_chunks) % wgs_per_pair;
+    const int p = blockIdx.x / (col_chunks * wgs_per_pair);
     const int2 pr = pairs[p];
     const FrameDev A = frames[pr.x], B = frames[pr.y];
-    if (rb * (ROWS_PER_WG / 32) >= A.ntiles) return;  // workgroup-uniform
+    const int tbeg = cc * CHUNK_TILES;
+    if (rb * (ROWS_PER_WG / 32) >= A.ntiles || tbeg >= B.ntiles) return;  // workgroup-uniform
     const int wb = rb * WAVES + wave;                  // 64-row wave-block of frame A
     const bool active = 2 * wb < A.ntiles;             // wave-uniform (ntiles is even)
-    const int T = B.ntiles;
-    const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag;
-    const gint_t Anorm = (gint_t)A.norm, Bnormb = (gint_t)B.normb;
+    const int T = min(B.ntiles - tbeg, CHUNK_TILES);   // tiles of this chunk, t below is chunk-local
+    const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag + (size_t)tbeg * TILE_V4;
+    const gint_t Anorm = (gint_t)A.norm, Bnormb = (gint_t)B.normb + 32 * tbeg;
 
     v4i a[2][KS];
     int base_r[2][16], rm1[2][16], rm2[2][16];
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
         bq[1] = sB[0][64 + lane];
     }
 
-    int2* cp = colpart + ((size_t)p * wb_stride + wb) * row_stride;
+    int2* cp = colpart + ((size_t)p * wb_stride + wb) * row_stride + 32 * tbeg;
 #ifdef EXP_STAMPS
     // diagnostic build: where does a wave's time go? (sums of s_memtime deltas per segment)
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
     // through this wave's private LDS slab so that lane i owns row i and scans the 32 partials.
     int2* slab = sR[wave];
-    int4* rr = rowres + (size_t)p * row_stride + 64 * wb;
+    int4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + 64 * wb;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
         long long f2 = min(max(b1, o1), min(b2, o2));
         if (h == 0) {
             int key1 = (int)(f1 >> 5), key2 = (int)(f2 >> 5);
-            int col1 = 32 * (key1 & KEY_MASK) + (int)(f1 & 31);
+            int col1 = 32 * (tbeg + (key1 & KEY_MASK)) + (int)(f1 & 31);
             rr[32 * s + cl] = make_int4(key1 >> KEY_SHIFT, col1, key2 >> KEY_SHIFT, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -372,7 +379,7 @@ constexpr int FIN_THREADS = 256;
 // out_matches[p][k] = {q, t} sorted by q; counts[p]; stats[p] = {|m12|, |m21|, |mutual|, edge}.
 __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
-    const int4* __restrict__ rowres, const int2* __restrict__ colpart, int wb_stride,
+    const int4* __restrict__ rowres, const int2* __restrict__ colpart, int col_chunks, int wb_stride,
     int row_stride, double ratio, int min_dir, int min_mutual, int mode,
     uint2* __restrict__ out_matches, int* __restrict__ counts, int4* __restrict__ stats) {
     extern __shared__ int smem[];
@@ -388,8 +395,19 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
     __syncthreads();
 
     int c12 = 0, c21 = 0;
+    const int nchunks = (B.ntiles + CHUNK_TILES - 1) / CHUNK_TILES;
     for (int q = tid; q < A.n; q += FIN_THREADS) {
-        int4 r = rowres[(size_t)p * row_stride + q];
+        int4 r = make_int4(INT_MAX >> KEY_SHIFT, -1, INT_MAX >> KEY_SHIFT, 0);
+        for (int ch = 0; ch < nchunks; ++ch) {  // ascending columns; strict '<' keeps the lower column on ties
+            const int4 e = rowres[((size_t)p * col_chunks + ch) * row_stride + q];
+            if (e.x < r.x) {
+                r.z = min(r.x, e.z);
+                r.x = e.x;
+                r.y = e.y;
+            } else {
+                r.z = min(r.z, e.x);
+            }
+        }
         int na = A.norm[q];
         bool ok = r.z + na < PAD_VALUE && ratio_pass(r.x + na, r.z + na, ratio);  // pad second => < 2 train rows
         fwd[q] = ok ? r.y : -1;
@@ -556,6 +574,7 @@ struct MatchPlan {
     int wb_stride;   // wave-blocks per frame (max over resident frames)
     int row_stride;  // padded rows per frame (max)
     int wgs_per_pair;
+    int col_chunks;  // sweeps of <= 4096 train rows per pair
     size_t off_rowres, off_colpart, off_matches, off_counts, total;
 };
 
@@ -567,7 +586,8 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
     pl.row_stride = max_tiles * 32;
     pl.wb_stride = max_tiles / 2;
     pl.wgs_per_pair = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32);
-    size_t per_pair = (size_t)pl.row_stride * sizeof(int4) + (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) +
+    pl.col_chunks = (max_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
+    size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) +
                       (size_t)pl.row_stride * sizeof(uint2) + sizeof(int);
     // bound the workspace near 1 GiB so the column partials of one batch stay cache-friendly
     size_t budget = (size_t)1 << 30;
@@ -575,7 +595,7 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
     pl.batch = std::max(batch, 1);
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     pl.off_rowres = 0;
-    pl.off_colpart = align(pl.off_rowres + (size_t)pl.batch * pl.row_stride * sizeof(int4));
+    pl.off_colpart = align(pl.off_rowres + (size_t)pl.batch * pl.col_chunks * pl.row_stride * sizeof(int4));
     pl.off_matches = align(pl.off_colpart + (size_t)pl.batch * pl.wb_stride * pl.row_stride * sizeof(int2));
     pl.off_counts = align(pl.off_matches + (size_t)pl.batch * pl.row_stride * sizeof(uint2));
     pl.total = align(pl.off_counts + (size_t)pl.batch * sizeof(int));
@@ -584,8 +604,8 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
 
 template <int KS>
 static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws) {
-    match_tile_kernel<KS><<<nb * pl.wgs_per_pair, WG_THREADS, 0, ctx->stream>>>(
-        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, (int4*)(ws + pl.off_rowres),
+    match_tile_kernel<KS><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
+        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (int4*)(ws + pl.off_rowres),
         (int2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
 }
 
@@ -601,6 +621,8 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
     if (rc) return rc;
     char* ws = (char*)ctx->ws;
     const size_t fin_smem = (size_t)2 * pl.row_stride * sizeof(int);
+    if (fin_smem > 48 * 1024)
+        EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)match_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_smem));
     for (int first = 0; first < npairs; first += pl.batch) {
         int nb = std::min(pl.batch, npairs - first);
         const int2* pb = pairs_dev + first;
@@ -617,7 +639,7 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE);
             match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, ctx->stream>>>(
                 ctx->frame_table_dev, pb, (const int4*)(ws + pl.off_rowres),
-                (const int2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride, ratio, min_dir,
+                (const int2*)(ws + pl.off_colpart), pl.col_chunks, pl.wb_stride, pl.row_stride, ratio, min_dir,
                 min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt,
                 stats_dev ? stats_dev + first : nullptr);
             if (mode == 0) {

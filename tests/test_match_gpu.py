@@ -108,6 +108,30 @@ def test_scene_parity_reference_thresholds(hip_ctx):
     assert (got[0] > 30).sum() >= 5
 
 
+def test_frames_beyond_one_column_chunk(hip_ctx):
+    """> 4096 rows per frame (config[0]: up to 15000 SIFT features): the sweep is split into column
+    chunks of 4096 and the per-chunk row results are merged; ties across the chunk border included."""
+    A = synth.random_u8_descriptors(5000, 64, 41, 0)
+    B = synth.random_u8_descriptors(4500, 64, 41, 1)
+    m = 2000
+    B[:m] = np.clip(A[:m] + np.rint(5 * synth.rng_normal(9, 3, (m, 64))), 0, 255)
+    B[4200:4300] = B[100:200]            # duplicates on both sides of the 4096 border: lower index wins
+    A[4097] = A[3]
+    _upload(hip_ctx, [A, B])
+    for a, b, X, Y in [(0, 1, A, B), (1, 0, B, A)]:
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(X, Y)
+        assert np.array_equal(q, qo) and np.array_equal(t, to) and len(q) > 1000
+    got = hip_ctx.match_all_pairs(np.array([[0, 1]]))
+    want = O.match_all_pairs([A, B], np.array([[0, 1]]))
+    _assert_csr_equal(got, want)
+    hip_ctx.clear_descriptors()
+    with pytest.raises(EachamError) as e:
+        hip_ctx.upload_descriptors(0, np.zeros((16385, 16), np.float32))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    hip_ctx.clear_descriptors()
+
+
 def test_feature_matcher_interface(hip_ctx):
     """FeatureMatcherFlann-shaped adapter: Match(d1, d2) -> {query: train}."""
     A = synth.random_u8_descriptors(150, 128, 3, 0)
