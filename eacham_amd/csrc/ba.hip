@@ -193,7 +193,7 @@ struct BaDev {
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
-    double *Et, *lmtry, *S, *Lm, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
+    double *Et, *lmtry, *S, *Lm, *Ldiag, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     int* flags;
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
@@ -565,19 +565,25 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
 //   * updates its tile A_ij -= L_ik L_jk^T;
 //   * tile (0,0), which holds the next diagonal block, factorises it in LDS and stores W_{k+1}.
 // The raw matrix A is never overwritten inside the columns a concurrent workgroup may still read.
-// Factor + invert one 32x32 SPD block: this is the serial chain of the whole factorisation (one per
-// launch), so it runs on ONE wave with the block in registers — lane i holds row i, pivots and
-// multipliers are broadcast with v_readlane (compile-time lane ids after full unrolling), no LDS
-// traffic and no workgroup barriers. Called by the first wave only; Dn must be complete.
+// The serial chain of the whole factorisation is the 32x32 diagonal-block Cholesky (one per launch),
+// so it runs on ONE wave with the block in registers — lane i holds row i, pivots and multipliers are
+// broadcast with v_readlane (compile-time lane ids after full unrolling): no LDS traffic, no
+// workgroup barriers. Only the FACTOR is on the critical path: the panels are solved against it by a
+// per-row triangular solve, and the explicit inverse W_k = L_kk^-1 that the back-substitution wants
+// is produced off the critical path by a spare workgroup of the next launch.
 __device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane is a compile-time constant
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
 
-__device__ void factor_invert_32(double (*Dn)[NB + 1], double* __restrict__ Wout, int* __restrict__ flags) {
+// Ldiag block layout: [NB][NB] lower factor, then [NB] reciprocals of its diagonal
+constexpr int LDB = NB * NB + NB;
+
+// first wave only; Dn complete. Writes L (lower) and 1/diag.
+__device__ void factor_32(double (*Dn)[NB + 1], double* __restrict__ Lout, int* __restrict__ flags) {
     const int i = threadIdx.x & 31;  // lanes 32..63 mirror lanes 0..31
-    double row[NB], dinv[NB];
+    double row[NB], dinv_own = 0.0;
 #pragma unroll
     for (int m = 0; m < NB; ++m) row[m] = Dn[i][m];
     bool bad = false;
@@ -595,29 +601,39 @@ __device__ void factor_invert_32(double (*Dn)[NB + 1], double* __restrict__ Wout
         y = y * (1.5 - 0.5 * d * y * y);
         double rs = d * y;
         rs = rs + 0.5 * y * (d - rs * rs);
-        dinv[j] = y;
+        if (i == j) dinv_own = y;
         const double lij = (i == j) ? rs : row[j] * y;
         row[j] = lij;
 #pragma unroll
         for (int l = j + 1; l < NB; ++l) row[l] -= lij * bcast(lij, l);
     }
     if (bad && threadIdx.x == 0) atomicOr(flags, 2);
-    double w[NB];  // lane c: column c of W = L^-1
+    if (threadIdx.x < NB) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m) Lout[i * NB + m] = (m <= i) ? row[m] : 0.0;
+        Lout[NB * NB + i] = dinv_own;
+    }
+}
+
+// first wave only: W = L^-1 (lower) from a factor block in LDS; lane c computes column c
+__device__ void invert_32(const double (*Ls)[NB + 1], const double* __restrict__ dinv, double* __restrict__ Wout) {
+    const int c = threadIdx.x & 31;
+    double w[NB];
 #pragma unroll
     for (int ii = 0; ii < NB; ++ii) {
-        double sacc = (ii == i) ? 1.0 : 0.0;
+        double sacc = (ii == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int m = 0; m < ii; ++m) sacc -= bcast(row[m], ii) * w[m];
+        for (int m = 0; m < ii; ++m) sacc -= Ls[ii][m] * w[m];  // same address in every lane: LDS broadcast
         w[ii] = sacc * dinv[ii];
     }
     if (threadIdx.x < NB) {
 #pragma unroll
-        for (int ii = 0; ii < NB; ++ii) Wout[ii * NB + i] = w[ii];
+        for (int ii = 0; ii < NB; ++ii) Wout[ii * NB + c] = w[ii];
     }
 }
 
-// W_0 of the first diagonal block
-__global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Winv,
+// L_0 of the first diagonal block
+__global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Ldiag,
                                                   int* __restrict__ flags) {
     __shared__ double Dn[NB][NB + 1];
     for (int idx = threadIdx.x; idx < NB * NB; idx += TPB) {
@@ -625,39 +641,61 @@ __global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, 
         Dn[i][j] = (i < n && j < n) ? (j <= i ? A[(size_t)i * ld + j] : 0.0) : (i == j ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (threadIdx.x < 64) factor_invert_32(Dn, Winv, flags);
+    if (threadIdx.x < 64) factor_32(Dn, Ldiag, flags);
 }
 
+// K-E step k. Grid = lower-triangular 64x64 tiles of the trailing matrix + ONE spare workgroup.
+//   * every tile workgroup loads L_kk and the RAW strips A[i.., k] of its tile and solves them
+//     against L_kk itself (thread = row; the first tile column also stores L_ik into Lm) — panel
+//     solve and trailing update share one launch; the raw matrix A is never overwritten inside the
+//     columns a concurrent workgroup may still read;
+//   * updates its tile A_ij -= L_ik L_jk^T;
+//   * tile (0,0), which holds the next diagonal block, factorises it on its first wave -> Ldiag[k+1];
+//   * the spare workgroup inverts L_kk -> Winv[k] for the back-substitution (off the critical path).
 __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr,
-                                                 int k0, double* __restrict__ Winv, int* __restrict__ flags) {
-    __shared__ double W[NB][NB + 1];
-    __shared__ double Ri[64][NB + 1], Rj[64][NB + 1];  // raw strips, then reused
+                                                 int k0, int ntiles, double* __restrict__ Ldiag, double* __restrict__ Winv,
+                                                 int* __restrict__ flags) {
+    __shared__ double Lk[NB][NB + 1];
+    __shared__ double dinv[NB];
     __shared__ double Li[64][NB + 1], Lj[64][NB + 1];
+    const int tid = threadIdx.x;
+    const double* Lsrc = Ldiag + (size_t)(k0 / NB) * LDB;
+    for (int idx = tid; idx < NB * NB; idx += TPB) Lk[idx / NB][idx % NB] = Lsrc[idx];
+    if (tid < NB) dinv[tid] = Lsrc[NB * NB + tid];
+    if ((int)blockIdx.x == ntiles) {  // spare workgroup
+        __syncthreads();
+        if (tid < 64) invert_32(Lk, dinv, Winv + (size_t)(k0 / NB) * NB * NB);
+        return;
+    }
     const int k1 = k0 + NB;  // columns >= n inside the block are zero padding, rows are masked below
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
     const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
-    const int tid = threadIdx.x;
-    const double* Wk = Winv + (size_t)(k0 / NB) * NB * NB;
-    for (int idx = tid; idx < NB * NB; idx += TPB) W[idx / NB][idx % NB] = Wk[idx];
-    for (int idx = tid; idx < 64 * NB; idx += TPB) {
-        const int r = idx / NB, l = idx % NB;
-        const int ri = i0 + r, rj = j0 + r;  // matrix rows < n, plus the rhs row nr
-        Ri[r][l] = ((ri < n || ri == nr) && k0 + l < n) ? A[(size_t)ri * ld + k0 + l] : 0.0;
-        Rj[r][l] = ((rj < n || rj == nr) && k0 + l < n) ? A[(size_t)rj * ld + k0 + l] : 0.0;
-    }
     __syncthreads();
-    for (int idx = tid; idx < 64 * NB; idx += TPB) {  // L = R W^T  (W lower: L[r][c] = sum_{m<=c} R[r][m] W[c][m])
-        const int r = idx / NB, c = idx % NB;
-        double si = 0.0, sj = 0.0;
-        for (int m = 0; m <= c; ++m) {
-            si += Ri[r][m] * W[c][m];
-            sj += Rj[r][m] * W[c][m];
+    if (tid < 128) {  // triangular solve, one row per thread: x L_kk^T = a
+        const bool second = tid >= 64;
+        const int r = tid & 63;
+        const int row = (second ? j0 : i0) + r;
+        const bool valid = row < n || row == nr;  // matrix rows, plus the rhs row nr
+        double x[NB];
+#pragma unroll
+        for (int l = 0; l < NB; ++l) x[l] = (valid && k0 + l < n) ? A[(size_t)row * ld + k0 + l] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double sacc = x[j];
+#pragma unroll
+            for (int l = 0; l < j; ++l) sacc -= x[l] * Lk[j][l];
+            x[j] = sacc * dinv[j];
         }
-        Li[r][c] = si;
-        Lj[r][c] = sj;
-        if (tj == 0 && (i0 + r < n || i0 + r == nr) && k0 + c < n) Lm[(size_t)(i0 + r) * ld + k0 + c] = si;
+        double (*dst)[NB + 1] = second ? Lj : Li;
+#pragma unroll
+        for (int l = 0; l < NB; ++l) dst[r][l] = x[l];
+        if (!second && tj == 0 && valid) {
+#pragma unroll
+            for (int l = 0; l < NB; ++l)
+                if (k0 + l < n) Lm[(size_t)row * ld + k0 + l] = x[l];
+        }
     }
     __syncthreads();
     const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;  // 4x4 outputs per thread
@@ -680,7 +718,8 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             for (int b = 0; b < 4; ++b) acc[a][b] += xi[a] * xj[b];
     }
     const bool next_diag = (t == 0) && (k1 < n);
-    double (*Dn)[NB + 1] = Ri;  // reuse (all reads of Ri are behind the barrier above)
+    __syncthreads();              // all reads of Li are done: its first rows are reused below
+    double (*Dn)[NB + 1] = Li;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -699,7 +738,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         }
     if (next_diag) {
         __syncthreads();
-        if (tid < 64) factor_invert_32(Dn, Winv + (size_t)(k1 / NB) * NB * NB, flags);
+        if (tid < 64) factor_32(Dn, Ldiag + (size_t)(k1 / NB) * LDB, flags);
     }
 }
 
@@ -1074,6 +1113,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 1) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
+    TRY(dev_alloc(ctx, h, &D.Ldiag, (size_t)((D.n + NB - 1) / NB + 1) * LDB));
     TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
     TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
     TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
@@ -1155,11 +1195,12 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
-        chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
+        chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Ldiag, D.flags);
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int k1 = k0 + NB;
             const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-            chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
+            chol_step<<<nt * (nt + 1) / 2 + 1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, nt * (nt + 1) / 2, D.Ldiag,
+                                                                      D.Winv, D.flags);
         }
         const int nblk = (n + NB - 1) / NB;
         chol_backsolve<<<1, 1024, sizeof(double) * (size_t)nblk * NB, ctx->stream>>>(D.Lm, D.ld, n, D.nr, D.Winv, D.delta_c);
