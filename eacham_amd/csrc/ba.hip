@@ -742,37 +742,82 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     }
 }
 
-// back substitution L^T x = y (y = row n of Lm) with the explicit block inverses, one workgroup
-__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nr,
-                                                       const double* __restrict__ Winv, double* __restrict__ xout) {
-    extern __shared__ double xs[];  // n (+ padding) doubles: running y, becomes x
-    __shared__ double W[NB][NB + 1];
-    __shared__ double yk[NB];
+// back substitution L^T x = y (y = row nr of Lm) in super-blocks of SB = 4 x NB columns, one launch per
+// super-block so that the n^2/2 doubles of L are streamed by many CUs instead of one (a single
+// workgroup reads ~14 GB/s). Launch for super-block K (descending):
+//   * workgroup s < K updates its own 128 columns  y_s -= L[K-rows, s-cols]^T x_K
+//   * workgroup K-1 then solves its own super-block (4 inner steps with the explicit inverses W_b)
+//     and publishes x_{K-1} for the next launch. The first launch only solves the last super-block.
+// xv holds y on entry (copied from row nr of Lm) and x on exit.
+constexpr int SB = 4 * NB;
+constexpr int BSTEP_THREADS = 1024;
+__global__ __launch_bounds__(BSTEP_THREADS) void chol_backstep(const double* __restrict__ Lm, int ld, int n, int K, int s_base,
+                                                               int solve_only, const double* __restrict__ Winv,
+                                                               double* __restrict__ xv) {
+    __shared__ double xK[SB];                     // x of super-block K (update) / running y of the solved block
+    __shared__ double part[BSTEP_THREADS / SB][SB];
+    __shared__ double Ws[SB / NB][NB][NB + 1];    // inverses of the 4 inner diagonal blocks (solver only)
+    __shared__ double Lin[SB][SB - NB + 1];       // rows of the super-block, columns left of their inner block
     const int tid = threadIdx.x;
-    const int nblk = (n + NB - 1) / NB;
-    for (int i = tid; i < nblk * NB; i += 1024) xs[i] = i < n ? Lm[(size_t)nr * ld + i] : 0.0;
-    __syncthreads();
-    for (int kb_i = nblk - 1; kb_i >= 0; --kb_i) {
-        const int k0 = kb_i * NB;
-        for (int idx = tid; idx < NB * NB; idx += 1024) W[idx / NB][idx % NB] = Winv[(size_t)kb_i * NB * NB + idx];
-        if (tid < NB) yk[tid] = xs[k0 + tid];
+    const int s = blockIdx.x + s_base;            // column slice = super-block index of this workgroup
+    const int c0 = s * SB;
+    const bool solver = solve_only || s == K - 1;
+    if (solver) {  // issue the solver's loads first: their latency overlaps the update below
+        for (int idx = tid; idx < (SB / NB) * NB * NB; idx += BSTEP_THREADS) {
+            const int b = idx / (NB * NB), e = idx % (NB * NB);
+            const int kb = c0 / NB + b;
+            Ws[b][e / NB][e % NB] = (kb * NB < n) ? Winv[(size_t)kb * NB * NB + e] : 0.0;
+        }
+        for (int idx = tid; idx < SB * (SB - NB); idx += BSTEP_THREADS) {
+            const int r = idx / (SB - NB), c = idx % (SB - NB);
+            Lin[r][c] = (c < (r / NB) * NB && c0 + r < n) ? Lm[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+        }
+    }
+    if (!solve_only) {
+        const int K0 = K * SB;
+        if (tid < SB) xK[tid] = (K0 + tid < n) ? xv[K0 + tid] : 0.0;
         __syncthreads();
-        if (tid < NB) {  // x_k = W^T y_k
-            double sacc = 0.0;
-            for (int m = tid; m < NB; ++m) sacc += W[m][tid] * yk[m];
-            xs[k0 + tid] = sacc;
+        // 8 threads per column, 16 rows each (rows are contiguous along columns: coalesced)
+        const int cl = tid & (SB - 1), pr = tid / SB, col = c0 + cl;
+        constexpr int RP = SB / (BSTEP_THREADS / SB);
+        double sacc = 0.0;
+        if (col < n) {
+#pragma unroll
+            for (int r = pr * RP; r < (pr + 1) * RP; ++r)
+                if (K0 + r < n) sacc += Lm[(size_t)(K0 + r) * ld + col] * xK[r];
+        }
+        part[pr][cl] = sacc;
+        __syncthreads();
+        if (tid < SB && c0 + tid < n) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < BSTEP_THREADS / SB; ++q) tot += part[q][tid];
+            xv[c0 + tid] -= tot;
+        }
+        if (!solver) return;
+    }
+    // solve super-block s: inner blocks b = 3..0, everything from LDS
+    __syncthreads();
+    double* ys = xK;
+    if (tid < SB) ys[tid] = (c0 + tid < n) ? xv[c0 + tid] : 0.0;
+    __syncthreads();
+    for (int b = SB / NB - 1; b >= 0; --b) {
+        double xb = 0.0;
+        if (tid < NB) {              // x_b = W^T y_b
+            for (int m = tid; m < NB; ++m) xb += Ws[b][m][tid] * ys[b * NB + m];
         }
         __syncthreads();
-        for (int col = tid; col < k0; col += 1024) {  // y[0..k0) -= L[k0.., col]^T x_k
+        if (tid < NB) ys[b * NB + tid] = xb;
+        __syncthreads();
+        if (tid < b * NB) {          // y[inner cols < b] -= L[block-b rows, col]^T x_b
             double sacc = 0.0;
 #pragma unroll 8
-            for (int j = 0; j < NB; ++j)
-                if (k0 + j < n) sacc += Lm[(size_t)(k0 + j) * ld + col] * xs[k0 + j];
-            xs[col] -= sacc;
+            for (int j = 0; j < NB; ++j) sacc += Lin[b * NB + j][tid] * ys[b * NB + j];
+            ys[tid] -= sacc;
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += 1024) xout[i] = xs[i];
+    if (tid < SB && c0 + tid < n) xv[c0 + tid] = ys[tid];
 }
 
 // ---- K-F: landmark back-substitution + tentative points + linearised-cost terms (thread = landmark) ----
@@ -1202,8 +1247,11 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
             chol_step<<<nt * (nt + 1) / 2 + 1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, nt * (nt + 1) / 2, D.Ldiag,
                                                                       D.Winv, D.flags);
         }
-        const int nblk = (n + NB - 1) / NB;
-        chol_backsolve<<<1, 1024, sizeof(double) * (size_t)nblk * NB, ctx->stream>>>(D.Lm, D.ld, n, D.nr, D.Winv, D.delta_c);
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+        const int nsb = (n + SB - 1) / SB;
+        chol_backstep<<<1, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, nsb - 1, 1, D.Winv, D.delta_c);
+        for (int K = nsb - 1; K >= 1; --K) chol_backstep<<<K, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, K, 0, 0, D.Winv, D.delta_c);
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
