@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--landmarks", type=int, default=50_000)
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (-1 = 4 per core, 0 = skip)")
     ap.add_argument("--ba-solves", type=int, default=5, help="timed RefineBA solves of the S200 window (0 = skip BA)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--all-on-device", type=int, default=-1, help="rehearsal: put every rank on this device index")
     return ap.parse_args()
 
 
@@ -55,10 +57,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.all_on_device >= 0:
+        local = args.all_on_device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from eacham_amd import HipContext, synth, capi, shard
 
@@ -156,7 +163,9 @@ def main():
                        "pairs_per_rank": npairs, "mutual_matches_rank0": n_matches,
                        "parallelism": f"pairs sharded over {world} GPU(s)" + (" + RCCL all-gather" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
-                         "frac": achieved / I8_MFMA_PEAK_TOPS, "traffic": None,
+                         "frac": achieved / I8_MFMA_PEAK_TOPS,
+                         # HBM bytes of one full-batch launch (1872 pairs x 8 workgroups x 256 threads)
+                         "traffic": measured_traffic("eacham::match_tile_kernel<8>", 1872 * 8 * 256) if args.kpts == 2000 and args.dim == 256 else None,
                          "kernel": "match_tile_kernel<8>", "launches": launches,
                          "avg_launch_ms": tile_ms / max(launches, 1),
                          "finalize_ms_per_step": fin_ms / args.steps},
@@ -172,6 +181,18 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def measured_traffic(kernel: str, grid_threads: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB units, FETCH
+    doubled per the gfx950 correction of MI355X_MICROARCH.md). None if that launch shape was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            d = json.load(f).get(f"{kernel} grid={grid_threads}")
+        return (2.0 * d["FETCH_SIZE_KB_mean_per_dispatch"] + d["WRITE_SIZE_KB_mean_per_dispatch"]) * 1024.0
+    except (OSError, KeyError, TypeError, ValueError):
+        return None
 
 
 def host_cores() -> int:

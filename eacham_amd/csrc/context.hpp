@@ -24,7 +24,7 @@ struct FrameDev {
     const int* norm;   // [ntiles*32] squared norm of the centred row; PAD_VALUE for padding rows
     const int* normb;  // [ntiles*32] norm + 2*sum of the centred row (train-role norm, see matcher.hip K1)
     int n;             // real rows
-    int ntiles;        // 32-row tiles, always even (a wave owns 2 tiles = 64 rows)
+    int ntiles;        // 32-row tiles, padded to a multiple of 4 (a wave owns 2 or 4 tiles)
 };
 
 struct FrameHost {

@@ -40,8 +40,13 @@ constexpr int CHUNK_TILES = 1 << KEY_SHIFT;  // column tiles one sweep can tag i
 constexpr int MAX_TILES = 512;               // 16384 rows per frame (K2 keeps two int per row in LDS)
 constexpr int WG_THREADS = 256;            // 4 waves (1 per SIMD); 2 workgroups per CU drift out of phase so MFMA and VALU overlap
 constexpr int WAVES = WG_THREADS / 64;
-constexpr int ROWS_PER_WAVE = 64;          // 2 MFMA tiles of 32 rows, A fragments live in VGPRs
+#ifndef EACHAM_MATCH_NSUB
+#define EACHAM_MATCH_NSUB 2
+#endif
+constexpr int MATCH_NSUB = EACHAM_MATCH_NSUB;        // 32-row MFMA sub-tiles per wave (A fragments live in VGPRs)
+constexpr int ROWS_PER_WAVE = 32 * MATCH_NSUB;
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
+constexpr int TILE_ALIGN = 4;                        // frames are padded to a multiple of 4 tiles (128 rows)
 
 __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
@@ -138,11 +143,14 @@ __device__ __forceinline__ void vkeys(int acc, int base_row_dir, int base_col_di
 __device__ unsigned long long g_dbg[16];
 #endif
 
-template <int KS>
-__global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
+template <int KS, int NSUB>
+__global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair, int col_chunks,
     int4* __restrict__ rowres, int2* __restrict__ colpart, int wb_stride, int row_stride) {
-    constexpr int TILE_V4 = KS * 64;                                   // int4 per B tile
+    constexpr int TILE_V4 = KS * 64;          // int4 per B tile
+    constexpr int ROWS_WAVE = 32 * NSUB;      // query rows a wave keeps in registers
+    constexpr int ROWS_WG = WAVES * ROWS_WAVE;
+    static_assert(ROWS_WAVE <= (1 << KEY_SHIFT), "the local row must fit the key's code field");
     __shared__ v4i sB[3][TILE_V4];
     __shared__ int2 sR[WAVES][32 * 32];
 
@@ -159,38 +167,38 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     const int2 pr = pairs[p];
     const FrameDev A = frames[pr.x], B = frames[pr.y];
     const int tbeg = cc * CHUNK_TILES;
-    if (rb * (ROWS_PER_WG / 32) >= A.ntiles || tbeg >= B.ntiles) return;  // workgroup-uniform
-    const int wb = rb * WAVES + wave;                  // 64-row wave-block of frame A
-    const bool active = 2 * wb < A.ntiles;             // wave-uniform (ntiles is even)
+    if (rb * (ROWS_WG / 32) >= A.ntiles || tbeg >= B.ntiles) return;  // workgroup-uniform
+    const int wb = rb * WAVES + wave;                  // wave-block (ROWS_WAVE rows) of frame A
+    const bool active = NSUB * wb < A.ntiles;          // wave-uniform (ntiles is a multiple of NSUB)
     const int T = min(B.ntiles - tbeg, CHUNK_TILES);   // tiles of this chunk, t below is chunk-local
     const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag + (size_t)tbeg * TILE_V4;
     const gint_t Anorm = (gint_t)A.norm, Bnormb = (gint_t)B.normb + 32 * tbeg;
 
-    v4i a[2][KS];
-    int base_r[2][16], rm1[2][16], rm2[2][16];
+    v4i a[NSUB][KS];
+    int base_r[NSUB][16], rm1[NSUB][16], rm2[NSUB][16];
     const int wbc = active ? wb : 0;  // inactive waves load a valid block and never use it
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NSUB; ++s) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(2 * wbc + s) * KS + ks) * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int lrow = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
-            base_r[s][r] = (Anorm[64 * wbc + lrow] << KEY_SHIFT) | lrow;
+            base_r[s][r] = (Anorm[ROWS_WAVE * wbc + lrow] << KEY_SHIFT) | lrow;
             rm1[s][r] = INT_MAX;
             rm2[s][r] = INT_MAX;
         }
     }
 
-    // Software pipeline (no extra registers): the two accumulators of a wave are half a tile apart.
-    //   phase A(t): issue the 8 MFMAs of acc1(t)   while the VALU runs the epilogue of acc0(t)
-    //   phase B(t): issue the 8 MFMAs of acc0(t+1) while the VALU runs the epilogue of acc1(t)
-    // so an MFMA chain (8 x 32 cycles) always hides under ~100 VALU ops (4 cycles each). Waves issue
-    // in order, hence the source interleaves one MFMA with two epilogue elements and pins that order
-    // with sched_barrier. B fragments are read from LDS just in time through a 3-deep register ring
-    // (each tile is read twice, once per accumulator) instead of holding a whole tile in VGPRs.
+    // Software pipeline (no extra registers): the NSUB accumulators of a wave are staggered by one
+    // sub-tile. The MFMA chains are issued in the order (t,0) (t,1) .. (t,NSUB-1) (t+1,0) ..., and
+    // while chain c+1 is being issued the VALU runs the epilogue of chain c — an MFMA chain
+    // (8 x 32 cycles) always hides under ~100 VALU ops (4 cycles each). Waves issue in order, hence
+    // the source interleaves one MFMA with two epilogue elements and pins that order with
+    // sched_barrier. B fragments are read from LDS just in time through a 3-deep register ring (a tile
+    // is read once per accumulator) instead of holding a whole tile in VGPRs.
     // LDS ring of 3 tiles: sB[t % 3] holds tile t. Tile t+2 is DMA-ed into sB[(t+2) % 3] from the
-    // top of iteration t (that slot held tile t-1, last read in phase A(t-1), i.e. before the
+    // top of iteration t (that slot held tile t-1, last read in iteration t-1, i.e. before the
     // previous barrier); the barrier at the end of the iteration (vmcnt(0) + s_barrier) publishes it.
     // Staging is LDS-DMA (global_load_lds_dwordx4): a wave-instruction moves 1 KiB = one k-step of
     // the fragment-major tile straight into LDS (destination = wave-uniform base + lane*16, which
@@ -216,9 +224,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     __builtin_amdgcn_s_waitcnt(0);  // every prologue load has landed (keeps vmcnt(0) out of the loop)
     __syncthreads();
 
-    v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v16i acc1 = acc0;
-    const v16i zero16 = acc0;
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v16i acc[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) acc[s] = zero16;
     v4i bq[3];  // fragment ring: step i of the (phase, ks) sequence lives in bq[i % 3]
     if (T > 0 && active) {
         v4i b0[KS];
@@ -226,8 +235,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
         for (int ks = 0; ks < KS; ++ks) b0[ks] = sB[0][ks * 64 + lane];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b0[ks], ks ? acc0 : zero16, 0, 0, 0);
-        bq[0] = sB[0][lane];       // steps 0 and 1 of iteration 0 (phase A re-reads tile 0)
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b0[ks], ks ? acc[0] : zero16, 0, 0, 0);
+        bq[0] = sB[0][lane];       // steps 0 and 1 of iteration 0 (chain (0,1) re-reads tile 0)
         bq[1] = sB[0][64 + lane];
     }
 
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
 #define STAMP(i) do {} while (0)
 #endif
     constexpr int EPK = 16 / KS;         // epilogue elements interleaved per MFMA (KS = 8 -> 2)
+    constexpr int NSTEP = NSUB * KS;     // (phase, ks) steps per tile
     int slot_cur = 0, slot_nxt = 1, slot_new = 2;  // t % 3, (t+1) % 3, (t+2) % 3
     for (int t = 0; t < T; ++t) {
         const int base_c = (nb_cur << KEY_SHIFT) | t;
@@ -251,37 +261,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
         if (active) {
             const v4i* curB = sB[slot_cur];
             const v4i* nxtB = sB[slot_nxt];
-            // 2*KS steps per iteration; 2*KS = 16 steps -> ring phase advances by 16 % 3 = 1 per
-            // iteration, so the loop body is written for a fixed phase and the ring is rotated at
-            // the end (three register moves) to keep every index a compile-time constant.
+            // The ring phase advances by NSTEP % 3 per iteration, so the loop body is written for a
+            // fixed phase and the ring is rotated at the end (register moves) to keep every index a
+            // compile-time constant.
 #pragma unroll
-            for (int i = 0; i < 2 * KS; ++i) {
-                const int ks = i % KS;
-                const bool phaseA = i < KS;
-                // prefetch the fragment of step i+2 (wrapping into the next iteration's phase A,
-                // which re-reads tile t+1)
+            for (int i = 0; i < NSTEP; ++i) {
+                const int ph = i / KS, ks = i % KS;  // phase ph: epilogue of acc[ph], MFMAs of the next chain
+                // prefetch the fragment of step i+2. Phase q < NSUB-1 issues chain (t, q+1): tile t;
+                // phase NSUB-1 issues chain (t+1, 0) and phase 0 of the next iteration chain (t+1, 1):
+                // tile t+1.
                 const int j = i + 2;
-                const v4i* src = (j < KS) ? curB : nxtB;
+                const v4i* src = (j / KS < NSUB - 1) ? curB : nxtB;
                 bq[j % 3] = src[(j % KS) * 64 + lane];
-                if (phaseA) {
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][ks], bq[i % 3], ks ? acc1 : zero16, 0, 0, 0);
-                } else {
-                    // (the last iteration recomputes tile T-1 into acc0; it is never read)
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], bq[i % 3], ks ? acc0 : zero16, 0, 0, 0);
-                }
+                const int q = (ph + 1) % NSUB;       // accumulator of the chain being issued
+                // (the last iteration recomputes tile T-1 into acc[0]; it is never read)
+                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q][ks], bq[i % 3], ks ? acc[q] : zero16, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < EPK; ++e) {
                     const int r = ks * EPK + e;
                     int kr, kc;
-                    if (phaseA) {
-                        vkeys(acc0[r], base_c, base_r[0][r], kr, kc);
-                        rm2[0][r] = vmed3(rm1[0][r], rm2[0][r], kr);
-                        rm1[0][r] = min(rm1[0][r], kr);
-                    } else {
-                        vkeys(acc1[r], base_c, base_r[1][r], kr, kc);
-                        rm2[1][r] = vmed3(rm1[1][r], rm2[1][r], kr);
-                        rm1[1][r] = min(rm1[1][r], kr);
-                    }
+                    vkeys(acc[ph][r], base_c, base_r[ph][r], kr, kc);
+                    rm2[ph][r] = vmed3(rm1[ph][r], rm2[ph][r], kr);
+                    rm1[ph][r] = min(rm1[ph][r], kr);
                     cm2 = vmed3(cm1, cm2, kc);
                     cm1 = min(cm1, kc);
                 }
@@ -289,9 +290,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
                 if (i == KS - 1) STAMP(1);
             }
             STAMP(2);
-            // steps 16 and 17 (= steps 0, 1 of the next iteration) sit in bq[16 % 3], bq[17 % 3]
+            // steps NSTEP and NSTEP+1 (= steps 0, 1 of the next iteration) sit in bq[NSTEP % 3], ...
             {
-                v4i s0 = bq[(2 * KS) % 3], s1 = bq[(2 * KS + 1) % 3];
+                v4i s0 = bq[NSTEP % 3], s1 = bq[(NSTEP + 1) % 3];
                 bq[0] = s0;
                 bq[1] = s1;
             }
@@ -325,9 +326,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
     // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
     // through this wave's private LDS slab so that lane i owns row i and scans the 32 partials.
     int2* slab = sR[wave];
-    int4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + 64 * wb;
+    int4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + ROWS_WAVE * wb;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NSUB; ++s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_tile_kernel(
         long long b1 = LLONG_MAX, b2 = LLONG_MAX;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int cc = 16 * h + ((j + lane) & 15);
-            int2 e = slab[cl * 32 + cc];
-            long long k1 = ((long long)e.x << 5) | cc, k2 = ((long long)e.y << 5) | cc;
+            int cidx = 16 * h + ((j + lane) & 15);
+            int2 e = slab[cl * 32 + cidx];
+            long long k1 = ((long long)e.x << 5) | cidx, k2 = ((long long)e.y << 5) | cidx;
             b2 = min(b2, max(b1, k1));
             b1 = min(b1, k1);
             b2 = min(b2, max(b1, k2));
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
         fwd[q] = ok ? r.y : -1;
         c12 += ok;
     }
-    const int nwb = A.ntiles / 2;
+    const int nwb = A.ntiles / MATCH_NSUB;
     for (int c = tid; c < B.n; c += FIN_THREADS) {
         int v1 = INT_MAX >> KEY_SHIFT, v2 = INT_MAX >> KEY_SHIFT, r1 = -1;
         const int2* cp = colpart + (size_t)p * wb_stride * row_stride + c;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
             if (va < v1) {
                 v2 = v1;
                 v1 = va;
-                r1 = 64 * wb + (e.x & KEY_MASK);
+                r1 = ROWS_PER_WAVE * wb + (e.x & KEY_MASK);
             } else if (va < v2) {
                 v2 = va;
             }
@@ -526,7 +527,7 @@ static int upload_frame(eacham_ctx* ctx, int frame_id, const float* src_dev, int
     if (ctx->ks_common && ctx->ks_common != ks)
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "all resident frames must share one descriptor dim class");
     int ntiles = (n + 31) / 32;
-    ntiles += ntiles & 1;
+    ntiles = (ntiles + TILE_ALIGN - 1) / TILE_ALIGN * TILE_ALIGN;
     if (ntiles > MAX_TILES)
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "frame has %d rows; this build supports <= %d", n, MAX_TILES * 32);
     if ((size_t)frame_id >= ctx->frames.size()) ctx->frames.resize(frame_id + 1);
@@ -579,12 +580,12 @@ struct MatchPlan {
 };
 
 static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
-    int max_tiles = 2;
+    int max_tiles = TILE_ALIGN;
     for (const auto& f : ctx->frames)
         if (f.n >= 0) max_tiles = std::max(max_tiles, f.ntiles);
     MatchPlan pl;
     pl.row_stride = max_tiles * 32;
-    pl.wb_stride = max_tiles / 2;
+    pl.wb_stride = max_tiles / MATCH_NSUB;
     pl.wgs_per_pair = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32);
     pl.col_chunks = (max_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
     size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) +
@@ -604,7 +605,7 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
 
 template <int KS>
 static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws) {
-    match_tile_kernel<KS><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
+    match_tile_kernel<KS, MATCH_NSUB><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
         ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (int4*)(ws + pl.off_rowres),
         (int2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
 }
