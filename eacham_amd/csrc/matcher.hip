@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
         nb_cur = Bnormb[32 * t1 + cl];
         stage_tile(t2, slot_new);  // lands during this iteration; the barrier below publishes it
-        int cm1 = INT_MAX, cm2 = INT_MAX;
+        int cm1 = INT_MAX, cm2 = INT_MAX, pend[3] = {0, 0, 0};
         STAMP(0);
         if (active) {
             const v4i* curB = sB[slot_cur];
@@ -283,8 +283,26 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                     vkeys(acc[ph][r], base_c, base_r[ph][r], kr, kc);
                     rm2[ph][r] = vmed3(rm1[ph][r], rm2[ph][r], kr);
                     rm1[ph][r] = min(rm1[ph][r], kr);
-                    cm2 = vmed3(cm1, cm2, kc);
-                    cm1 = min(cm1, kc);
+                    // Column direction: all NCOL keys of the tile belong to this lane's column, so they
+                    // are taken three at a time — {min3, med3} of a triple (2 ops) then one sorted-pair
+                    // insert (3 ops) = 5 ops per 3 keys instead of 6 (and the first triple needs no insert).
+                    constexpr int NCOL = NSUB * 16;
+                    const int eg = i * EPK + e;  // compile-time after unrolling
+                    pend[eg % 3] = kc;
+                    if (eg % 3 == 2) {
+                        const int s1 = min(min(pend[0], pend[1]), pend[2]);
+                        const int s2 = vmed3(pend[0], pend[1], pend[2]);
+                        if (eg == 2) {
+                            cm1 = s1;
+                            cm2 = s2;
+                        } else {
+                            cm2 = min(min(max(cm1, s1), cm2), s2);
+                            cm1 = min(cm1, s1);
+                        }
+                    } else if (eg >= NCOL - NCOL % 3) {  // leftover keys of an incomplete last triple
+                        cm2 = vmed3(cm1, cm2, kc);
+                        cm1 = min(cm1, kc);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i == KS - 1) STAMP(1);
