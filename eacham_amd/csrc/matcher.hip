@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     constexpr int ROWS_WG = WAVES * ROWS_WAVE;
     static_assert(ROWS_WAVE <= (1 << KEY_SHIFT), "the local row must fit the key's code field");
     __shared__ v4i sB[3][TILE_V4];
-    __shared__ int2 sR[WAVES][32 * 32];
+    __shared__ int2 sR[WAVES][32 * 33];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -342,7 +342,10 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     if (!active) return;
 
     // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
-    // through this wave's private LDS slab so that lane i owns row i and scans the 32 partials.
+    // through this wave's private LDS slab (rows padded to 33 entries: conflict-free) so that lane
+    // (row, half) scans 16 of the 32 lane-partials of its row in ASCENDING lane-column order with a
+    // strict '<': equal keys (same rank, same tile) then keep the lower column, which makes plain
+    // 32-bit key compares exact — (key, lane-column) lexicographic == (rank, column) lexicographic.
     int2* slab = sR[wave];
     int4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + ROWS_WAVE * wb;
 #pragma unroll
@@ -350,29 +353,27 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            slab[row * 32 + cl] = make_int2(rm1[s][r], rm2[s][r]);
+            slab[row * 33 + cl] = make_int2(rm1[s][r], rm2[s][r]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // candidate order: (key, lane-column) lexicographic == (rank, column) lexicographic
-        long long b1 = LLONG_MAX, b2 = LLONG_MAX;
+        int b1 = INT_MAX, b2 = INT_MAX, c1 = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int cidx = 16 * h + ((j + lane) & 15);
-            int2 e = slab[cl * 32 + cidx];
-            long long k1 = ((long long)e.x << 5) | cidx, k2 = ((long long)e.y << 5) | cidx;
-            b2 = min(b2, max(b1, k1));
-            b1 = min(b1, k1);
-            b2 = min(b2, max(b1, k2));
-            b1 = min(b1, k2);
+            const int cidx = 16 * h + j;
+            const int2 e = slab[cl * 33 + cidx];
+            const bool lt = e.x < b1;
+            b2 = lt ? b1 : min(b2, e.x);
+            c1 = lt ? cidx : c1;
+            b1 = min(b1, e.x);
+            b2 = min(b2, e.y);  // e.y >= e.x: it can only be a runner-up
         }
-        long long o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
-        long long f1 = min(b1, o1);
-        long long f2 = min(max(b1, o1), min(b2, o2));
-        if (h == 0) {
-            int key1 = (int)(f1 >> 5), key2 = (int)(f2 >> 5);
-            int col1 = 32 * (tbeg + (key1 & KEY_MASK)) + (int)(f1 & 31);
+        const int o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32), oc = __shfl_xor(c1, 32);
+        if (h == 0) {  // the other half holds the higher columns: it wins only with a strictly smaller key
+            const bool lt = o1 < b1;
+            const int key1 = lt ? o1 : b1, key2 = lt ? min(b1, o2) : min(b2, o1);
+            const int col1 = 32 * (tbeg + (key1 & KEY_MASK)) + (lt ? oc : c1);
             rr[32 * s + cl] = make_int4(key1 >> KEY_SHIFT, col1, key2 >> KEY_SHIFT, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
