@@ -54,6 +54,7 @@ def lib() -> C.CDLL:
     L.eacham_version.restype = C.c_char_p
     L.eacham_upload_descriptors.argtypes = [vp, i32, vp, i32, i32]
     L.eacham_upload_descriptors_dev.argtypes = [vp, i32, vp, i32, i32]
+    L.eacham_upload_descriptors_f32.argtypes = [vp, i32, vp, i32, i32]
     L.eacham_frame_rows.argtypes = [vp, i32]
     L.eacham_clear_descriptors.argtypes = [vp]
     L.eacham_match_pair.argtypes = [vp, i32, i32, dbl, vp, vp, i32, C.POINTER(i32)]

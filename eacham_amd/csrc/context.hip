@@ -137,6 +137,7 @@ int eacham_clear_descriptors(eacham_ctx* ctx) {
     }
     ctx->frames.clear();
     ctx->ks_common = 0;
+    ctx->kind_common = 0;
     ctx->frame_table_dirty = true;
     return EACHAM_OK;
 }

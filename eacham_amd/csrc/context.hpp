@@ -58,7 +58,9 @@ struct eacham_ctx {
     int frame_table_cap = 0;
     bool frame_table_dirty = true;
     int* flag_dev = nullptr;  // [0] = non-integer descriptor seen, [1..] scratch
-    int ks_common = 0;        // KS shared by all resident frames (0 = none yet)
+    int ks_common = 0;        // k-step class shared by all resident frames (0 = none yet)
+    int kind_common = 0;      // 0 = int8 fragments (matcher.hip), 1 = fp32 fragments (matcher_f32.hip)
+    void* last_matches = nullptr;  // per-pair match lists of the last run (directed API reads them back)
 
     // matcher workspace (grown on demand, never inside a timed launch sequence after warm-up)
     void* ws = nullptr;
@@ -94,6 +96,16 @@ namespace eacham {
 int ensure_workspace(eacham_ctx* ctx, size_t bytes);
 int ensure_io(eacham_ctx* ctx, size_t bytes);
 int sync_frame_table(eacham_ctx* ctx);
+
+// matcher_f32.hip
+int upload_frame_f32(eacham_ctx* ctx, int frame_id, const float* src_dev, int n, int dim);
+int run_match_f32(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double ratio, int min_dir, int min_mutual, int mode,
+                  int* counts_dev, long long* offsets_dev, uint2* edges_dev, long long edge_cap, long long* total_dev,
+                  int4* stats_dev);
+// matcher.hip
+void launch_scan_counts(eacham_ctx* ctx, const int* counts, int n, long long* offsets, long long* total, int first, int is_last);
+void launch_compact_edges(eacham_ctx* ctx, int nb, const uint2* matches, const int* counts, const long long* offsets,
+                          int row_stride, uint2* edges, long long edge_cap);
 
 // RAII: records a start/stop HIP event pair around a launch sequence when profiling is on.
 struct ProfileScope {

@@ -543,8 +543,8 @@ static int upload_frame(eacham_ctx* ctx, int frame_id, const float* src_dev, int
     if (n < 0) return ctx->fail(EACHAM_ERR_INVALID, "negative row count");
     int ks = ks_for_dim(dim);
     if (!ks) return ctx->fail(EACHAM_ERR_UNSUPPORTED, "descriptor dim %d: need a multiple of 16, <= 256", dim);
-    if (ctx->ks_common && ctx->ks_common != ks)
-        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "all resident frames must share one descriptor dim class");
+    if (ctx->ks_common && (ctx->ks_common != ks || ctx->kind_common != 0))
+        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "all resident frames must share one descriptor kind (int8 / f32) and dim class");
     int ntiles = (n + 31) / 32;
     ntiles = (ntiles + TILE_ALIGN - 1) / TILE_ALIGN * TILE_ALIGN;
     if (ntiles > MAX_TILES)
@@ -573,11 +573,13 @@ static int upload_frame(eacham_ctx* ctx, int frame_id, const float* src_dev, int
     f.ks = ks;
     f.ntiles = ntiles;
     ctx->ks_common = ks;
+    ctx->kind_common = 0;
     ctx->frame_table_dirty = true;
     return EACHAM_OK;
 }
 
 static int check_integer_flag(eacham_ctx* ctx) {
+    if (ctx->kind_common == 1) return EACHAM_OK;  // fp32 frames take any value
     int flag = 0;
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -636,10 +638,14 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
     int rc = sync_frame_table(ctx);
     if (rc) return rc;
     if (npairs <= 0) return EACHAM_OK;
+    if (ctx->kind_common == 1)
+        return run_match_f32(ctx, pairs_dev, npairs, ratio, min_dir, min_mutual, mode, counts_dev, offsets_dev, edges_dev,
+                             edge_cap, total_dev, stats_dev);
     MatchPlan pl = make_plan(ctx, npairs);
     rc = ensure_workspace(ctx, pl.total);
     if (rc) return rc;
     char* ws = (char*)ctx->ws;
+    ctx->last_matches = ws + pl.off_matches;
     const size_t fin_smem = (size_t)2 * pl.row_stride * sizeof(int);
     if (fin_smem > 48 * 1024)
         EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)match_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_smem));
@@ -673,6 +679,14 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
         EACHAM_HIP_TRY(ctx, hipGetLastError());
     }
     return EACHAM_OK;
+}
+
+void launch_scan_counts(eacham_ctx* ctx, const int* counts, int n, long long* offsets, long long* total, int first, int is_last) {
+    scan_counts_kernel<<<1, 1024, 0, ctx->stream>>>(counts, n, offsets, total, first, is_last);
+}
+void launch_compact_edges(eacham_ctx* ctx, int nb, const uint2* matches, const int* counts, const long long* offsets,
+                          int row_stride, uint2* edges, long long edge_cap) {
+    compact_edges_kernel<<<nb, 256, 0, ctx->stream>>>(matches, counts, offsets, row_stride, edges, edge_cap);
 }
 
 static int check_pairs_host(eacham_ctx* ctx, const int32_t* pairs, int npairs) {
@@ -758,10 +772,8 @@ int eacham_match_pair(eacham_ctx* ctx, int f1, int f2, double ratio, uint32_t* o
     *out_count = count;
     if (count > cap) return ctx->fail(EACHAM_ERR_CAPACITY, "%d matches but capacity %d", count, cap);
     if (count > 0) {
-        MatchPlan pl = make_plan(ctx, 1);
         std::vector<uint2> tmp(count);
-        EACHAM_HIP_TRY(ctx, hipMemcpy(tmp.data(), (char*)ctx->ws + pl.off_matches, sizeof(uint2) * count,
-                                      hipMemcpyDeviceToHost));
+        EACHAM_HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->last_matches, sizeof(uint2) * count, hipMemcpyDeviceToHost));
         for (int k = 0; k < count; ++k) {
             out_q[k] = tmp[k].x;
             out_t[k] = tmp[k].y;

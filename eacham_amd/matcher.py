@@ -72,6 +72,13 @@ class HipContext:
             raise ValueError("descriptors must be an N x D matrix")
         self._check(self._L.eacham_upload_descriptors(self._h, frame_id, d.ctypes.data, d.shape[0], d.shape[1]))
 
+    def upload_descriptors_f32(self, frame_id: int, desc: np.ndarray):
+        """Float descriptors (SuperPoint / LightGlue style): fp32 MFMA path, any values."""
+        d = np.ascontiguousarray(desc, dtype=np.float32)
+        if d.ndim != 2:
+            raise ValueError("descriptors must be an N x D matrix")
+        self._check(self._L.eacham_upload_descriptors_f32(self._h, frame_id, d.ctypes.data, d.shape[0], d.shape[1]))
+
     def upload_descriptors_dev(self, frame_id: int, dev_ptr: int, n: int, dim: int):
         self._check(self._L.eacham_upload_descriptors_dev(self._h, frame_id, C.c_void_p(dev_ptr), n, dim))
 

@@ -195,6 +195,18 @@ def random_u8_descriptors(n: int, dim: int, seed: int, stream: int = 0, spread: 
     return np.ascontiguousarray(np.clip(np.rint(np.abs(spread * g)), 0, 255), dtype=np.float32)
 
 
+def unit_float_descriptors(n: int, dim: int, seed: int, stream: int = 0, shared: np.ndarray | None = None,
+                           noise: float = 0.15) -> np.ndarray:
+    """SuperPoint / LightGlue style descriptors (mode F32 of SURVEY.md §8(d)): unit-norm fp32 rows.
+    `shared` (m x dim, unit rows) seeds the first m rows with noisy copies, i.e. true correspondences."""
+    g = rng_normal(seed, 500_000 + stream, (n, dim))
+    if shared is not None:
+        m = min(n, shared.shape[0])
+        g[:m] = shared[:m] * np.sqrt(dim) + noise * rng_normal(seed, 600_000 + stream, (m, dim))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    return np.ascontiguousarray(g, dtype=np.float32)
+
+
 def all_pairs(n_frames: int) -> np.ndarray:
     """Unordered frame pairs (i<j), the unit of the pair loop in apps/sfm/main.cpp:84-92."""
     i, j = np.triu_indices(n_frames, k=1)

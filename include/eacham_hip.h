@@ -67,6 +67,12 @@ int eacham_upload_descriptors(eacham_ctx* ctx, int frame_id, const float* rowmaj
 /* Same, source already on the device (enqueued on the context stream; the integrality check is
  * reported by the next synchronising call). */
 int eacham_upload_descriptors_dev(eacham_ctx* ctx, int frame_id, const float* rowmajor_dev, int n, int dim);
+/* Float descriptors (SuperPoint / LightGlue style, modules/onnx/lightglue/feature/Types.h:11-14: 256-D
+ * fp32, any values): kept resident as fp32 MFMA fragments and matched with
+ *   d2 = max(fma(-2, a.b, |a|^2 + |b|^2), 0)   (fp32, a.b and the norms as k-ordered fma chains)
+ * on the f32 matrix cores. Same Match / mutual-check semantics, ties -> lower index. All resident
+ * frames must be of one kind (int8 via eacham_upload_descriptors, or fp32 via this call). dim <= 256. */
+int eacham_upload_descriptors_f32(eacham_ctx* ctx, int frame_id, const float* rowmajor, int n, int dim);
 /* Number of rows of a resident frame, or a negative error code. */
 int eacham_frame_rows(eacham_ctx* ctx, int frame_id);
 /* Drops all resident frames. */

@@ -70,6 +70,23 @@ static inline float ssd_f32(const float* a, const float* b, int dim) {
     return s;
 }
 
+/* "L2 via dot product" in fp32, the form the device's float path evaluates on the f32 MFMA:
+ *   dot = fma chain over k ascending, |x|^2 likewise, d2 = max(fma(-2, dot, |a|^2 + |b|^2), 0).
+ * (v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain, MI355X guide §3.) This is NOT the
+ * rounding of sum (a-b)^2 — near-duplicate descriptors cancel differently — so the float path's
+ * parity is stated against THIS restatement, and its agreement with ssd_f32 is reported by the tests. */
+static inline float sqnorm_f32(const float* a, int dim) {
+    float s = 0.0f;
+    for (int k = 0; k < dim; ++k) s = fmaf(a[k], a[k], s);
+    return s;
+}
+static inline float dist2_dot_f32(const float* a, const float* b, int dim, float na, float nb) {
+    float dot = 0.0f;
+    for (int k = 0; k < dim; ++k) dot = fmaf(a[k], b[k], dot);
+    float d2 = fmaf(-2.0f, dot, na + nb);
+    return d2 > 0.0f ? d2 : 0.0f;
+}
+
 /* exact integer squared L2 for u8 data (vectorises; equals ssd_f32 bit-for-bit on such data
  * because every partial sum is an integer < 2^24) */
 static inline int32_t ssd_u8(const uint8_t* a, const uint8_t* b, int dim) {
@@ -95,8 +112,8 @@ static int to_u8(const float* x, int64_t count, uint8_t* out) {
  * Both directions of one unordered pair from a single pass over the distance matrix.
  * fwd[q] (n1 entries) / bwd[t] (n2 entries): top-2 state of each row of A against B / each row of
  * B against A. The q-outer / t-inner loop visits train candidates in ascending order for both.
- * force_f32 != 0 disables the (bit-identical) integer fast path; used by the tests to prove the
- * two paths agree.
+ * force_f32 = 1 disables the (bit-identical) integer fast path (the tests prove the two agree);
+ * force_f32 = 2 selects the fp32 dot-product form of the device's float path.
  */
 static void top2_both(const float* A, int n1, const float* B, int n2, int dim, int force_f32,
                       top2_t* fwd, top2_t* bwd) {
@@ -109,10 +126,18 @@ static void top2_both(const float* A, int n1, const float* B, int n2, int dim, i
         b8 = (uint8_t*)malloc((size_t)n2 * dim);
         use_u8 = a8 && b8 && to_u8(A, (int64_t)n1 * dim, a8) && to_u8(B, (int64_t)n2 * dim, b8);
     }
+    float *na = NULL, *nb = NULL;
+    if (force_f32 == 2) {
+        na = (float*)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
+        nb = (float*)malloc(sizeof(float) * (size_t)(n2 > 0 ? n2 : 1));
+        for (int q = 0; q < n1; ++q) na[q] = sqnorm_f32(A + (size_t)q * dim, dim);
+        for (int t = 0; t < n2; ++t) nb[t] = sqnorm_f32(B + (size_t)t * dim, dim);
+    }
     for (int q = 0; q < n1; ++q) {
         for (int t = 0; t < n2; ++t) {
-            float d2 = use_u8 ? (float)ssd_u8(a8 + (size_t)q * dim, b8 + (size_t)t * dim, dim)
-                              : ssd_f32(A + (size_t)q * dim, B + (size_t)t * dim, dim);
+            float d2 = force_f32 == 2 ? dist2_dot_f32(A + (size_t)q * dim, B + (size_t)t * dim, dim, na[q], nb[t])
+                       : use_u8     ? (float)ssd_u8(a8 + (size_t)q * dim, b8 + (size_t)t * dim, dim)
+                                    : ssd_f32(A + (size_t)q * dim, B + (size_t)t * dim, dim);
             float d = sqrtf(d2);
             top2_push(&fwd[q], d, t);
             top2_push(&bwd[t], d, q);
@@ -120,6 +145,8 @@ static void top2_both(const float* A, int n1, const float* B, int n2, int dim, i
     }
     free(a8);
     free(b8);
+    free(na);
+    free(nb);
 }
 
 /* Directed Match(A, B): returns the number of (q, t) written, sorted by q. */
@@ -212,7 +239,7 @@ int oracle_match_mutual(const float* A, int n1, const float* B, int n2, int dim,
 int oracle_match_all_pairs(const float* const* desc, const int32_t* n, int dim,
                            const int32_t* pairs, int npairs, double ratio, int min_dir,
                            int min_mutual, int nthreads, int32_t* counts, uint32_t* matches,
-                           int stride, int32_t* stats) {
+                           int stride, int32_t* stats, int force_f32) {
     int used = 1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -225,7 +252,7 @@ int oracle_match_all_pairs(const float* const* desc, const int32_t* n, int dim,
         uint32_t* q = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap);
         uint32_t* t = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap);
         int c = oracle_match_mutual(desc[f1], n[f1], desc[f2], n[f2], dim, ratio, min_dir,
-                                    min_mutual, 0, q, t, stats ? stats + 4 * p : NULL);
+                                    min_mutual, force_f32, q, t, stats ? stats + 4 * p : NULL);
         counts[p] = c;
         for (int k = 0; k < c && k < stride; ++k) {
             matches[((size_t)p * stride + k) * 2 + 0] = q[k];

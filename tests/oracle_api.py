@@ -55,7 +55,7 @@ def match_mutual(A, B, ratio=0.8, min_dir=30, min_mutual=30, force_f32=False):
     return q[:cnt].copy(), t[:cnt].copy(), stats
 
 
-def match_all_pairs(descs, pairs, ratio=0.8, min_dir=30, min_mutual=30, nthreads=0):
+def match_all_pairs(descs, pairs, ratio=0.8, min_dir=30, min_mutual=30, nthreads=0, force_f32=0):
     """Returns (counts, offsets, q, t, stats, threads_used) in the CSR form of the C-ABI."""
     L = oracle.lib()
     descs = [_f32(d) for d in descs]
@@ -72,7 +72,7 @@ def match_all_pairs(descs, pairs, ratio=0.8, min_dir=30, min_mutual=30, nthreads
     used = L.oracle_match_all_pairs(ptrs, C.c_void_p(n.ctypes.data), dim, C.c_void_p(pairs.ctypes.data),
                                     npairs, C.c_double(ratio), min_dir, min_mutual, nthreads,
                                     C.c_void_p(counts.ctypes.data), C.c_void_p(matches.ctypes.data),
-                                    stride, C.c_void_p(stats.ctypes.data))
+                                    stride, C.c_void_p(stats.ctypes.data), int(force_f32))
     offsets = np.zeros(npairs + 1, dtype=np.int64)
     np.cumsum(counts, out=offsets[1:])
     q = np.concatenate([matches[p, :counts[p], 0] for p in range(npairs)]) if npairs else np.zeros(0, np.uint32)

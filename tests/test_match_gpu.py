@@ -192,3 +192,67 @@ def test_full_size_properties(hip_ctx):
     got = hip_ctx.match_all_pairs(pairs[:2])
     _assert_csr_equal(got, want)
     hip_ctx.clear_descriptors()
+
+
+# ---- float descriptors (SuperPoint / LightGlue style): fp32 MFMA path ---------------------------------
+def _float_frames(ns, dim, seed=61):
+    base = synth.unit_float_descriptors(max(ns), dim, seed, 99)
+    return [synth.unit_float_descriptors(n, dim, seed, k, shared=base[: n // 2]) for k, n in enumerate(ns)]
+
+
+def _upload_f32(ctx, descs):
+    ctx.clear_descriptors()
+    for f, d in enumerate(descs):
+        ctx.upload_descriptors_f32(f, d)
+
+
+@pytest.mark.parametrize("ns,dim", [((300, 257), 256), ((130, 64, 1, 0, 97), 128), ((200, 333), 60), ((2000, 1900), 256)])
+def test_f32_path_is_bit_exact_against_the_dot_form_oracle(hip_ctx, ns, dim):
+    descs = _float_frames(ns, dim)
+    _upload_f32(hip_ctx, descs)
+    for a in range(len(ns)):
+        for b in range(len(ns)):
+            if a == b or (len(ns) > 2 and abs(a - b) > 1):
+                continue
+            q, t = hip_ctx.match_pair(a, b)
+            qo, to = O.match_directed(descs[a], descs[b], force_f32=2)
+            assert np.array_equal(q, qo) and np.array_equal(t, to), (a, b)
+    pairs = synth.all_pairs(len(ns))
+    got = hip_ctx.match_all_pairs(pairs, min_dir=3, min_mutual=2)
+    want = O.match_all_pairs(descs, pairs, min_dir=3, min_mutual=2, force_f32=2)
+    _assert_csr_equal(got, want)
+    assert got[0].sum() > 0 or min(ns) < 8
+    hip_ctx.clear_descriptors()
+
+
+def test_f32_path_agrees_with_sum_of_squared_differences(hip_ctx):
+    """The dot-product form rounds differently from OpenCV's sum (a-b)^2; on well-separated
+    descriptors the match lists must coincide (index-agreement report of SURVEY.md §8(d), mode F32)."""
+    descs = _float_frames((1500, 1400), 256, seed=5)
+    _upload_f32(hip_ctx, descs)
+    q, t = hip_ctx.match_pair(0, 1)
+    qs, ts = O.match_directed(descs[0], descs[1], force_f32=1)
+    got, ref = dict(zip(q.tolist(), t.tolist())), dict(zip(qs.tolist(), ts.tolist()))
+    same = sum(1 for k, v in ref.items() if got.get(k) == v)
+    agreement = same / max(len(ref), 1)
+    print(f"f32 index agreement with the SSD form: {same}/{len(ref)} = {agreement:.5f}; extra {len(got) - same}")
+    assert len(ref) > 500 and agreement >= 0.999 and abs(len(got) - len(ref)) <= max(2, len(ref) // 500)
+    hip_ctx.clear_descriptors()
+
+
+def test_f32_ties_and_kind_mixing(hip_ctx):
+    A = synth.unit_float_descriptors(70, 64, 3, 0)
+    B = np.concatenate([synth.unit_float_descriptors(40, 64, 3, 1), A[:8], A[:8]])  # duplicated train rows
+    _upload_f32(hip_ctx, [A, B])
+    for a, b, X, Y in [(0, 1, A, B), (1, 0, B, A)]:
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(X, Y, force_f32=2)
+        assert np.array_equal(q, qo) and np.array_equal(t, to)
+    with pytest.raises(EachamError) as e:   # int8 and fp32 frames cannot be resident together
+        hip_ctx.upload_descriptors(2, np.zeros((4, 64), np.float32))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    hip_ctx.clear_descriptors()
+    hip_ctx.upload_descriptors(0, np.zeros((4, 64), np.float32))
+    with pytest.raises(EachamError):
+        hip_ctx.upload_descriptors_f32(1, A)
+    hip_ctx.clear_descriptors()
