@@ -155,7 +155,15 @@ class FeatureMatcherHip:
 
     def Match(self, descriptor1: np.ndarray, descriptor2: np.ndarray) -> dict:
         a, b = self._scratch, self._scratch + 1
-        self.ctx.upload_descriptors(a, descriptor1)
-        self.ctx.upload_descriptors(b, descriptor2)
+        self.ctx.clear_descriptors()
+        try:  # SIFT-style integers: exact int8 path; other floats: fp32 MFMA path
+            self.ctx.upload_descriptors(a, descriptor1)
+            self.ctx.upload_descriptors(b, descriptor2)
+        except capi.EachamError as e:
+            if e.code not in (capi.ERR_NOT_INTEGER, capi.ERR_UNSUPPORTED):
+                raise
+            self.ctx.clear_descriptors()
+            self.ctx.upload_descriptors_f32(a, descriptor1)
+            self.ctx.upload_descriptors_f32(b, descriptor2)
         q, t = self.ctx.match_pair(a, b, self.ratio)
         return dict(zip(q.tolist(), t.tolist()))

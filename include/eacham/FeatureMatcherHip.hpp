@@ -72,8 +72,18 @@ public:
 
     MatchType Match(const DescriptorView& d1, const DescriptorView& d2) override {
         std::lock_guard<std::mutex> lock(mu_);  // the two scratch frame slots are shared
-        ctx_.check(eacham_upload_descriptors(ctx_.get(), kSlotA, d1.data, d1.rows, d1.dim));
-        ctx_.check(eacham_upload_descriptors(ctx_.get(), kSlotB, d2.data, d2.rows, d2.dim));
+        // SIFT-style integer descriptors take the exact int8 path; anything else (SuperPoint /
+        // LightGlue floats, modules/onnx/lightglue/feature/Types.h:11-14) the fp32 MFMA path.
+        ctx_.check(eacham_clear_descriptors(ctx_.get()));
+        int rc = eacham_upload_descriptors(ctx_.get(), kSlotA, d1.data, d1.rows, d1.dim);
+        if (rc == EACHAM_OK) rc = eacham_upload_descriptors(ctx_.get(), kSlotB, d2.data, d2.rows, d2.dim);
+        if (rc == EACHAM_ERR_NOT_INTEGER || rc == EACHAM_ERR_UNSUPPORTED) {
+            ctx_.check(eacham_clear_descriptors(ctx_.get()));
+            ctx_.check(eacham_upload_descriptors_f32(ctx_.get(), kSlotA, d1.data, d1.rows, d1.dim));
+            ctx_.check(eacham_upload_descriptors_f32(ctx_.get(), kSlotB, d2.data, d2.rows, d2.dim));
+        } else {
+            ctx_.check(rc);
+        }
         std::vector<uint32_t> q(d1.rows > 0 ? d1.rows : 1), t(q.size());
         int count = 0;
         ctx_.check(eacham_match_pair(ctx_.get(), kSlotA, kSlotB, ratio_, q.data(), t.data(), (int)q.size(), &count));

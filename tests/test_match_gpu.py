@@ -140,6 +140,13 @@ def test_feature_matcher_interface(hip_ctx):
     got = m.Match(A, B)
     q, t = O.match_directed(A, B)
     assert got == dict(zip(q.tolist(), t.tolist())) and len(got) > 100
+    # float descriptors go through the same interface (fp32 path)
+    base = synth.unit_float_descriptors(120, 256, 2, 9)
+    Af = synth.unit_float_descriptors(120, 256, 2, 0, shared=base)
+    Bf = synth.unit_float_descriptors(140, 256, 2, 1, shared=base)
+    got = m.Match(Af, Bf)
+    q, t = O.match_directed(Af, Bf, force_f32=2)
+    assert got == dict(zip(q.tolist(), t.tolist())) and len(got) > 60
     hip_ctx.clear_descriptors()
 
 
