@@ -165,8 +165,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_MFMA_PEAK_TOPS,
                          # HBM bytes of one full-batch launch (1872 pairs x 8 workgroups x 256 threads)
-                         "traffic": measured_traffic("eacham::match_tile_kernel<8>", 1872 * 8 * 256) if args.kpts == 2000 and args.dim == 256 else None,
-                         "kernel": "match_tile_kernel<8>", "launches": launches,
+                         "traffic": measured_traffic("eacham::match_tile_kernel<8, 2>", 1872 * 8 * 256) if args.kpts == 2000 and args.dim == 256 else None,
+                         "kernel": "match_tile_kernel<8, 2>", "launches": launches,
                          "avg_launch_ms": tile_ms / max(launches, 1),
                          "finalize_ms_per_step": fin_ms / args.steps},
         }
