@@ -5,7 +5,7 @@
 // of apps/sfm/main.cpp:84-147); only the arithmetic differs:
 //     d2(q,t) = max(fma(-2, a_q.b_t, |a_q|^2 + |b_t|^2), 0)      all fp32
 // with a.b accumulated by v_mfma_f32_32x32x2_f32, which is bit-for-bit a k-ordered fmaf chain, and the
-// norms accumulated by the same chain. oracle/match_oracle.c (force_f32 = 2) restates exactly this,
+// norms accumulated by the same chain. The CPU restatement used by the tests (its dot-product mode) evaluates exactly this,
 // so indices are bit-exact against it; agreement with the sum-of-squared-differences form is
 // reported by tests/test_match_gpu.py. Ties resolve to the lower index like the reference's scan.
 //
