@@ -21,6 +21,7 @@ KERNEL_BA_LINEARIZE = 2
 KERNEL_BA_SCHUR = 3
 KERNEL_BA_SOLVE = 4
 KERNEL_BA_ERROR = 5
+KERNEL_TRIANGULATE = 6
 
 
 class EachamError(RuntimeError):
@@ -66,6 +67,8 @@ def lib() -> C.CDLL:
     L.eacham_ba_release.argtypes = [vp, vp]
     L.eacham_ba_release.restype = None
     L.eacham_ba_debug_step.argtypes = [vp, vp, dbl, vp, vp, vp, vp, vp, vp]
+    L.eacham_triangulate_tracks.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
+    L.eacham_reprojection_errors.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.eacham_profile_enable.argtypes = [vp, i32]
     L.eacham_profile_reset.argtypes = [vp]
     L.eacham_profile_get.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(dbl)]

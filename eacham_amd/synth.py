@@ -211,3 +211,35 @@ def all_pairs(n_frames: int) -> np.ndarray:
     """Unordered frame pairs (i<j), the unit of the pair loop in apps/sfm/main.cpp:84-92."""
     i, j = np.triu_indices(n_frames, k=1)
     return np.ascontiguousarray(np.stack([i, j], axis=1), dtype=np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# triangulation tracks
+# --------------------------------------------------------------------------------------------
+
+def make_tracks(scene, n_tracks: int | None = None, seed: int = MASTER_SEED, min_obs: int = 2, max_obs: int | None = None,
+                outlier_frac: float = 0.15, outlier_px: float = 30.0, use_true_poses: bool = True):
+    """Candidate tracks as TriangulateFrame builds them (Triangulator.cpp:248-262): per landmark a
+    subset of its observers (sorted by frame id, as the reference's std::map iterates), the noisy
+    pixels of the scene, and for `outlier_frac` of the tracks one observation displaced by
+    `outlier_px`. Returns dict(transforms n_cams x 16, track_ptr, obs_frame, obs_uv, K, landmark)."""
+    n_lm = scene["points_true"].shape[0]
+    k = int(scene["observers"][0])
+    max_obs = k if max_obs is None else min(max_obs, k)
+    n_tracks = n_lm if n_tracks is None else min(n_tracks, n_lm)
+    cam = scene["obs_cam"].reshape(n_lm, k)[:n_tracks]
+    uv = scene["obs_uv"].reshape(n_lm, k, 2)[:n_tracks]
+    m = min_obs + (rng_u64(seed, 700_001, np.arange(n_tracks)) % _U64(max_obs - min_obs + 1)).astype(np.int64)
+    rank = np.argsort(rng_u64(seed, 700_002, np.arange(n_tracks * k)).reshape(n_tracks, k), axis=1, kind="stable")
+    keep = rank < m[:, None]  # m random observers per track, original (frame-sorted) order kept
+    track_ptr = np.zeros(n_tracks + 1, dtype=np.int32)
+    track_ptr[1:] = np.cumsum(m)
+    obs_frame = cam[keep].astype(np.uint32)
+    obs_uv = uv[keep].copy()
+    bad = rng_uniform(seed, 700_003, (n_tracks,)) < outlier_frac
+    which = (rng_u64(seed, 700_004, np.arange(n_tracks)) % m.astype(np.uint64)).astype(np.int64)
+    sel = track_ptr[:-1][bad] + which[bad]
+    obs_uv[sel] += outlier_px
+    T = scene["T_true"] if use_true_poses else scene["T_init"]
+    return {"transforms": np.ascontiguousarray(T.reshape(-1, 16)), "track_ptr": track_ptr, "obs_frame": obs_frame,
+            "obs_uv": np.ascontiguousarray(obs_uv), "K": scene["K"].copy(), "landmark": np.arange(n_tracks)}

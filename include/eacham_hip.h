@@ -208,6 +208,32 @@ int eacham_ba_debug_step(eacham_ctx* ctx, const eacham_ba_problem* problem, doub
                          double* S, double* g, double* delta_cams, double* delta_points,
                          double* error, double* lin_change);
 
+/* ---- triangulation -------------------------------------------------
+ * Batch form of TriangulateFrame's per-point call of TriangulatePointRansac
+ * (/root/reference/modules/sfm/reconstruction/Triangulator.cpp:96-186 and :248-275; call sites
+ * apps/sfm/main.cpp:203-210 with config.maxReprError / config.minTriAngle in radians).
+ *   transforms   n_frames x 16 row-major world->camera matrices (Node::GetTransform)
+ *   track_ptr    n_tracks+1 CSR offsets into the observation arrays (track = one candidate point;
+ *                at most 64 observations per track, else EACHAM_ERR_CAPACITY)
+ *   obs_frame    row of `transforms` per observation;  obs_uv  pixel (x, y) per observation
+ *   K            fx, fy, cx, cy
+ * Outputs (host): points n_tracks x 3 = the `point3d` the reference leaves behind (the LAST pair's
+ * triangulation); status[t] bit 0 = TriangulatePointRansac's return value, bit 1 = mask non-empty
+ * and every observation an inlier — TriangulateFrame adds the point iff status[t] == 3 (:270-275);
+ * masks = the reference's `inliers` vector per observation.
+ * Tracks with fewer than 2 observations get status 0 and a zero point, as :104-107 does. */
+int eacham_triangulate_tracks(eacham_ctx* ctx, const double* transforms, int n_frames, int n_tracks,
+                              const int32_t* track_ptr, const uint32_t* obs_frame, const double* obs_uv,
+                              const double* K, float max_repr_error, float min_tri_angle, double* points,
+                              int32_t* status, uint8_t* masks);
+
+/* Reprojection error of n (frame, map point, pixel) items: CalcReprojectionError(uv,
+ * transformPoint3d(point, T[frame]), K) as a float (ProjectionHelper.cpp:32-38), the re-observation
+ * gate of TriangulateFrame (Triangulator.cpp:222-236). */
+int eacham_reprojection_errors(eacham_ctx* ctx, const double* transforms, int n_frames, int n,
+                               const uint32_t* frame, const double* points, const double* uv, const double* K,
+                               float* err);
+
 /* ---- kernel timing (HIP events on the context stream; used for roofline reporting) ---------- */
 
 #define EACHAM_KERNEL_MATCH_TILE 0     /* all-pairs int8 MFMA distance + fused row/col top-2      */
@@ -216,6 +242,7 @@ int eacham_ba_debug_step(eacham_ctx* ctx, const eacham_ba_problem* problem, doub
 #define EACHAM_KERNEL_BA_SCHUR 3
 #define EACHAM_KERNEL_BA_SOLVE 4
 #define EACHAM_KERNEL_BA_ERROR 5
+#define EACHAM_KERNEL_TRIANGULATE 6     /* pair DLT + scoring and the per-track selection          */
 #define EACHAM_KERNEL_COUNT 8
 
 /* Enables (1) / disables (0) per-launch HIP-event timing of the kernels above. */

@@ -89,3 +89,57 @@ def ba_error_np(arrays, T_wc=None, points=None, K=None):
     # calibration prior
     err += 0.5 * np.sum(((Kv - K0) / np.array([25, 25, 1e-5, 1e-4, 1e-4])) ** 2)
     return float(err)
+
+
+# ---- triangulation (numpy SVD as the third opinion) ------------------------------------------
+
+def tri_point(T1, T2, uv1, uv2, K4):
+    """Triangulator.cpp:49-77 with numpy's LAPACK SVD instead of a Jacobi SVD."""
+    T1, T2 = np.reshape(T1, (4, 4)), np.reshape(T2, (4, 4))
+    x1, y1 = (uv1[0] - K4[2]) / K4[0], (uv1[1] - K4[3]) / K4[1]
+    x2, y2 = (uv2[0] - K4[2]) / K4[0], (uv2[1] - K4[3]) / K4[1]
+    A = np.stack([y1 * T1[2] - T1[1], x1 * T1[2] - T1[0], y2 * T2[2] - T2[1], x2 * T2[2] - T2[0]])
+    v = np.linalg.svd(A)[2][3]
+    return v[:3] / v[3]
+
+
+def tri_angle(T1, T2, X):
+    c1 = np.linalg.inv(np.reshape(T1, (4, 4)))[:3, 3]
+    c2 = np.linalg.inv(np.reshape(T2, (4, 4)))[:3, 3]
+    r1, r2 = X - c1, X - c2
+    n1, n2 = np.linalg.norm(r1), np.linalg.norm(r2)
+    if n1 < np.float32(0.0000001) or n2 < np.float32(0.0000001):
+        return 0.0
+    a = np.arccos(r1 @ r2 / (n1 * n2))
+    return min(a, np.pi - a)
+
+
+def tri_inlier(T, uv, K4, X, max_err):
+    T = np.reshape(T, (4, 4))
+    p = T[:3, :3] @ X + T[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u, v = K4[0] * p[0] / p[2] + K4[2], K4[1] * p[1] / p[2] + K4[3]
+        err = np.float32(np.sqrt((uv[0] - u) ** 2 + (uv[1] - v) ** 2))
+    return bool(err < np.float32(max_err)) and bool(T[2] @ np.append(X, 1.0) >= np.finfo(float).eps)
+
+
+def tri_ransac(Ts, uvs, K4, max_err, min_angle):
+    """Triangulator.cpp:96-186 literally. Returns (ok, point, mask list)."""
+    m = len(Ts)
+    if m < 2:
+        return False, np.zeros(3), []
+    if m < 3:
+        X = tri_point(Ts[0], Ts[1], uvs[0], uvs[1], K4)
+        if tri_angle(Ts[0], Ts[1], X) < np.float32(min_angle):
+            return False, X, []
+        mask = [tri_inlier(Ts[i], uvs[i], K4, X, max_err) for i in range(m)]
+        return bool(X[2] > 0), X, mask
+    best, mask, X = 0, [], np.zeros(3)
+    for r1 in range(m - 1):
+        for r2 in range(r1 + 1, m):
+            X = tri_point(Ts[r1], Ts[r2], uvs[r1], uvs[r2], K4)
+            if tri_angle(Ts[r1], Ts[r2], X) >= np.float32(min_angle):
+                loc = [tri_inlier(Ts[i], uvs[i], K4, X, max_err) for i in range(m)]
+                if sum(loc) > best:
+                    best, mask = sum(loc), loc
+    return bool(X[2] > 0 and best > 2), X, mask

@@ -141,3 +141,56 @@ def ba_solve(arrays, cfg, min_landmarks=50, trace_cap=1024, nthreads=0):
                             extra=(C.c_int(nthreads),))
     assert rc == 0, rc
     return out
+
+
+# ---- triangulation ---------------------------------------------------------------------------
+
+def tri_point(T1, T2, uv1, uv2, K4):
+    L = oracle.lib()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (np.reshape(T1, 16), np.reshape(T2, 16), uv1, uv2, K4)]
+    out = np.zeros(3)
+    L.oracle_triangulate_point.restype = None
+    L.oracle_triangulate_point(*[C.c_void_p(x.ctypes.data) for x in a], C.c_void_p(out.ctypes.data))
+    return out
+
+
+def tri_angle(T1, T2, X):
+    L = oracle.lib()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (np.reshape(T1, 16), np.reshape(T2, 16), X)]
+    L.oracle_triangulation_angle.restype = C.c_double
+    return L.oracle_triangulation_angle(*[C.c_void_p(x.ctypes.data) for x in a])
+
+
+def tri_tracks(transforms, track_ptr, obs_frame, obs_uv, K4, max_err, min_angle):
+    L = oracle.lib()
+    T = np.ascontiguousarray(transforms, dtype=np.float64).reshape(-1, 16)
+    tp = np.ascontiguousarray(track_ptr, dtype=np.int32)
+    of = np.ascontiguousarray(obs_frame, dtype=np.uint32)
+    uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2)
+    K4 = np.ascontiguousarray(K4, dtype=np.float64)
+    n = tp.size - 1
+    pts = np.zeros((n, 3))
+    status = np.zeros(n, dtype=np.int32)
+    masks = np.zeros(of.size, dtype=np.uint8)
+    vp = C.c_void_p
+    rc = L.oracle_triangulate_tracks(vp(T.ctypes.data), C.c_int(n), vp(tp.ctypes.data), vp(of.ctypes.data), vp(uv.ctypes.data),
+                                     vp(K4.ctypes.data), C.c_float(max_err), C.c_float(min_angle), vp(pts.ctypes.data),
+                                     vp(status.ctypes.data), vp(masks.ctypes.data))
+    if rc != 0:
+        raise ValueError("oracle_triangulate_tracks: a track has more than 64 observations")
+    return pts, status, masks
+
+
+def reprojection_errors(transforms, frame, points, uv, K4):
+    L = oracle.lib()
+    T = np.ascontiguousarray(transforms, dtype=np.float64).reshape(-1, 16)
+    fr = np.ascontiguousarray(frame, dtype=np.uint32)
+    P = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    U = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+    K4 = np.ascontiguousarray(K4, dtype=np.float64)
+    err = np.zeros(fr.size, dtype=np.float32)
+    vp = C.c_void_p
+    L.oracle_reprojection_errors.restype = None
+    L.oracle_reprojection_errors(vp(T.ctypes.data), C.c_int(fr.size), vp(fr.ctypes.data), vp(P.ctypes.data), vp(U.ctypes.data),
+                                 vp(K4.ctypes.data), vp(err.ctypes.data))
+    return err

@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _build(tmp):
-    exe = os.path.join(tmp, "adapter_driver")
+def _build(tmp, name="adapter_driver"):
+    exe = os.path.join(tmp, name)
     lib = os.path.join(ROOT, "eacham_amd", "lib")
-    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_driver.cpp"),
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
            "-o", exe, "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
@@ -114,3 +114,140 @@ def test_cpp_adapters_against_oracle(tmp_path):
         assert np.abs(Ps[lm - 100] - ref.points[idx]).max() < 1e-7 and st_out[lm - 100] == 1
     untouched = [j for j in range(n_lm) if (j + 100) not in lm_index]
     assert np.array_equal(Ps[untouched], bsc["points_init"][untouched]) and np.array_equal(st_out[untouched], status[untouched].astype(np.int32))
+
+
+def test_cpp_triangulate_frame_against_oracle_walk(tmp_path):
+    """TriangulatorHip.hpp: TriangulatePointRansac + TriangulateFrame (Triangulator.cpp:96-300)."""
+    tmp = str(tmp_path)
+    exe = _build(tmp, "tri_driver")
+    sc = synth.make_scene(8, 300, 5, seed=31, pixel_noise=1.0)
+    ids = [3, 4, 7, 9, 12, 15, 16, 20]
+    valid = [1, 1, 1, 0, 1, 1, 1, 1]
+    cur = 5                                            # node 15 is being inserted
+    frame_id = ids[cur]
+    K, T = sc["K"], sc["T_true"]
+    K9 = np.array([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1.0])
+    max_err, min_angle, min_obs = np.float32(4.0), np.float32(3.0 * 3.141592 / 180.0), 2
+    # keypoints per node, in observation order; keypoint pixels are stored as float (cv::Point2f)
+    kp = {i: [] for i in ids}
+    kp_of = {}                                         # (node, landmark) -> keypoint index
+    for o in range(len(sc["obs_cam"])):
+        node = ids[int(sc["obs_cam"][o])]
+        lm = int(sc["obs_lm"][o])
+        kp_of[(node, lm)] = len(kp[node])
+        uv = sc["obs_uv"][o].astype(np.float32)
+        if lm % 7 == 0 and node == frame_id:
+            uv = uv + np.float32(40.0)                  # bad keypoints in the new frame
+        kp[node].append(uv)
+    # existing map: landmarks 0,3,6,... were triangulated earlier from the other frames
+    p3 = {i: {} for i in ids}
+    mpts = {}
+    for lm in range(0, 300, 3):
+        obs = {n: kp_of[(n, lm)] for n in ids if n != frame_id and (n, lm) in kp_of}
+        if len(obs) < 2:
+            continue
+        if lm % 2 == 0:
+            obs = dict(list(obs.items())[:2])          # only two observers: fails the `> 2` gate
+        pid = 1000 + lm
+        mpts[pid] = {"p": sc["points_true"][lm] + 0.001, "valid": True, "obs": dict(obs)}
+        for n, k in obs.items():
+            p3[n][k] = pid
+    factors = {}
+    for n in ids:
+        if n == frame_id:
+            continue
+        mm = [(kp_of[(frame_id, lm)], kp_of[(n, lm)]) for lm in range(300) if (frame_id, lm) in kp_of and (n, lm) in kp_of]
+        if mm:
+            factors[n] = mm
+
+    fin, fout = os.path.join(tmp, "tin.bin"), os.path.join(tmp, "tout.bin")
+    first = sorted(factors)[0]
+    lm_single = [lm for lm in range(300) if sum((n, lm) in kp_of for n in ids) >= 3][0]
+    single = [(n, kp_of[(n, lm_single)]) for n in ids if (n, lm_single) in kp_of]
+    with open(fin, "wb") as f:
+        f.write(struct.pack("i", len(ids)))
+        for k, i in enumerate(ids):
+            f.write(struct.pack("Ii", i, valid[k])); f.write(T[k].astype(np.float64).tobytes())
+            f.write(struct.pack("i", len(kp[i]))); f.write(np.array(kp[i], np.float32).reshape(-1).tobytes())
+            f.write(struct.pack("i", len(p3[i])))
+            for a, b in sorted(p3[i].items()):
+                f.write(struct.pack("II", a, b))
+            fs = factors if i == frame_id else {}
+            f.write(struct.pack("i", len(fs)))
+            for other in sorted(fs):
+                f.write(struct.pack("Ii", other, len(fs[other]))); f.write(np.array(fs[other], np.uint32).tobytes())
+        f.write(struct.pack("i", len(mpts)))
+        for pid in sorted(mpts):
+            f.write(struct.pack("I", pid)); f.write(mpts[pid]["p"].astype(np.float64).tobytes())
+            f.write(struct.pack("ii", 1, len(mpts[pid]["obs"])))
+            for a, b in sorted(mpts[pid]["obs"].items()):
+                f.write(struct.pack("II", a, b))
+        f.write(K9.tobytes()); f.write(struct.pack("IIff", frame_id, min_obs, max_err, min_angle))
+        f.write(struct.pack("i", len(single)))
+        for n, k in single:
+            f.write(T[ids.index(n)].astype(np.float64).tobytes()); f.write(kp[n][k].astype(np.float64).tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    # ---- the same walk in Python on the oracle ----
+    Tt = T.reshape(-1, 16)
+    row = {n: k for k, n in enumerate(ids)}
+    full = {}
+    reobs = 0
+    for other in sorted(factors):
+        if not valid[row[other]]:
+            continue
+        for m1, m2 in factors[other]:
+            if m2 in p3[other]:
+                pid = p3[other][m2]
+                err = O.reprojection_errors(Tt, [row[frame_id]], [mpts[pid]["p"]], [kp[frame_id][m1].astype(np.float64)], K)[0]
+                if len(mpts[pid]["obs"]) > 2 and err < max_err:
+                    p3[frame_id][m1] = pid
+                    mpts[pid]["obs"][frame_id] = m1
+                    reobs += 1
+                    continue
+            full.setdefault(m1, {})[frame_id] = m1
+            full[m1][other] = m2
+    tp, fr, uv, tracks = [0], [], [], []
+    for m1 in sorted(full):
+        if len(full[m1]) < min_obs:
+            continue
+        for n in sorted(full[m1]):
+            fr.append(row[n]); uv.append(kp[n][full[m1][n]].astype(np.float64))
+        tp.append(len(fr)); tracks.append(full[m1])
+    pts, status, _ = O.tri_tracks(Tt, tp, fr, np.array(uv), K, max_err, min_angle)
+    next_id = max(mpts)
+    added = 0
+    for t, obs in enumerate(tracks):
+        if status[t] == 3:
+            next_id += 1
+            mpts[next_id] = {"p": pts[t], "valid": True, "obs": {}}
+            for n in sorted(obs):
+                k = obs[n]
+                if k in p3[n]:
+                    old = p3[n][k]
+                    mpts[old]["obs"].pop(n, None); mpts[old]["valid"] = False
+                p3[n][k] = next_id
+                mpts[next_id]["obs"][n] = k
+            added += 1
+    assert added > 10 and reobs > 5 and added < len(tracks)
+
+    with open(fout, "rb") as f:
+        sgl, X = _vec(f, np.int32), _vec(f, np.float64)
+        spts, sst, smask = O.tri_tracks(np.array([T[ids.index(n)].reshape(16) for n, _ in single]), [0, len(single)], np.arange(len(single)),
+                                        np.array([kp[n][k].astype(np.float64) for n, k in single]), K, max_err, min_angle)
+        assert sgl[0] == (sst[0] & 1) and np.allclose(X, spts[0], rtol=1e-9)
+        assert sgl[1:].tolist() == (smask.tolist() if smask.any() else [])
+        meta = _vec(f, np.uint32)
+        assert meta.tolist() == [len(tracks), added, reobs, next_id]
+        for n in ids:
+            flat = _vec(f, np.uint32).reshape(-1, 2)
+            assert dict(map(tuple, flat.tolist())) == p3[n], n
+        gid, gvalid, gP, gobs = _vec(f, np.uint32), _vec(f, np.uint32), _vec(f, np.float64).reshape(-1, 3), _vec(f, np.uint32)
+    assert gid.tolist() == sorted(mpts)
+    pos = 0
+    for j, pid in enumerate(gid.tolist()):
+        assert bool(gvalid[j]) == mpts[pid]["valid"], pid
+        assert np.allclose(gP[j], mpts[pid]["p"], rtol=1e-9, atol=1e-12), pid
+        cnt = int(gobs[pos]); flat = gobs[pos + 1:pos + 1 + 2 * cnt].reshape(-1, 2); pos += 1 + 2 * cnt
+        assert dict(map(tuple, flat.tolist())) == mpts[pid]["obs"], pid
