@@ -165,7 +165,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_MFMA_PEAK_TOPS,
                          # HBM bytes of one full-batch launch (1872 pairs x 8 workgroups x 256 threads)
-                         "traffic": measured_traffic("eacham::match_tile_kernel<8, 2>", 1872 * 8 * 256) if args.kpts == 2000 and args.dim == 256 else None,
+                         "traffic": measured_traffic("eacham::match_tile_kernel<8, 2>") if args.kpts == 2000 and args.dim == 256 else None,
                          "kernel": "match_tile_kernel<8, 2>", "launches": launches,
                          "avg_launch_ms": tile_ms / max(launches, 1),
                          "finalize_ms_per_step": fin_ms / args.steps},
@@ -183,13 +183,16 @@ def main():
     ctx.close()
 
 
-def measured_traffic(kernel: str, grid_threads: int):
+def measured_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB units, FETCH
-    doubled per the gfx950 correction of MI355X_MICROARCH.md). None if that launch shape was not profiled."""
+    (profiles/r01_pmc_hbm_traffic.json, written by tools/pmc_traffic_json.py; FETCH_SIZE and WRITE_SIZE in
+    separate passes, KB units, FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md). The entry
+    of the largest grid = the full-batch launch the roofline line is about. None if not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            d = json.load(f).get(f"{kernel} grid={grid_threads}")
+            tab = json.load(f)
+        keys = [k for k in tab if k.startswith(kernel + " grid=")]
+        d = tab[max(keys, key=lambda k: int(k.rsplit("=", 1)[1]))]
         return (2.0 * d["FETCH_SIZE_KB_mean_per_dispatch"] + d["WRITE_SIZE_KB_mean_per_dispatch"]) * 1024.0
     except (OSError, KeyError, TypeError, ValueError):
         return None

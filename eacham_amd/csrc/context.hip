@@ -33,6 +33,11 @@ int ensure_io(eacham_ctx* ctx, size_t bytes) {
     return EACHAM_OK;
 }
 
+__global__ void gather_tiles_kernel(const FrameDev* __restrict__ frames, int n, int* __restrict__ used) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) used[i] = frames[i].meta ? frames[i].meta[1] : frames[i].ntiles;
+}
+
 int sync_frame_table(eacham_ctx* ctx) {
     if (!ctx->frame_table_dirty) return EACHAM_OK;
     int need = (int)ctx->frames.size();
@@ -52,6 +57,9 @@ int sync_frame_table(eacham_ctx* ctx) {
         tab[i].frag = f.frag;
         tab[i].norm = f.norm;
         tab[i].normb = f.normb;
+        tab[i].orig = f.orig;
+        tab[i].pos = f.pos;
+        tab[i].meta = f.meta;
         tab[i].n = f.n < 0 ? 0 : f.n;
         tab[i].ntiles = f.n < 0 ? 0 : f.ntiles;
     }
@@ -59,13 +67,23 @@ int sync_frame_table(eacham_ctx* ctx) {
         // pageable source: hipMemcpyAsync stages it before returning, so `tab` may die here
         EACHAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_table_dev, tab.data(), sizeof(FrameDev) * need,
                                            hipMemcpyHostToDevice, ctx->stream));
-        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // tiles in use per frame (the parity split of an int8 frame is decided on the device): one
+        // small read-back per table rebuild lets the host size strides and grids exactly
+        int* used_dev = nullptr;
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&used_dev, sizeof(int) * need));
+        gather_tiles_kernel<<<(need + 255) / 256, 256, 0, ctx->stream>>>(ctx->frame_table_dev, need, used_dev);
+        std::vector<int> used(need);
+        hipError_t e = hipMemcpyAsync(used.data(), used_dev, sizeof(int) * need, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(used_dev);
+        EACHAM_HIP_TRY(ctx, e);
+        for (int i = 0; i < need; ++i) ctx->frames[i].tiles_used = used[i];
     }
     ctx->frame_table_dirty = false;
     return EACHAM_OK;
 }
 
-ProfileScope::ProfileScope(eacham_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
+ProfileScope::ProfileScope(eacham_ctx* c, int kernel_id, hipStream_t on) : ctx(c), id(kernel_id), stream(on ? on : c->stream) {
     if (!ctx->profile) return;
     ProfileSlot& s = ctx->prof[id];
     if (s.used == s.events.size()) {
@@ -74,12 +92,12 @@ ProfileScope::ProfileScope(eacham_ctx* c, int kernel_id) : ctx(c), id(kernel_id)
         s.events.emplace_back(a, b);
     }
     auto& ev = s.events[s.used++];
-    (void)hipEventRecord(ev.first, ctx->stream);
+    (void)hipEventRecord(ev.first, stream);
     stop = ev.second;
 }
 
 ProfileScope::~ProfileScope() {
-    if (stop) (void)hipEventRecord(stop, ctx->stream);
+    if (stop) (void)hipEventRecord(stop, stream);
 }
 
 static void profile_drain(eacham_ctx* ctx) {
@@ -115,6 +133,12 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     ctx->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_tile[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_tile[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fin[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fin[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&ctx->flag_dev, 64 * sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->flag_dev, 0, 64 * sizeof(int), ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -159,6 +183,9 @@ void eacham_ctx_destroy(eacham_ctx* ctx) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
+    for (hipEvent_t e : {ctx->ev_tile[0], ctx->ev_tile[1], ctx->ev_fin[0], ctx->ev_fin[1], ctx->ev_join})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

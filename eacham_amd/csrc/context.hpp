@@ -19,22 +19,32 @@
 namespace eacham {
 
 // Descriptor of one resident frame as the kernels see it (device-side table entry).
+// int8 frames are stored PARITY-SORTED: rows whose centred squared norm is even come first (stable),
+// padded to whole 32-row tiles, then the odd ones; `orig`/`pos` translate between stored position
+// and the caller's row index (see matcher.hip). fp32 frames keep the caller's order (orig = pos = null).
 struct FrameDev {
     const int4* frag;  // [ntiles][KS][64] 16-byte MFMA operand fragments (int8, centred by -128)
-    const int* norm;   // [ntiles*32] squared norm of the centred row; PAD_VALUE for padding rows
-    const int* normb;  // [ntiles*32] norm + 2*sum of the centred row (train-role norm, see matcher.hip K1)
+    const int* norm;   // int8: floor(|c|^2 / 2) per stored position (query role, MFMA C-init); fp32: |x|^2 as float bits
+    const int* normb;  // int8: floor(|c|^2 / 2) + sum(c) per stored position (train role)
+    const int* orig;   // int8: stored position -> caller's row (-1 = padding)
+    const int* pos;    // int8: caller's row -> stored position
+    const int* meta;   // int8: {tiles of the even class, tiles in use}; written by the upload kernels
     int n;             // real rows
-    int ntiles;        // 32-row tiles, padded to a multiple of 4 (a wave owns 2 or 4 tiles)
+    int ntiles;        // allocated 32-row tiles (upper bound of meta[1] for int8 frames)
 };
 
 struct FrameHost {
     int4* frag = nullptr;
-    int* norm = nullptr;
-    int* normb = nullptr;  // second half of the `norm` allocation
+    int* norm = nullptr;   // one allocation: norm | normb | orig | pos | scratch (int8 path)
+    int* normb = nullptr;
+    int* orig = nullptr;
+    int* pos = nullptr;
+    int* meta = nullptr;
     int n = -1;  // -1 = not resident
     int dim = 0;
     int ks = 0;
-    int ntiles = 0;
+    int ntiles = 0;      // allocated tiles
+    int tiles_used = 0;  // tiles in use (<= ntiles), known after sync_frame_table
 };
 
 struct ProfileSlot {
@@ -49,6 +59,8 @@ struct ProfileSlot {
 struct eacham_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // finalize/compaction of batch i runs here beside the tile kernel of batch i+1
+    hipEvent_t ev_tile[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr}, ev_join = nullptr;
     std::mutex mu;
     std::string err;
 
@@ -112,7 +124,8 @@ struct ProfileScope {
     eacham_ctx* ctx;
     int id;
     hipEvent_t stop = nullptr;
-    ProfileScope(eacham_ctx* c, int kernel_id);
+    hipStream_t stream;
+    ProfileScope(eacham_ctx* c, int kernel_id, hipStream_t on = nullptr);
     ~ProfileScope();
 };
 

@@ -10,17 +10,25 @@
 // serves as the A operand (queries, rows of the distance tile) and the B operand (train, columns).
 //
 // Arithmetic (all integer, hence independent of summation order => bit-exact vs the CPU oracle):
-//     d2(q,t) = |a_q|^2 + |b_t|^2 - 2 a_q.b_t         a.b from the int8 MFMA, int32 accumulate
-// Row direction (q -> best t) ranks by  |b_t|^2 - 2 a.b  (|a_q|^2 is constant per row),
-// column direction (t -> best q) by     |a_q|^2 - 2 a.b.
-// Both rank values fit 25 signed bits for D <= 256, so a candidate is one int32 key
-//     key = (rank << 7) | code        code = column-tile index (row dir) / local row (col dir)
-// and a running top-2 costs two VALU ops:  m2 = med3(m1, m2, key); m1 = min(m1, key).
-// Ties resolve to the lower index because `code` is monotone in the index within a lane.
+//     d2(q,t) = |a_q|^2 + |b_t|^2 - 2 a_q.b_t = 2 H + pa + pb
+//     H = floor(|a_q|^2 / 2) + floor(|b_t|^2 / 2) - a_q.b_t   (int8 MFMA, int32 accumulate, C-init;
+//         stored with a +1 bias so that it is never negative)
+//     pa, pb = parities of the two squared norms
+// One int32 key per distance serves BOTH directions:
+//     key = (H << 8) | (pb << 7) | column-tile index
+// Row direction (q -> best t): pa is constant, keys order by (2H + pb, tile) — exact, ties to the
+// lower column. Column direction (t -> best q): pb and the tile are constant, keys order by H, which
+// is the order of d2 as long as pa is constant among the rows compared — so frames are stored
+// PARITY-SORTED (even squared norms first, each class padded to whole 32-row tiles): a sub-tile has
+// one parity, and the one wave-block that may straddle the boundary keeps two column partials. The column direction only needs VALUES: a row q is column t's unique best
+// iff d2(q,t) equals the column minimum and the column passes the ratio test (a tie gives quotient
+// 1, which no ratio <= 1 accepts), so no row index is carried through the column reduction.
+// A running top-2 costs two VALU ops:  m2 = med3(m1, m2, key); m1 = min(m1, key).
 #include "context.hpp"
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 namespace eacham {
 
@@ -31,13 +39,13 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef const v4i __attribute__((address_space(1)))* gfrag_t;
 typedef const int __attribute__((address_space(1)))* gint_t;
 
-// norm of padding rows/columns: above any real d2 (<= 256*255^2 = 16,646,400) and low enough that
-// PAD_VALUE + 2^16 still fits the 25-bit signed rank field of a key
-constexpr int PAD_VALUE = 16700000;
-constexpr int KEY_SHIFT = 7;
+// H constant of padding rows/columns: above any real H (<= 256*255^2/2 = 8,323,200) and small
+// enough that pad x pad (2 * PADH) still fits the 24-bit H field of a key
+constexpr int PADH = 8350000;
+constexpr int KEY_SHIFT = 7;               // tile field; key >> 7 = 2H + pb
 constexpr int KEY_MASK = (1 << KEY_SHIFT) - 1;
 constexpr int CHUNK_TILES = 1 << KEY_SHIFT;  // column tiles one sweep can tag in a key: 128 * 32 = 4096 train rows
-constexpr int MAX_TILES = 512;               // 16384 rows per frame (K2 keeps two int per row in LDS)
+constexpr int MAX_ROWS = 16384;              // rows per frame (K2 keeps two int per stored row in LDS)
 constexpr int WG_THREADS = 256;            // 4 waves (1 per SIMD); 2 workgroups per CU drift out of phase so MFMA and VALU overlap
 constexpr int WAVES = WG_THREADS / 64;
 #ifndef EACHAM_MATCH_NSUB
@@ -46,7 +54,7 @@ constexpr int WAVES = WG_THREADS / 64;
 constexpr int MATCH_NSUB = EACHAM_MATCH_NSUB;        // 32-row MFMA sub-tiles per wave (A fragments live in VGPRs)
 constexpr int ROWS_PER_WAVE = 32 * MATCH_NSUB;
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
-constexpr int TILE_ALIGN = 4;                        // frames are padded to a multiple of 4 tiles (128 rows)
+constexpr int GROUP_TILES = MATCH_NSUB;              // tiles in use are padded to whole wave-blocks
 
 __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
@@ -54,47 +62,104 @@ __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b),
 // upload: fp32 row-major -> fragment-major int8 + squared norms
 // ------------------------------------------------------------------------------------------------
 
-__global__ void init_norm_kernel(int* __restrict__ norm, int* __restrict__ normb, int n, int npad) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npad) {
-        norm[i] = i < n ? 0 : PAD_VALUE;
-        normb[i] = i < n ? 0 : PAD_VALUE;
+// U1: per-row sum of squares / sum of the centred values + integrality flag (thread per 16 values)
+__global__ void rowsum_kernel(const float* __restrict__ src, int n, int dim, int* __restrict__ s2,
+                              int* __restrict__ s1, int* __restrict__ bad_flag) {
+    const int chunks = (dim + 15) / 16;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * chunks) return;
+    const int row = (int)(idx / chunks), ch = (int)(idx % chunks);
+    int sq = 0, sum = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = ch * 16 + j;
+        if (k < dim) {
+            const float v = src[(size_t)row * dim + k];
+            if (!(v >= 0.0f && v <= 255.0f) || v != floorf(v)) bad = true;
+            const int c = (int)v - 128;
+            sq += c * c;
+            sum += c;
+        }
+    }
+    if (sq) atomicAdd(&s2[row], sq);
+    if (sum) atomicAdd(&s1[row], sum);
+    if (bad) atomicOr(bad_flag, 1);
+}
+
+// U2 (one workgroup): stable partition of the rows by the parity of |c|^2; fills the per-position
+// constants and the two index maps. meta = {tiles of the even class, tiles in use}.
+__global__ __launch_bounds__(1024) void partition_kernel(const int* __restrict__ s2, const int* __restrict__ s1, int n,
+                                                         int npad, int group_rows, int* __restrict__ ca,
+                                                         int* __restrict__ hb, int* __restrict__ orig,
+                                                         int* __restrict__ pos, int* __restrict__ meta) {
+    __shared__ int sc[1024];
+    __shared__ int s_n0, s_carry;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < npad; j += 1024) {
+        ca[j] = PADH;
+        hb[j] = PADH;
+        orig[j] = -1;
+    }
+    if (tid == 0) s_n0 = 0, s_carry = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < n; i += 1024) mine += !(s2[i] & 1);
+    atomicAdd(&s_n0, mine);
+    __syncthreads();
+    const int n0 = s_n0;
+    const int even_pad = (n0 + 31) / 32 * 32;   // each parity class fills whole 32-row tiles
+    const int odd_pad = (n - n0 + 31) / 32 * 32;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const int even = i < n ? !(s2[i] & 1) : 0;
+        sc[tid] = even;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            const int v = tid >= off ? sc[tid - off] : 0;
+            __syncthreads();
+            sc[tid] += v;
+            __syncthreads();
+        }
+        if (i < n) {
+            const int rank_even = s_carry + sc[tid] - even;          // evens before row i
+            const int j = even ? rank_even : even_pad + (i - rank_even);
+            const int half = s2[i] >> 1;
+            ca[j] = half + 1;  // +1 keeps H >= 0 when d2 = 0 between two odd-norm rows (d2 = 2 (H - 1) + pa + pb)
+            hb[j] = half + s1[i];
+            orig[j] = i;
+            pos[i] = j;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += sc[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        meta[0] = even_pad / 32;
+        meta[1] = (even_pad + odd_pad + group_rows - 1) / group_rows * (group_rows / 32);  // whole wave-blocks
     }
 }
 
-// norm[row]  = sum c^2             (c = x - 128, the stored int8)            -> query role
-// normb[row] = sum c^2 + 2 sum c   (absorbs the -1 of the ~a trick, see K1)  -> train role
-__global__ void quantize_kernel(const float* __restrict__ src, int n, int dim, int KS, int npad,
-                                v4i* __restrict__ frag, int* __restrict__ norm,
-                                int* __restrict__ normb, int* __restrict__ bad_flag) {
+// U3: fp32 row-major -> fragment-major int8 at the stored (parity-sorted) position
+__global__ void quantize_kernel(const float* __restrict__ src, int dim, int KS, int npad,
+                                const int* __restrict__ orig, v4i* __restrict__ frag) {
     const int chunks = KS * 2;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)npad * chunks) return;
-    int row = (int)(idx / chunks), ch = (int)(idx % chunks);
-    int ks = ch >> 1, h = ch & 1, tile = row >> 5, r = row & 31;
+    const int j = (int)(idx / chunks), ch = (int)(idx % chunks);
+    const int ks = ch >> 1, h = ch & 1, tile = j >> 5, r = j & 31;
+    const int row = orig[j];
     unsigned w[4] = {0u, 0u, 0u, 0u};
-    int sq = 0, sum = 0;
-    bool bad = false;
-    if (row < n) {
+    if (row >= 0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            int k = ks * 32 + h * 16 + j;
-            int c = 0;  // centred value of a padded dimension
-            if (k < dim) {
-                float v = src[(size_t)row * dim + k];
-                if (!(v >= 0.0f && v <= 255.0f) || v != floorf(v)) bad = true;
-                c = (int)v - 128;
-            }
-            sq += c * c;
-            sum += c;
-            w[j >> 2] |= (unsigned)(c & 0xff) << (8 * (j & 3));
+        for (int e = 0; e < 16; ++e) {
+            const int k = ks * 32 + h * 16 + e;
+            const int c = k < dim ? (int)src[(size_t)row * dim + k] - 128 : 0;  // padded dimensions are centred zeros
+            w[e >> 2] |= (unsigned)(c & 0xff) << (8 * (e & 3));
         }
     }
-    v4i out = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    const v4i out = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
     frag[((size_t)tile * KS + ks) * 64 + h * 32 + r] = out;
-    if (sq) atomicAdd(&norm[row], sq);
-    if (sq + 2 * sum) atomicAdd(&normb[row], sq + 2 * sum);
-    if (bad) atomicOr(bad_flag, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -107,52 +172,52 @@ __global__ void quantize_kernel(const float* __restrict__ src, int n, int dim, i
 //         (A-stationary), B tiles (32 train rows = KS KiB) stream through LDS once per workgroup.
 //
 // The kernel is VALU-bound (each wave64 integer op costs 4 cycles per SIMD, the int8 MFMAs of a
-// tile only 16 x 32), so the epilogue is cut to 6 ops per distance:
-//   * the query fragments are complemented once (a' = ~a = -a-1 per byte), so the MFMA returns
-//     acc = -a.b - sum(b) and each key is ONE v_lshl_add_u32:
-//         row key  = (acc << 8) + ((normb_c << 7) | t)        rank = |b|^2 - 2 a.b
-//         col key  = (acc << 8) + ((norm_r  << 7) | lrow)     rank = |a|^2 - 2 a.b - 2 sum(b)
-//     (normb = |b|^2 + 2 sum(b) is precomputed at upload; the -2 sum(b) offset of the column
-//     rank is constant per column and is added back by K2);
-//   * each running top-2 update is v_med3_i32 + v_min_i32.
+// tile only 16 x 32), so the epilogue is cut to ~4.7 ops per distance:
+//   * the query fragments are complemented once (a' = ~a = -a-1 per byte) and the accumulator starts
+//     at floor(|a|^2/2) (C-init), so the MFMA returns acc = floor(|a|^2/2) - a.b - sum(b) and the
+//     key is ONE v_lshl_add_u32:  key = (acc << 8) + ((hb_c << 8) | pb << 7 | t),
+//     hb = floor(|b|^2/2) + sum(b) precomputed at upload;
+//   * the row top-2 update is v_med3_u32 + v_min_u32 (2 ops per key);
+//   * the column top-2 runs on the SAME keys, three at a time (5 ops per 3 keys).
 // Measured on MI355X (tools/valu_ubench.hip, tools/mfma_ubench.hip): a wave64 integer VALU op costs
-// ~4 cycles of its SIMD whatever the number of resident waves, the int8 32x32x32 MFMA 32 cycles.
-// With 6 ops per distance the VALU floor is 192 ops = 768 cycles per 64x32 wave-tile against 512
-// MFMA cycles, so the MFMA chains are software-pipelined UNDER the epilogue (see the main loop).
-// out   rowres[p][q]      = {rank1, col1, rank2, 0}   final over all columns (d2 = rank + norm_q)
-//       colpart[p][wb][c] = {key1, key2}              top-2 over the 64 rows of wave-block wb
-//                                                     (d2 = (key >> 7) + normb_c, row = key & 127)
-__device__ __forceinline__ int vmed3(int a, int b, int c) {
-    int d;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+// ~4 cycles of its SIMD whatever the number of resident waves, the int8 32x32x32 MFMA 32 cycles, so
+// the MFMA chains are software-pipelined UNDER the epilogue (see the main loop).
+// out   rowres[p][cc][j]   = {v1, col1, v2, 0}   top-2 of stored row j over the columns of chunk cc,
+//                                                v = 2H + pb = d2 - pa_j, col = stored column position
+//       colpart[p][k][c]   = {key1, key2}        top-2 keys of stored column c over the rows of one
+//                                                parity of a workgroup (d2 = 2 (key >> 8) + pa_k + pb_c - 2)
+__device__ __forceinline__ unsigned vmed3(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
 
-// Two keys from one accumulator, each ONE v_lshl_add_u32. The empty asm hides the second use of
-// `acc` from CSE (hipcc would otherwise share the shift: 3 ops); it emits no instruction, so the
-// MFMA->VALU wait states stay under the compiler's control (an asm that READS an MFMA result
-// directly gets no hazard padding and returned stale data).
-__device__ __forceinline__ void vkeys(int acc, int base_row_dir, int base_col_dir, int& kr, int& kc) {
-    kr = (acc << (KEY_SHIFT + 1)) + base_row_dir;
-    int again = acc;
-    asm("" : "+v"(again));
-    kc = (again << (KEY_SHIFT + 1)) + base_col_dir;
-}
-
-#ifdef EXP_STAMPS
+#if defined(EXP_STAMPS) || defined(EXP_CLOCK)
 __device__ unsigned long long g_dbg[16];
 #endif
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+// 16-byte LDS read the compiler does not track (the caller places the s_waitcnt).
+template <class V>
+__device__ __forceinline__ void lds_read_frag(V& dst, unsigned addr, int offset_bytes) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offset_bytes));
+}
 
 template <int KS, int NSUB>
 __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair, int col_chunks,
-    int4* __restrict__ rowres, int2* __restrict__ colpart, int wb_stride, int row_stride) {
+    uint4* __restrict__ rowres, uint2* __restrict__ colpart, int wb_stride, int row_stride) {
     constexpr int TILE_V4 = KS * 64;          // int4 per B tile
     constexpr int ROWS_WAVE = 32 * NSUB;      // query rows a wave keeps in registers
     constexpr int ROWS_WG = WAVES * ROWS_WAVE;
     static_assert(ROWS_WAVE <= (1 << KEY_SHIFT), "the local row must fit the key's code field");
     __shared__ v4i sB[3][TILE_V4];
-    __shared__ int2 sR[WAVES][32 * 33];
+    __shared__ uint2 sR[WAVES][32 * 33];
+    __shared__ uint2 sC[2][2][WAVES][32];     // column partials of the 4 waves: [tile parity][row-parity group][wave][column]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -167,15 +232,18 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     const int2 pr = pairs[p];
     const FrameDev A = frames[pr.x], B = frames[pr.y];
     const int tbeg = cc * CHUNK_TILES;
-    if (rb * (ROWS_WG / 32) >= A.ntiles || tbeg >= B.ntiles) return;  // workgroup-uniform
+    const int A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];  // tiles of the even class / in use
+    const int B_even = ((gint_t)B.meta)[0], B_tiles = ((gint_t)B.meta)[1];
+    if (rb * (ROWS_WG / 32) >= A_tiles || tbeg >= B_tiles) return;  // workgroup-uniform
     const int wb = rb * WAVES + wave;                  // wave-block (ROWS_WAVE rows) of frame A
-    const bool active = NSUB * wb < A.ntiles;          // wave-uniform (ntiles is a multiple of NSUB)
-    const int T = min(B.ntiles - tbeg, CHUNK_TILES);   // tiles of this chunk, t below is chunk-local
+    const bool active = NSUB * wb < A_tiles;           // wave-uniform (tiles in use are a multiple of NSUB)
+    const int T = min(B_tiles - tbeg, CHUNK_TILES);    // tiles of this chunk, t below is chunk-local
     const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag + (size_t)tbeg * TILE_V4;
-    const gint_t Anorm = (gint_t)A.norm, Bnormb = (gint_t)B.normb + 32 * tbeg;
+    const gint_t Aca = (gint_t)A.norm, Bhb = (gint_t)B.normb + 32 * tbeg;
 
     v4i a[NSUB][KS];
-    int base_r[NSUB][16], rm1[NSUB][16], rm2[NSUB][16];
+    v16i cinit[NSUB];                 // floor(|a|^2/2) of this lane's 16 rows per sub-tile: the MFMA C-init
+    unsigned rm1[NSUB][16], rm2[NSUB][16];
     const int wbc = active ? wb : 0;  // inactive waves load a valid block and never use it
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -184,9 +252,9 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int lrow = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
-            base_r[s][r] = (Anorm[ROWS_WAVE * wbc + lrow] << KEY_SHIFT) | lrow;
-            rm1[s][r] = INT_MAX;
-            rm2[s][r] = INT_MAX;
+            cinit[s][r] = Aca[ROWS_WAVE * wbc + lrow];
+            rm1[s][r] = 0xffffffffu;
+            rm2[s][r] = 0xffffffffu;
         }
     }
 
@@ -220,7 +288,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         stage_tile(0, 0);
         stage_tile(min(1, T - 1), 1);
     }
-    int nb_cur = T > 0 ? Bnormb[cl] : 0;
+    int hb_cur = T > 0 ? Bhb[cl] : 0;
     __builtin_amdgcn_s_waitcnt(0);  // every prologue load has landed (keeps vmcnt(0) out of the loop)
     __syncthreads();
 
@@ -235,12 +303,32 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         for (int ks = 0; ks < KS; ++ks) b0[ks] = sB[0][ks * 64 + lane];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b0[ks], ks ? acc[0] : zero16, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b0[ks], ks ? acc[0] : cinit[0], 0, 0, 0);
         bq[0] = sB[0][lane];       // steps 0 and 1 of iteration 0 (chain (0,1) re-reads tile 0)
         bq[1] = sB[0][64 + lane];
     }
 
-    int2* cp = colpart + ((size_t)p * wb_stride + wb) * row_stride + 32 * tbeg;
+    // Column partials leave the workgroup merged over its 4 wave-blocks (a quarter of the traffic of
+    // per-wave partials). Rows of different parity must not be merged, so a workgroup owns the slots
+    // rb (its even rows) and rb + 1 (its odd rows); only the one workgroup of a frame that straddles
+    // the even/odd boundary fills both, every other workgroup fills the one of its parity. K2 knows
+    // from A_even which slots are in use: slot k holds even rows iff 8k < A_even.
+    const int wg_tile0 = rb * (ROWS_WG / 32);
+    const bool split = wg_tile0 < A_even && wg_tile0 + ROWS_WG / 32 > A_even;  // workgroup-uniform
+    const int slot0 = rb + ((!split && wg_tile0 >= A_even) ? 1 : 0);
+    auto merge_cols = [&](int tt) {  // one wave, after the barrier that published tile tt's partials
+        const int g = split ? h : 0;
+        if (split || h == 0) {
+            uint2 m = sC[tt & 1][g][0][cl];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const uint2 e = sC[tt & 1][g][w][cl];
+                m.y = umin(umin(umax(m.x, e.x), m.y), e.y);
+                m.x = umin(m.x, e.x);
+            }
+            colpart[((size_t)p * wb_stride + slot0 + g) * row_stride + 32 * (tbeg + tt) + cl] = m;
+        }
+    };
 #ifdef EXP_STAMPS
     // diagnostic build: where does a wave's time go? (sums of s_memtime deltas per segment)
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
@@ -248,19 +336,36 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
 #else
 #define STAMP(i) do {} while (0)
 #endif
+#ifdef EXP_CLOCK
+    // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the main loop
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int EPK = 16 / KS;         // epilogue elements interleaved per MFMA (KS = 8 -> 2)
+#ifdef EXP_NO_EPI
+    constexpr bool EPK_ON = false;       // diagnostic build: MFMA + LDS + DMA only
+#else
+    constexpr bool EPK_ON = true;
+#endif
     constexpr int NSTEP = NSUB * KS;     // (phase, ks) steps per tile
     int slot_cur = 0, slot_nxt = 1, slot_new = 2;  // t % 3, (t+1) % 3, (t+2) % 3
     for (int t = 0; t < T; ++t) {
-        const int base_c = (nb_cur << KEY_SHIFT) | t;
+        // per-column part of this tile's keys: (hb << 8) | pb << 7 | t  (pb is wave-uniform per tile)
+        const unsigned lowc = ((unsigned)hb_cur << (KEY_SHIFT + 1)) | (unsigned)((tbeg + t >= B_even ? (1 << KEY_SHIFT) : 0) | t);
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
-        nb_cur = Bnormb[32 * t1 + cl];
+        hb_cur = Bhb[32 * t1 + cl];
+        if (t > 0 && wave == ((t - 1) & (WAVES - 1))) merge_cols(t - 1);  // the waves take turns
+#ifndef EXP_NO_DMA
         stage_tile(t2, slot_new);  // lands during this iteration; the barrier below publishes it
-        int cm1 = INT_MAX, cm2 = INT_MAX, pend[3] = {0, 0, 0};
+#endif
+        unsigned cm1[NSUB], cm2[NSUB], pend[3] = {0, 0, 0};  // column top-2 per sub-tile (a sub-tile has one parity)
         STAMP(0);
         if (active) {
-            const v4i* curB = sB[slot_cur];
-            const v4i* nxtB = sB[slot_nxt];
+            // LDS byte addresses of this lane's 16 bytes in the two live slots. The fragment reads
+            // are inline asm with hand-placed s_waitcnt lgkmcnt(1): hipcc waits with lgkmcnt(0)
+            // before every second MFMA, i.e. also for the read it issued one step earlier
+            // (~50 cycles ago, well short of the LDS latency). Nothing else in the loop uses lgkmcnt.
+            const unsigned curB = lds_addr(&sB[slot_cur][lane]);
+            const unsigned nxtB = lds_addr(&sB[slot_nxt][lane]);
             // The ring phase advances by NSTEP % 3 per iteration, so the loop body is written for a
             // fixed phase and the ring is rotated at the end (register moves) to keep every index a
             // compile-time constant.
@@ -271,37 +376,49 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                 // phase NSUB-1 issues chain (t+1, 0) and phase 0 of the next iteration chain (t+1, 1):
                 // tile t+1.
                 const int j = i + 2;
-                const v4i* src = (j / KS < NSUB - 1) ? curB : nxtB;
-                bq[j % 3] = src[(j % KS) * 64 + lane];
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[i % 3]));  // step i landed (i+1 may be in flight)
+#ifndef EXP_NO_LDSREAD
+                lds_read_frag(bq[j % 3], (j / KS < NSUB - 1) ? curB : nxtB, (j % KS) * 1024);
+#endif
                 const int q = (ph + 1) % NSUB;       // accumulator of the chain being issued
                 // (the last iteration recomputes tile T-1 into acc[0]; it is never read)
-                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q][ks], bq[i % 3], ks ? acc[q] : zero16, 0, 0, 0);
+#if defined(EXP_SHAPE16)
+                {   // diagnostic build (wrong results): same MACs issued as two 16x16x64 MFMAs per 32x32x32
+                    v4i lo = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]}, hi = {acc[q][4], acc[q][5], acc[q][6], acc[q][7]};
+                    lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[i % 3], lo, 0, 0, 0);
+                    hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[i % 3], hi, 0, 0, 0);
+                    acc[q][0] = lo[0]; acc[q][1] = lo[1]; acc[q][2] = lo[2]; acc[q][3] = lo[3];
+                    acc[q][4] = hi[0]; acc[q][5] = hi[1]; acc[q][6] = hi[2]; acc[q][7] = hi[3];
+                }
+#elif !defined(EXP_NO_MFMA)
+                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q][ks], bq[i % 3], ks ? acc[q] : cinit[q], 0, 0, 0);
+#else
+                acc[q][ks] += bq[i % 3][0] + a[q][ks][0];
+#endif
 #pragma unroll
-                for (int e = 0; e < EPK; ++e) {
+                for (int e = 0; e < (EPK_ON ? EPK : 0); ++e) {
                     const int r = ks * EPK + e;
-                    int kr, kc;
-                    vkeys(acc[ph][r], base_c, base_r[ph][r], kr, kc);
-                    rm2[ph][r] = vmed3(rm1[ph][r], rm2[ph][r], kr);
-                    rm1[ph][r] = min(rm1[ph][r], kr);
-                    // Column direction: all NCOL keys of the tile belong to this lane's column, so they
+                    const unsigned key = ((unsigned)acc[ph][r] << (KEY_SHIFT + 1)) + lowc;  // one v_lshl_add_u32
+                    rm2[ph][r] = vmed3(rm1[ph][r], rm2[ph][r], key);
+                    rm1[ph][r] = umin(rm1[ph][r], key);
+                    // Column direction: the 16 keys of a sub-tile belong to this lane's column, so they
                     // are taken three at a time — {min3, med3} of a triple (2 ops) then one sorted-pair
                     // insert (3 ops) = 5 ops per 3 keys instead of 6 (and the first triple needs no insert).
-                    constexpr int NCOL = NSUB * 16;
-                    const int eg = i * EPK + e;  // compile-time after unrolling
-                    pend[eg % 3] = kc;
+                    const int eg = ks * EPK + e;  // 0..15 within the sub-tile, compile-time after unrolling
+                    pend[eg % 3] = key;
                     if (eg % 3 == 2) {
-                        const int s1 = min(min(pend[0], pend[1]), pend[2]);
-                        const int s2 = vmed3(pend[0], pend[1], pend[2]);
+                        const unsigned s1 = umin(umin(pend[0], pend[1]), pend[2]);
+                        const unsigned s2 = vmed3(pend[0], pend[1], pend[2]);
                         if (eg == 2) {
-                            cm1 = s1;
-                            cm2 = s2;
+                            cm1[ph] = s1;
+                            cm2[ph] = s2;
                         } else {
-                            cm2 = min(min(max(cm1, s1), cm2), s2);
-                            cm1 = min(cm1, s1);
+                            cm2[ph] = umin(umin(umax(cm1[ph], s1), cm2[ph]), s2);
+                            cm1[ph] = umin(cm1[ph], s1);
                         }
-                    } else if (eg >= NCOL - NCOL % 3) {  // leftover keys of an incomplete last triple
-                        cm2 = vmed3(cm1, cm2, kc);
-                        cm1 = min(cm1, kc);
+                    } else if (eg == 15) {  // 16 = 5 triples + 1
+                        cm2[ph] = vmed3(cm1[ph], cm2[ph], key);
+                        cm1[ph] = umin(cm1[ph], key);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -309,18 +426,45 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             }
             STAMP(2);
             // steps NSTEP and NSTEP+1 (= steps 0, 1 of the next iteration) sit in bq[NSTEP % 3], ...
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));  // before any register move
             {
                 v4i s0 = bq[NSTEP % 3], s1 = bq[(NSTEP + 1) % 3];
                 bq[0] = s0;
                 bq[1] = s1;
             }
+            // Merge the sub-tiles that share a parity: all of them, except in the workgroup that
+            // straddles the even/odd boundary of frame A, which keeps the two parities apart.
+            unsigned g1[2] = {0xffffffffu, 0xffffffffu}, g2[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                const int g = (split && NSUB * wb + s >= A_even) ? 1 : 0;  // wave-uniform
+                if (g == 0) {
+                    g2[0] = umin(umin(umax(g1[0], cm1[s]), g2[0]), cm2[s]);
+                    g1[0] = umin(g1[0], cm1[s]);
+                } else {
+                    g2[1] = umin(umin(umax(g1[1], cm1[s]), g2[1]), cm2[s]);
+                    g1[1] = umin(g1[1], cm1[s]);
+                }
+            }
             // lanes l and l+32 hold the same column, rows 4h.. of each 8-row group: merge halves
             // (v_permlane32_swap: lanes 0-31 of the 2nd operand <-> lanes 32-63 of the 1st, pure VALU)
-            auto w1 = __builtin_amdgcn_permlane32_swap(cm1, cm1, false, false);
-            auto w2 = __builtin_amdgcn_permlane32_swap(cm2, cm2, false, false);
-            int n1 = min((int)w1[0], (int)w1[1]);
-            int n2 = min(max((int)w1[0], (int)w1[1]), min((int)w2[0], (int)w2[1]));
-            if (h == 0) cp[32 * t + cl] = make_int2(n1, n2);
+            {
+                auto w1 = __builtin_amdgcn_permlane32_swap(g1[0], g1[0], false, false);
+                auto w2 = __builtin_amdgcn_permlane32_swap(g2[0], g2[0], false, false);
+                const unsigned n1 = umin(w1[0], w1[1]);
+                const unsigned n2 = umin(umax(w1[0], w1[1]), umin(w2[0], w2[1]));
+                if (h == 0) sC[t & 1][0][wave][cl] = make_uint2(n1, n2);
+            }
+            if (split) {
+                auto w1 = __builtin_amdgcn_permlane32_swap(g1[1], g1[1], false, false);
+                auto w2 = __builtin_amdgcn_permlane32_swap(g2[1], g2[1], false, false);
+                const unsigned n1 = umin(w1[0], w1[1]);
+                const unsigned n2 = umin(umax(w1[0], w1[1]), umin(w2[0], w2[1]));
+                if (h == 0) sC[t & 1][1][wave][cl] = make_uint2(n1, n2);
+            }
+        } else {  // a wave beyond the frame's rows contributes nothing
+            if (h == 0) sC[t & 1][0][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
+            if (split && h == 0) sC[t & 1][1][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
         }
         STAMP(3);
         STAMP(4);
@@ -328,9 +472,20 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         slot_cur = slot_nxt;
         slot_nxt = slot_new;
         slot_new = tmp;
+#ifndef EXP_NO_BARRIER
         __syncthreads();
+#endif
         STAMP(5);
     }
+#ifdef EXP_CLOCK
+    if (lane == 0 && active && blockIdx.x % 61 == 0) {
+        const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_dbg[8], ck_t1 - ck_t0);
+        atomicAdd(&g_dbg[9], ck_r1 - ck_r0);
+        atomicAdd(&g_dbg[10], 1ull);
+        atomicAdd(&g_dbg[11], (unsigned long long)T);
+    }
+#endif
 #ifdef EXP_STAMPS
     if (lane == 0 && blockIdx.x % 97 == 0) {
         unsigned long long* dbg = g_dbg;
@@ -339,6 +494,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         atomicAdd(&dbg[7], (unsigned long long)T);
     }
 #endif
+    if (T > 0 && wave == ((T - 1) & (WAVES - 1))) merge_cols(T - 1);  // published by the loop's last barrier
     if (!active) return;
 
     // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
@@ -346,35 +502,37 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     // (row, half) scans 16 of the 32 lane-partials of its row in ASCENDING lane-column order with a
     // strict '<': equal keys (same rank, same tile) then keep the lower column, which makes plain
     // 32-bit key compares exact — (key, lane-column) lexicographic == (rank, column) lexicographic.
-    int2* slab = sR[wave];
-    int4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + ROWS_WAVE * wb;
+    uint2* slab = sR[wave];
+    uint4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + ROWS_WAVE * wb;
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            slab[row * 33 + cl] = make_int2(rm1[s][r], rm2[s][r]);
+            slab[row * 33 + cl] = make_uint2(rm1[s][r], rm2[s][r]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int b1 = INT_MAX, b2 = INT_MAX, c1 = 0;
+        unsigned b1 = 0xffffffffu, b2 = 0xffffffffu;
+        int c1 = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int cidx = 16 * h + j;
-            const int2 e = slab[cl * 33 + cidx];
+            const uint2 e = slab[cl * 33 + cidx];
             const bool lt = e.x < b1;
-            b2 = lt ? b1 : min(b2, e.x);
+            b2 = lt ? b1 : umin(b2, e.x);
             c1 = lt ? cidx : c1;
-            b1 = min(b1, e.x);
-            b2 = min(b2, e.y);  // e.y >= e.x: it can only be a runner-up
+            b1 = umin(b1, e.x);
+            b2 = umin(b2, e.y);  // e.y >= e.x: it can only be a runner-up
         }
-        const int o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32), oc = __shfl_xor(c1, 32);
+        const unsigned o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+        const int oc = __shfl_xor(c1, 32);
         if (h == 0) {  // the other half holds the higher columns: it wins only with a strictly smaller key
             const bool lt = o1 < b1;
-            const int key1 = lt ? o1 : b1, key2 = lt ? min(b1, o2) : min(b2, o1);
-            const int col1 = 32 * (tbeg + (key1 & KEY_MASK)) + (lt ? oc : c1);
-            rr[32 * s + cl] = make_int4(key1 >> KEY_SHIFT, col1, key2 >> KEY_SHIFT, 0);
+            const unsigned key1 = lt ? o1 : b1, key2 = lt ? umin(b1, o2) : umin(b2, o1);
+            const unsigned col1 = 32 * (tbeg + (key1 & KEY_MASK)) + (lt ? oc : c1);
+            rr[32 * s + cl] = make_uint4(key1 >> KEY_SHIFT, col1, key2 >> KEY_SHIFT, 0);  // key >> 7 = 2H + pb
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -397,9 +555,10 @@ constexpr int FIN_THREADS = 256;
 
 // mode 0: mutual matches + thresholds (apps/sfm/main.cpp:111-146); mode 1: directed list m12.
 // out_matches[p][k] = {q, t} sorted by q; counts[p]; stats[p] = {|m12|, |m21|, |mutual|, edge}.
+// Rows/columns are addressed by stored position inside; q and t leave in the caller's numbering.
 __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
-    const int4* __restrict__ rowres, const int2* __restrict__ colpart, int col_chunks, int wb_stride,
+    const uint4* __restrict__ rowres, const uint2* __restrict__ colpart, int col_chunks, int wb_stride,
     int row_stride, double ratio, int min_dir, int min_mutual, int mode,
     uint2* __restrict__ out_matches, int* __restrict__ counts, int4* __restrict__ stats) {
     extern __shared__ int smem[];
@@ -407,64 +566,77 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
     const int p = blockIdx.x;
     const int2 pr = pairs[p];
     const FrameDev A = frames[pr.x], B = frames[pr.y];
-    int* fwd = smem;               // [row_stride]
-    int* bwd = smem + row_stride;  // [row_stride]
+    const int A_even = A.meta[0], A_tiles = A.meta[1], B_even = B.meta[0], B_tiles = B.meta[1];
+    int* keepcol = smem;           // [row_stride] by stored row: stored column of the kept match or -1
+    int* bwd = smem + row_stride;  // [row_stride] by stored column: d2 of the column's best if it passes the ratio test, else -1
     __shared__ int s_cnt[3];
     __shared__ int s_scan[FIN_THREADS];
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
+    constexpr unsigned PAD_V = 2u * PADH;  // v = 2H + parity of anything involving a padding row/column
 
+    // columns first: top-2 VALUES of every stored column over the wave-blocks of A
     int c12 = 0, c21 = 0;
-    const int nchunks = (B.ntiles + CHUNK_TILES - 1) / CHUNK_TILES;
-    for (int q = tid; q < A.n; q += FIN_THREADS) {
-        int4 r = make_int4(INT_MAX >> KEY_SHIFT, -1, INT_MAX >> KEY_SHIFT, 0);
-        for (int ch = 0; ch < nchunks; ++ch) {  // ascending columns; strict '<' keeps the lower column on ties
-            const int4 e = rowres[((size_t)p * col_chunks + ch) * row_stride + q];
-            if (e.x < r.x) {
-                r.z = min(r.x, e.z);
-                r.x = e.x;
-                r.y = e.y;
-            } else {
-                r.z = min(r.z, e.x);
+    constexpr int WG_TILES = ROWS_PER_WG / 32;
+    const int nslots = (A_tiles + WG_TILES - 1) / WG_TILES + 1;  // workgroup rb fills slot rb (even rows) and/or rb + 1 (odd rows)
+    const int first_odd = A_even / WG_TILES + 1;
+    for (int c = tid; c < 32 * B_tiles; c += FIN_THREADS) {
+        int d = -1;
+        if (B.orig[c] >= 0) {
+            unsigned v1 = 0xffffffffu, v2 = 0xffffffffu;
+            const uint2* cp = colpart + (size_t)p * wb_stride * row_stride + c;
+            for (int k = 0; k < nslots; ++k) {
+                const bool even = WG_TILES * k < A_even;
+                if (!even && k < first_odd) continue;                     // the slot between the classes when A_even % 8 == 0
+                const uint2 e = cp[(size_t)k * row_stride];
+                const unsigned pa = even ? 0u : 1u;                        // one parity per slot
+                const unsigned va = ((e.x >> (KEY_SHIFT + 1)) << 1) | pa, vb = ((e.y >> (KEY_SHIFT + 1)) << 1) | pa;
+                v2 = umin(umin(umax(v1, va), v2), vb);  // (va <= vb) merged into (v1 <= v2)
+                v1 = umin(v1, va);
             }
+            const unsigned pb = (c >> 5) >= B_even ? 1u : 0u;
+            const bool ok = v2 < PAD_V && ratio_pass((int)(v1 + pb) - 2, (int)(v2 + pb) - 2, ratio);  // pad second => < 2 query rows
+            d = ok ? (int)(v1 + pb) - 2 : -1;
+            c21 += ok;
         }
-        int na = A.norm[q];
-        bool ok = r.z + na < PAD_VALUE && ratio_pass(r.x + na, r.z + na, ratio);  // pad second => < 2 train rows
-        fwd[q] = ok ? r.y : -1;
-        c12 += ok;
+        bwd[c] = d;
     }
-    const int nwb = A.ntiles / MATCH_NSUB;
-    for (int c = tid; c < B.n; c += FIN_THREADS) {
-        int v1 = INT_MAX >> KEY_SHIFT, v2 = INT_MAX >> KEY_SHIFT, r1 = -1;
-        const int2* cp = colpart + (size_t)p * wb_stride * row_stride + c;
-        for (int wb = 0; wb < nwb; ++wb) {  // ascending rows; strict '<' keeps the lower row on ties
-            int2 e = cp[(size_t)wb * row_stride];
-            int va = e.x >> KEY_SHIFT, vb = e.y >> KEY_SHIFT;
-            if (va < v1) {
-                v2 = v1;
-                v1 = va;
-                r1 = ROWS_PER_WAVE * wb + (e.x & KEY_MASK);
-            } else if (va < v2) {
-                v2 = va;
+    __syncthreads();
+    const int nchunks = (B_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
+    for (int j = tid; j < 32 * A_tiles; j += FIN_THREADS) {
+        int keep = -1;
+        if (A.orig[j] >= 0) {
+            unsigned v1 = 0xffffffffu, v2 = 0xffffffffu, col = 0;
+            for (int ch = 0; ch < nchunks; ++ch) {  // ascending columns; strict '<' keeps the lower column on ties
+                const uint4 e = rowres[((size_t)p * col_chunks + ch) * row_stride + j];
+                if (e.x < v1) {
+                    v2 = umin(v1, e.z);
+                    v1 = e.x;
+                    col = e.y;
+                } else {
+                    v2 = umin(v2, e.x);
+                }
             }
-            if (vb < v2) v2 = vb;  // e.y >= e.x, it can only become the runner-up
+            const unsigned pa = (j >> 5) >= A_even ? 1u : 0u;
+            const bool ok = v2 < PAD_V && ratio_pass((int)(v1 + pa) - 2, (int)(v2 + pa) - 2, ratio);  // pad second => < 2 train rows
+            c12 += ok;
+            // main.cpp:133-140: q is kept iff t's own best match is q, i.e. iff t passes the ratio
+            // test (unique minimum for any ratio <= 1) and its minimum is d2(q, t)
+            if (ok && (mode == 1 || bwd[col] == (int)(v1 + pa) - 2)) keep = (int)col;
         }
-        int nb = B.normb[c];  // column ranks are d2 - normb_c
-        bool ok = v2 + nb < PAD_VALUE && ratio_pass(v1 + nb, v2 + nb, ratio);
-        bwd[c] = ok ? r1 : -1;
-        c21 += ok;
+        keepcol[j] = keep;
     }
     atomicAdd(&s_cnt[0], c12);
     atomicAdd(&s_cnt[1], c21);
     __syncthreads();
 
-    // ordered compaction over q in chunks of FIN_THREADS
+    // ordered compaction over the caller's q in chunks of FIN_THREADS
     uint2* out = out_matches + (size_t)p * row_stride;
     int base = 0;
     for (int q0 = 0; q0 < A.n; q0 += FIN_THREADS) {
-        int q = q0 + tid;
-        int t = q < A.n ? fwd[q] : -1;
-        bool keep = t >= 0 && (mode == 1 || bwd[t] == q);  // main.cpp:133-140
+        const int q = q0 + tid;
+        const int t = q < A.n ? keepcol[A.pos[q]] : -1;
+        const bool keep = t >= 0;
         s_scan[tid] = keep;
         __syncthreads();
         for (int off = 1; off < FIN_THREADS; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -473,7 +645,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
             s_scan[tid] += v;
             __syncthreads();
         }
-        if (keep) out[base + s_scan[tid] - 1] = make_uint2((unsigned)q, (unsigned)t);
+        if (keep) out[base + s_scan[tid] - 1] = make_uint2((unsigned)q, (unsigned)B.orig[t]);
         base += s_scan[FIN_THREADS - 1];
         __syncthreads();
     }
@@ -545,28 +717,40 @@ static int upload_frame(eacham_ctx* ctx, int frame_id, const float* src_dev, int
     if (!ks) return ctx->fail(EACHAM_ERR_UNSUPPORTED, "descriptor dim %d: need a multiple of 16, <= 256", dim);
     if (ctx->ks_common && (ctx->ks_common != ks || ctx->kind_common != 0))
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "all resident frames must share one descriptor kind (int8 / f32) and dim class");
-    int ntiles = (n + 31) / 32;
-    ntiles = (ntiles + TILE_ALIGN - 1) / TILE_ALIGN * TILE_ALIGN;
-    if (ntiles > MAX_TILES)
-        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "frame has %d rows; this build supports <= %d", n, MAX_TILES * 32);
+    // each parity class is padded to whole tiles (at most one extra tile), the total to whole wave-blocks
+    const int group_rows = 32 * GROUP_TILES;
+    const int ntiles = n > 0 ? ((n + 31) / 32 + 1 + GROUP_TILES - 1) / GROUP_TILES * GROUP_TILES : 0;
+    if (n > MAX_ROWS)
+        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "frame has %d rows; this build supports <= %d", n, MAX_ROWS);
     if ((size_t)frame_id >= ctx->frames.size()) ctx->frames.resize(frame_id + 1);
     FrameHost& f = ctx->frames[frame_id];
     if (f.frag || f.norm) {
         EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (f.frag) (void)hipFree(f.frag);
-        if (f.norm) (void)hipFree(f.norm);  // normb shares the allocation
+        if (f.norm) (void)hipFree(f.norm);  // the other per-row arrays share the allocation
         f = FrameHost();
     }
     const int npad = ntiles * 32;
-    if (npad > 0) {
-        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.frag, (size_t)ntiles * ks * 64 * sizeof(int4)));
-        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.norm, (size_t)2 * npad * sizeof(int)));
+    {
+        // norm (ca) | normb (hb) | orig | pos | s2 | s1 | meta[2]
+        const size_t ints = (size_t)6 * npad + 2;
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.norm, ints * sizeof(int)));
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(f.norm, 0, ints * sizeof(int), ctx->stream));
         f.normb = f.norm + npad;
-        init_norm_kernel<<<(npad + 255) / 256, 256, 0, ctx->stream>>>(f.norm, f.normb, n, npad);
-        long long work = (long long)npad * ks * 2;
-        quantize_kernel<<<(unsigned)((work + 255) / 256), 256, 0, ctx->stream>>>(
-            src_dev, n, dim, ks, npad, (v4i*)f.frag, f.norm, f.normb, ctx->flag_dev);
-        EACHAM_HIP_TRY(ctx, hipGetLastError());
+        f.orig = f.norm + 2 * (size_t)npad;
+        f.pos = f.norm + 3 * (size_t)npad;
+        int* s2 = f.norm + 4 * (size_t)npad;
+        int* s1 = f.norm + 5 * (size_t)npad;
+        f.meta = f.norm + 6 * (size_t)npad;
+        if (npad > 0) {
+            EACHAM_HIP_TRY(ctx, hipMalloc((void**)&f.frag, (size_t)ntiles * ks * 64 * sizeof(int4)));
+            const long long sums = (long long)n * ((dim + 15) / 16);
+            rowsum_kernel<<<(unsigned)((sums + 255) / 256), 256, 0, ctx->stream>>>(src_dev, n, dim, s2, s1, ctx->flag_dev);
+            partition_kernel<<<1, 1024, 0, ctx->stream>>>(s2, s1, n, npad, group_rows, f.norm, f.normb, f.orig, f.pos, f.meta);
+            const long long work = (long long)npad * ks * 2;
+            quantize_kernel<<<(unsigned)((work + 255) / 256), 256, 0, ctx->stream>>>(src_dev, dim, ks, npad, f.orig, (v4i*)f.frag);
+            EACHAM_HIP_TRY(ctx, hipGetLastError());
+        }
     }
     f.n = n;
     f.dim = dim;
@@ -597,38 +781,46 @@ struct MatchPlan {
     int row_stride;  // padded rows per frame (max)
     int wgs_per_pair;
     int col_chunks;  // sweeps of <= 4096 train rows per pair
-    size_t off_rowres, off_colpart, off_matches, off_counts, total;
+    int slots;       // workspace copies: batch i+1's tile kernel overlaps batch i's finalize
+    size_t off_rowres, off_colpart, off_matches, slot_bytes, total;
 };
 
 static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
-    int max_tiles = TILE_ALIGN;
+    int max_tiles = std::max(4, GROUP_TILES);
     for (const auto& f : ctx->frames)
-        if (f.n >= 0) max_tiles = std::max(max_tiles, f.ntiles);
+        if (f.n >= 0) max_tiles = std::max(max_tiles, f.tiles_used);
     MatchPlan pl;
     pl.row_stride = max_tiles * 32;
-    pl.wb_stride = max_tiles / MATCH_NSUB;
+    pl.wb_stride = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32) + 1;  // column-partial slots per pair: one per workgroup + 1
     pl.wgs_per_pair = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32);
     pl.col_chunks = (max_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
     size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) +
-                      (size_t)pl.row_stride * sizeof(uint2) + sizeof(int);
-    // bound the workspace near 1 GiB so the column partials of one batch stay cache-friendly
+                      (size_t)pl.row_stride * sizeof(uint2);
+    // bound a slot near 1 GiB so the column partials of one batch stay cache-friendly
     size_t budget = (size_t)1 << 30;
     int batch = (int)std::min<size_t>(std::max<size_t>(budget / per_pair, 1), (size_t)npairs);
+    // whole rounds of workgroups (2 per CU x 256 CUs) keep the tail of a launch short
+    const int wgs = pl.wgs_per_pair * pl.col_chunks;
+    int round_pairs = 512;
+    for (int g = 512; g >= 1; g >>= 1)
+        if (wgs % g == 0) { round_pairs = 512 / g; break; }
+    if (batch < npairs && batch > round_pairs) batch -= batch % round_pairs;
     pl.batch = std::max(batch, 1);
+    pl.slots = (pl.batch < npairs && !getenv("EACHAM_NO_OVERLAP")) ? 2 : 1;  // env: diagnostic switch
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     pl.off_rowres = 0;
     pl.off_colpart = align(pl.off_rowres + (size_t)pl.batch * pl.col_chunks * pl.row_stride * sizeof(int4));
     pl.off_matches = align(pl.off_colpart + (size_t)pl.batch * pl.wb_stride * pl.row_stride * sizeof(int2));
-    pl.off_counts = align(pl.off_matches + (size_t)pl.batch * pl.row_stride * sizeof(uint2));
-    pl.total = align(pl.off_counts + (size_t)pl.batch * sizeof(int));
+    pl.slot_bytes = align(pl.off_matches + (size_t)pl.batch * pl.row_stride * sizeof(uint2));
+    pl.total = pl.slot_bytes * pl.slots;
     return pl;
 }
 
 template <int KS>
 static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws) {
     match_tile_kernel<KS, MATCH_NSUB><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
-        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (int4*)(ws + pl.off_rowres),
-        (int2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
+        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_rowres),
+        (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
 }
 
 // Core driver. mode 0 = mutual (CSR out), mode 1 = directed single pair (fixed-stride out in ws).
@@ -638,46 +830,60 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
     int rc = sync_frame_table(ctx);
     if (rc) return rc;
     if (npairs <= 0) return EACHAM_OK;
+    if (mode == 0 && !(ratio <= 1.0))  // the mutual check relies on a passing column having a unique minimum
+        return ctx->fail(EACHAM_ERR_INVALID, "ratio %g: mutual matching supports 0 < ratio <= 1 (the reference uses 0.8)", ratio);
     if (ctx->kind_common == 1)
         return run_match_f32(ctx, pairs_dev, npairs, ratio, min_dir, min_mutual, mode, counts_dev, offsets_dev, edges_dev,
                              edge_cap, total_dev, stats_dev);
     MatchPlan pl = make_plan(ctx, npairs);
     rc = ensure_workspace(ctx, pl.total);
     if (rc) return rc;
-    char* ws = (char*)ctx->ws;
-    ctx->last_matches = ws + pl.off_matches;
+    ctx->last_matches = (char*)ctx->ws + pl.off_matches;
     const size_t fin_smem = (size_t)2 * pl.row_stride * sizeof(int);
     if (fin_smem > 48 * 1024)
         EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)match_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_smem));
-    for (int first = 0; first < npairs; first += pl.batch) {
-        int nb = std::min(pl.batch, npairs - first);
+    // Two streams: the tile kernels run back to back on the context stream; finalize, scan and
+    // compaction of a batch run on stream2 beside the next batch's tile kernel (they are bound by
+    // HBM/L2, the tile kernel by the vector ALU), each batch in its own workspace slot.
+    hipStream_t st1 = ctx->stream, st2 = pl.slots == 2 || npairs <= pl.batch ? ctx->stream2 : ctx->stream;
+    EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st1));        // inputs queued on the context stream
+    EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_join, 0));
+    int b = 0;
+    for (int first = 0; first < npairs; first += pl.batch, ++b) {
+        const int nb = std::min(pl.batch, npairs - first);
+        const int slot = b % pl.slots;
+        char* ws = (char*)ctx->ws + (size_t)slot * pl.slot_bytes;
         const int2* pb = pairs_dev + first;
+        if (b >= pl.slots) EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st1, ctx->ev_fin[slot], 0));  // slot free again
         {
-            ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_TILE);
+            ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_TILE, st1);
             switch (ctx->ks_common) {
                 case 2: launch_tile<2>(ctx, pl, pb, nb, ws); break;
                 case 4: launch_tile<4>(ctx, pl, pb, nb, ws); break;
                 default: launch_tile<8>(ctx, pl, pb, nb, ws); break;
             }
         }
+        EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_tile[slot], st1));
+        EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_tile[slot], 0));
         int* cnt = mode == 1 ? counts_dev : counts_dev + first;
         {
-            ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE);
-            match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, ctx->stream>>>(
-                ctx->frame_table_dev, pb, (const int4*)(ws + pl.off_rowres),
-                (const int2*)(ws + pl.off_colpart), pl.col_chunks, pl.wb_stride, pl.row_stride, ratio, min_dir,
+            ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE, st2);
+            match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(
+                ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres),
+                (const uint2*)(ws + pl.off_colpart), pl.col_chunks, pl.wb_stride, pl.row_stride, ratio, min_dir,
                 min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt,
                 stats_dev ? stats_dev + first : nullptr);
             if (mode == 0) {
-                scan_counts_kernel<<<1, 1024, 0, ctx->stream>>>(cnt, nb, offsets_dev, total_dev, first,
-                                                                first + nb == npairs);
-                compact_edges_kernel<<<nb, 256, 0, ctx->stream>>>((const uint2*)(ws + pl.off_matches), cnt,
-                                                                  offsets_dev + first, pl.row_stride,
-                                                                  edges_dev, edge_cap);
+                scan_counts_kernel<<<1, 1024, 0, st2>>>(cnt, nb, offsets_dev, total_dev, first, first + nb == npairs);
+                compact_edges_kernel<<<nb, 256, 0, st2>>>((const uint2*)(ws + pl.off_matches), cnt, offsets_dev + first,
+                                                          pl.row_stride, edges_dev, edge_cap);
             }
         }
+        EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_fin[slot], st2));
         EACHAM_HIP_TRY(ctx, hipGetLastError());
     }
+    EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));         // later work on the context stream sees the results
+    EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st1, ctx->ev_join, 0));
     return EACHAM_OK;
 }
 
@@ -704,7 +910,7 @@ using namespace eacham;
 
 extern "C" {
 
-#ifdef EXP_STAMPS
+#if defined(EXP_STAMPS) || defined(EXP_CLOCK)
 int eacham_debug_read(unsigned long long* out, int n, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n) != hipSuccess) return -1;
     if (reset) {
