@@ -216,8 +216,12 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     constexpr int ROWS_WG = WAVES * ROWS_WAVE;
     static_assert(ROWS_WAVE <= (1 << KEY_SHIFT), "the local row must fit the key's code field");
     __shared__ v4i sB[3][TILE_V4];
-    __shared__ uint2 sR[WAVES][32 * 33];
-    __shared__ uint2 sC[2][2][WAVES][32];     // column partials of the 4 waves: [tile parity][row-parity group][wave][column]
+    // One LDS region, two lives: during the sweep it buffers the column partials of the 4 waves for
+    // bursts of BURST tiles (double-buffered), after the sweep it is the row-transposition slab.
+    constexpr int BURST = 8;
+    struct ColBuf { uint2 e[2][BURST][2][WAVES][32]; };  // [buffer][tile % BURST][row-parity group][wave][column]
+    struct RowSlab { uint2 e[WAVES][32 * 33]; };
+    __shared__ union { ColBuf c; RowSlab r; } sU;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -316,17 +320,21 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     const int wg_tile0 = rb * (ROWS_WG / 32);
     const bool split = wg_tile0 < A_even && wg_tile0 + ROWS_WG / 32 > A_even;  // workgroup-uniform
     const int slot0 = rb + ((!split && wg_tile0 >= A_even) ? 1 : 0);
-    auto merge_cols = [&](int tt) {  // one wave, after the barrier that published tile tt's partials
-        const int g = split ? h : 0;
-        if (split || h == 0) {
-            uint2 m = sC[tt & 1][g][0][cl];
+    // Burst merge of the published tiles [t0, t0 + BURST) by the whole workgroup: thread -> (tile, column).
+    auto merge_burst = [&](int t0) {
+        const int tt = t0 + 2 * wave + h;  // tid >> 5
+        if (tt < T) {
+            for (int g = 0; g < (split ? 2 : 1); ++g) {
+                const uint2(*src)[32] = sU.c.e[(t0 / BURST) & 1][tt % BURST][g];
+                uint2 m = src[0][cl];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                const uint2 e = sC[tt & 1][g][w][cl];
-                m.y = umin(umin(umax(m.x, e.x), m.y), e.y);
-                m.x = umin(m.x, e.x);
+                for (int w = 1; w < WAVES; ++w) {
+                    const uint2 e = src[w][cl];
+                    m.y = umin(umin(umax(m.x, e.x), m.y), e.y);
+                    m.x = umin(m.x, e.x);
+                }
+                colpart[((size_t)p * wb_stride + slot0 + g) * row_stride + 32 * (tbeg + tt) + cl] = m;
             }
-            colpart[((size_t)p * wb_stride + slot0 + g) * row_stride + 32 * (tbeg + tt) + cl] = m;
         }
     };
 #ifdef EXP_STAMPS
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         const unsigned lowc = ((unsigned)hb_cur << (KEY_SHIFT + 1)) | (unsigned)((tbeg + t >= B_even ? (1 << KEY_SHIFT) : 0) | t);
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
         hb_cur = Bhb[32 * t1 + cl];
-        if (t > 0 && wave == ((t - 1) & (WAVES - 1))) merge_cols(t - 1);  // the waves take turns
+        if (t > 0 && t % BURST == 0) merge_burst(t - BURST);  // tiles t-8 .. t-1 are published; their buffer is rewritten from tile t+8 on
 #ifndef EXP_NO_DMA
         stage_tile(t2, slot_new);  // lands during this iteration; the barrier below publishes it
 #endif
@@ -453,18 +461,18 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                 auto w2 = __builtin_amdgcn_permlane32_swap(g2[0], g2[0], false, false);
                 const unsigned n1 = umin(w1[0], w1[1]);
                 const unsigned n2 = umin(umax(w1[0], w1[1]), umin(w2[0], w2[1]));
-                if (h == 0) sC[t & 1][0][wave][cl] = make_uint2(n1, n2);
+                if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][0][wave][cl] = make_uint2(n1, n2);
             }
             if (split) {
                 auto w1 = __builtin_amdgcn_permlane32_swap(g1[1], g1[1], false, false);
                 auto w2 = __builtin_amdgcn_permlane32_swap(g2[1], g2[1], false, false);
                 const unsigned n1 = umin(w1[0], w1[1]);
                 const unsigned n2 = umin(umax(w1[0], w1[1]), umin(w2[0], w2[1]));
-                if (h == 0) sC[t & 1][1][wave][cl] = make_uint2(n1, n2);
+                if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][1][wave][cl] = make_uint2(n1, n2);
             }
         } else {  // a wave beyond the frame's rows contributes nothing
-            if (h == 0) sC[t & 1][0][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
-            if (split && h == 0) sC[t & 1][1][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
+            if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][0][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
+            if (split && h == 0) sU.c.e[(t / BURST) & 1][t % BURST][1][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
         }
         STAMP(3);
         STAMP(4);
@@ -494,7 +502,8 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         atomicAdd(&dbg[7], (unsigned long long)T);
     }
 #endif
-    if (T > 0 && wave == ((T - 1) & (WAVES - 1))) merge_cols(T - 1);  // published by the loop's last barrier
+    if (T > 0) merge_burst((T - 1) / BURST * BURST);  // the last 1..8 tiles, published by the loop's last barrier
+    __syncthreads();                                  // the region becomes the row slab
     if (!active) return;
 
     // Row direction: every lane holds, per row, its top-2 over the columns {32t + cl}. Transpose
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     // (row, half) scans 16 of the 32 lane-partials of its row in ASCENDING lane-column order with a
     // strict '<': equal keys (same rank, same tile) then keep the lower column, which makes plain
     // 32-bit key compares exact — (key, lane-column) lexicographic == (rank, column) lexicographic.
-    uint2* slab = sR[wave];
+    uint2* slab = sU.r.e[wave];
     uint4* rr = rowres + ((size_t)p * col_chunks + cc) * row_stride + ROWS_WAVE * wb;
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {

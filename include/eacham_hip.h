@@ -97,7 +97,10 @@ int eacham_match_pair(eacham_ctx* ctx, int f1, int f2, double ratio,
  * (npairs+1 entries); (q[k], t[k]) for k in [offsets[p], offsets[p+1]) sorted by q, q indexing
  * frame pairs[2p], t indexing frame pairs[2p+1]  (= Graph::Connect(n1,n2,best12); the reverse
  * edge Connect(n2,n1,best21) is its inverse, main.cpp:144-145).
- * stats (optional, may be NULL): npairs x {|m12|, |m21|, |mutual|, edge?1:0}. */
+ * stats (optional, may be NULL): npairs x {|m12|, |m21|, |mutual|, edge?1:0}.
+ * ratio must be in (0, 1] here (the reference uses 0.8): the mutual check identifies m21[t] == q by
+ * "column t passes the ratio test and its minimum is d(q,t)", which relies on a passing column having
+ * a unique minimum; EACHAM_ERR_INVALID otherwise. eacham_match_pair accepts any ratio. */
 int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio,
                            int min_dir, int min_mutual,
                            int32_t* counts, int64_t* offsets,
