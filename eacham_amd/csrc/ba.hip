@@ -581,6 +581,8 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane i
 constexpr int LDB = NB * NB + NB;
 
 // first wave only; Dn complete. Writes L (lower) and 1/diag.
+// (An LDS scratch column read back with broadcast ds_reads instead of the readlanes was measured
+// 1.8x slower: the write -> read latency lands on the critical path of every column step.)
 __device__ void factor_32(double (*Dn)[NB + 1], double* __restrict__ Lout, int* __restrict__ flags) {
     const int i = threadIdx.x & 31;  // lanes 32..63 mirror lanes 0..31
     double row[NB], dinv_own = 0.0;
@@ -652,19 +654,30 @@ __global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, 
 //   * updates its tile A_ij -= L_ik L_jk^T;
 //   * tile (0,0), which holds the next diagonal block, factorises it on its first wave -> Ldiag[k+1];
 //   * the spare workgroup inverts L_kk -> Winv[k] for the back-substitution (off the critical path).
+#ifdef EXP_BA_STAMPS
+__device__ unsigned long long g_ba_dbg[16];
+#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_ba_dbg[i], now_ - st_prev); st_prev = now_; } } while (0)
+#else
+#define BSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr,
-                                                 int k0, int ntiles, double* __restrict__ Ldiag, double* __restrict__ Winv,
+                                                 int k0, int ntiles, const double* __restrict__ Ldiag_in,
+                                                 double* __restrict__ Ldiag, double* __restrict__ Winv,
                                                  int* __restrict__ flags) {
+#ifdef EXP_BA_STAMPS
+    unsigned long long st_prev = __builtin_readcyclecounter();
+#endif
+    constexpr int LS = NB + 2;  // even row stride: 16-byte aligned pairs for ds_read_b128, still conflict-free
     __shared__ double Lk[NB][NB + 1];
-    __shared__ double dinv[NB];
-    __shared__ double Li[64][NB + 1], Lj[64][NB + 1];
+    __shared__ double dinv_s[NB];
+    __shared__ __attribute__((aligned(16))) double Li[64][LS], Lj[64][LS];
     const int tid = threadIdx.x;
-    const double* Lsrc = Ldiag + (size_t)(k0 / NB) * LDB;
+    const double* __restrict__ Lsrc = Ldiag_in + (size_t)(k0 / NB) * LDB;
     for (int idx = tid; idx < NB * NB; idx += TPB) Lk[idx / NB][idx % NB] = Lsrc[idx];
-    if (tid < NB) dinv[tid] = Lsrc[NB * NB + tid];
+    if (tid < NB) dinv_s[tid] = Lsrc[NB * NB + tid];
     if ((int)blockIdx.x == ntiles) {  // spare workgroup
         __syncthreads();
-        if (tid < 64) invert_32(Lk, dinv, Winv + (size_t)(k0 / NB) * NB * NB);
+        if (tid < 64) invert_32(Lk, dinv_s, Winv + (size_t)(k0 / NB) * NB * NB);
         return;
     }
     const int k1 = k0 + NB;  // columns >= n inside the block are zero padding, rows are masked below
@@ -672,23 +685,39 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
     const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
-    __syncthreads();
-    if (tid < 128) {  // triangular solve, one row per thread: x L_kk^T = a
-        const bool second = tid >= 64;
-        const int r = tid & 63;
-        const int row = (second ? j0 : i0) + r;
-        const bool valid = row < n || row == nr;  // matrix rows, plus the rhs row nr
-        double x[NB];
+    // every global read of this workgroup is issued up front: the panel strip of this thread's row and
+    // the 4x4 outputs it will update, so their latencies overlap each other and the solve
+    const bool second = tid >= 64;
+    const int r = tid & 63;
+    const int row = (second ? j0 : i0) + r;
+    const bool valid = row < n || row == nr;  // matrix rows, plus the rhs row nr
+    double x[NB];
+    if (tid < 128) {
 #pragma unroll
         for (int l = 0; l < NB; ++l) x[l] = (valid && k0 + l < n) ? A[(size_t)row * ld + k0 + l] : 0.0;
+    }
+    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;  // 4x4 outputs per thread
+    double old[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + tr + a, j = j0 + tc + b;
+            const bool inside = (i < n || i == nr) && j < n && j <= i;
+            old[a][b] = inside ? A[(size_t)i * ld + j] : 0.0;
+        }
+    __syncthreads();
+    BSTAMP(0);
+    if (tid < 128) {  // triangular solve x L_kk^T = a, one row per thread, column-oriented: the 31-j
+                      // updates of a step are independent (the row-oriented form is one 496-long FMA chain)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            double sacc = x[j];
+            const double xj = x[j] * dinv_s[j];
+            x[j] = xj;
 #pragma unroll
-            for (int l = 0; l < j; ++l) sacc -= x[l] * Lk[j][l];
-            x[j] = sacc * dinv[j];
+            for (int l = j + 1; l < NB; ++l) x[l] -= xj * Lk[l][j];
         }
-        double (*dst)[NB + 1] = second ? Lj : Li;
+        double (*dst)[LS] = second ? Lj : Li;
 #pragma unroll
         for (int l = 0; l < NB; ++l) dst[r][l] = x[l];
         if (!second && tj == 0 && valid) {
@@ -698,28 +727,32 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         }
     }
     __syncthreads();
-    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;  // 4x4 outputs per thread
+    BSTAMP(1);
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-    for (int l = 0; l < NB; ++l) {
-        double xi[4], xj[4];
+#pragma unroll 4
+    for (int l = 0; l < NB; l += 2) {
+        double2 xi[4], xj[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            xi[a] = Li[tr + a][l];
-            xj[a] = Lj[tc + a][l];
+            xi[a] = *reinterpret_cast<const double2*>(&Li[tr + a][l]);
+            xj[a] = *reinterpret_cast<const double2*>(&Lj[tc + a][l]);
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += xi[a] * xj[b];
+            for (int b = 0; b < 4; ++b) {
+                acc[a][b] += xi[a].x * xj[b].x;
+                acc[a][b] += xi[a].y * xj[b].y;
+            }
     }
     const bool next_diag = (t == 0) && (k1 < n);
     __syncthreads();              // all reads of Li are done: its first rows are reused below
-    double (*Dn)[NB + 1] = Li;
+    BSTAMP(2);
+    double (*Dn)[NB + 1] = Lk;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -728,7 +761,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             double v = 0.0;
             const bool inside = (i < n || i == nr) && j < n && j <= i;
             if (inside) {
-                v = A[(size_t)i * ld + j] - acc[a][b];
+                v = old[a][b] - acc[a][b];
                 A[(size_t)i * ld + j] = v;
             }
             if (next_diag && tr + a < NB && tc + b < NB) {
@@ -738,7 +771,12 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         }
     if (next_diag) {
         __syncthreads();
+        BSTAMP(3);
         if (tid < 64) factor_32(Dn, Ldiag + (size_t)(k1 / NB) * LDB, flags);
+        BSTAMP(4);
+#ifdef EXP_BA_STAMPS
+        if (tid == 0) atomicAdd(&g_ba_dbg[8], 1ull);
+#endif
     }
 }
 
@@ -1244,7 +1282,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int k1 = k0 + NB;
             const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-            chol_step<<<nt * (nt + 1) / 2 + 1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, nt * (nt + 1) / 2, D.Ldiag,
+            chol_step<<<nt * (nt + 1) / 2 + 1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, nt * (nt + 1) / 2, D.Ldiag, D.Ldiag,
                                                                       D.Winv, D.flags);
         }
         EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
@@ -1378,6 +1416,15 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
 }
 
 }  // namespace eacham
+
+#ifdef EXP_BA_STAMPS
+extern "C" int eacham_ba_debug_read(unsigned long long* out, int n) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(eacham::g_ba_dbg), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(eacham::g_ba_dbg), z, sizeof(z));
+    return 0;
+}
+#endif
 
 extern "C" {
 
