@@ -132,6 +132,71 @@ def test_frames_beyond_one_column_chunk(hip_ctx):
     hip_ctx.clear_descriptors()
 
 
+def _with_norm_parity(D, parity):
+    """Forces the parity of every row's centred squared norm (= the parity of its count of odd
+    values, 128 being even): parity 0/1 per row, or None to leave the row alone."""
+    D = D.copy()
+    odd = (D.astype(np.int64) % 2).sum(1) % 2
+    for r in range(D.shape[0]):
+        if parity[r] is not None and odd[r] != parity[r]:
+            D[r, 0] += 1 if D[r, 0] < 255 else -1
+    return D
+
+
+@pytest.mark.parametrize("n1,n2,mode", [(300, 280, "even"), (300, 280, "odd"), (256, 512, "split8"),
+                                        (257, 255, "split8"), (290, 301, "one_odd"), (33, 65, "mixed"),
+                                        (1, 3, "mixed"), (600, 520, "mixed"), (96, 96, "even_then_odd")])
+def test_parity_sorted_layout_edges(hip_ctx, n1, n2, mode):
+    """Frames are stored sorted by the parity of the squared norm: all-even and all-odd
+    frames, class sizes on and off the 32 / 256-row boundaries, a single odd row, tiny frames; exact
+    duplicates across parity classes cannot exist, within a class they must keep the lower index."""
+    dim = 128
+    A = synth.random_u8_descriptors(n1, dim, 77, 0)
+    B = synth.random_u8_descriptors(n2, dim, 77, 1)
+    m = min(n1, n2) // 2
+    B[:m] = np.clip(A[:m] + np.rint(5 * synth.rng_normal(6, 3, (m, dim))), 0, 255)
+    if n2 > 40:
+        B[30:34] = B[10:14]  # duplicated train rows (same parity by construction): ties to the lower index
+    par = {"even": lambda n: [0] * n, "odd": lambda n: [1] * n, "one_odd": lambda n: [0] * (n - 1) + [1],
+           "split8": lambda n: [0] * 256 + [1] * (n - 256) if n > 256 else [0] * n,
+           "even_then_odd": lambda n: [0] * (n // 2) + [1] * (n - n // 2), "mixed": lambda n: [None] * n}[mode]
+    A, B = _with_norm_parity(A, par(n1)), _with_norm_parity(B, par(n2))
+    if n2 > 40:
+        B[30:34] = B[10:14]
+    _upload(hip_ctx, [A, B])
+    for a, b, X, Y in [(0, 1, A, B), (1, 0, B, A)]:
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(X, Y)
+        assert np.array_equal(q, qo) and np.array_equal(t, to)
+    for md in (0, 5):
+        got = hip_ctx.match_all_pairs(np.array([[0, 1], [1, 0]]), min_dir=md, min_mutual=md)
+        want = O.match_all_pairs([A, B], np.array([[0, 1], [1, 0]]), min_dir=md, min_mutual=md)
+        _assert_csr_equal(got, want)
+    hip_ctx.clear_descriptors()
+
+
+def test_ratio_range(hip_ctx):
+    """The mutual entry points take 0 < ratio <= 1; the directed one takes any ratio
+    and must agree with the oracle also when ties pass (ratio > 1: the lower index wins)."""
+    A = synth.random_u8_descriptors(120, 64, 5, 0)
+    B = synth.random_u8_descriptors(140, 64, 5, 1)
+    B[50:60] = B[20:30]
+    B[:40] = np.clip(A[:40] + np.rint(4 * synth.rng_normal(2, 3, (40, 64))), 0, 255)
+    _upload(hip_ctx, [A, B])
+    with pytest.raises(EachamError) as e:
+        hip_ctx.match_all_pairs(np.array([[0, 1]]), ratio=1.5)
+    assert e.value.code == capi.ERR_INVALID
+    for ratio in (1.0, 0.95, 0.6):
+        got = hip_ctx.match_all_pairs(np.array([[0, 1]]), ratio=ratio, min_dir=0, min_mutual=0)
+        want = O.match_all_pairs([A, B], np.array([[0, 1]]), ratio=ratio, min_dir=0, min_mutual=0)
+        _assert_csr_equal(got, want)
+    for ratio in (1.5, 1.0):
+        q, t = hip_ctx.match_pair(1, 0, ratio)
+        qo, to = O.match_directed(B, A, ratio)
+        assert np.array_equal(q, qo) and np.array_equal(t, to)
+    hip_ctx.clear_descriptors()
+
+
 def test_feature_matcher_interface(hip_ctx):
     """FeatureMatcherFlann-shaped adapter: Match(d1, d2) -> {query: train}."""
     A = synth.random_u8_descriptors(150, 128, 3, 0)

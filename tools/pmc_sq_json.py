@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Builds profiles/r01_pmc_sq_match_tile.json from the three SQ counter passes of tools/pmc.sh
+(gpurun_out/sq_a, sq_b, sq_c): mean per dispatch of the LARGEST-grid match_tile_kernel launch + the
+derived fractions quoted in DESIGN.md (formulas in the `derived_from` field)."""
+import collections, csv, glob, json, os, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("sq_a", "sq_b", "sq_c"):
+    for fn in glob.glob(os.path.join(root, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                if "match_tile_kernel" in row["Kernel_Name"]:
+                    acc[int(row["Grid_Size"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+grid = max(acc)
+c = {k: sum(v) / len(v) for k, v in acc[grid].items()}
+tiles = float(sys.argv[1]) if len(sys.argv) > 1 else 64.0
+cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+simds = 256 * 4
+out = {
+    "kernel": f"match_tile_kernel<8, 2>, grid {grid} threads, 64-frame reduced S200 set (tools/pmc.sh, three --pmc passes)",
+    "counters_mean_per_dispatch": dict(sorted(c.items())),
+    "derived": {
+        "gpu_cycles_per_dispatch": cyc,
+        "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * simds),
+        "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * simds),
+        "valu_mfma_coexec_frac": c["SQ_VALU_MFMA_COEXEC_CYCLES"] / (cyc * simds),
+        "valu_insts_per_wave_tile": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / tiles,
+        "mfma_insts_per_wave_tile": c["SQ_INSTS_MFMA"] / c["SQ_WAVES"] / tiles,
+        "waves_resident_per_simd": c["SQ_WAVE_CYCLES"] * 4 / (cyc * simds),
+        "wave_time_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                            "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                            "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]},
+    },
+    "derived_from": "cycles = GRBM_GUI_ACTIVE/8 (sum over 8 XCDs); SQ_ACTIVE_*/SQ_WAVE_CYCLES/SQ_WAIT_* count quad-cycles; "
+                    "busy fractions are per SIMD (1024 SIMDs); per-wave-tile counts divide by SQ_WAVES and the tiles of a sweep",
+}
+dst = os.path.join(root, "profiles", "r01_pmc_sq_match_tile.json")
+with open(dst, "w") as f:
+    json.dump(out, f, indent=1)
+print(dst, json.dumps(out["derived"]))
