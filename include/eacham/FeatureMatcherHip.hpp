@@ -145,5 +145,41 @@ inline MatchGraph MatchAllPairs(Context& ctx, const std::vector<DescriptorView>&
     return g;
 }
 
+// ---- view-graph query on the CSR match graph ---------------------------------------------------
+// std::tuple<unsigned, unsigned, unsigned> Graph::GetBestPairForValid(const std::set<unsigned>& excluded)
+//     /root/reference/modules/sfm/data/Graph.h:59-106
+// evaluated on the wire format MatchAllPairs returns, no Graph::Connect round trip needed.
+//   valid[f]     Node::IsValid();   excluded (may be empty) = the `excluded` set as flags per frame
+//   has3d[f][k]  node f HasPoint3d(k) && !IsPoint3dTwoView(k)
+struct BestPair {
+    unsigned id = 0xffffffffu, id2 = 0xffffffffu, points3dCount = 0;
+};
+
+inline BestPair GetBestPairForValid(Context& ctx, const std::vector<std::pair<unsigned, unsigned>>& pairs, const MatchGraph& g,
+                                    const std::vector<uint8_t>& valid, const std::vector<std::vector<uint8_t>>& has3d,
+                                    const std::vector<uint8_t>& excluded = {}) {
+    const int nFrames = (int)valid.size();
+    if ((int)has3d.size() != nFrames || (!excluded.empty() && (int)excluded.size() != nFrames))
+        throw std::runtime_error("GetBestPairForValid: per-frame arrays disagree");
+    std::vector<int32_t> flat(2 * pairs.size());
+    for (size_t p = 0; p < pairs.size(); ++p) {
+        flat[2 * p] = (int32_t)pairs[p].first;
+        flat[2 * p + 1] = (int32_t)pairs[p].second;
+    }
+    std::vector<int64_t> kpOffsets(nFrames + 1, 0);
+    for (int f = 0; f < nFrames; ++f) kpOffsets[f + 1] = kpOffsets[f] + (int64_t)has3d[f].size();
+    std::vector<uint8_t> flags((size_t)kpOffsets[nFrames] + 1);
+    for (int f = 0; f < nFrames; ++f) std::copy(has3d[f].begin(), has3d[f].end(), flags.begin() + kpOffsets[f]);
+    uint32_t best[3] = {0, 0, 0};
+    ctx.check(eacham_graph_best_pair(ctx.get(), nFrames, flat.data(), (int)pairs.size(), g.counts.data(), g.offsets.data(),
+                                     g.q.data(), g.t.data(), valid.data(), excluded.empty() ? nullptr : excluded.data(),
+                                     kpOffsets.data(), flags.data(), nullptr, best));
+    BestPair r;
+    r.id = best[0];
+    r.id2 = best[1];
+    r.points3dCount = best[2];
+    return r;
+}
+
 }  // namespace hip
 }  // namespace eacham

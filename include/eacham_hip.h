@@ -237,6 +237,23 @@ int eacham_reprojection_errors(eacham_ctx* ctx, const double* transforms, int n_
                                const uint32_t* frame, const double* points, const double* uv, const double* K,
                                float* err);
 
+/* ---- view-graph query on the CSR match graph --------------------------
+ * Graph::GetBestPairForValid (/root/reference/modules/sfm/data/Graph.h:59-106) evaluated directly on the
+ * wire format of eacham_match_all_pairs: pair p with counts[p] > 0 is the factor f1 -> f2 with matches
+ * q -> t and the factor f2 -> f1 with t -> q (Graph::Connect both ways, apps/sfm/main.cpp:144-145).
+ *   valid[f]        Node::IsValid();  excluded[f] (may be NULL) = the `excluded` set
+ *   kp_offsets      n_frames+1 offsets into kp_has3d;  kp_has3d[kp_offsets[f] + k] = 1 iff
+ *                   node f HasPoint3d(k) && !IsPoint3dTwoView(k)
+ * best = {id, id2, points3dCount} of the reference's tuple ({UINT_MAX, UINT_MAX, 0} when no valid node
+ * has a not-yet-valid, not-excluded neighbour). A candidate replaces the best unless
+ * `bestScore > count`, so among equal counts the last visited wins; nodes are visited in ascending id
+ * as in the reference and neighbours in ascending id (the reference's unordered_map has no order).
+ * edge_counts (optional, 2*npairs): points3dCount of f1 -> f2 and of f2 -> f1 for every pair. */
+int eacham_graph_best_pair(eacham_ctx* ctx, int n_frames, const int32_t* pairs, int npairs, const int32_t* counts,
+                           const int64_t* offsets, const uint32_t* q, const uint32_t* t, const uint8_t* valid,
+                           const uint8_t* excluded, const int64_t* kp_offsets, const uint8_t* kp_has3d,
+                           uint32_t* edge_counts, uint32_t* best);
+
 /* ---- kernel timing (HIP events on the context stream; used for roofline reporting) ---------- */
 
 #define EACHAM_KERNEL_MATCH_TILE 0     /* all-pairs int8 MFMA distance + fused row/col top-2      */

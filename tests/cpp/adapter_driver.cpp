@@ -59,6 +59,19 @@ int main(int argc, char** argv) {
         for (unsigned j = i + 1; j < (unsigned)F; ++j) pairs.push_back({i, j});
     MatchGraph g = MatchAllPairs(matcher.context(), frames, pairs, 0.8, 5, 5);
     wr(out, g.counts); wr(out, g.q); wr(out, g.t);
+    {   // GetBestPairForValid on that graph: frames 0 and 1 valid, every third keypoint has a 3-D point
+        std::vector<uint8_t> valid(F, 0);
+        valid[0] = 1;
+        if (F > 1) valid[1] = 1;
+        std::vector<std::vector<uint8_t>> has3d(F);
+        for (int f = 0; f < F; ++f) {
+            has3d[f].resize(frames[f].rows);
+            for (int k = 0; k < frames[f].rows; ++k) has3d[f][k] = valid[f] && (k % 3 == 0);
+        }
+        BestPair bp = GetBestPairForValid(matcher.context(), pairs, g, valid, has3d);
+        std::vector<uint32_t> b = {bp.id, bp.id2, bp.points3dCount};
+        wr(out, b);
+    }
 
     // ---- RefineBA on a graph/map view ----
     GraphView graph; MapView map;

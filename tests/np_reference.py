@@ -143,3 +143,26 @@ def tri_ransac(Ts, uvs, K4, max_err, min_angle):
                 if sum(loc) > best:
                     best, mask = sum(loc), loc
     return bool(X[2] > 0 and best > 2), X, mask
+
+
+# ---- view-graph query (Graph.h:59-106 walked literally on dict-of-dict factors) ----------------
+
+def graph_best_pair(n_frames, pairs, counts, offsets, q, t, valid, has3d, excluded=None):
+    factors = {f: {} for f in range(n_frames)}
+    for p, (f1, f2) in enumerate(np.asarray(pairs).reshape(-1, 2).tolist()):
+        if counts[p] > 0:
+            sl = slice(int(offsets[p]), int(offsets[p]) + int(counts[p]))
+            factors[f1][f2] = np.asarray(q[sl])          # m1 of the factor f1 -> f2
+            factors[f2][f1] = np.asarray(t[sl])          # m1 of the factor f2 -> f1
+    best_score, best = 0.0, (0xFFFFFFFF, 0xFFFFFFFF, 0)
+    for node in range(n_frames):                        # std::map: ascending id
+        if not valid[node]:
+            continue
+        for other in sorted(factors[node]):             # neighbours in ascending id (documented choice)
+            if valid[other] or (excluded is not None and excluded[other]):
+                continue
+            cnt = int(np.asarray(has3d[node])[factors[node][other]].sum())
+            if best_score > cnt:
+                continue
+            best_score, best = float(cnt), (node, other, cnt)
+    return best

@@ -194,3 +194,27 @@ def reprojection_errors(transforms, frame, points, uv, K4):
     L.oracle_reprojection_errors(vp(T.ctypes.data), C.c_int(fr.size), vp(fr.ctypes.data), vp(P.ctypes.data), vp(U.ctypes.data),
                                  vp(K4.ctypes.data), vp(err.ctypes.data))
     return err
+
+
+# ---- view-graph query --------------------------------------------------------------------------
+
+def graph_best_pair(n_frames, pairs, counts, offsets, q, t, valid, has3d_per_frame, excluded=None):
+    from eacham_amd.graph import pack_has3d
+    L = oracle.lib()
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    q = np.ascontiguousarray(q, dtype=np.uint32)
+    t = np.ascontiguousarray(t, dtype=np.uint32)
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    excl = None if excluded is None else np.ascontiguousarray(excluded, dtype=np.uint8)
+    kpo, flat = pack_has3d(has3d_per_frame)
+    ec = np.zeros((pairs.shape[0], 2), dtype=np.uint32)
+    best = np.zeros(3, dtype=np.uint32)
+    vp = C.c_void_p
+    L.oracle_graph_best_pair.restype = None
+    L.oracle_graph_best_pair(C.c_int(n_frames), vp(pairs.ctypes.data), C.c_int(pairs.shape[0]), vp(counts.ctypes.data),
+                             vp(offsets.ctypes.data), vp(q.ctypes.data), vp(t.ctypes.data), vp(valid.ctypes.data),
+                             vp(excl.ctypes.data) if excl is not None else None, vp(kpo.ctypes.data), vp(flat.ctypes.data),
+                             vp(ec.ctypes.data), vp(best.ctypes.data))
+    return (int(best[0]), int(best[1]), int(best[2])), ec

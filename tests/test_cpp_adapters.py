@@ -83,6 +83,11 @@ def test_cpp_adapters_against_oracle(tmp_path):
         counts, gq, gt = _vec(f, np.int32), _vec(f, np.uint32), _vec(f, np.uint32)
         want = O.match_all_pairs(descs, synth.all_pairs(4), min_dir=5, min_mutual=5)
         assert np.array_equal(counts, want[0]) and np.array_equal(gq, want[2]) and np.array_equal(gt, want[3]) and counts.sum() > 0
+        bp = _vec(f, np.uint32)
+        valid4 = np.array([1, 1, 0, 0], np.uint8)
+        has3d = [(np.arange(d.shape[0]) % 3 == 0) & bool(valid4[k]) for k, d in enumerate(descs)]
+        wbp, _ = O.graph_best_pair(4, synth.all_pairs(4), want[0], want[1], want[2], want[3], valid4, has3d)
+        assert tuple(bp.tolist()) == wbp and wbp[2] > 0
         meta, K_out = _vec(f, np.float64), _vec(f, np.float64)
         Ts, Ps, st_out = _vec(f, np.float64).reshape(-1, 4, 4), _vec(f, np.float64).reshape(-1, 3), _vec(f, np.int32)
 

@@ -1,0 +1,57 @@
+"""GPU: eacham_graph_best_pair through the C-ABI against the oracle."""
+import numpy as np
+import pytest
+
+import oracle_api as O
+from eacham_amd import HipContext, capi, synth
+from eacham_amd import graph as G
+from test_graph_oracle import scenario
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with HipContext(0) as c:
+        yield c
+
+
+@pytest.mark.parametrize("n_frames,seed", [(5, 0), (9, 1), (17, 2), (40, 3), (64, 4)])
+def test_matches_oracle(ctx, n_frames, seed):
+    pairs, counts, offsets, q, t, valid, has3d, excluded = scenario(n_frames, seed)
+    for ex in (None, excluded):
+        got, ec = G.best_pair_for_valid(ctx, n_frames, pairs, counts, offsets, q, t, valid, has3d, ex, want_edge_counts=True)
+        want, wec = O.graph_best_pair(n_frames, pairs, counts, offsets, q, t, valid, has3d, ex)
+        assert got == want and np.array_equal(ec, wec)
+
+
+def test_on_a_real_match_graph(ctx):
+    """The matcher's own CSR output feeds the query without any re-packing."""
+    sc = synth.make_scene(8, 2500, 4, seed=3)
+    descs, ids = synth.make_frame_descriptors(sc, 400, 128, seed=3)
+    for f, d in enumerate(descs):
+        ctx.upload_descriptors(f, d)
+    pairs = synth.all_pairs(8)
+    counts, offsets, q, t, _ = ctx.match_all_pairs(pairs, min_dir=5, min_mutual=5)
+    assert (counts > 0).sum() >= 4
+    valid = np.array([1, 1, 1, 0, 0, 0, 0, 0], np.uint8)
+    has3d = [(np.asarray(i) >= 0) & bool(valid[f]) for f, i in enumerate(ids)]   # keypoints that see a landmark
+    got = G.best_pair_for_valid(ctx, 8, pairs, counts, offsets, q, t, valid, has3d)
+    want, _ = O.graph_best_pair(8, pairs, counts, offsets, q, t, valid, has3d)
+    assert got == want and got[2] > 0 and valid[got[0]] and not valid[got[1]]
+    ctx.clear_descriptors()
+
+
+def test_empty_and_invalid(ctx):
+    z32, z64, zu = np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, np.uint32)
+    assert G.best_pair_for_valid(ctx, 3, np.zeros((0, 2), np.int32), z32, z64, zu, zu, np.ones(3, np.uint8),
+                                 [np.zeros(2)] * 3) == (G.NONE, G.NONE, 0)
+    pairs = np.array([[0, 1]], np.int32)
+    with pytest.raises(capi.EachamError) as e:    # a match index beyond the frame's keypoints never reaches the kernel
+        G.best_pair_for_valid(ctx, 2, pairs, np.array([1], np.int32), np.array([0, 1], np.int64), np.array([5], np.uint32),
+                              np.array([0], np.uint32), np.array([1, 0], np.uint8), [np.zeros(2), np.zeros(2)])
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.EachamError) as e:
+        G.best_pair_for_valid(ctx, 2, np.array([[0, 7]], np.int32), np.array([0], np.int32), np.array([0, 0], np.int64), zu, zu,
+                              np.array([1, 0], np.uint8), [np.zeros(2), np.zeros(2)])
+    assert e.value.code == capi.ERR_INVALID
