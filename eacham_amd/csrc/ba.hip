@@ -194,6 +194,8 @@ struct BaDev {
     double *E, *lmlin, *camlin, *klin;
     // per try
     double *Et, *lmtry, *S, *Lm, *Ldiag, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
+    // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
+    double *dl_nc, *dl_nl, *dl_part;
     int* flags;
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
@@ -1007,6 +1009,134 @@ __global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_
     }
 }
 
+// ---- DogLeg (GTSAM DoglegOptimizerImpl): scalar forms of the steepest-descent direction g = A^T b and the
+// Gauss-Newton step n on the UNDAMPED linearised system H = A^T A (blocks of K-A/K-B), all sums in
+// fixed order. forms = {g.g, g.n, n.n, g^T H g, g^T H n, n^T H n}; landmark part here, thread = landmark.
+__global__ __launch_bounds__(TPB) void ba_dl_forms_landmarks(BaDev D) {
+    __shared__ double sm[(TPB / 64) * 6];
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    double f[6] = {0, 0, 0, 0, 0, 0};
+    if (j < D.nl) {
+        const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
+        if (o1 > o0) {
+            const double* in = D.lmlin + (size_t)LMLIN * j;
+            const double gl[3] = {in[6], in[7], in[8]};
+            const double nl[3] = {D.dl_nl[3 * (size_t)j], D.dl_nl[3 * (size_t)j + 1], D.dl_nl[3 * (size_t)j + 2]};
+            const double* gK = D.klin + 25;
+            const double* nK = D.dl_nc + 6 * D.nc;
+            // a_x = ElK^T x_K + sum_o E_o^T x_c(o): the part of H x that lands on this landmark from cameras and K
+            double ag[3] = {0, 0, 0}, an[3] = {0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    ag[c] += in[9 + 3 * a + c] * gK[a];
+                    an[c] += in[9 + 3 * a + c] * nK[a];
+                }
+            for (int o = o0; o < o1; ++o) {
+                const double* E = D.E + 18 * (size_t)o;
+                const int cam = (int)D.obs_cam[o];
+                const double* gc = D.camlin + (size_t)CAMLIN * cam + 66;
+                const double* nc = D.dl_nc + 6 * (size_t)cam;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        ag[c] += E[3 * a + c] * gc[a];
+                        an[c] += E[3 * a + c] * nc[a];
+                    }
+            }
+            const double H00 = in[0], H01 = in[1], H02 = in[2], H11 = in[3], H12 = in[4], H22 = in[5];
+            const double hg[3] = {H00 * gl[0] + H01 * gl[1] + H02 * gl[2], H01 * gl[0] + H11 * gl[1] + H12 * gl[2],
+                                  H02 * gl[0] + H12 * gl[1] + H22 * gl[2]};
+            const double hn[3] = {H00 * nl[0] + H01 * nl[1] + H02 * nl[2], H01 * nl[0] + H11 * nl[1] + H12 * nl[2],
+                                  H02 * nl[0] + H12 * nl[1] + H22 * nl[2]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                f[0] += gl[c] * gl[c];
+                f[1] += gl[c] * nl[c];
+                f[2] += nl[c] * nl[c];
+                f[3] += gl[c] * hg[c] + 2.0 * ag[c] * gl[c];
+                f[4] += gl[c] * hn[c] + ag[c] * nl[c] + an[c] * gl[c];
+                f[5] += nl[c] * hn[c] + 2.0 * an[c] * nl[c];
+            }
+        }
+    }
+    block_sum<6>(f, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) D.dl_part[6 * (size_t)blockIdx.x + k] = f[k];
+}
+
+// camera + K part and the final fixed-order sums -> scal[4..9]
+__global__ __launch_bounds__(TPB) void ba_dl_forms_final(BaDev D) {
+    __shared__ double sm[(TPB / 64) * 6];
+    double f[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < D.n_lm_blocks; i += TPB)
+        for (int k = 0; k < 6; ++k) f[k] += D.dl_part[6 * (size_t)i + k];
+    const double* gK = D.klin + 25;
+    const double* nK = D.dl_nc + 6 * D.nc;
+    for (int c = threadIdx.x; c < D.nc; c += TPB) {
+        const double* cl = D.camlin + (size_t)CAMLIN * c;
+        const double* gc = cl + 66;
+        const double* nc = D.dl_nc + 6 * (size_t)c;
+        double hg[6], hn[6];  // Hcc x_c + HcK x_K
+        for (int a = 0; a < 6; ++a) {
+            double sg = 0.0, sn = 0.0;
+            for (int b = 0; b < 6; ++b) {
+                sg += cl[6 * a + b] * gc[b];
+                sn += cl[6 * a + b] * nc[b];
+            }
+            double kg = 0.0, kn = 0.0;
+            for (int b = 0; b < 5; ++b) {
+                kg += cl[36 + 5 * a + b] * gK[b];
+                kn += cl[36 + 5 * a + b] * nK[b];
+            }
+            hg[a] = sg + 2.0 * kg;  // x_c^T Hcc y_c + x_c^T HcK y_K + y_c^T HcK x_K, folded per form below
+            hn[a] = sn + 2.0 * kn;
+            f[0] += gc[a] * gc[a];
+            f[1] += gc[a] * nc[a];
+            f[2] += nc[a] * nc[a];
+            f[3] += gc[a] * hg[a];
+            f[4] += gc[a] * (sn + kn) + nc[a] * kg;
+            f[5] += nc[a] * hn[a];
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 5; ++a) {
+            double sg = 0.0, sn = 0.0;
+            for (int b = 0; b < 5; ++b) {
+                sg += D.klin[5 * a + b] * gK[b];
+                sn += D.klin[5 * a + b] * nK[b];
+            }
+            f[0] += gK[a] * gK[a];
+            f[1] += gK[a] * nK[a];
+            f[2] += nK[a] * nK[a];
+            f[3] += gK[a] * sg;
+            f[4] += gK[a] * sn;
+            f[5] += nK[a] * sn;
+        }
+    }
+    block_sum<6>(f, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) D.scal[4 + k] = f[k];
+}
+
+// x_d = cu * g + cn * n -> delta_c / delta_l (the inputs of the retraction and error kernels) and pt_new
+__global__ __launch_bounds__(TPB) void ba_dl_apply(BaDev D, double cu, double cn) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < 3 * D.nl) {
+        const int j = i / 3;
+        const double g = D.lm_ptr[j + 1] > D.lm_ptr[j] ? D.lmlin[(size_t)LMLIN * j + 6 + i % 3] : 0.0;
+        const double d = cu * g + cn * D.dl_nl[i];
+        D.delta_l[i] = d;
+        D.pt_new[i] = D.pt[i] + d;
+    }
+    if (i < D.n) {
+        const double g = i < 6 * D.nc ? D.camlin[(size_t)CAMLIN * (i / 6) + 66 + i % 6] : D.klin[25 + (i - 6 * D.nc)];
+        D.delta_c[i] = cu * g + cn * D.dl_nc[i];
+    }
+}
+
 }  // namespace eacham
 
 // ====================================================================================================
@@ -1206,6 +1336,9 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
     TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
     TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
+    TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
+    TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
+    TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
     TRY(dev_alloc(ctx, h, &D.flags, 4));
 #undef TRY
     hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
@@ -1333,7 +1466,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
         R->initial_error = R->final_error = NAN;
         return download();
     }
-    if (O->method != EACHAM_BA_LM) return ctx->fail(EACHAM_ERR_UNSUPPORTED, "only method LM is implemented on the device (DogLeg is not)");
+    if (O->method != EACHAM_BA_LM && O->method != EACHAM_BA_DOGLEG) return ctx->fail(EACHAM_ERR_INVALID, "unknown BA method %d", O->method);
     // use_preconditioner (PCG + block-Jacobi at 1e-10) asks GTSAM for an iterative solve of the same
     // system; the direct Schur/Cholesky solve here is its limit, so the flag needs no separate path.
 
@@ -1348,7 +1481,109 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
     double error = sc[0];
     R->initial_error = error;
     double newErrorOuter = error, currentError = error;
-    if (error > errorTol && iterations < O->max_iter) {
+    if (O->method == EACHAM_BA_DOGLEG) {
+        // DoglegOptimizer (BundleAdjuster.cpp:204-214; GTSAM 4.1.1 DoglegOptimizer.cpp, DoglegOptimizerImpl.h):
+        // per iterate() one linearisation, the Gauss-Newton step n (the LM pipeline at lambda = 0), the
+        // steepest-descent point u = (g.g / g^T H g) g, then DoglegOptimizerImpl::Iterate in mode
+        // ONE_STEP_PER_ITERATION. Every candidate x_d = cu u + cn n needs one retraction + error pass; the
+        // model decrease M(0) - M(x_d) = g.x_d - 1/2 x_d^T H x_d comes from six scalars computed once.
+        double delta = (double)O->delta;
+        if (error > errorTol && iterations < O->max_iter) {
+            for (;;) {  // NonlinearOptimizer::defaultOptimize
+                currentError = newErrorOuter;
+                launch_linearize(ctx, h);
+                rc = launch_try(ctx, h, 0.0, nullptr);
+                if (rc) return rc;
+                EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.dl_nc, D.delta_c, sizeof(double) * (size_t)D.n, hipMemcpyDeviceToDevice, ctx->stream));
+                if (D.nl) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.dl_nl, D.delta_l, sizeof(double) * 3 * (size_t)D.nl, hipMemcpyDeviceToDevice, ctx->stream));
+                {
+                    ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
+                    ba_dl_forms_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D);
+                    ba_dl_forms_final<<<1, TPB, 0, ctx->stream>>>(D);
+                }
+                double s10[10];
+                EACHAM_HIP_TRY(ctx, hipMemcpyAsync(s10, D.scal, sizeof(s10), hipMemcpyDeviceToHost, ctx->stream));
+                EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (!(s10[2] == 0.0) || !std::isfinite(s10[1])) break;  // GTSAM would throw IndeterminantLinearSystemException
+                const double gg = s10[4], gn0 = s10[5], nn = s10[6], gHg = s10[7], gHn = s10[8], nHn = s10[9];
+                const double alpha = gg / gHg;  // u = alpha g
+                const double uu = alpha * alpha * gg, un = alpha * gn0, uHu = alpha * alpha * gHg, uHn = alpha * gHn;
+                const double gu = alpha * gg, gn = gn0;
+                double f_new = error;
+                bool zero_step = false;
+                for (bool stay = true; stay;) {
+                    double cu, cn;  // DoglegOptimizerImpl::ComputeDoglegPoint / ComputeBlend
+                    const double DeltaSq = delta * delta;
+                    if (DeltaSq < uu) {
+                        cu = std::sqrt(DeltaSq / uu);
+                        cn = 0.0;
+                    } else if (DeltaSq < nn) {
+                        const double a = uu - 2. * un + nn, b = 2. * (un - uu), c = uu - DeltaSq;
+                        const double sq = std::sqrt(b * b - 4 * a * c);
+                        const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
+                        const double tau = (0.0 <= tau1 && tau1 <= 1.0) ? tau1 : tau2;
+                        cu = 1. - tau;
+                        cn = tau;
+                    } else {
+                        cu = 0.0;
+                        cn = 1.0;
+                    }
+                    const double dnorm = std::sqrt(cu * cu * uu + 2 * cu * cn * un + cn * cn * nn);
+                    {
+                        ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
+                        const int na = std::max(3 * D.nl, D.n);
+                        ba_dl_apply<<<(na + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, cu * alpha, cn);
+                        ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
+                        ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
+                        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0);
+                    }
+                    rc = read_scal(ctx, h, sc);
+                    if (rc) return rc;
+                    f_new = sc[0];
+                    const double decrease = (cu * gu + cn * gn) - 0.5 * (cu * cu * uHu + 2 * cu * cn * uHn + cn * cn * nHn);  // M(0) - M(x_d)
+                    const double rho = (std::fabs(error - f_new) < 1e-15 || std::fabs(decrease) < 1e-15) ? 0.5 : (error - f_new) / decrease;
+                    bool accepted = true;
+                    const double delta_used = delta;
+                    if (rho >= 0.75) {
+                        delta = std::max(delta, 3.0 * dnorm);
+                        stay = false;
+                    } else if (rho >= 0.25) {
+                        stay = false;
+                    } else if (rho >= 0.0) {
+                        if (delta > 1e-5) delta = 0.5 * delta;
+                        stay = false;  // ONE_STEP_PER_ITERATION
+                    } else {           // f increased (or NaN): shrink the region and try again
+                        accepted = false;
+                        if (delta > 1e-5) {
+                            delta *= 0.5;
+                        } else {
+                            zero_step = true;  // dx_d.setZero(): the values and the error stay
+                            stay = false;
+                        }
+                    }
+                    if (R->trace && R->trace_len < R->trace_cap) {
+                        eacham_ba_trace_row* tr = &R->trace[R->trace_len++];
+                        tr->lambda = delta_used; tr->new_error = f_new; tr->lin_change = decrease;
+                        tr->accepted = accepted ? 1 : 0; tr->outer = iterations;
+                    }
+                    ++inner;
+                }
+                if (!zero_step) {
+                    std::swap(D.pose, D.pose_new);
+                    std::swap(D.pt, D.pt_new);
+                    std::swap(D.Kc, D.K_new);
+                    error = f_new;
+                }
+                ++iterations;
+                newErrorOuter = error;
+                if (newErrorOuter <= errorTol) break;
+                const double absDec = currentError - newErrorOuter, relDec = absDec / currentError;
+                const bool converged = (relTol != 0.0 && relDec <= relTol) || (absDec <= absTol);
+                if (!(iterations < O->max_iter) || converged || !std::isfinite(currentError)) break;
+            }
+        }
+        lambda = delta;  // reported as final_lambda
+    } else if (error > errorTol && iterations < O->max_iter) {
         for (;;) {  // NonlinearOptimizer::defaultOptimize
             currentError = newErrorOuter;
             launch_linearize(ctx, h);  // iterate(): linearize once, then tryLambda until it returns true

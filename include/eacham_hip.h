@@ -189,7 +189,9 @@ typedef struct eacham_ba_result {
 /* Runs RefineBA's optimisation on the device. Host pointers in, host pointers out; all state stays
  * resident on the device during the LM loop, only scalars (errors, lambda decisions) cross PCIe
  * per inner iteration. Returns EACHAM_OK also when the problem is skipped (see result->status).
- * EACHAM_ERR_UNSUPPORTED for method DogLeg. */
+ * Method DogLeg (BundleAdjuster.cpp:204-214) runs GTSAM's DoglegOptimizer control flow (mode
+ * ONE_STEP_PER_ITERATION, deltaInitial = options->delta) on the same linearisation and Gauss-Newton solve;
+ * its trace rows carry the trust-region radius in `lambda` and the model decrease in `lin_change`. */
 int eacham_ba_solve(eacham_ctx* ctx, const eacham_ba_problem* problem, const eacham_ba_options* options,
                     eacham_ba_result* result);
 

@@ -676,6 +676,82 @@ static void retract(const state_t* S, const double* dc, const double* dl, state_
     for (int a = 0; a < 5; ++a) out->K[a] = S->K[a] + dc[6 * S->nc + a];
 }
 
+/* ---- DoglegOptimizer pieces (GTSAM 4.1.1 DoglegOptimizer.cpp / DoglegOptimizerImpl.{h,cpp}) ----- */
+/* g = A^T b over all factors (GTSAM's gradientAtZero is -g), layout like dc | dl */
+static void gradient(const ba_t* B, const lin_t* L, double* gc, double* gl) {
+    const eacham_ba_problem* P = B->P;
+    const state_t* S = &B->S;
+    const int nc = S->nc;
+    memset(gc, 0, sizeof(double) * (size_t)(6 * nc + 5));
+    memset(gl, 0, sizeof(double) * 3 * (size_t)S->nl);
+    for (int o = 0; o < S->no; ++o) {
+        const int c = (int)P->obs_cam[o], j = (int)P->obs_point[o];
+        const double *Ap = L->Ap + 12 * (size_t)o, *Al = L->Al + 6 * (size_t)o, *Ak = L->Ak + 10 * (size_t)o, *b = L->b + 2 * (size_t)o;
+        for (int a = 0; a < 6; ++a) gc[6 * c + a] += Ap[a] * b[0] + Ap[6 + a] * b[1];
+        for (int a = 0; a < 3; ++a) gl[3 * j + a] += Al[a] * b[0] + Al[3 + a] * b[1];
+        for (int a = 0; a < 5; ++a) gc[6 * nc + a] += Ak[a] * b[0] + Ak[5 + a] * b[1];
+    }
+    for (int i = 0; i < nc; ++i)
+        for (int a = 0; a < 6; ++a) gc[6 * i + a] += L->Pw[6 * i + a] * L->Pb[6 * i + a];
+    for (int j = 0; j < S->nl; ++j) {
+        if (B->lm_ptr[j + 1] == B->lm_ptr[j]) continue;
+        for (int a = 0; a < 3; ++a) gl[3 * j + a] += L->Lw[j] * L->Lb[3 * j + a];
+    }
+    for (int a = 0; a < 5; ++a) gc[6 * nc + a] += L->Kw[a] * L->Kb[a];
+}
+
+/* (A x) . (A y) over all factors */
+static double hessian_form(const ba_t* B, const lin_t* L, const double* xc, const double* xl, const double* yc, const double* yl) {
+    const eacham_ba_problem* P = B->P;
+    const state_t* S = &B->S;
+    const int nc = S->nc;
+    double tot = 0.0;
+#pragma omp parallel for reduction(+ : tot) schedule(static)
+    for (int o = 0; o < S->no; ++o) {
+        const int c = (int)P->obs_cam[o], j = (int)P->obs_point[o];
+        const double *Ap = L->Ap + 12 * (size_t)o, *Al = L->Al + 6 * (size_t)o, *Ak = L->Ak + 10 * (size_t)o;
+        double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        for (int a = 0; a < 6; ++a) { x0 += Ap[a] * xc[6 * c + a]; x1 += Ap[6 + a] * xc[6 * c + a]; y0 += Ap[a] * yc[6 * c + a]; y1 += Ap[6 + a] * yc[6 * c + a]; }
+        for (int a = 0; a < 3; ++a) { x0 += Al[a] * xl[3 * j + a]; x1 += Al[3 + a] * xl[3 * j + a]; y0 += Al[a] * yl[3 * j + a]; y1 += Al[3 + a] * yl[3 * j + a]; }
+        for (int a = 0; a < 5; ++a) { x0 += Ak[a] * xc[6 * nc + a]; x1 += Ak[5 + a] * xc[6 * nc + a]; y0 += Ak[a] * yc[6 * nc + a]; y1 += Ak[5 + a] * yc[6 * nc + a]; }
+        tot += x0 * y0 + x1 * y1;
+    }
+    for (int i = 0; i < nc; ++i)
+        for (int a = 0; a < 6; ++a) tot += L->Pw[6 * i + a] * L->Pw[6 * i + a] * xc[6 * i + a] * yc[6 * i + a];
+    for (int j = 0; j < S->nl; ++j) {
+        if (B->lm_ptr[j + 1] == B->lm_ptr[j]) continue;
+        for (int a = 0; a < 3; ++a) tot += L->Lw[j] * L->Lw[j] * xl[3 * j + a] * yl[3 * j + a];
+    }
+    for (int a = 0; a < 5; ++a) tot += L->Kw[a] * L->Kw[a] * xc[6 * nc + a] * yc[6 * nc + a];
+    return tot;
+}
+
+static double dot2(const double* ac, const double* al, const double* bc, const double* bl, int n, int nl3) {
+    double t = 0.0;
+    for (int k = 0; k < n; ++k) t += ac[k] * bc[k];
+    for (int k = 0; k < nl3; ++k) t += al[k] * bl[k];
+    return t;
+}
+
+/* DoglegOptimizerImpl::ComputeDoglegPoint / ComputeBlend: x_d = cu * x_u + cn * x_n */
+static void dogleg_point(double delta, double uu, double un, double nn, double* cu, double* cn) {
+    const double DeltaSq = delta * delta;
+    if (DeltaSq < uu) {
+        *cu = sqrt(DeltaSq / uu);
+        *cn = 0.0;
+    } else if (DeltaSq < nn) {
+        const double a = uu - 2. * un + nn, b = 2. * (un - uu), c = uu - DeltaSq;
+        const double sq = sqrt(b * b - 4 * a * c);
+        const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
+        const double tau = (0.0 <= tau1 && tau1 <= 1.0) ? tau1 : tau2;
+        *cu = 1. - tau;
+        *cn = tau;
+    } else {
+        *cu = 0.0;
+        *cn = 1.0;
+    }
+}
+
 /* ---- exported: error at the initial values ---------------------------------------------------- */
 double oracle_ba_error(const eacham_ba_problem* P) {
     ba_t B;
@@ -723,7 +799,7 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
         ba_free(&B);
         return 0;
     }
-    if (O->method != EACHAM_BA_LM) { ba_free(&B); return -4; }
+    if (O->method != EACHAM_BA_LM && O->method != EACHAM_BA_DOGLEG) { ba_free(&B); return -4; }
     state_t* S = &B.S;
     const int n = 6 * S->nc + 5;
     state_t N = *S; /* tentative values */
@@ -742,7 +818,93 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
     double error = graph_error(&B, S);
     R->initial_error = error;
     double newErrorOuter = error, currentError = error;
-    if (error > errorTol && iterations < O->max_iter) {
+    if (O->method == EACHAM_BA_DOGLEG) { /* DoglegOptimizer (BundleAdjuster.cpp:204-214): delta0 = config.delta */
+        double delta = (double)O->delta;
+        double* gc = (double*)calloc((size_t)n, sizeof(double));
+        double* gl = (double*)calloc((size_t)3 * (S->nl > 0 ? S->nl : 1), sizeof(double));
+        const int nl3 = 3 * S->nl;
+        if (error > errorTol && iterations < O->max_iter) {
+            do { /* NonlinearOptimizer::defaultOptimize */
+                currentError = newErrorOuter;
+                /* ---- DoglegOptimizer::iterate() ---- */
+                linearize(&B, S, &L);
+                gradient(&B, &L, gc, gl);                       /* g = A^T b = -gradientAtZero */
+                const double gg = dot2(gc, gl, gc, gl, n, nl3);
+                const double gHg = hessian_form(&B, &L, gc, gl, gc, gl);
+                const double alpha = gg / gHg;                  /* dx_u = -(g.g / |R g|^2) grad = alpha * g */
+                memset(dl, 0, sizeof(double) * (size_t)nl3);
+                const int solved = solve_step(&B, &L, 0.0, 0, dc, dl, 0, 0); /* dx_n: the Gauss-Newton step */
+                if (!solved) break;                             /* GTSAM would throw IndeterminantLinearSystemException */
+                const double uu = alpha * alpha * gg, un = alpha * dot2(gc, gl, dc, dl, n, nl3), nn = dot2(dc, dl, dc, dl, n, nl3);
+                const double uHu = alpha * alpha * gHg, uHn = alpha * hessian_form(&B, &L, gc, gl, dc, dl),
+                             nHn = hessian_form(&B, &L, dc, dl, dc, dl);
+                const double gu = alpha * gg, gn = dot2(gc, gl, dc, dl, n, nl3);
+                const double M_error = linear_error(&B, &L, 0, 0);
+                /* DoglegOptimizerImpl::Iterate, mode ONE_STEP_PER_ITERATION */
+                double f_new = error, cu = 0, cn = 0;
+                int zero_step = 0;
+                for (int stay = 1; stay;) {
+                    dogleg_point(delta, uu, un, nn, &cu, &cn);
+                    const double dnorm = sqrt(cu * cu * uu + 2 * cu * cn * un + cn * cn * nn);
+                    {
+                        double* xc = (double*)malloc(sizeof(double) * (size_t)n);
+                        double* xl = (double*)malloc(sizeof(double) * (size_t)(nl3 > 0 ? nl3 : 1));
+                        for (int k = 0; k < n; ++k) xc[k] = cu * alpha * gc[k] + cn * dc[k];
+                        for (int k = 0; k < nl3; ++k) xl[k] = cu * alpha * gl[k] + cn * dl[k];
+                        retract(S, xc, xl, &N);
+                        free(xc); free(xl);
+                    }
+                    f_new = graph_error(&B, &N);
+                    /* M(x) = M(0) - g.x + 1/2 x^T H x */
+                    const double new_M_error = M_error - (cu * gu + cn * gn) + 0.5 * (cu * cu * uHu + 2 * cu * cn * uHn + cn * cn * nHn);
+                    const double rho = (fabs(error - f_new) < 1e-15 || fabs(M_error - new_M_error) < 1e-15)
+                                           ? 0.5 : (error - f_new) / (M_error - new_M_error);
+                    int accepted = 1;
+                    const double delta_used = delta;
+                    if (rho >= 0.75) {
+                        const double nd = 3.0 * dnorm;
+                        delta = delta > nd ? delta : nd;
+                        stay = 0;
+                    } else if (rho >= 0.25) {
+                        stay = 0;
+                    } else if (rho >= 0.0) {
+                        if (delta > 1e-5) delta = 0.5 * delta;
+                        stay = 0;                               /* ONE_STEP_PER_ITERATION */
+                    } else {                                    /* f increased (or NaN): shrink and retry */
+                        if (delta > 1e-5) {
+                            delta *= 0.5;
+                            accepted = 0;
+                        } else {
+                            zero_step = 1;                      /* dx_d.setZero(); f_error unchanged */
+                            stay = 0;
+                            accepted = 0;
+                        }
+                    }
+                    if (R->trace && R->trace_len < R->trace_cap) {
+                        eacham_ba_trace_row* tr = &R->trace[R->trace_len++];
+                        tr->lambda = delta_used; tr->new_error = f_new; tr->lin_change = M_error - new_M_error;
+                        tr->accepted = accepted; tr->outer = iterations;
+                    }
+                    ++inner;
+                }
+                if (!zero_step) {
+                    pose_t* tp = S->pose; S->pose = N.pose; N.pose = tp;
+                    double* tq = S->pt; S->pt = N.pt; N.pt = tq;
+                    memcpy(S->K, N.K, sizeof(S->K));
+                    error = f_new;
+                }
+                ++iterations;
+                newErrorOuter = error;
+                /* checkConvergence */
+                if (newErrorOuter <= errorTol) break;
+                const double absDec = currentError - newErrorOuter, relDec = absDec / currentError;
+                const int converged = (relTol != 0.0 && relDec <= relTol) || (absDec <= absTol);
+                if (!(iterations < O->max_iter) || converged || !isfinite(currentError)) break;
+            } while (1);
+        }
+        lambda = delta; /* reported in final_lambda */
+        free(gc); free(gl);
+    } else if (error > errorTol && iterations < O->max_iter) {
         do { /* NonlinearOptimizer::defaultOptimize */
             currentError = newErrorOuter;
             /* ---- iterate() ---- */

@@ -100,6 +100,37 @@ def test_hard_start_with_rejected_steps(hip_ctx):
     assert rel(out.points, ref.points) < POSE_POINT_RTOL and rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL
 
 
+@pytest.mark.parametrize("delta", [10.0, 0.05])
+def test_dogleg_parity(hip_ctx, delta):
+    """method "DogLeg" (BundleAdjuster.cpp:204-214): GTSAM's DoglegOptimizer control flow; the trace
+    carries (trust radius, f(x_d), model decrease, accepted, outer)."""
+    sc, A = scene_arrays(seed=21, n_cams=12, n_lm=900, k=5)
+    cfg = ba.OptimizerConfig("DogLeg", 100, 1e-5, delta, False)
+    out = ba.RefineBA(hip_ctx, A, cfg)
+    ref = O.ba_solve(A, cfg)
+    lm = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
+    assert out.status == ref.status == 0
+    assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+    assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :3], ref.trace[:, :3], rtol=1e-6)
+    assert rel(out.cam_T_wc, ref.cam_T_wc) < 1e-7 and rel(out.points, ref.points) < 1e-7
+    assert np.allclose(out.K, ref.K, rtol=1e-9) and np.isclose(out.final_error, ref.final_error, rtol=1e-9)
+    assert np.isclose(out.final_lambda, ref.final_lambda, rtol=1e-6)          # the final trust radius
+    assert np.isclose(out.final_error, lm.final_error, rtol=1e-4)             # same optimum as LM
+    if delta < 1:
+        assert out.trace[0, 0] == np.float32(delta) and out.trace[1, 0] > out.trace[0, 0]  # the region grows by 3 |x_d|
+
+
+def test_dogleg_hard_start_shrinks_the_region(hip_ctx):
+    sc = synth.make_scene(6, 90, 2, seed=0, rot_noise=0.5, trans_noise=0.5, point_noise=0.8)
+    A = ba.BaArrays.from_scene(sc)
+    cfg = ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, False)
+    out = ba.RefineBA(hip_ctx, A, cfg)
+    ref = O.ba_solve(A, cfg)
+    assert (ref.trace[:, 3] == 0).sum() >= 1  # the case does exercise the rho < 0 branch
+    assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :2], ref.trace[:, :2], rtol=1e-6)
+    assert rel(out.points, ref.points) < POSE_POINT_RTOL and rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL
+
+
 def test_fewer_than_50_landmarks_is_a_silent_no_op(hip_ctx):
     sc, A = scene_arrays(n_cams=4, n_lm=49, k=3, outliers=False)
     out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
@@ -109,9 +140,6 @@ def test_fewer_than_50_landmarks_is_a_silent_no_op(hip_ctx):
 
 def test_errors(hip_ctx):
     sc, A = scene_arrays(n_cams=4, n_lm=60, k=3)
-    with pytest.raises(EachamError) as e:
-        ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("DogLeg", 10, 1e-5, 10.0, False))
-    assert e.value.code == capi.ERR_UNSUPPORTED
     A.obs_cam = A.obs_cam.copy()
     A.obs_cam[0] = 99
     with pytest.raises(EachamError) as e:

@@ -160,3 +160,23 @@ def test_golden_fixture(name):
     assert np.allclose(out.cam_T_wc, g["out_T_wc"], rtol=0, atol=1e-9)
     assert np.allclose(out.points, g["out_points"], rtol=0, atol=1e-9) and np.allclose(out.K, g["out_K"], rtol=1e-10)
     assert np.isclose(out.final_error, float(g["final_error"]), rtol=1e-9)
+
+
+def test_dogleg_reaches_the_lm_optimum_and_adapts_the_region():
+    """DoglegOptimizer restatement (GTSAM 4.1.1 DoglegOptimizerImpl::Iterate, ONE_STEP_PER_ITERATION)."""
+    from eacham_amd import ba, synth
+    sc = synth.make_scene(6, 90, 4, seed=12345)
+    A = ba.BaArrays.from_scene(sc)
+    lm = O.ba_solve(A, ba.OptimizerConfig.refine_ba(), nthreads=1)
+    big = O.ba_solve(A, ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, False), nthreads=1)
+    small = O.ba_solve(A, ba.OptimizerConfig("DogLeg", 100, 1e-5, 0.05, False), nthreads=1)
+    assert np.isclose(big.final_error, lm.final_error, rtol=1e-5) and np.isclose(small.final_error, lm.final_error, rtol=1e-5)
+    assert small.outer_iterations > big.outer_iterations                 # a tiny region needs more steps ...
+    r = small.trace[:, 0]
+    assert r[0] == np.float32(0.05) and np.allclose(r[1:4] / r[0:3], 3.0)  # ... and grows by 3 |x_d| while rho >= 0.75
+    assert (np.diff(small.trace[:, 1]) < 0).all()                         # monotone decrease of the error
+    hard = synth.make_scene(6, 90, 2, seed=0, rot_noise=0.5, trans_noise=0.5, point_noise=0.8)
+    H = ba.BaArrays.from_scene(hard)
+    out = O.ba_solve(H, ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, False), nthreads=1)
+    rej = out.trace[:, 3] == 0
+    assert rej.any() and np.allclose(out.trace[1:, 0][rej[:-1]] / out.trace[:-1, 0][rej[:-1]], 0.5)  # rho < 0 halves the region
