@@ -211,6 +211,46 @@ __global__ __launch_bounds__(TRI_BLOCK) void reproject_kernel(const double* __re
     err[i] = (float)sqrt((p.x - u) * (p.x - u) + (p.y - v) * (p.y - v));
 }
 
+// Two-view structure for candidate relative poses (ReconstructionManager.cpp:118-143, :162-186):
+// thread = (transform, match); camera 1 is the identity.
+__global__ __launch_bounds__(TRI_BLOCK) void two_view_kernel(int n, const double2* __restrict__ uv1,
+                                                             const double2* __restrict__ uv2, const double* __restrict__ Kdev,
+                                                             int nt, const double* __restrict__ transforms, float max_err,
+                                                             float min_angle, int angle_strict, double* __restrict__ points,
+                                                             unsigned char* __restrict__ keep) {
+    const long long id = (long long)blockIdx.x * TRI_BLOCK + threadIdx.x;
+    if (id >= (long long)n * nt) return;
+    const int k = (int)(id / n), i = (int)(id % n);
+    const double K[4] = {Kdev[0], Kdev[1], Kdev[2], Kdev[3]};
+    const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const double* T = transforms + 16 * (size_t)k;
+    const double2 p1 = uv1[i], p2 = uv2[i];
+    const double x1 = (p1.x - K[2]) / K[0], y1 = (p1.y - K[3]) / K[1];
+    const double x2 = (p2.x - K[2]) / K[0], y2 = (p2.y - K[3]) / K[1];
+    double A[4][4], x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        A[1][j] = x1 * I4[8 + j] - I4[j];
+        A[0][j] = y1 * I4[8 + j] - I4[4 + j];
+        A[3][j] = x2 * T[8 + j] - T[j];
+        A[2][j] = y2 * T[8 + j] - T[4 + j];
+    }
+    null_vector_4x4(A, x);
+    const double X[3] = {x[0] / x[3], x[1] / x[3], x[2] / x[3]};
+    double* out = points + 3 * (size_t)id;
+    out[0] = X[0];
+    out[1] = X[1];
+    out[2] = X[2];
+    bool ok = false;
+    if (!(X[2] <= 0.0)) {
+        const double u = (K[0] * X[0]) / X[2] + K[2], v = (K[1] * X[1]) / X[2] + K[3];
+        const float err = (float)sqrt((p1.x - u) * (p1.x - u) + (p1.y - v) * (p1.y - v));
+        const double ang = tri_angle(I4, T, X);
+        ok = err < max_err && (angle_strict ? ang > (double)min_angle : !(ang < (double)min_angle));
+    }
+    keep[id] = ok ? 1 : 0;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -317,5 +357,49 @@ extern "C" int eacham_reprojection_errors(eacham_ctx* ctx, const double* transfo
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(err, base + o_e, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
     EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return EACHAM_OK;
+}
+
+extern "C" int eacham_two_view_points(eacham_ctx* ctx, int n_matches, const double* uv1, const double* uv2, const double* K,
+                                      int n_transforms, const double* transforms, float max_repr_error, float min_tri_angle,
+                                      int angle_strict, double* points, uint8_t* keep, int32_t* counts) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_matches < 0 || n_transforms < 0 || !K) return ctx->fail(EACHAM_ERR_INVALID, "two_view: null argument or negative size");
+    if (counts)
+        for (int k = 0; k < n_transforms; ++k) counts[k] = 0;
+    const long long total = (long long)n_matches * n_transforms;
+    if (total == 0) return EACHAM_OK;
+    if (!uv1 || !uv2 || !transforms || !points || !keep || !counts) return ctx->fail(EACHAM_ERR_INVALID, "two_view: null array");
+    if (total > (1ll << 31) - 1) return ctx->fail(EACHAM_ERR_CAPACITY, "two_view: too many (transform, match) items");
+    EACHAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    const size_t o_u1 = take(sizeof(double) * 2 * (size_t)n_matches), o_u2 = take(sizeof(double) * 2 * (size_t)n_matches);
+    const size_t o_K = take(sizeof(double) * 4), o_T = take(sizeof(double) * 16 * (size_t)n_transforms);
+    const size_t o_p = take(sizeof(double) * 3 * (size_t)total), o_k = take((size_t)total);
+    if (int rc = ensure_io(ctx, off)) return rc;
+    char* base = (char*)ctx->io;
+    hipStream_t st = ctx->stream;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_u1, uv1, sizeof(double) * 2 * (size_t)n_matches, hipMemcpyHostToDevice, st));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_u2, uv2, sizeof(double) * 2 * (size_t)n_matches, hipMemcpyHostToDevice, st));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4, hipMemcpyHostToDevice, st));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_T, transforms, sizeof(double) * 16 * (size_t)n_transforms, hipMemcpyHostToDevice, st));
+    {
+        ProfileScope scope(ctx, EACHAM_KERNEL_TRIANGULATE);
+        two_view_kernel<<<(unsigned)((total + TRI_BLOCK - 1) / TRI_BLOCK), TRI_BLOCK, 0, st>>>(
+            n_matches, (const double2*)(base + o_u1), (const double2*)(base + o_u2), (const double*)(base + o_K), n_transforms,
+            (const double*)(base + o_T), max_repr_error, min_tri_angle, angle_strict, (double*)(base + o_p),
+            (unsigned char*)(base + o_k));
+    }
+    EACHAM_HIP_TRY(ctx, hipGetLastError());
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(points, base + o_p, sizeof(double) * 3 * (size_t)total, hipMemcpyDeviceToHost, st));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(keep, base + o_k, (size_t)total, hipMemcpyDeviceToHost, st));
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < n_transforms; ++k) {  // counts on the host: the masks are here anyway
+        int32_t c = 0;
+        for (int i = 0; i < n_matches; ++i) c += keep[(size_t)k * n_matches + i];
+        counts[k] = c;
+    }
     return EACHAM_OK;
 }

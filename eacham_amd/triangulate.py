@@ -81,3 +81,23 @@ def reprojection_errors(ctx: HipContext, transforms, frame, points, uv, K) -> np
     ctx._check(ctx._L.eacham_reprojection_errors(ctx.handle, T.ctypes.data, T.shape[0], fr.size, fr.ctypes.data,
                                                  P.ctypes.data, U.ctypes.data, K4.ctypes.data, err.ctypes.data))
     return err
+
+
+def two_view_points(ctx: HipContext, uv1, uv2, K, transforms, max_repr_error: float, min_tri_angle: float,
+                    angle_strict: bool):
+    """RecoverPoseTwoView's per-match loops (ReconstructionManager.cpp:118-143 / :162-186) for candidate
+    relative poses. Returns (points nt x n x 3, keep nt x n uint8, counts nt)."""
+    U1 = np.ascontiguousarray(uv1, dtype=np.float64).reshape(-1, 2)
+    U2 = np.ascontiguousarray(uv2, dtype=np.float64).reshape(-1, 2)
+    T = np.ascontiguousarray(transforms, dtype=np.float64).reshape(-1, 16)
+    if U1.shape != U2.shape:
+        raise ValueError("uv1 / uv2 lengths disagree")
+    n, nt = U1.shape[0], T.shape[0]
+    K4 = _K4(K)
+    pts = np.zeros((nt, n, 3), dtype=np.float64)
+    keep = np.zeros((nt, n), dtype=np.uint8)
+    counts = np.zeros(nt, dtype=np.int32)
+    ctx._check(ctx._L.eacham_two_view_points(ctx.handle, n, U1.ctypes.data, U2.ctypes.data, K4.ctypes.data, nt, T.ctypes.data,
+                                             float(max_repr_error), float(min_tri_angle), int(bool(angle_strict)),
+                                             pts.ctypes.data, keep.ctypes.data, counts.ctypes.data))
+    return pts, keep, counts

@@ -19,6 +19,7 @@
 // this adapter visits neighbours in ascending id and matches in the order given.
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <map>
 #include <stdexcept>
@@ -62,6 +63,50 @@ inline bool TriangulatePointRansac(Context& ctx, const std::vector<EstimatorData
     if (any)
         for (int i = 0; i < m; ++i) inliers.push_back(mask[i] != 0);
     return (status & 1) != 0;
+}
+
+// ---- two-view structure for candidate relative poses --------------------------------------------
+// The per-match loops of ReconstructionManager::RecoverPoseTwoView
+// (/root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:118-143 over the solutions of
+// cv::decomposeHomographyMat, :162-186 for the pose of cv::recoverPose): triangulate every match
+// against each candidate transform, keep it iff z > 0, the reprojection error in camera 1 is below
+// maxReprError and the triangulation angle passes (strictly greater in the homography branch).
+struct TwoViewSolution {
+    std::vector<std::pair<unsigned, std::array<double, 3>>> matches;  // (index into the match list, point3d)
+};
+
+inline std::vector<TwoViewSolution> TwoViewPoints(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2,
+                                                  const double* K, const std::vector<double>& transforms /* k x 16 */,
+                                                  float maxReprError, float minTriAngle, bool homographyBranch) {
+    const int n = (int)(uv1.size() / 2), nt = (int)(transforms.size() / 16);
+    if (uv2.size() != uv1.size()) throw std::runtime_error("TwoViewPoints: point lists disagree");
+    const double K4[4] = {K[0], K[4], K[2], K[5]};
+    std::vector<double> pts((size_t)3 * n * nt + 3);
+    std::vector<uint8_t> keep((size_t)n * nt + 1);
+    std::vector<int32_t> counts(nt + 1);
+    ctx.check(eacham_two_view_points(ctx.get(), n, uv1.data(), uv2.data(), K4, nt, transforms.data(), maxReprError, minTriAngle,
+                                     homographyBranch ? 1 : 0, pts.data(), keep.data(), counts.data()));
+    std::vector<TwoViewSolution> out(nt);
+    for (int k = 0; k < nt; ++k)
+        for (int i = 0; i < n; ++i)
+            if (keep[(size_t)k * n + i]) {
+                const double* p = &pts[3 * ((size_t)k * n + i)];
+                out[k].matches.push_back({(unsigned)i, {p[0], p[1], p[2]}});
+            }
+    return out;
+}
+
+// The reference's choice among the homography solutions (:139-150): the first with the strictly
+// largest number of kept matches, accepted only above 20 matches; -1 otherwise.
+inline int BestTwoViewSolution(const std::vector<TwoViewSolution>& sols) {
+    int best = -1;
+    size_t bestSize = 0;
+    for (size_t k = 0; k < sols.size(); ++k)
+        if (sols[k].matches.size() > bestSize) {
+            bestSize = sols[k].matches.size();
+            best = (int)k;
+        }
+    return bestSize > 20 ? best : -1;
 }
 
 // ---- views for TriangulateFrame ---------------------------------------------------------------

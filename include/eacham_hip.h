@@ -239,6 +239,19 @@ int eacham_reprojection_errors(eacham_ctx* ctx, const double* transforms, int n_
                                const uint32_t* frame, const double* points, const double* uv, const double* K,
                                float* err);
 
+/* Two-view structure for candidate relative poses (first part of SURVEY.md §8(f) rank 3): the per-match
+ * loops of RecoverPoseTwoView (/root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:118-143
+ * for the solutions of cv::decomposeHomographyMat, :162-186 for the pose of cv::recoverPose). Camera 1
+ * is the identity; transforms[k] (row-major 4x4) maps camera-1 to camera-2 coordinates. For every
+ * (transform k, match i): points[k][i] = TriangulatePoint(p1, p2, K, transform); keep[k][i] = 1 iff
+ * z > 0 && reprojection error in camera 1 (rounded to float) < max_repr_error && the triangulation
+ * angle passes: > min_tri_angle when angle_strict != 0 (the homography branch, :132), >= otherwise
+ * (:170). counts[k] = kept matches (the reference picks the first k with the strictly largest count
+ * and needs more than 20, :139-150). The robust E/H estimation itself stays with the caller. */
+int eacham_two_view_points(eacham_ctx* ctx, int n_matches, const double* uv1, const double* uv2, const double* K,
+                           int n_transforms, const double* transforms, float max_repr_error, float min_tri_angle,
+                           int angle_strict, double* points, uint8_t* keep, int32_t* counts);
+
 /* ---- view-graph query on the CSR match graph --------------------------
  * Graph::GetBestPairForValid (/root/reference/modules/sfm/data/Graph.h:59-106) evaluated directly on the
  * wire format of eacham_match_all_pairs: pair p with counts[p] > 0 is the factor f1 -> f2 with matches

@@ -176,3 +176,31 @@ void oracle_reprojection_errors(const double* transforms, int n, const uint32_t*
         err[i] = (float)sqrt((uv[2 * i] - u) * (uv[2 * i] - u) + (uv[2 * i + 1] - v) * (uv[2 * i + 1] - v));
     }
 }
+
+/* Two-view structure for candidate relative poses: the per-match loops of RecoverPoseTwoView
+ * (/root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:118-143 homography branch,
+ * :162-186 essential-matrix branch). Camera 1 is the identity, `transforms[k]` maps camera-1 to camera-2
+ * coordinates. keep = z > 0 && reprojection error in camera 1 (rounded to float) < max_err &&
+ * angle > min_angle (angle_strict, the homography branch) or angle >= min_angle (the other branch). */
+void oracle_two_view_points(int n, const double* uv1, const double* uv2, const double* K, int nt, const double* transforms,
+                            float max_err, float min_angle, int angle_strict, double* points, uint8_t* keep, int32_t* counts) {
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int k = 0; k < nt; ++k) {
+        const double* T = transforms + 16 * (size_t)k;
+        int32_t cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            double* X = points + 3 * ((size_t)k * n + i);
+            oracle_triangulate_point(I4, T, uv1 + 2 * (size_t)i, uv2 + 2 * (size_t)i, K, X);
+            int ok = 0;
+            if (!(X[2] <= 0.0)) {
+                const double u = (K[0] * X[0]) / X[2] + K[2], v = (K[1] * X[1]) / X[2] + K[3];
+                const float err = (float)sqrt((uv1[2 * i] - u) * (uv1[2 * i] - u) + (uv1[2 * i + 1] - v) * (uv1[2 * i + 1] - v));
+                const double ang = oracle_triangulation_angle(I4, T, X);
+                ok = err < max_err && (angle_strict ? ang > (double)min_angle : !(ang < (double)min_angle));
+            }
+            keep[(size_t)k * n + i] = (uint8_t)ok;
+            cnt += ok;
+        }
+        counts[k] = cnt;
+    }
+}

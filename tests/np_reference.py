@@ -166,3 +166,21 @@ def graph_best_pair(n_frames, pairs, counts, offsets, q, t, valid, has3d, exclud
                 continue
             best_score, best = float(cnt), (node, other, cnt)
     return best
+
+
+def two_view(uv1, uv2, K4, T, max_err, min_angle, strict):
+    """ReconstructionManager.cpp:118-143 (strict) / :162-186 per match, with LAPACK's SVD."""
+    I4 = np.eye(4)
+    T = np.reshape(T, (4, 4))
+    pts, keep = [], []
+    for p1, p2 in zip(uv1, uv2):
+        X = tri_point(I4, T, p1, p2, K4)
+        ok = False
+        if not (X[2] <= 0.0):
+            u, v = K4[0] * X[0] / X[2] + K4[2], K4[1] * X[1] / X[2] + K4[3]
+            err = np.float32(np.sqrt((p1[0] - u) ** 2 + (p1[1] - v) ** 2))
+            ang = tri_angle(I4, T, X)
+            ok = bool(err < np.float32(max_err)) and (ang > np.float32(min_angle) if strict else not (ang < np.float32(min_angle)))
+        pts.append(X)
+        keep.append(ok)
+    return np.array(pts), np.array(keep)

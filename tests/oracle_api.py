@@ -218,3 +218,21 @@ def graph_best_pair(n_frames, pairs, counts, offsets, q, t, valid, has3d_per_fra
                              vp(excl.ctypes.data) if excl is not None else None, vp(kpo.ctypes.data), vp(flat.ctypes.data),
                              vp(ec.ctypes.data), vp(best.ctypes.data))
     return (int(best[0]), int(best[1]), int(best[2])), ec
+
+
+def two_view_points(uv1, uv2, K4, transforms, max_err, min_angle, angle_strict):
+    L = oracle.lib()
+    U1 = np.ascontiguousarray(uv1, dtype=np.float64).reshape(-1, 2)
+    U2 = np.ascontiguousarray(uv2, dtype=np.float64).reshape(-1, 2)
+    T = np.ascontiguousarray(transforms, dtype=np.float64).reshape(-1, 16)
+    K4 = np.ascontiguousarray(K4, dtype=np.float64)
+    n, nt = U1.shape[0], T.shape[0]
+    pts = np.zeros((nt, n, 3))
+    keep = np.zeros((nt, n), dtype=np.uint8)
+    counts = np.zeros(nt, dtype=np.int32)
+    vp = C.c_void_p
+    L.oracle_two_view_points.restype = None
+    L.oracle_two_view_points(C.c_int(n), vp(U1.ctypes.data), vp(U2.ctypes.data), vp(K4.ctypes.data), C.c_int(nt), vp(T.ctypes.data),
+                             C.c_float(max_err), C.c_float(min_angle), C.c_int(int(bool(angle_strict))), vp(pts.ctypes.data),
+                             vp(keep.ctypes.data), vp(counts.ctypes.data))
+    return pts, keep, counts

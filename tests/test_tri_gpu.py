@@ -100,3 +100,17 @@ def test_reprojection_errors(ctx):
     b = O.reprojection_errors(tr["transforms"], tr["obs_frame"], X, tr["obs_uv"], tr["K"])
     assert np.allclose(a, b, rtol=2e-7, atol=1e-6)
     assert (np.abs(a - b) > 0).mean() < 0.05  # float rounding of an fp64 value: nearly always identical
+
+
+def test_two_view_points(ctx):
+    from test_tri_oracle import _two_view_case
+    uv1, uv2, K, Ts = _two_view_case(seed=5, n=2000)
+    for strict in (True, False):
+        pts, keep, counts = tri.two_view_points(ctx, uv1, uv2, K, Ts, MAX_ERR, MIN_ANGLE, strict)
+        opts, okeep, ocounts = O.two_view_points(uv1, uv2, K, Ts, MAX_ERR, MIN_ANGLE, strict)
+        assert np.array_equal(keep, okeep) and np.array_equal(counts, ocounts)
+        fin = np.isfinite(opts).all(2)
+        assert np.allclose(pts[fin], opts[fin], rtol=1e-9, atol=1e-11)
+        assert counts.argmax() == 2 and counts[2] > 1500
+    pts, keep, counts = tri.two_view_points(ctx, np.zeros((0, 2)), np.zeros((0, 2)), K, Ts, MAX_ERR, MIN_ANGLE, True)
+    assert pts.shape == (4, 0, 3) and counts.tolist() == [0, 0, 0, 0]

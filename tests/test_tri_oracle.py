@@ -92,3 +92,31 @@ def test_golden_fixture():
     fin = np.isfinite(g["points"]).all(1)
     assert np.allclose(pts[fin], g["points"][fin], rtol=1e-9, atol=1e-12)
     assert set(np.unique(status)) == {0, 1, 2, 3}
+
+
+def _two_view_case(seed=2, n=300):
+    """Two cameras of a scene; camera 1 = identity: relative pose T21 = T2 T1^-1, plus wrong candidates
+    (as cv::decomposeHomographyMat returns up to four)."""
+    sc = synth.make_scene(8, n, 8, seed=seed, pixel_noise=1.0)
+    T1, T2 = sc["T_true"][2], sc["T_true"][4]
+    rel = T2 @ np.linalg.inv(T1)
+    uv = sc["obs_uv"].reshape(n, 8, 2)
+    uv1, uv2 = uv[:, 2].copy(), uv[:, 4].copy()
+    uv2[::9] += 25.0                                   # wrong matches
+    flip = rel.copy(); flip[:3, 3] *= -1               # the mirrored solution: points behind the cameras
+    twist = rel.copy(); twist[:3, :3] = synth.so3_exp(np.array([0.0, 0.2, 0.0])) @ rel[:3, :3]
+    scaled = rel.copy(); scaled[:3, 3] *= 0.01         # the scale of t is free: the same structure, 100x smaller
+    return uv1, uv2, sc["K"], np.stack([flip, twist, rel, scaled])
+
+
+def test_two_view_points_match_literal_restatement():
+    uv1, uv2, K, Ts = _two_view_case()
+    for strict in (True, False):
+        pts, keep, counts = O.two_view_points(uv1, uv2, K, Ts, MAX_ERR, MIN_ANGLE, strict)
+        for k in range(len(Ts)):
+            rp, rk = R.two_view(uv1, uv2, K, Ts[k], MAX_ERR, MIN_ANGLE, strict)
+            assert np.array_equal(keep[k].astype(bool), rk), (strict, k)
+            fin = np.isfinite(rp).all(1)
+            assert np.allclose(pts[k][fin], rp[fin], rtol=1e-7, atol=1e-9)
+            assert counts[k] == rk.sum()
+        assert counts.argmax() == 2 and counts[2] > 200 and counts[0] == 0 and counts[1] < 30 and counts[3] == counts[2]
