@@ -693,25 +693,60 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     const int r = tid & 63;
     const int row = (second ? j0 : i0) + r;
     const bool valid = row < n || row == nr;  // matrix rows, plus the rhs row nr
-    double x[NB];
-    if (tid < 128) {
+    // the two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes) and are handed to
+    // their row's thread through LDS: a thread reading its own row directly touches 64 lines per load
+    double praw[16];
 #pragma unroll
-        for (int l = 0; l < NB; ++l) x[l] = (valid && k0 + l < n) ? A[(size_t)row * ld + k0 + l] : 0.0;
+    for (int m = 0; m < 16; ++m) {
+        const int idx = tid + TPB * m, rr = idx / NB, l = idx % NB;  // rr: 0..63 strip i, 64..127 strip j
+        const int grow = (rr < 64 ? i0 : j0 - 64) + rr;
+        const bool ok = (grow < n || grow == nr) && k0 + l < n;
+        praw[m] = ok ? A[(size_t)grow * ld + k0 + l] : 0.0;
     }
-    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;  // 4x4 outputs per thread
+    // Tile 0 holds the next diagonal block. Its workgroup is the critical path of the whole chain, so it
+    // first updates only that 32x32 block with all 256 threads (4 outputs each), then wave 0 factorises
+    // it while waves 1-2 update the other three quarters of the tile beside it.
+    const bool first = t == 0;
+    const int mr = tid / 8, mc = (tid % 8) * 4;                                   // mini: row mr, columns mc..mc+3
+    const int rest_idx = tid - 64;                                                // waves 1-2: 128 blocks of 4x4 below
+    const bool rest_thread = first && rest_idx >= 0 && rest_idx < 128;
+    const int tr = first ? 32 + (rest_idx / 16) * 4 : (tid / 16) * 4, tc = first ? (rest_idx % 16) * 4 : (tid % 16) * 4;
+    const bool block_thread = first ? rest_thread : true;
     double old[4][4];
+    if (block_thread) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = i0 + tr + a, j = j0 + tc + b;
+                const bool inside = (i < n || i == nr) && j < n && j <= i;
+                old[a][b] = inside ? A[(size_t)i * ld + j] : 0.0;
+            }
+    }
+    double mold[4] = {0.0, 0.0, 0.0, 0.0};
+    if (first) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int i = i0 + tr + a, j = j0 + tc + b;
+            const int i = i0 + mr, j = j0 + mc + b;
             const bool inside = (i < n || i == nr) && j < n && j <= i;
-            old[a][b] = inside ? A[(size_t)i * ld + j] : 0.0;
+            mold[b] = inside ? A[(size_t)i * ld + j] : 0.0;
         }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int idx = tid + TPB * m, rr = idx / NB, l = idx % NB;
+        (rr < 64 ? Li[rr] : Lj[rr - 64])[l] = praw[m];
+    }
     __syncthreads();
     BSTAMP(0);
     if (tid < 128) {  // triangular solve x L_kk^T = a, one row per thread, column-oriented: the 31-j
                       // updates of a step are independent (the row-oriented form is one 496-long FMA chain)
+        double x[NB];
+        {
+            const double (*src)[LS] = second ? Lj : Li;
+#pragma unroll
+            for (int l = 0; l < NB; ++l) x[l] = src[r][l];
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const double xj = x[j] * dinv_s[j];
@@ -730,6 +765,43 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     }
     __syncthreads();
     BSTAMP(1);
+    const bool next_diag = first && (k1 < n);
+    double (*Dn)[NB + 1] = Lk;  // L_kk is not read after the solve
+    if (first) {
+        double macc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int l = 0; l < NB; l += 2) {
+            const double2 xi = *reinterpret_cast<const double2*>(&Li[mr][l]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double2 xj = *reinterpret_cast<const double2*>(&Lj[mc + b][l]);
+                macc[b] += xi.x * xj.x;
+                macc[b] += xi.y * xj.y;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + mr, j = j0 + mc + b;
+            double v = 0.0;
+            const bool inside = (i < n || i == nr) && j < n && j <= i;
+            if (inside) {
+                v = mold[b] - macc[b];
+                A[(size_t)i * ld + j] = v;
+            }
+            if (next_diag) Dn[mr][mc + b] = (k1 + mr < n && k1 + mc + b < n) ? (mc + b <= mr ? v : 0.0) : (mr == mc + b ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        BSTAMP(2);
+        if (tid < 64) {
+            if (next_diag) factor_32(Dn, Ldiag + (size_t)(k1 / NB) * LDB, flags);
+            BSTAMP(4);
+#ifdef EXP_BA_STAMPS
+            if (tid == 0 && next_diag) atomicAdd(&g_ba_dbg[8], 1ull);
+#endif
+            return;
+        }
+        if (!rest_thread) return;
+    }
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -751,35 +823,14 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
                 acc[a][b] += xi[a].y * xj[b].y;
             }
     }
-    const bool next_diag = (t == 0) && (k1 < n);
-    __syncthreads();              // all reads of Li are done: its first rows are reused below
-    BSTAMP(2);
-    double (*Dn)[NB + 1] = Lk;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int i = i0 + tr + a, j = j0 + tc + b;
-            double v = 0.0;
             const bool inside = (i < n || i == nr) && j < n && j <= i;
-            if (inside) {
-                v = old[a][b] - acc[a][b];
-                A[(size_t)i * ld + j] = v;
-            }
-            if (next_diag && tr + a < NB && tc + b < NB) {
-                const int ra = tr + a, cb = tc + b;
-                Dn[ra][cb] = (k1 + ra < n && k1 + cb < n) ? (cb <= ra ? v : 0.0) : (ra == cb ? 1.0 : 0.0);
-            }
+            if (inside) A[(size_t)i * ld + j] = old[a][b] - acc[a][b];
         }
-    if (next_diag) {
-        __syncthreads();
-        BSTAMP(3);
-        if (tid < 64) factor_32(Dn, Ldiag + (size_t)(k1 / NB) * LDB, flags);
-        BSTAMP(4);
-#ifdef EXP_BA_STAMPS
-        if (tid == 0) atomicAdd(&g_ba_dbg[8], 1ull);
-#endif
-    }
 }
 
 // back substitution L^T x = y (y = row nr of Lm) in super-blocks of SB = 4 x NB columns, one launch per
