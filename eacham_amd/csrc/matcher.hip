@@ -814,6 +814,9 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
     for (int g = 512; g >= 1; g >>= 1)
         if (wgs % g == 0) { round_pairs = 512 / g; break; }
     if (batch < npairs && batch > round_pairs) batch -= batch % round_pairs;
+    // a job that fits one launch (a shard of a multi-GPU run) is still cut in two, so that the finalize
+    // of its first half runs beside the tile kernel of the second
+    if (batch >= npairs && npairs >= 8 * round_pairs) batch = ((npairs + 1) / 2 + round_pairs - 1) / round_pairs * round_pairs;
     pl.batch = std::max(batch, 1);
     pl.slots = (pl.batch < npairs && !getenv("EACHAM_NO_OVERLAP")) ? 2 : 1;  // env: diagnostic switch
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
