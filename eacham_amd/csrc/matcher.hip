@@ -222,6 +222,10 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     struct ColBuf { uint2 e[2][BURST][2][WAVES][32]; };  // [buffer][tile % BURST][row-parity group][wave][column]
     struct RowSlab { uint2 e[WAVES][32 * 33]; };
     __shared__ union { ColBuf c; RowSlab r; } sU;
+#ifdef EXP_ONE_WG
+    __shared__ int exp_pad[24 * 1024];  // diagnostic build: 96 KB more LDS -> one workgroup per CU (one wave per SIMD)
+    if (blockIdx.x == 0x7fffffff) exp_pad[threadIdx.x] = 1;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
