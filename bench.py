@@ -259,7 +259,14 @@ def bench_ba(ctx, scene, args, rank, world, dev):
             "final_error": first.final_error, "initial_error": first.initial_error, **stage,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
-                         "note": "algorithmic bytes of one inner iteration (SURVEY.md §8(d)) / summed kernel time"}}
+                         "note": "algorithmic bytes of one inner iteration (SURVEY.md §8(d)) / summed kernel time",
+                         # the dense reduced solve against the fp64 vector peak (SURVEY.md §8(d) asks for both)
+                         "solve": {"bound": "fp64", "achieved": (n ** 3 / 3.0) / (stage["solve_ms_per_inner_iter"] * 1e-3) / 1e12
+                                   if stage["solve_ms_per_inner_iter"] > 0 else 0.0,
+                                   "peak": 78.6, "unit": "TFLOP/s",
+                                   "frac": ((n ** 3 / 3.0) / (stage["solve_ms_per_inner_iter"] * 1e-3) / 1e12 / 78.6)
+                                   if stage["solve_ms_per_inner_iter"] > 0 else 0.0,
+                                   "note": "n^3/3 flops of the Cholesky factorisation / solve time; the chain of 38 dependent block steps is latency-bound"}}}
 
 
 def cpu_baseline_ba(scene):
