@@ -1200,6 +1200,7 @@ struct eacham_ba_handle {
     std::vector<void*> allocs;
     std::vector<int> lm_order;  // landmark-sorted observation index -> caller's observation index
     double *kpart = nullptr, *err_cam = nullptr, *lin_cam = nullptr;
+    double* scal_host = nullptr;  // pinned: the per-try scalar read-back sits on the LM loop's critical path
     double *pose_init = nullptr, *pt_init = nullptr, *K_init = nullptr;
     int n_landmarks_used = 0;
     size_t bytes_linearize = 0, bytes_try = 0;
@@ -1410,6 +1411,7 @@ static void ba_release(eacham_ctx* ctx, eacham_ba_handle* h) {
     if (!h) return;
     (void)hipStreamSynchronize(ctx->stream);
     for (void* q : h->allocs) (void)hipFree(q);
+    if (h->scal_host) (void)hipHostFree(h->scal_host);
     delete h;
 }
 
@@ -1487,8 +1489,10 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
 }
 
 static int read_scal(eacham_ctx* ctx, eacham_ba_handle* h, double* out3) {
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(out3, h->D.scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (!h->scal_host) EACHAM_HIP_TRY(ctx, hipHostMalloc((void**)&h->scal_host, SCAL * sizeof(double), hipHostMallocDefault));
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(h->scal_host, h->D.scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) out3[k] = h->scal_host[k];
     return EACHAM_OK;
 }
 
