@@ -53,7 +53,7 @@ static Noise make_noise() {
 }
 
 constexpr int TPB = 256;           // threads per block of the streaming kernels
-constexpr int PAIR_CHUNK = 64;     // pair-list entries summed by one wave (one per lane)
+constexpr int PAIR_CHUNK = 256;    // pair-list entries summed by one wave (lane e takes entries e, e+64, ...)
 constexpr int NB = 32;             // Cholesky block size
 constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) ElK(15)
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
@@ -451,18 +451,23 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
 
 // ---- K-D1: Schur pair products (wave = chunk of <= 64 entries of one camera block's pair list) ------
 // lane e computes the 6x6 product Et[o_e] Et[o'_e]^T of its entry (all loads independent: the
-// gathers of a whole chunk are in flight together), then the 36 sums are reduced over the wave by
-// a fixed shuffle tree: deterministic, no atomics.
+// gathers of a whole chunk are in flight together). The 36 sums over the wave's entries go through a
+// wave-private LDS transpose: lane e writes its 36 products as column e, lane v < 36 then adds row v in
+// entry order — 36 writes + 64 reads + 64 adds per wave instead of the 36 x 6 x (2 bpermute + add) of a
+// shuffle tree. Fixed order, no atomics: deterministic.
 __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
+    constexpr int ROW = 65;  // odd stride in doubles: the row reads of the 36 summing lanes spread over the banks
+    __shared__ double tr[TPB / 64][36 * ROW];
     const int chunk = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (chunk >= D.n_chunks) return;
     const int lane = threadIdx.x & 63;
+    double* buf = tr[threadIdx.x >> 6];
     const int4 ch = D.pair_chunks[chunk];
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    if (lane < ch.z) {
-        const int2 pr = D.pair_entries[ch.y + lane];
+    for (int e = lane; e < ch.z; e += 64) {  // entries e, e+64, ... in order: a fixed summation order per lane
+        const int2 pr = D.pair_entries[ch.y + e];
         const double* xp = D.Et + 18 * (size_t)pr.x;
         const double* yp = D.Et + 18 * (size_t)pr.y;
         double x[18], y[18];
@@ -474,19 +479,24 @@ __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) acc[6 * a + b] = x[3 * a] * y[3 * b] + x[3 * a + 1] * y[3 * b + 1] + x[3 * a + 2] * y[3 * b + 2];
+            for (int b = 0; b < 6; ++b) acc[6 * a + b] += x[3 * a] * y[3 * b] + x[3 * a + 1] * y[3 * b + 1] + x[3 * a + 2] * y[3 * b + 2];
     }
 #pragma unroll
-    for (int k = 0; k < 36; ++k) {
-        double v = acc[k];
+    for (int k = 0; k < 36; ++k) buf[k * ROW + lane] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 36) {
+        const double* rowp = buf + lane * ROW;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four interleaved partial sums, combined in a fixed order
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        acc[k] = v;
-    }
-    if (lane == 0) {
-        double* out = D.partial + (size_t)36 * chunk;
-#pragma unroll
-        for (int k = 0; k < 36; ++k) out[k] = acc[k];
+        for (int e = 0; e < 64; e += 4) {
+            s0 += rowp[e];
+            s1 += rowp[e + 1];
+            s2 += rowp[e + 2];
+            s3 += rowp[e + 3];
+        }
+        D.partial[(size_t)36 * chunk + lane] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -542,10 +552,16 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
                 D.S[(size_t)D.nr * D.ld + 6 * c + a] = cl[66 + a] - acc[30 + a];  // rhs row
             }
         }
-    } else if (threadIdx.x < 30) {
-        const int i = threadIdx.x;
+    } else if (threadIdx.x < 240) {
+        // K corner: 8 lanes per entry take every 8th partial (independent loads), then a fixed 3-step
+        // shuffle tree — one thread per entry walking all partials in turn was the longest path of the kernel
+        const int i = threadIdx.x >> 3, part = threadIdx.x & 7;
         double s = 0.0;
-        for (int k = 0; k < D.n_lm_blocks; ++k) s += D.kk_part[(size_t)30 * k + i];
+        for (int k = part; k < D.n_lm_blocks; k += 8) s += D.kk_part[(size_t)30 * k + i];
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (part != 0) return;
         if (i < 25) {
             const int a = i / 5, bb = i % 5;
             double v = D.klin[i] - s;
