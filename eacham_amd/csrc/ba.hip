@@ -22,6 +22,8 @@
 // (HBM-bound); see DESIGN.md for the per-kernel byte counts.
 #include "context.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -927,6 +929,113 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backstep(const double* __r
     if (tid < SB && c0 + tid < n) xv[c0 + tid] = ys[tid];
 }
 
+// Back substitution in ONE launch: workgroup s owns super-block s, the super-blocks hand their solutions
+// down through global memory with release/acquire flags instead of kernel boundaries (the chain of
+// launches cost ~18 us per super-block: launch + dependent global round trips; the hand-off ~7 us).
+// Every workgroup is resident at once (<= 64 workgroups on 256 CUs) and every wait is bounded: a
+// workgroup that times out raises flags[0] bit 2 (the solve counts as failed) and publishes anyway, so
+// no wave can spin forever. Protocol (cdna_hip_programming.md section 6, Guideline 16): the producer's waves drain their
+// stores (vmcnt(0)), barrier, one lane issues an agent-scope release fence and sets the flag with an
+// agent-scope atomic; the consumer polls it with an agent-scope atomic, then fences (acquire, agent
+// scope) before any wave reads the published values.
+__global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nsb,
+                                                                const double* __restrict__ Winv, double* __restrict__ xv,
+                                                                int* __restrict__ flags) {
+    __shared__ double xK[SB];
+    __shared__ double ys[SB];
+    __shared__ double part[BSTEP_THREADS / SB][SB];
+    __shared__ double Ws[SB / NB][NB][NB + 1];
+    __shared__ double Lin[SB][SB - NB + 1];
+    __shared__ int timed_out;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x;
+    const int c0 = s * SB;
+    int* handoff = flags + 4;
+    if (tid == 0) timed_out = 0;
+    for (int idx = tid; idx < (SB / NB) * NB * NB; idx += BSTEP_THREADS) {
+        const int b = idx / (NB * NB), e = idx % (NB * NB);
+        const int kb = c0 / NB + b;
+        Ws[b][e / NB][e % NB] = (kb * NB < n) ? Winv[(size_t)kb * NB * NB + e] : 0.0;
+    }
+    for (int idx = tid; idx < SB * (SB - NB); idx += BSTEP_THREADS) {
+        const int r = idx / (SB - NB), c = idx % (SB - NB);
+        Lin[r][c] = (c < (r / NB) * NB && c0 + r < n) ? Lm[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+    }
+    if (tid < SB) ys[tid] = (c0 + tid < n) ? xv[c0 + tid] : 0.0;
+    // 8 threads per column, 16 rows each (rows are contiguous along columns: coalesced)
+    const int cl = tid & (SB - 1), pr = tid / SB, col = c0 + cl;
+    constexpr int RP = SB / (BSTEP_THREADS / SB);
+    double lnext[RP];
+    auto fetch = [&](int K) {  // the L block of super-block K over my columns: independent of any x
+        const int K0 = K * SB;
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            const int row = K0 + pr * RP + r;
+            lnext[r] = (col < n && row < n) ? Lm[(size_t)row * ld + col] : 0.0;
+        }
+    };
+    if (s < nsb - 1) fetch(nsb - 1);
+    __syncthreads();
+    for (int K = nsb - 1; K > s; --K) {
+        double lcur[RP];
+#pragma unroll
+        for (int r = 0; r < RP; ++r) lcur[r] = lnext[r];
+        if (K - 1 > s) fetch(K - 1);  // in flight while this workgroup waits for x_K
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&handoff[K], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (++spins > (1 << 22)) {
+                    timed_out = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid < SB) xK[tid] = (K * SB + tid < n) ? __builtin_nontemporal_load(&xv[K * SB + tid]) : 0.0;
+        __syncthreads();
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < RP; ++r) sacc += lcur[r] * xK[pr * RP + r];
+        part[pr][cl] = sacc;
+        __syncthreads();
+        if (tid < SB) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < BSTEP_THREADS / SB; ++q) tot += part[q][tid];
+            ys[tid] -= tot;
+        }
+        __syncthreads();
+    }
+    // solve super-block s: inner blocks b = 3..0, everything from LDS
+    for (int b = SB / NB - 1; b >= 0; --b) {
+        double xb = 0.0;
+        if (tid < NB) {              // x_b = W^T y_b
+            for (int m = tid; m < NB; ++m) xb += Ws[b][m][tid] * ys[b * NB + m];
+        }
+        __syncthreads();
+        if (tid < NB) ys[b * NB + tid] = xb;
+        __syncthreads();
+        if (tid < b * NB) {          // y[inner cols < b] -= L[block-b rows, col]^T x_b
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < NB; ++j) sacc += Lin[b * NB + j][tid] * ys[b * NB + j];
+            ys[tid] -= sacc;
+        }
+        __syncthreads();
+    }
+    if (tid < SB && c0 + tid < n) xv[c0 + tid] = ys[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (timed_out) atomicOr(flags, 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&handoff[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- K-F: landmark back-substitution + tentative points + linearised-cost terms (thread = landmark) ----
 // delta_l = Linv^T (gt - sum_o Et_o^T dc[c_o] - EKt^T dK);  lin += 1/2 (dl.gl + lambda dl.D dl)
 __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lambda) {
@@ -1407,7 +1516,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
     TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
     TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
-    TRY(dev_alloc(ctx, h, &D.flags, 4));
+    TRY(dev_alloc(ctx, h, &D.flags, 4 + 64));  // [0..3] status, [4..] hand-off flags of the back-substitution
 #undef TRY
     hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
     if (e != hipSuccess) {
@@ -1462,7 +1571,7 @@ static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
 static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, double* S_copy /* host, optional */) {
     BaDev& D = h->D;
     const int n = D.n;
-    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, 4 * sizeof(int), ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (4 + 64) * sizeof(int), ctx->stream));
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
         EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 1) * D.ld, ctx->stream));
@@ -1490,8 +1599,12 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
                                            hipMemcpyDeviceToDevice, ctx->stream));
         const int nsb = (n + SB - 1) / SB;
-        chol_backstep<<<1, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, nsb - 1, 1, D.Winv, D.delta_c);
-        for (int K = nsb - 1; K >= 1; --K) chol_backstep<<<K, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, K, 0, 0, D.Winv, D.delta_c);
+        if (nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES")) {
+            chol_backsolve<<<nsb, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, D.Winv, D.delta_c, D.flags);
+        } else {  // more super-blocks than hand-off flags (n > 8192), or the diagnostic switch: one launch per super-block
+            chol_backstep<<<1, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, nsb - 1, 1, D.Winv, D.delta_c);
+            for (int K = nsb - 1; K >= 1; --K) chol_backstep<<<K, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, K, 0, 0, D.Winv, D.delta_c);
+        }
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
