@@ -601,6 +601,13 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane i
 constexpr int LDB = NB * NB + NB;
 
 // first wave only; Dn complete. Writes L (lower) and 1/diag.
+// Lane i holds row i; pivots and multipliers are broadcast with v_readlane into SGPR pairs that feed
+// v_fma_f64 directly. hipcc, left alone, funnels every broadcast through ONE SGPR pair (readlane,
+// readlane, s_nop, fma, 36 cycles per update, all serialised by that pair); here the updates are issued
+// in groups of four — eight readlanes into four pairs, then four FMAs, the order pinned with
+// sched_group_barrier — so the readlane -> VALU wait states of a group overlap. The non-positive-pivot
+// test is kept off the critical path: a bad pivot is only recorded (flags bit 1, the solve then counts
+// as failed and its NaNs are never used), it is not replaced.
 // (An LDS scratch column read back with broadcast ds_reads instead of the readlanes was measured
 // 1.8x slower: the write -> read latency lands on the critical path of every column step.)
 __device__ void factor_32(double (*Dn)[NB + 1], double* __restrict__ Lout, int* __restrict__ flags) {
@@ -609,25 +616,55 @@ __device__ void factor_32(double (*Dn)[NB + 1], double* __restrict__ Lout, int* 
 #pragma unroll
     for (int m = 0; m < NB; ++m) row[m] = Dn[i][m];
     bool bad = false;
+    constexpr int G = 4;  // updates per group: 2G readlanes into G SGPR pairs, then G FMAs
+    // 1/sqrt(d): hardware estimate + two Newton steps y <- y (1.5 - (d/2) y^2) (fp64 sqrt and divide are
+    // ~30-instruction sequences each)
+    double d = bcast(row[0], 0);
+    bad = bad || !(d > 0.0);
+    double h = 0.5 * d, y = __builtin_amdgcn_rsq(d);
+    double p = h * y, q = __builtin_fma(-p, y, 1.5);
+    y = y * q;
+    p = h * y;
+    q = __builtin_fma(-p, y, 1.5);
+    y = y * q;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {  // right-looking Cholesky
-        double d = bcast(row[j], j);
-        if (!(d > 0.0)) {
-            bad = true;
-            d = 1.0;
-        }
-        // 1/sqrt(d): hardware estimate + two Newton steps (fp64 sqrt and divide are ~30-instruction
-        // sequences each; this sits on the critical path of every block step)
-        double y = __builtin_amdgcn_rsq(d);
-        y = y * (1.5 - 0.5 * d * y * y);
-        y = y * (1.5 - 0.5 * d * y * y);
-        double rs = d * y;
-        rs = rs + 0.5 * y * (d - rs * rs);
-        if (i == j) dinv_own = y;
-        const double lij = (i == j) ? rs : row[j] * y;
+    for (int j = 0; j < NB; ++j) {  // right-looking Cholesky; on entry d = pivot j, y = 1/sqrt(d)
+        const double dj = d, yj = y;
+        double rs = dj * yj;
+        rs = rs + 0.5 * yj * (dj - rs * rs);
+        if (i == j) dinv_own = yj;
+        const double lij = (i == j) ? rs : row[j] * yj;
         row[j] = lij;
+        // the updates of this column, in groups; the first group holds the entry of the next pivot, whose
+        // chain (readlane -> rsq -> Newton) is then issued one operation at a time between the other
+        // groups, so the serial chain of column j+1 hides behind the updates of column j
 #pragma unroll
-        for (int l = j + 1; l < NB; ++l) row[l] -= lij * bcast(lij, l);
+        for (int l0 = j + 1, g = 0; l0 < NB || g < 8; l0 += G, ++g) {
+            if (l0 < NB) {
+                double b[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) b[u] = (l0 + u < NB) ? bcast(lij, (l0 + u < NB) ? l0 + u : 0) : 0.0;
+                __builtin_amdgcn_sched_group_barrier(0x002, 2 * G, 0);
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+                    if (l0 + u < NB) row[l0 + u] -= lij * b[u];
+                __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
+            }
+            if (j + 1 < NB) {  // one statement of the next pivot's chain per group
+                if (g == 0) {
+                    d = bcast(row[j + 1], j + 1);
+                    bad = bad || !(d > 0.0);
+                    h = 0.5 * d;
+                    y = __builtin_amdgcn_rsq(d);
+                } else if (g == 1) p = h * y;
+                else if (g == 2) q = __builtin_fma(-p, y, 1.5);
+                else if (g == 3) y = y * q;
+                else if (g == 4) p = h * y;
+                else if (g == 5) q = __builtin_fma(-p, y, 1.5);
+                else if (g == 6) y = y * q;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
     if (bad && threadIdx.x == 0) atomicOr(flags, 2);
     if (threadIdx.x < NB) {
