@@ -103,19 +103,36 @@ def main():
         if world > 1:
             dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
         edge_cap = max(int(cap_t.item()), 1)
-        edges = torch.zeros(edge_cap * 2, dtype=torch.int32, device=dev)
-        if world > 1:
-            g_counts = torch.zeros(world * shard_max, dtype=torch.int32, device=dev)
-            g_edges = torch.zeros(world * edge_cap * 2, dtype=torch.int32, device=dev)
+        # two output sets: the all-gather of step i (its own RCCL stream) overlaps the matching of step i+1
+        sets = []
+        for _ in range(2 if world > 1 else 1):
+            st = {"counts": torch.zeros(shard_max, dtype=torch.int32, device=dev),
+                  "edges": torch.zeros(edge_cap * 2, dtype=torch.int32, device=dev), "pending": []}
+            if world > 1:
+                st["g_counts"] = torch.zeros(world * shard_max, dtype=torch.int32, device=dev)
+                st["g_edges"] = torch.zeros(world * edge_cap * 2, dtype=torch.int32, device=dev)
+            sets.append(st)
+    step_no = [0]
 
     def step():
+        st = sets[step_no[0] % len(sets)]
+        step_no[0] += 1
         with torch.cuda.stream(ext):
-            ctx.match_all_pairs_dev(pairs_dev.data_ptr(), npairs, counts.data_ptr(), offsets.data_ptr(),
-                                    edges.data_ptr(), edge_cap, total.data_ptr())
+            for w in st["pending"]:  # the exchange that last used this set must be done before it is overwritten
+                w.wait()
+            st["pending"] = []
+            ctx.match_all_pairs_dev(pairs_dev.data_ptr(), npairs, st["counts"].data_ptr(), offsets.data_ptr(),
+                                    st["edges"].data_ptr(), edge_cap, total.data_ptr())
             if world > 1:  # RCCL all-gather of the match graph (counts + padded edge lists) over xGMI
-                shard.all_gather_match_graph(counts, edges, shard_max, edge_cap, world, g_counts, g_edges)
+                _, _, st["pending"] = shard.all_gather_match_graph(st["counts"], st["edges"], shard_max, edge_cap, world,
+                                                                   st["g_counts"], st["g_edges"], async_op=True)
 
     def fence():
+        with torch.cuda.stream(ext):
+            for st in sets:
+                for w in st["pending"]:
+                    w.wait()
+                st["pending"] = []
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

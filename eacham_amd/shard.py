@@ -35,7 +35,8 @@ def shard_capacity(npairs: int, world: int) -> int:
     return -(-npairs // world) if world > 0 else npairs
 
 
-def all_gather_match_graph(counts, edges, shard_cap: int, edge_cap: int, world: int, g_counts=None, g_edges=None):
+def all_gather_match_graph(counts, edges, shard_cap: int, edge_cap: int, world: int, g_counts=None, g_edges=None,
+                           async_op: bool = False):
     """The collective step. counts: int32 [shard_cap] (this rank's per-pair counts, zero padded),
     edges: int32 [2*edge_cap] ({q, t} pairs, this rank's CSR payload, padded). Returns the gathered
     (world*shard_cap, world*2*edge_cap) tensors; preallocate g_* to keep the step allocation-free."""
@@ -45,6 +46,9 @@ def all_gather_match_graph(counts, edges, shard_cap: int, edge_cap: int, world: 
         g_counts = torch.empty(world * shard_cap, dtype=counts.dtype, device=counts.device)
     if g_edges is None:
         g_edges = torch.empty(world * 2 * edge_cap, dtype=edges.dtype, device=edges.device)
+    if async_op:  # the caller overlaps the exchange with the next batch of matching and waits before reusing the buffers
+        return g_counts, g_edges, [dist.all_gather_into_tensor(g_counts, counts, async_op=True),
+                                   dist.all_gather_into_tensor(g_edges, edges, async_op=True)]
     dist.all_gather_into_tensor(g_counts, counts)
     dist.all_gather_into_tensor(g_edges, edges)
     return g_counts, g_edges
