@@ -33,6 +33,38 @@ int ensure_io(eacham_ctx* ctx, size_t bytes) {
     return EACHAM_OK;
 }
 
+__global__ void sanitize_pairs_kernel(const int2* __restrict__ in, int npairs, const FrameDev* __restrict__ frames, int n_frames,
+                                      int2* __restrict__ out, int* __restrict__ flag) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    int2 pr = in[p];
+    const bool ok = pr.x >= 0 && pr.y >= 0 && pr.x < n_frames && pr.y < n_frames && frames[pr.x].resident && frames[pr.y].resident;
+    if (!ok) {
+        pr = make_int2(n_frames, n_frames);  // the empty stand-in: the pair yields no match
+        atomicOr(flag, 1);
+    }
+    out[p] = pr;
+}
+
+int sanitize_pairs(eacham_ctx* ctx, const int2* pairs_dev, int npairs, const int2** out) {
+    if (npairs > ctx->pairs_safe_cap) {
+        if (ctx->pairs_safe) {
+            EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            EACHAM_HIP_TRY(ctx, hipFree(ctx->pairs_safe));
+            ctx->pairs_safe = nullptr;
+            ctx->pairs_safe_cap = 0;
+        }
+        const int cap = npairs + npairs / 2 + 64;
+        EACHAM_HIP_TRY(ctx, hipMalloc((void**)&ctx->pairs_safe, sizeof(int2) * (size_t)cap));
+        ctx->pairs_safe_cap = cap;
+    }
+    sanitize_pairs_kernel<<<(npairs + 255) / 256, 256, 0, ctx->stream>>>(pairs_dev, npairs, ctx->frame_table_dev, (int)ctx->frames.size(),
+                                                                          ctx->pairs_safe, ctx->flag_dev + 1);
+    EACHAM_HIP_TRY(ctx, hipGetLastError());
+    *out = ctx->pairs_safe;
+    return EACHAM_OK;
+}
+
 __global__ void gather_tiles_kernel(const FrameDev* __restrict__ frames, int n, int* __restrict__ used) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) used[i] = frames[i].meta ? frames[i].meta[1] : frames[i].ntiles;
@@ -41,7 +73,7 @@ __global__ void gather_tiles_kernel(const FrameDev* __restrict__ frames, int n, 
 int sync_frame_table(eacham_ctx* ctx) {
     if (!ctx->frame_table_dirty) return EACHAM_OK;
     int need = (int)ctx->frames.size();
-    if (need > ctx->frame_table_cap) {
+    if (need + 1 > ctx->frame_table_cap) {
         if (ctx->frame_table_dev) {
             EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             EACHAM_HIP_TRY(ctx, hipFree(ctx->frame_table_dev));
@@ -51,7 +83,13 @@ int sync_frame_table(eacham_ctx* ctx) {
         EACHAM_HIP_TRY(ctx, hipMalloc((void**)&ctx->frame_table_dev, sizeof(FrameDev) * cap));
         ctx->frame_table_cap = cap;
     }
-    std::vector<FrameDev> tab(need);
+    std::vector<FrameDev> tab(need + 1);
+    {   // entry [need]: an empty frame that invalid device-side pairs are redirected to
+        FrameDev& e = tab[need];
+        e.frag = nullptr; e.norm = nullptr; e.normb = nullptr;
+        e.orig = ctx->flag_dev + 16; e.pos = ctx->flag_dev + 16; e.meta = ctx->flag_dev + 8;
+        e.n = 0; e.ntiles = 0; e.resident = 1;
+    }
     for (int i = 0; i < need; ++i) {
         const FrameHost& f = ctx->frames[i];
         tab[i].frag = f.frag;
@@ -62,14 +100,19 @@ int sync_frame_table(eacham_ctx* ctx) {
         tab[i].meta = f.meta;
         tab[i].n = f.n < 0 ? 0 : f.n;
         tab[i].ntiles = f.n < 0 ? 0 : f.ntiles;
+        tab[i].resident = f.n < 0 ? 0 : 1;
     }
-    if (need > 0) {
+    {
         // pageable source: hipMemcpyAsync stages it before returning, so `tab` may die here
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_table_dev, tab.data(), sizeof(FrameDev) * need,
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_table_dev, tab.data(), sizeof(FrameDev) * (need + 1),
                                            hipMemcpyHostToDevice, ctx->stream));
         // tiles in use per frame (the parity split of an int8 frame is decided on the device): one
         // small read-back per table rebuild lets the host size strides and grids exactly
         int* used_dev = nullptr;
+        if (need == 0) {
+            ctx->frame_table_dirty = false;
+            return EACHAM_OK;
+        }
         EACHAM_HIP_TRY(ctx, hipMalloc((void**)&used_dev, sizeof(int) * need));
         gather_tiles_kernel<<<(need + 255) / 256, 256, 0, ctx->stream>>>(ctx->frame_table_dev, need, used_dev);
         std::vector<int> used(need);
@@ -176,6 +219,7 @@ void eacham_ctx_destroy(eacham_ctx* ctx) {
     }
     if (ctx->frame_table_dev) (void)hipFree(ctx->frame_table_dev);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
+    if (ctx->pairs_safe) (void)hipFree(ctx->pairs_safe);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->io) (void)hipFree(ctx->io);
     for (auto& s : ctx->prof)
@@ -197,6 +241,12 @@ int eacham_ctx_sync(eacham_ctx* ctx) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
     EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int bad = 0;
+    EACHAM_HIP_TRY(ctx, hipMemcpy(&bad, ctx->flag_dev + 1, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) {
+        EACHAM_HIP_TRY(ctx, hipMemset(ctx->flag_dev + 1, 0, sizeof(int)));
+        return ctx->fail(EACHAM_ERR_INVALID, "a device-side pair list named a frame that is not resident (those pairs produced no match)");
+    }
     return EACHAM_OK;
 }
 

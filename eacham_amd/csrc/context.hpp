@@ -31,6 +31,7 @@ struct FrameDev {
     const int* meta;   // int8: {tiles of the even class, tiles in use}; written by the upload kernels
     int n;             // real rows
     int ntiles;        // allocated 32-row tiles (upper bound of meta[1] for int8 frames)
+    int resident;      // 0: no descriptors uploaded under this id (device-side pair lists naming it are neutralised)
 };
 
 struct FrameHost {
@@ -69,7 +70,8 @@ struct eacham_ctx {
     eacham::FrameDev* frame_table_dev = nullptr;
     int frame_table_cap = 0;
     bool frame_table_dirty = true;
-    int* flag_dev = nullptr;  // [0] = non-integer descriptor seen, [1..] scratch
+    int* flag_dev = nullptr;  // [0] = non-integer descriptor seen, [1] = a device-side pair list named a frame that is not
+                              // resident, [8..9] = meta of the empty stand-in frame (zeros), [16..] scratch
     int ks_common = 0;        // k-step class shared by all resident frames (0 = none yet)
     int kind_common = 0;      // 0 = int8 fragments (matcher.hip), 1 = fp32 fragments (matcher_f32.hip)
     void* last_matches = nullptr;  // per-pair match lists of the last run (directed API reads them back)
@@ -77,6 +79,8 @@ struct eacham_ctx {
     // matcher workspace (grown on demand, never inside a timed launch sequence after warm-up)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    int2* pairs_safe = nullptr;  // sanitised copy of the caller's device-side pair list
+    int pairs_safe_cap = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
 
@@ -108,6 +112,9 @@ namespace eacham {
 int ensure_workspace(eacham_ctx* ctx, size_t bytes);
 int ensure_io(eacham_ctx* ctx, size_t bytes);
 int sync_frame_table(eacham_ctx* ctx);
+// copies `pairs` into the workspace tail with every pair that names a missing frame redirected to the empty
+// stand-in entry frames[n_frames] (and flags it); returns the sanitised device pointer in *out
+int sanitize_pairs(eacham_ctx* ctx, const int2* pairs_dev, int npairs, const int2** out);
 
 // matcher_f32.hip
 int upload_frame_f32(eacham_ctx* ctx, int frame_id, const float* src_dev, int n, int dim);

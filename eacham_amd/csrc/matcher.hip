@@ -848,6 +848,8 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
     if (npairs <= 0) return EACHAM_OK;
     if (mode == 0 && !(ratio <= 1.0))  // the mutual check relies on a passing column having a unique minimum
         return ctx->fail(EACHAM_ERR_INVALID, "ratio %g: mutual matching supports 0 < ratio <= 1 (the reference uses 0.8)", ratio);
+    rc = sanitize_pairs(ctx, pairs_dev, npairs, &pairs_dev);  // a bad frame id in a device-side list must not reach the kernels
+    if (rc) return rc;
     if (ctx->kind_common == 1)
         return run_match_f32(ctx, pairs_dev, npairs, ratio, min_dir, min_mutual, mode, counts_dev, offsets_dev, edges_dev,
                              edge_cap, total_dev, stats_dev);

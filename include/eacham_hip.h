@@ -110,7 +110,8 @@ int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, do
 /* Device-resident, asynchronous form used by the benchmark and the multi-GPU shard driver.
  * pairs_dev: npairs x 2 int32. counts_dev: npairs int32. offsets_dev: npairs+1 int64.
  * edges_dev: edge_cap x {uint32 q, uint32 t}; entries beyond edge_cap are dropped and
- * *total_dev (int64, device) still holds the uncapped total. stats_dev: npairs x 4 int32 or NULL. */
+ * *total_dev (int64, device) still holds the uncapped total. stats_dev: npairs x 4 int32 or NULL.  * A pair naming a frame that is not resident yields no match (count 0) and raises a sticky error that
+ * the next eacham_ctx_sync returns as EACHAM_ERR_INVALID; it never reaches the kernels. */
 int eacham_match_all_pairs_dev(eacham_ctx* ctx, const int32_t* pairs_dev, int npairs, double ratio,
                                int min_dir, int min_mutual,
                                int32_t* counts_dev, int64_t* offsets_dev,

@@ -197,6 +197,36 @@ def test_ratio_range(hip_ctx):
     hip_ctx.clear_descriptors()
 
 
+def test_device_side_pair_list_with_a_bad_frame_id(hip_ctx):
+    """eacham_match_all_pairs_dev cannot validate a pair list that lives on the device: a pair naming a frame
+    that is not resident must yield no match, never fault, and surface at the next eacham_ctx_sync."""
+    import torch
+    A = synth.random_u8_descriptors(300, 64, 31, 0)
+    B = synth.random_u8_descriptors(280, 64, 31, 1)
+    B[:150] = np.clip(A[:150] + np.rint(4 * synth.rng_normal(3, 3, (150, 64))), 0, 255)
+    _upload(hip_ctx, [A, B])
+    dev = torch.device("cuda", 0)
+    pairs = np.array([[0, 1], [0, 7], [1, 0], [-3, 1], [5000000, 0]], np.int32)
+    ext = torch.cuda.ExternalStream(hip_ctx.stream, device=dev)
+    with torch.cuda.stream(ext):
+        pd = torch.from_numpy(pairs).to(dev)
+        counts = torch.full((len(pairs),), -1, dtype=torch.int32, device=dev)
+        offsets = torch.zeros(len(pairs) + 1, dtype=torch.int64, device=dev)
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+        edges = torch.zeros(2 * 1000, dtype=torch.int32, device=dev)
+        hip_ctx.match_all_pairs_dev(pd.data_ptr(), len(pairs), counts.data_ptr(), offsets.data_ptr(), edges.data_ptr(), 1000,
+                                    total.data_ptr(), min_dir=5, min_mutual=5)
+        with pytest.raises(EachamError) as e:
+            hip_ctx.sync()
+        assert e.value.code == capi.ERR_INVALID
+        hip_ctx.sync()  # the error is reported once
+    want = O.match_all_pairs([A, B], np.array([[0, 1], [1, 0]]), min_dir=5, min_mutual=5)
+    c = counts.cpu().numpy()
+    assert c.tolist() == [int(want[0][0]), 0, int(want[0][1]), 0, 0] and want[0][0] > 50
+    assert int(total.item()) == int(want[0].sum())
+    hip_ctx.clear_descriptors()
+
+
 def test_feature_matcher_interface(hip_ctx):
     """FeatureMatcherFlann-shaped adapter: Match(d1, d2) -> {query: train}."""
     A = synth.random_u8_descriptors(150, 128, 3, 0)
