@@ -20,7 +20,8 @@
 // lower column. Column direction (t -> best q): pb and the tile are constant, keys order by H, which
 // is the order of d2 as long as pa is constant among the rows compared — so frames are stored
 // PARITY-SORTED (even squared norms first, each class padded to whole 32-row tiles): a sub-tile has
-// one parity, and the one wave-block that may straddle the boundary keeps two column partials. The column direction only needs VALUES: a row q is column t's unique best
+// one parity, and the one workgroup that may straddle the boundary keeps two column partials.
+// The column direction only needs VALUES: a row q is column t's unique best
 // iff d2(q,t) equals the column minimum and the column passes the ratio test (a tie gives quotient
 // 1, which no ratio <= 1 accepts), so no row index is carried through the column reduction.
 // A running top-2 costs two VALU ops:  m2 = med3(m1, m2, key); m1 = min(m1, key).
@@ -55,8 +56,6 @@ constexpr int MATCH_NSUB = EACHAM_MATCH_NSUB;        // 32-row MFMA sub-tiles pe
 constexpr int ROWS_PER_WAVE = 32 * MATCH_NSUB;
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 constexpr int GROUP_TILES = MATCH_NSUB;              // tiles in use are padded to whole wave-blocks
-
-__device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
 // ------------------------------------------------------------------------------------------------
 // upload: fp32 row-major -> fragment-major int8 + squared norms
