@@ -61,6 +61,7 @@ constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) E
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
 constexpr int KLIN = 30;           // HKK(25) gK(5)
 constexpr int SCAL = 16;           // scalar block read back per try
+constexpr int BSEG = 4;            // segments a camera's observations are cut into by the border kernel
 
 __device__ __forceinline__ double huber_weight(double n, double k) { return n <= k ? 1.0 : k / n; }
 __device__ __forceinline__ double huber_loss(double n, double k) { return n <= k ? 0.5 * n * n : k * (n - 0.5 * k); }
@@ -198,6 +199,7 @@ struct BaDev {
     double *Et, *lmtry, *S, *Lm, *Ldiag, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
     double *dl_nc, *dl_nl, *dl_part;
+    double* bpart;  // [nc][BSEG][36] partial border sums
     int* flags;
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(64) void ba_finish_klin(BaDev D, const double* __re
 }
 
 // ---- K-C: per-landmark elimination for one lambda (thread = landmark) -------------------------------
-// Hd = Hll + lambda clamp(diag), Hd = L L^T, Linv; Et_o = E_o Linv^T, EKt = ElK Linv^T, gt = Linv gl.
+// Hd = Hll + lambda clamp(diag), Hd = L L^T, Linv; EKt = ElK Linv^T, gt = Linv gl (Et_o = E_o Linv^T: K-C2).
 // Also this block's share of the (K,K) Schur term: sum EKt EKt^T (25) and EKt gt (5) -> kk_part.
 __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double lambda) {
     __shared__ double sm[(TPB / 64) * 30];
@@ -430,17 +432,6 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
                     kk[5 * a + bb] = ek[3 * a] * ek[3 * bb] + ek[3 * a + 1] * ek[3 * bb + 1] + ek[3 * a + 2] * ek[3 * bb + 2];
                 kk[25 + a] = ek[3 * a] * t0 + ek[3 * a + 1] * t1 + ek[3 * a + 2] * t2;
             }
-            for (int o = o0; o < o1; ++o) {
-                const double* E = D.E + 18 * (size_t)o;
-                double* Et = D.Et + 18 * (size_t)o;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double e0 = E[3 * a], e1 = E[3 * a + 1], e2 = E[3 * a + 2];
-                    Et[3 * a] = m00 * e0;
-                    Et[3 * a + 1] = m10 * e0 + m11 * e1;
-                    Et[3 * a + 2] = m20 * e0 + m21 * e1 + m22 * e2;
-                }
-            }
         } else {
 #pragma unroll
             for (int k = 0; k < LMLIN; ++k) out[k] = 0.0;
@@ -449,6 +440,22 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
     block_sum<30>(kk, sm);
     if (threadIdx.x == 0)
         for (int k = 0; k < 30; ++k) D.kk_part[(size_t)30 * blockIdx.x + k] = kk[k];
+}
+
+// ---- K-C2: Et_o = E_o Linv^T (thread = one 3-vector row of one observation: consecutive threads touch
+// consecutive 24 bytes, and half a million observations give the launch its parallelism; inside K-C the
+// same work was a per-landmark loop of strided 144-byte records) ------------------------------------
+__global__ __launch_bounds__(TPB) void ba_eliminate_observations(BaDev D) {
+    const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= 6ll * D.no) return;
+    const int o = (int)(idx / 6);
+    const double* m = D.lmtry + (size_t)LMLIN * D.obs_lm[o];  // Linv (lower): m00; m10 m11; m20 m21 m22
+    const double* E = D.E + 3 * (size_t)idx;
+    double* Et = D.Et + 3 * (size_t)idx;
+    const double e0 = E[0], e1 = E[1], e2 = E[2];
+    Et[0] = m[0] * e0;
+    Et[1] = m[1] * e0 + m[2] * e1;
+    Et[2] = m[3] * e0 + m[4] * e1 + m[5] * e2;
 }
 
 // ---- K-D1: Schur pair products (wave = chunk of <= 64 entries of one camera block's pair list) ------
@@ -521,42 +528,56 @@ __global__ __launch_bounds__(TPB) void ba_assemble_blocks(BaDev D, double lambda
     if (B.x != B.y) D.S[(size_t)(6 * B.y + b) * D.ld + 6 * B.x + a] = v;
 }
 
-// ---- K-D3: the calibration border and the right-hand side (block = camera, last block = K corner) ----
-__global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda) {
+// ---- K-D3: the calibration border and the right-hand side -------------------------------------------
+// Stage 1 (block = one of BSEG segments of a camera's observations): partial sums of Et EKt^T (6x5) and
+// Et gt (6) -> bpart. Stage 2 (thread = border entry): adds a camera's segments in order and writes S;
+// its last block reduces the (K,K) corner. Two stages because 200 cameras alone do not fill the chip.
+__global__ __launch_bounds__(TPB) void ba_border_partials(BaDev D) {
     __shared__ double sm[(TPB / 64) * 36];
+    const int c = blockIdx.x / BSEG, seg = blockIdx.x % BSEG;
+    const int p0 = D.cam_ptr[c], p1 = D.cam_ptr[c + 1];
+    const int len = (p1 - p0 + BSEG - 1) / BSEG;
+    const int q0 = p0 + seg * len, q1 = min(q0 + len, p1);
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    for (int p = q0 + threadIdx.x; p < q1; p += TPB) {
+        const int o = D.cam_obs[p];
+        const double* Et = D.Et + 18 * (size_t)o;
+        const double* lt = D.lmtry + (size_t)LMLIN * D.obs_lm[o];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double e0 = Et[3 * a], e1 = Et[3 * a + 1], e2 = Et[3 * a + 2];
+#pragma unroll
+            for (int bb = 0; bb < 5; ++bb) acc[5 * a + bb] += e0 * lt[9 + 3 * bb] + e1 * lt[10 + 3 * bb] + e2 * lt[11 + 3 * bb];
+            acc[30 + a] += e0 * lt[6] + e1 * lt[7] + e2 * lt[8];
+        }
+    }
+    block_sum<36>(acc, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 36; ++k) D.bpart[(size_t)36 * blockIdx.x + k] = acc[k];
+}
+
+__global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda) {
     const int c = blockIdx.x;
     if (c < D.nc) {
-        const int p0 = D.cam_ptr[c], p1 = D.cam_ptr[c + 1];
-        double acc[36];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-        for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
-            const int o = D.cam_obs[p];
-            const double* Et = D.Et + 18 * (size_t)o;
-            const double* lt = D.lmtry + (size_t)LMLIN * D.obs_lm[o];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const double e0 = Et[3 * a], e1 = Et[3 * a + 1], e2 = Et[3 * a + 2];
-#pragma unroll
-                for (int bb = 0; bb < 5; ++bb) acc[5 * a + bb] += e0 * lt[9 + 3 * bb] + e1 * lt[10 + 3 * bb] + e2 * lt[11 + 3 * bb];
-                acc[30 + a] += e0 * lt[6] + e1 * lt[7] + e2 * lt[8];
-            }
-        }
-        block_sum<36>(acc, sm);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 36) {
+            const int k = threadIdx.x;
+            double s = 0.0;
+            for (int seg = 0; seg < BSEG; ++seg) s += D.bpart[(size_t)36 * (c * BSEG + seg) + k];
             const double* cl = D.camlin + (size_t)CAMLIN * c;
-            for (int a = 0; a < 6; ++a) {
-                for (int bb = 0; bb < 5; ++bb) {
-                    const double v = cl[36 + 5 * a + bb] - acc[5 * a + bb];
-                    D.S[(size_t)(6 * c + a) * D.ld + 6 * D.nc + bb] = v;
-                    D.S[(size_t)(6 * D.nc + bb) * D.ld + 6 * c + a] = v;
-                }
-                D.S[(size_t)D.nr * D.ld + 6 * c + a] = cl[66 + a] - acc[30 + a];  // rhs row
+            if (k < 30) {
+                const int a = k / 5, bb = k % 5;
+                const double v = cl[36 + k] - s;
+                D.S[(size_t)(6 * c + a) * D.ld + 6 * D.nc + bb] = v;
+                D.S[(size_t)(6 * D.nc + bb) * D.ld + 6 * c + a] = v;
+            } else {
+                D.S[(size_t)D.nr * D.ld + 6 * c + (k - 30)] = cl[66 + (k - 30)] - s;  // rhs row
             }
         }
     } else if (threadIdx.x < 240) {
         // K corner: 8 lanes per entry take every 8th partial (independent loads), then a fixed 3-step
-        // shuffle tree — one thread per entry walking all partials in turn was the longest path of the kernel
+        // shuffle tree
         const int i = threadIdx.x >> 3, part = threadIdx.x & 7;
         double s = 0.0;
         for (int k = part; k < D.n_lm_blocks; k += 8) s += D.kk_part[(size_t)30 * k + i];
@@ -1550,6 +1571,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
     TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
     TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
+    TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * BSEG * std::max(D.nc, 1)));
     TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
     TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
     TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
@@ -1613,8 +1635,10 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
         EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 1) * D.ld, ctx->stream));
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
+        if (D.no > 0) ba_eliminate_observations<<<(unsigned)((6ll * D.no + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<(D.n_chunks + TPB / 64 - 1) / (TPB / 64), TPB, 0, ctx->stream>>>(D);
         if (D.n_blocks > 0) ba_assemble_blocks<<<(unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D, lambda);
+        if (D.nc > 0) ba_border_partials<<<D.nc * BSEG, TPB, 0, ctx->stream>>>(D);
         ba_assemble_border<<<D.nc + 1, TPB, 0, ctx->stream>>>(D, lambda);
     }
     if (S_copy) {
