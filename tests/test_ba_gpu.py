@@ -164,3 +164,25 @@ def test_metric_scene_s200(hip_ctx):
     assert out.final_error < 0.05 * out.initial_error
     assert np.abs(out.points - sc["points_true"]).max() < 0.05
     assert np.abs(out.K - sc["K"]).max() < 5.0
+
+
+def test_config4_size_properties(hip_ctx):
+    """BASELINE configs[3]: 500 cams / 100k landmarks / 1M observations (n = 3005, 94 Cholesky block steps, 24
+    super-blocks in the single-launch back-substitution). Too large for the oracle to finish in seconds, so
+    the check is by size-independent properties: determinism, a large error drop, recovery of the truth, and
+    agreement of LM and DogLeg on the optimum."""
+    sc = synth.make_scene(500, 100_000, 10, seed=4)
+    A = ba.BaArrays.from_scene(sc)
+    solver = ba.PreparedBA(hip_ctx, A)
+    out = solver.run(ba.OptimizerConfig.refine_ba())
+    again = solver.run(ba.OptimizerConfig.refine_ba())
+    dl = solver.run(ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, False))
+    solver.close()
+    assert out.status == 0 and 2 <= out.outer_iterations <= 20
+    assert np.array_equal(out.points, again.points) and np.array_equal(out.cam_T_wc, again.cam_T_wc)
+    assert out.final_error < 0.05 * out.initial_error
+    err = np.linalg.norm(out.points - sc["points_true"], axis=1)
+    err0 = np.linalg.norm(sc["points_init"] - sc["points_true"], axis=1)
+    assert np.median(err) < 0.35 * np.median(err0), (np.median(err), np.median(err0), err.max())
+    assert np.isclose(dl.final_error, out.final_error, rtol=1e-4)
+    assert (np.diff(out.trace[out.trace[:, 3] == 1, 1]) < 0).all()   # accepted steps only ever lower the error
