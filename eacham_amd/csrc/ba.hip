@@ -179,7 +179,7 @@ __device__ __forceinline__ void pose_local(const double* x, const double* p, dou
 
 // ---- device-side view of a prepared problem --------------------------------------------------------
 struct BaDev {
-    int nc, nl, no, n, ld, nr;  // n = 6 nc + 5; S is (nr+1) x ld, nr = n rounded up to the Cholesky
+    int nc, nl, no, n, ld, nr;  // n = 6 nc + 5; S is (nr+64) x ld, nr = n rounded up to the Cholesky
                                 // block size; rows n..nr-1 are padding, row nr is the right-hand side
     // values
     double *pose, *pose0, *pose_new, *pt, *pt0, *pt_new, *Kc, *K0, *K_new;  // Kc: fx fy s u0 v0
@@ -751,9 +751,17 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     __shared__ __attribute__((aligned(16))) double Li[64][LS], Lj[64][LS];
     const int tid = threadIdx.x;
     const double* __restrict__ Lsrc = Ldiag_in + (size_t)(k0 / NB) * LDB;
-    for (int idx = tid; idx < NB * NB; idx += TPB) Lk[idx / NB][idx % NB] = Lsrc[idx];
-    if (tid < NB) dinv_s[tid] = Lsrc[NB * NB + tid];
+    // L_kk goes through registers so that its loads are in flight together with the panel and tile loads
+    // below: a load -> LDS-store loop costs one full memory round trip per trip, on the critical path
+    static_assert(NB * NB == 4 * TPB, "L_kk is four values per thread");
+    double lkraw[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) lkraw[m] = Lsrc[tid + TPB * m];
+    const double dinv_raw = Lsrc[NB * NB + (tid & (NB - 1))];
     if ((int)blockIdx.x == ntiles) {  // spare workgroup
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Lk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = lkraw[m];
+        if (tid < NB) dinv_s[tid] = dinv_raw;
         __syncthreads();
         if (tid < 64) invert_32(Lk, dinv_s, Winv + (size_t)(k0 / NB) * NB * NB);
         return;
@@ -767,17 +775,17 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     // the 4x4 outputs it will update, so their latencies overlap each other and the solve
     const bool second = tid >= 64;
     const int r = tid & 63;
-    const int row = (second ? j0 : i0) + r;
-    const bool valid = row < n || row == nr;  // matrix rows, plus the rhs row nr
-    // the two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes) and are handed to
-    // their row's thread through LDS: a thread reading its own row directly touches 64 lines per load
-    double praw[16];
+    // the two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes, fetched as 16-byte
+    // pairs) and are handed to their row's thread through LDS: a thread reading its own row directly touches
+    // 64 lines per load. No load of this kernel is predicated: S is allocated with 64 rows and columns of
+    // zero padding beyond the rhs row / the last block (ba_prepare), rows n..nr-1 and columns >= n stay zero,
+    // and values read outside the lower triangle only feed outputs that are never stored. That keeps the
+    // ~750 instructions of address arithmetic and branches off the front of the critical path.
+    double2 praw[8];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int idx = tid + TPB * m, rr = idx / NB, l = idx % NB;  // rr: 0..63 strip i, 64..127 strip j
-        const int grow = (rr < 64 ? i0 : j0 - 64) + rr;
-        const bool ok = (grow < n || grow == nr) && k0 + l < n;
-        praw[m] = ok ? A[(size_t)grow * ld + k0 + l] : 0.0;
+    for (int m = 0; m < 8; ++m) {
+        const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;  // m < 4: strip i, else strip j
+        praw[m] = *reinterpret_cast<const double2*>(&A[(size_t)((m < 4 ? i0 : j0) + rr) * ld + k0 + lp]);
     }
     // Tile 0 holds the next diagonal block. Its workgroup is the critical path of the whole chain, so it
     // first updates only that 32x32 block with all 256 threads (4 outputs each), then wave 0 factorises
@@ -791,27 +799,25 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     double old[4][4];
     if (block_thread) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = i0 + tr + a, j = j0 + tc + b;
-                const bool inside = (i < n || i == nr) && j < n && j <= i;
-                old[a][b] = inside ? A[(size_t)i * ld + j] : 0.0;
-            }
+        for (int a = 0; a < 4; ++a) {
+            const double2* src = reinterpret_cast<const double2*>(&A[(size_t)(i0 + tr + a) * ld + j0 + tc]);
+            const double2 lo = src[0], hi = src[1];
+            old[a][0] = lo.x, old[a][1] = lo.y, old[a][2] = hi.x, old[a][3] = hi.y;
+        }
     }
     double mold[4] = {0.0, 0.0, 0.0, 0.0};
     if (first) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = i0 + mr, j = j0 + mc + b;
-            const bool inside = (i < n || i == nr) && j < n && j <= i;
-            mold[b] = inside ? A[(size_t)i * ld + j] : 0.0;
-        }
+        const double2* src = reinterpret_cast<const double2*>(&A[(size_t)(i0 + mr) * ld + j0 + mc]);
+        const double2 lo = src[0], hi = src[1];
+        mold[0] = lo.x, mold[1] = lo.y, mold[2] = hi.x, mold[3] = hi.y;
     }
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int idx = tid + TPB * m, rr = idx / NB, l = idx % NB;
-        (rr < 64 ? Li[rr] : Lj[rr - 64])[l] = praw[m];
+    for (int m = 0; m < 4; ++m) Lk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = lkraw[m];
+    if (tid < NB) dinv_s[tid] = dinv_raw;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;
+        *reinterpret_cast<double2*>(&(m < 4 ? Li : Lj)[rr][lp]) = praw[m];
     }
     __syncthreads();
     BSTAMP(0);
@@ -833,14 +839,20 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         double (*dst)[LS] = second ? Lj : Li;
 #pragma unroll
         for (int l = 0; l < NB; ++l) dst[r][l] = x[l];
-        if (!second && tj == 0 && valid) {
-#pragma unroll
-            for (int l = 0; l < NB; ++l)
-                if (k0 + l < n) Lm[(size_t)row * ld + k0 + l] = x[l];
-        }
     }
     __syncthreads();
     BSTAMP(1);
+    // the tiles of the first tile column keep L_ik for the back-substitution. The store is made from LDS,
+    // coalesced, after the barrier — by the idle fourth wave in tile 0, by everybody elsewhere — instead of
+    // 32 row-strided stores on the wave that has just finished the solve.
+    auto store_panel = [&](int lane, int nlanes) {
+        for (int e = lane; e < 64 * (NB / 2); e += nlanes) {
+            const int rr = e / (NB / 2), lp = (e % (NB / 2)) * 2, grow = i0 + rr;
+            if ((grow < n || grow == nr) && k0 + lp < n)
+                *reinterpret_cast<double2*>(&Lm[(size_t)grow * ld + k0 + lp]) = *reinterpret_cast<const double2*>(&Li[rr][lp]);
+        }
+    };
+    if (tj == 0 && t != 0) store_panel(tid, TPB);
     const bool next_diag = first && (k1 < n);
     double (*Dn)[NB + 1] = Lk;  // L_kk is not read after the solve
     if (first) {
@@ -876,7 +888,10 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 #endif
             return;
         }
-        if (!rest_thread) return;
+        if (!rest_thread) {
+            store_panel(tid - 192, 64);
+            return;
+        }
     }
     double acc[4][4];
 #pragma unroll
@@ -1437,7 +1452,11 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     memset(&D, 0, sizeof(D));
     D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
     D.nr = ((D.n + NB - 1) / NB) * NB;
-    D.ld = D.nr + NB;
+    // 64 columns (and, for S, 64 rows) of zero padding beyond the last 64x64 tile a Cholesky step can touch:
+    // chol_step reads its tiles without bounds tests. An odd multiple of 256 bytes as the row stride keeps
+    // a column of S from landing on one memory channel.
+    D.ld = D.nr + 64;
+    if ((D.ld / 32) % 2 == 0) D.ld += 32;
     D.nz = make_noise();
     D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
 
@@ -1558,7 +1577,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
     TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
     TRY(dev_alloc(ctx, h, &h->kpart, (size_t)KLIN * nc));
-    TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 1) * D.ld));
+    TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
     TRY(dev_alloc(ctx, h, &D.Ldiag, (size_t)((D.n + NB - 1) / NB + 1) * LDB));
@@ -1633,7 +1652,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (4 + 64) * sizeof(int), ctx->stream));
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
-        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 1) * D.ld, ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         if (D.no > 0) ba_eliminate_observations<<<(unsigned)((6ll * D.no + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<(D.n_chunks + TPB / 64 - 1) / (TPB / 64), TPB, 0, ctx->stream>>>(D);
