@@ -622,77 +622,134 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane i
 constexpr int LDB = NB * NB + NB;
 
 // first wave only; Dn complete. Writes L (lower) and 1/diag.
-// Lane i holds row i; pivots and multipliers are broadcast with v_readlane into SGPR pairs that feed
-// v_fma_f64 directly. hipcc, left alone, funnels every broadcast through ONE SGPR pair (readlane,
-// readlane, s_nop, fma, 36 cycles per update, all serialised by that pair); here the updates are issued
-// in groups of four — eight readlanes into four pairs, then four FMAs, the order pinned with
-// sched_group_barrier — so the readlane -> VALU wait states of a group overlap. The non-positive-pivot
-// test is kept off the critical path: a bad pivot is only recorded (flags bit 1, the solve then counts
-// as failed and its NaNs are never used), it is not replaced.
-// (An LDS scratch column read back with broadcast ds_reads instead of the readlanes was measured
-// 1.8x slower: the write -> read latency lands on the critical path of every column step.)
-__device__ void factor_32(double (*Dn)[NB + 1], double* __restrict__ Lout, int* __restrict__ flags) {
-    const int i = threadIdx.x & 31;  // lanes 32..63 mirror lanes 0..31
-    double row[NB], dinv_own = 0.0;
-#pragma unroll
-    for (int m = 0; m < NB; ++m) row[m] = Dn[i][m];
-    bool bad = false;
-    constexpr int G = 4;  // updates per group: 2G readlanes into G SGPR pairs, then G FMAs
+// The 32x32 block lives in the accumulators of v_mfma_f64_16x16x4_f64 (three 16x16 blocks of the lower
+// triangle; C/D layout col = lane & 15, row = (lane >> 4) + 4 reg) and is factorised four columns at a time:
+//   1. the 16-column slab holding the four pivot columns is dumped to LDS (P) — the only cross-lane step;
+//   2. every lane reads the 4x4 pivot block (same addresses: LDS broadcast) and the four entries of ITS two
+//      rows (l & 15 and 16 + (l & 15)), factorises the 4x4 block and solves its rows against it — all of it
+//      in-lane, redundantly in the four lanes that share a row: no readlane, no broadcast;
+//   3. lane l keeps component k = l >> 4 of its rows' solution: that IS the A (and B) operand layout of the
+//      16x16x4 MFMA, so the rank-4 update of the trailing blocks is one MFMA per 16x16 block.
+// The former version (lane = row, pivots and multipliers broadcast with 992 v_readlane into SGPR pairs feeding
+// 496 v_fma_f64) spent 13.6k cycles per block, 47 % of the chain of a Cholesky step.
+// The non-positive-pivot test stays off the critical path: a bad pivot is only recorded (flags bit 1, the
+// solve then counts as failed and its NaNs are never used), it is not replaced. Rows and columns that are
+// already factorised keep dead values in the accumulators; they only ever feed other dead elements.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int PLD = 18;  // row stride of the slab image P[32][PLD]: 16 columns + padding, 16-byte aligned rows
+
+__device__ __forceinline__ double rsqrt_newton(double d) {
     // 1/sqrt(d): hardware estimate + two Newton steps y <- y (1.5 - (d/2) y^2) (fp64 sqrt and divide are
     // ~30-instruction sequences each)
-    double d = bcast(row[0], 0);
-    bad = bad || !(d > 0.0);
-    double h = 0.5 * d, y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    double y = __builtin_amdgcn_rsq(d);
     double p = h * y, q = __builtin_fma(-p, y, 1.5);
     y = y * q;
     p = h * y;
     q = __builtin_fma(-p, y, 1.5);
-    y = y * q;
+    return y * q;
+}
+
+__device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB * PLD] /* LDS slab image */,
+                                          double* __restrict__ Lout, int* __restrict__ flags) {
+    static_assert(NB == 32, "two 16-row halves");
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    mfma_d4 acc00, acc10, acc11;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {  // right-looking Cholesky; on entry d = pivot j, y = 1/sqrt(d)
-        const double dj = d, yj = y;
-        double rs = dj * yj;
-        rs = rs + 0.5 * yj * (dj - rs * rs);
-        if (i == j) dinv_own = yj;
-        const double lij = (i == j) ? rs : row[j] * yj;
-        row[j] = lij;
-        // the updates of this column, in groups; the first group holds the entry of the next pivot, whose
-        // chain (readlane -> rsq -> Newton) is then issued one operation at a time between the other
-        // groups, so the serial chain of column j+1 hides behind the updates of column j
+    for (int reg = 0; reg < 4; ++reg) {
+        acc00[reg] = Dn[g + 4 * reg][c];
+        acc10[reg] = Dn[16 + g + 4 * reg][c];
+        acc11[reg] = Dn[16 + g + 4 * reg][16 + c];
+    }
+    bool bad = false;
 #pragma unroll
-        for (int l0 = j + 1, g = 0; l0 < NB || g < 8; l0 += G, ++g) {
-            if (l0 < NB) {
-                double b[G];
+    for (int s = 0; s < NB / 4; ++s) {
+        const int j0 = 4 * s, jb = s >> 2, c0 = j0 & 15;
+        // 1. slab -> LDS
+        asm volatile("" ::: "memory");
+        if (jb == 0) {
 #pragma unroll
-                for (int u = 0; u < G; ++u) b[u] = (l0 + u < NB) ? bcast(lij, (l0 + u < NB) ? l0 + u : 0) : 0.0;
-                __builtin_amdgcn_sched_group_barrier(0x002, 2 * G, 0);
-#pragma unroll
-                for (int u = 0; u < G; ++u)
-                    if (l0 + u < NB) row[l0 + u] -= lij * b[u];
-                __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
+            for (int reg = 0; reg < 4; ++reg) {
+                P[(g + 4 * reg) * PLD + c] = acc00[reg];
+                P[(16 + g + 4 * reg) * PLD + c] = acc10[reg];
             }
-            if (j + 1 < NB) {  // one statement of the next pivot's chain per group
-                if (g == 0) {
-                    d = bcast(row[j + 1], j + 1);
-                    bad = bad || !(d > 0.0);
-                    h = 0.5 * d;
-                    y = __builtin_amdgcn_rsq(d);
-                } else if (g == 1) p = h * y;
-                else if (g == 2) q = __builtin_fma(-p, y, 1.5);
-                else if (g == 3) y = y * q;
-                else if (g == 4) p = h * y;
-                else if (g == 5) q = __builtin_fma(-p, y, 1.5);
-                else if (g == 6) y = y * q;
-                __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) P[(16 + g + 4 * reg) * PLD + c] = acc11[reg];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // 2. pivot block (lower triangle) and this lane's rows
+        double dd[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double2* src = reinterpret_cast<const double2*>(&P[(j0 + a) * PLD + c0]);
+            const double2 lo = src[0], hi = src[1];
+            dd[a][0] = lo.x, dd[a][1] = lo.y, dd[a][2] = hi.x, dd[a][3] = hi.y;
+        }
+        double xr[2][4];
+#pragma unroll
+        for (int h = jb; h < 2; ++h) {
+            const double2* src = reinterpret_cast<const double2*>(&P[(16 * h + c) * PLD + c0]);
+            const double2 lo = src[0], hi = src[1];
+            xr[h][0] = lo.x, xr[h][1] = lo.y, xr[h][2] = hi.x, xr[h][3] = hi.y;
+        }
+        // 4x4 Cholesky of the pivot block, column by column, the rows of this lane solved alongside
+        double y[4], rs[4], l[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double d = dd[k][k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) d = __builtin_fma(-l[k][m], l[k][m], d);
+            bad = bad || !(d > 0.0);
+            y[k] = rsqrt_newton(d);
+            rs[k] = d * y[k];  // the diagonal of L is informational: every consumer uses 1/diag
+#pragma unroll
+            for (int a = k + 1; a < 4; ++a) {
+                double v = dd[a][k];
+#pragma unroll
+                for (int m = 0; m < k; ++m) v = __builtin_fma(-l[a][m], l[k][m], v);
+                l[a][k] = v * y[k];
             }
+#pragma unroll
+            for (int h = jb; h < 2; ++h) {
+                double v = xr[h][k];
+#pragma unroll
+                for (int m = 0; m < k; ++m) v = __builtin_fma(-xr[h][m], l[k][m], v);
+                xr[h][k] = v * y[k];
+            }
+        }
+        // L and 1/diag of these four columns (lanes 0..15 hold rows c and 16 + c); off the critical path
+        if (g == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 16 * h + c;
+                double2 lo, hi;
+                double o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = (h < jb || j0 + k > row) ? 0.0 : (j0 + k == row ? rs[k] : xr[h][k]);
+                lo.x = o[0], lo.y = o[1], hi.x = o[2], hi.y = o[3];
+                double2* dst = reinterpret_cast<double2*>(&Lout[row * NB + j0]);
+                dst[0] = lo, dst[1] = hi;
+            }
+            if (c == 0) {
+                double2* dst = reinterpret_cast<double2*>(&Lout[NB * NB + j0]);
+                dst[0] = double2{y[0], y[1]}, dst[1] = double2{y[2], y[3]};
+            }
+        }
+        // 3. rank-4 update of the trailing blocks
+        if (s < NB / 4 - 1) {
+            // the blocks the next step dumps go first
+            const double b1 = g == 0 ? xr[1][0] : (g == 1 ? xr[1][1] : (g == 2 ? xr[1][2] : xr[1][3]));
+            if (s < 3) {
+                const double b0 = g == 0 ? xr[0][0] : (g == 1 ? xr[0][1] : (g == 2 ? xr[0][2] : xr[0][3]));
+                acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-b0, b0, acc00, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-b1, b0, acc10, 0, 0, 0);
+            }
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-b1, b1, acc11, 0, 0, 0);
         }
     }
     if (bad && threadIdx.x == 0) atomicOr(flags, 2);
-    if (threadIdx.x < NB) {
-#pragma unroll
-        for (int m = 0; m < NB; ++m) Lout[i * NB + m] = (m <= i) ? row[m] : 0.0;
-        Lout[NB * NB + i] = dinv_own;
-    }
 }
 
 // first wave only: W = L^-1 (lower) from a factor block in LDS; lane c computes column c
@@ -716,12 +773,13 @@ __device__ void invert_32(const double (*Ls)[NB + 1], const double* __restrict__
 __global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Ldiag,
                                                   int* __restrict__ flags) {
     __shared__ double Dn[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
     for (int idx = threadIdx.x; idx < NB * NB; idx += TPB) {
         const int i = idx / NB, j = idx % NB;
         Dn[i][j] = (i < n && j < n) ? (j <= i ? A[(size_t)i * ld + j] : 0.0) : (i == j ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (threadIdx.x < 64) factor_32(Dn, Ldiag, flags);
+    if (threadIdx.x < 64) factor_32(Dn, Pslab, Ldiag, flags);
 }
 
 // K-E step k. Grid = lower-triangular 64x64 tiles of the trailing matrix + ONE spare workgroup.
@@ -749,6 +807,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     __shared__ double Lk[NB][NB + 1];
     __shared__ double dinv_s[NB];
     __shared__ __attribute__((aligned(16))) double Li[64][LS], Lj[64][LS];
+    __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
     const int tid = threadIdx.x;
     const double* __restrict__ Lsrc = Ldiag_in + (size_t)(k0 / NB) * LDB;
     // L_kk goes through registers so that its loads are in flight together with the panel and tile loads
@@ -788,10 +847,13 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         praw[m] = *reinterpret_cast<const double2*>(&A[(size_t)((m < 4 ? i0 : j0) + rr) * ld + k0 + lp]);
     }
     // Tile 0 holds the next diagonal block. Its workgroup is the critical path of the whole chain, so it
-    // first updates only that 32x32 block with all 256 threads (4 outputs each), then wave 0 factorises
-    // it while waves 1-2 update the other three quarters of the tile beside it.
+    // first updates only that 32x32 block — waves 0-2 take one 16x16 block of its lower triangle each, eight
+    // v_mfma_f64_16x16x4_f64 over the 32 panel columns — then wave 0 factorises it while waves 1-2 update the
+    // other three quarters of the tile beside it. The block itself is not written back to A: nothing reads
+    // rows k1..k1+31 of A after this step.
     const bool first = t == 0;
-    const int mr = tid / 8, mc = (tid % 8) * 4;                                   // mini: row mr, columns mc..mc+3
+    const int wv = tid >> 6, mc = tid & 15, mg = (tid >> 4) & 3;                  // mini: MFMA column / row group
+    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;                     // block (0,0), (1,0), (1,1)
     const int rest_idx = tid - 64;                                                // waves 1-2: 128 blocks of 4x4 below
     const bool rest_thread = first && rest_idx >= 0 && rest_idx < 128;
     const int tr = first ? 32 + (rest_idx / 16) * 4 : (tid / 16) * 4, tc = first ? (rest_idx % 16) * 4 : (tid % 16) * 4;
@@ -805,11 +867,10 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             old[a][0] = lo.x, old[a][1] = lo.y, old[a][2] = hi.x, old[a][3] = hi.y;
         }
     }
-    double mold[4] = {0.0, 0.0, 0.0, 0.0};
-    if (first) {
-        const double2* src = reinterpret_cast<const double2*>(&A[(size_t)(i0 + mr) * ld + j0 + mc]);
-        const double2 lo = src[0], hi = src[1];
-        mold[0] = lo.x, mold[1] = lo.y, mold[2] = hi.x, mold[3] = hi.y;
+    mfma_d4 mold = {0.0, 0.0, 0.0, 0.0};
+    if (first && wv < 3) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(size_t)(i0 + mbi + mg + 4 * reg) * ld + j0 + mbj + mc];
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) Lk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = lkraw[m];
@@ -856,32 +917,25 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     const bool next_diag = first && (k1 < n);
     double (*Dn)[NB + 1] = Lk;  // L_kk is not read after the solve
     if (first) {
-        double macc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int l = 0; l < NB; l += 2) {
-            const double2 xi = *reinterpret_cast<const double2*>(&Li[mr][l]);
+        if (wv < 3 && next_diag) {
+            mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};  // two accumulators: two independent MFMA chains
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const double2 xj = *reinterpret_cast<const double2*>(&Lj[mc + b][l]);
-                macc[b] += xi.x * xj.x;
-                macc[b] += xi.y * xj.y;
+            for (int ks = 0; ks < NB / 4; ks += 2) {
+                const double a0 = Li[mbi + mc][4 * ks + mg], b0 = Li[mbj + mc][4 * ks + mg];
+                const double a1 = Li[mbi + mc][4 * ks + 4 + mg], b1 = Li[mbj + mc][4 * ks + 4 + mg];
+                m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
+                m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
             }
-        }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = i0 + mr, j = j0 + mc + b;
-            double v = 0.0;
-            const bool inside = (i < n || i == nr) && j < n && j <= i;
-            if (inside) {
-                v = mold[b] - macc[b];
-                A[(size_t)i * ld + j] = v;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = mbi + mg + 4 * reg, cc = mbj + mc;  // rows / columns past n: identity padding
+                Dn[rr][cc] = (k1 + rr < n && k1 + cc < n) ? m0[reg] + m1[reg] : (rr == cc ? 1.0 : 0.0);
             }
-            if (next_diag) Dn[mr][mc + b] = (k1 + mr < n && k1 + mc + b < n) ? (mc + b <= mr ? v : 0.0) : (mr == mc + b ? 1.0 : 0.0);
         }
         __syncthreads();
         BSTAMP(2);
         if (tid < 64) {
-            if (next_diag) factor_32(Dn, Ldiag + (size_t)(k1 / NB) * LDB, flags);
+            if (next_diag) factor_32(Dn, Pslab, Ldiag + (size_t)(k1 / NB) * LDB, flags);
             BSTAMP(4);
 #ifdef EXP_BA_STAMPS
             if (tid == 0 && next_diag) atomicAdd(&g_ba_dbg[8], 1ull);
