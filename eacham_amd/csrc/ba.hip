@@ -806,6 +806,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     constexpr int LS = NB + 2;  // even row stride: 16-byte aligned pairs for ds_read_b128, still conflict-free
     __shared__ double Lk[NB][NB + 1];
     __shared__ double dinv_s[NB];
+    __shared__ double dtab[NB][2];  // [j][half]: 1/diag_j for the half that owns column j, 1.0 for the other
     __shared__ __attribute__((aligned(16))) double Li[64][LS], Lj[64][LS];
     __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
     const int tid = threadIdx.x;
@@ -816,11 +817,11 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     double lkraw[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) lkraw[m] = Lsrc[tid + TPB * m];
-    const double dinv_raw = Lsrc[NB * NB + (tid & (NB - 1))];
+    const double dinv_raw = Lsrc[NB * NB + ((tid >> 1) & (NB - 1))];  // pivot reciprocal of column tid / 2
     if ((int)blockIdx.x == ntiles) {  // spare workgroup
 #pragma unroll
         for (int m = 0; m < 4; ++m) Lk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = lkraw[m];
-        if (tid < NB) dinv_s[tid] = dinv_raw;
+        if (tid < 2 * NB && !(tid & 1)) dinv_s[tid >> 1] = dinv_raw;
         __syncthreads();
         if (tid < 64) invert_32(Lk, dinv_s, Winv + (size_t)(k0 / NB) * NB * NB);
         return;
@@ -832,8 +833,6 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
     // every global read of this workgroup is issued up front: the panel strip of this thread's row and
     // the 4x4 outputs it will update, so their latencies overlap each other and the solve
-    const bool second = tid >= 64;
-    const int r = tid & 63;
     // the two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes, fetched as 16-byte
     // pairs) and are handed to their row's thread through LDS: a thread reading its own row directly touches
     // 64 lines per load. No load of this kernel is predicated: S is allocated with 64 rows and columns of
@@ -872,9 +871,14 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(size_t)(i0 + mbi + mg + 4 * reg) * ld + j0 + mbj + mc];
     }
+    // the solve below never reads the diagonal of L_kk (it multiplies by 1/diag): a zero there turns the one
+    // update per step that only half of the lanes need into a no-op for the other half
 #pragma unroll
-    for (int m = 0; m < 4; ++m) Lk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = lkraw[m];
-    if (tid < NB) dinv_s[tid] = dinv_raw;
+    for (int m = 0; m < 4; ++m) {
+        const int rr = (tid + TPB * m) / NB, cc = (tid + TPB * m) % NB;
+        Lk[rr][cc] = rr == cc ? 0.0 : lkraw[m];
+    }
+    if (tid < 2 * NB) dtab[tid >> 1][tid & 1] = (tid & 1) == ((tid >> 1) & 1) ? dinv_raw : 1.0;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;
@@ -882,24 +886,47 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     }
     __syncthreads();
     BSTAMP(0);
-    if (tid < 128) {  // triangular solve x L_kk^T = a, one row per thread, column-oriented: the 31-j
-                      // updates of a step are independent (the row-oriented form is one 496-long FMA chain)
-        double x[NB];
-        {
-            const double (*src)[LS] = second ? Lj : Li;
+    {   // triangular solve x L_kk^T = a, column-oriented (the 31-j updates of a step are independent; the
+        // row-oriented form is one 496-long FMA chain). A wave takes 32 rows, and the two halves of the wave
+        // share each row: lanes 0-31 own its even columns, lanes 32-63 its odd ones, so a step costs half the
+        // v_fma_f64 (8 issue cycles each for a lone wave) and half the L_kk reads. The pivot entry x_j is
+        // scaled by its owner (the other half multiplies its own entry by 1.0: dtab) and handed across with
+        // v_permlane32_swap — pure VALU, no LDS on the chain.
+        const int wv4 = tid >> 6, hh = (tid >> 5) & 1, r2 = 32 * (wv4 & 1) + (tid & 31);
+        double (*strip)[LS] = wv4 < 2 ? Li : Lj;
+        double xo[NB / 2];
 #pragma unroll
-            for (int l = 0; l < NB; ++l) x[l] = src[r][l];
-        }
+        for (int m = 0; m < NB / 2; ++m) xo[m] = strip[r2][2 * m + hh];
+        const double* lkh = &Lk[hh][0];  // row 2m + hh of L_kk starts at lkh + 2m (NB + 1)
+        // Left to itself the compiler turns this back into per-entry dot-product chains with the LDS reads
+        // just in time (fewest registers; every FMA then waits for its predecessor and its read). So the
+        // order is pinned: the multipliers of step j + 1 are read while step j computes, and nothing crosses
+        // a step boundary.
+        double lcur[NB / 2], lnxt[NB / 2], dcur, dnxt;
+#pragma unroll
+        for (int m = 0; m < NB / 2; ++m) lnxt[m] = lkh[2 * m * (NB + 1)];
+        dnxt = dtab[0][hh];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double xj = x[j] * dinv_s[j];
-            x[j] = xj;
 #pragma unroll
-            for (int l = j + 1; l < NB; ++l) x[l] -= xj * Lk[l][j];
+            for (int m = (j + 1) >> 1; m < NB / 2; ++m) lcur[m] = lnxt[m];
+            dcur = dnxt;
+            if (j + 1 < NB) {
+#pragma unroll
+                for (int m = (j + 2) >> 1; m < NB / 2; ++m) lnxt[m] = lkh[2 * m * (NB + 1) + j + 1];
+                dnxt = dtab[j + 1][hh];
+            }
+            const double cand = xo[j >> 1] * dcur;
+            xo[j >> 1] = cand;
+            const auto wl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(cand), (unsigned)__double2loint(cand), false, false);
+            const auto wh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(cand), (unsigned)__double2hiint(cand), false, false);
+            const double xj = __hiloint2double((int)wh[j & 1], (int)wl[j & 1]);
+#pragma unroll
+            for (int m = (j + 1) >> 1; m < NB / 2; ++m) xo[m] -= xj * lcur[m];
+            __builtin_amdgcn_sched_barrier(0);
         }
-        double (*dst)[LS] = second ? Lj : Li;
 #pragma unroll
-        for (int l = 0; l < NB; ++l) dst[r][l] = x[l];
+        for (int m = 0; m < NB / 2; ++m) strip[r2][2 * m + hh] = xo[m];
     }
     __syncthreads();
     BSTAMP(1);
