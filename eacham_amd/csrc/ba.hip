@@ -618,7 +618,8 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane i
     return __hiloint2double(hi, lo);
 }
 
-// Ldiag block layout: [NB][NB] lower factor, then [NB] reciprocals of its diagonal
+// Ldiag block layout: [NB][NB] factor (only its strictly lower triangle is defined), then [NB] reciprocals of
+// its diagonal
 constexpr int LDB = NB * NB + NB;
 
 // first wave only; Dn complete. Writes L (lower) and 1/diag.
@@ -694,15 +695,16 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
             xr[h][0] = lo.x, xr[h][1] = lo.y, xr[h][2] = hi.x, xr[h][3] = hi.y;
         }
         // 4x4 Cholesky of the pivot block, column by column, the rows of this lane solved alongside
-        double y[4], rs[4], l[4][4];
+        double y[4], l[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double d = dd[k][k];
 #pragma unroll
             for (int m = 0; m < k; ++m) d = __builtin_fma(-l[k][m], l[k][m], d);
-            bad = bad || !(d > 0.0);
+            // a non-positive pivot turns into NaN (rsq of a negative, 0 x inf) and stays NaN through every
+            // later pivot — rows of identity padding included, 0 x NaN = NaN — so only the last one is tested
+            if (s == NB / 4 - 1 && k == 3) bad = !(d > 0.0);
             y[k] = rsqrt_newton(d);
-            rs[k] = d * y[k];  // the diagonal of L is informational: every consumer uses 1/diag
 #pragma unroll
             for (int a = k + 1; a < 4; ++a) {
                 double v = dd[a][k];
@@ -718,19 +720,14 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
                 xr[h][k] = v * y[k];
             }
         }
-        // L and 1/diag of these four columns (lanes 0..15 hold rows c and 16 + c); off the critical path
+        // L and 1/diag of these four columns (lanes 0..15 hold rows c and 16 + c); off the critical path.
+        // Only the STRICTLY LOWER triangle of the stored block is meaningful: its consumers (the panel solve,
+        // invert_32) read nothing else, so the diagonal and what lands above it are left as computed.
         if (g == 0) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = 16 * h + c;
-                double2 lo, hi;
-                double o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    o[k] = (h < jb || j0 + k > row) ? 0.0 : (j0 + k == row ? rs[k] : xr[h][k]);
-                lo.x = o[0], lo.y = o[1], hi.x = o[2], hi.y = o[3];
-                double2* dst = reinterpret_cast<double2*>(&Lout[row * NB + j0]);
-                dst[0] = lo, dst[1] = hi;
+            for (int h = jb; h < 2; ++h) {
+                double2* dst = reinterpret_cast<double2*>(&Lout[(16 * h + c) * NB + j0]);
+                dst[0] = double2{xr[h][0], xr[h][1]}, dst[1] = double2{xr[h][2], xr[h][3]};
             }
             if (c == 0) {
                 double2* dst = reinterpret_cast<double2*>(&Lout[NB * NB + j0]);
