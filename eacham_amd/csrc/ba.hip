@@ -1080,15 +1080,35 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backstep(const double* __r
     if (tid < SB && c0 + tid < n) xv[c0 + tid] = ys[tid];
 }
 
+// sum of v over aligned groups of W lanes inside a 16-lane DPP row; valid in each group's last lane
+template <int W>
+__device__ __forceinline__ double dpp_row_sum(double v) {
+    static_assert(W == 8 || W == 16, "row_shr steps 1, 2, 4 (, 8)");
+#define EACHAM_DPP_STEP(ctrl)                                                                       \
+    {                                                                                               \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);     \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);     \
+        v += __hiloint2double(hi, lo);                                                              \
+    }
+    EACHAM_DPP_STEP(0x111)  // row_shr:1
+    EACHAM_DPP_STEP(0x112)  // row_shr:2
+    EACHAM_DPP_STEP(0x114)  // row_shr:4
+    if (W == 16) EACHAM_DPP_STEP(0x118)  // row_shr:8
+#undef EACHAM_DPP_STEP
+    return v;
+}
+
 // Back substitution in ONE launch: workgroup s owns super-block s, the super-blocks hand their solutions
 // down through global memory with release/acquire flags instead of kernel boundaries (the chain of
 // launches cost ~18 us per super-block: launch + dependent global round trips; the hand-off ~7 us).
 // Every workgroup is resident at once (<= 64 workgroups on 256 CUs) and every wait is bounded: a
 // workgroup that times out raises flags[0] bit 2 (the solve counts as failed) and publishes anyway, so
-// no wave can spin forever. Protocol (cdna_hip_programming.md section 6, Guideline 16): the producer's waves drain their
-// stores (vmcnt(0)), barrier, one lane issues an agent-scope release fence and sets the flag with an
-// agent-scope atomic; the consumer polls it with an agent-scope atomic, then fences (acquire, agent
-// scope) before any wave reads the published values.
+// no wave can spin forever. Protocol (cdna_hip_programming.md section 6, Guideline 16, write-through form): the
+// solution x_s is stored with agent-scope atomic stores (sc1: write-through, no release fence), the storing
+// waves drain (vmcnt(0)), barrier, one lane sets the flag with an agent-scope atomic; the consumer polls it with
+// an agent-scope atomic, barrier, and reads x_s with agent-scope atomic loads (sc1: they bypass this CU's L1),
+// so no acquire fence either — every other load of the kernel reads bytes no workgroup writes in this launch.
+// The two fences cost ~3 us per hand-off, on a chain of nsb - 1 hand-offs.
 __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nsb,
                                                                 const double* __restrict__ Winv, double* __restrict__ xv,
                                                                 int* __restrict__ flags) {
@@ -1143,8 +1163,8 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
             }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (tid < SB) xK[tid] = (K * SB + tid < n) ? __builtin_nontemporal_load(&xv[K * SB + tid]) : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
+        if (tid < SB) xK[tid] = (K * SB + tid < n) ? __hip_atomic_load(&xv[K * SB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         __syncthreads();
         double sacc = 0.0;
 #pragma unroll
@@ -1159,30 +1179,35 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
         }
         __syncthreads();
     }
-    // solve super-block s: inner blocks b = 3..0, everything from LDS
+    // solve super-block s: inner blocks b = 3..0, everything from LDS. Both products of an inner step are spread
+    // over the whole workgroup and summed inside DPP rows (a 32-term dot product on one thread is a chain of
+    // 32 dependent v_fma_f64, ~0.2 us, eight times per super-block on the hand-off chain).
     for (int b = SB / NB - 1; b >= 0; --b) {
-        double xb = 0.0;
-        if (tid < NB) {              // x_b = W^T y_b
-            for (int m = tid; m < NB; ++m) xb += Ws[b][m][tid] * ys[b * NB + m];
+        {   // x_b = W^T y_b: output i on the 16 lanes of row tid / 16 (tid < 512), two terms per lane
+            const int i = (tid >> 4) & (NB - 1), p = tid & 15;
+            double v = Ws[b][p][i] * ys[b * NB + p] + Ws[b][p + 16][i] * ys[b * NB + p + 16];
+            v = dpp_row_sum<16>(v);
+            __syncthreads();  // every read of y_b is done
+            if (tid < 16 * NB && p == 15) ys[b * NB + i] = v;
         }
         __syncthreads();
-        if (tid < NB) ys[b * NB + tid] = xb;
-        __syncthreads();
-        if (tid < b * NB) {          // y[inner cols < b] -= L[block-b rows, col]^T x_b
-            double sacc = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < NB; ++j) sacc += Lin[b * NB + j][tid] * ys[b * NB + j];
-            ys[tid] -= sacc;
+        if (b > 0) {  // y[inner cols < b NB] -= L[block-b rows, col]^T x_b: column on 8 lanes, four terms per lane
+            const int cidx = tid >> 3, q = tid & 7;
+            double v = 0.0;
+            if (cidx < b * NB) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v += Lin[b * NB + 4 * q + jj][cidx] * ys[b * NB + 4 * q + jj];
+            }
+            v = dpp_row_sum<8>(v);
+            if (cidx < b * NB && q == 7) ys[cidx] -= v;
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (tid < SB && c0 + tid < n) xv[c0 + tid] = ys[tid];
+    if (tid < SB && c0 + tid < n) __hip_atomic_store(&xv[c0 + tid], ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         if (timed_out) atomicOr(flags, 4);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&handoff[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
