@@ -196,7 +196,7 @@ struct BaDev {
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
-    double *Et, *lmtry, *S, *Lm, *Ldiag, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
+    double *Et, *lmtry, *S, *Lm, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
     double *dl_nc, *dl_nl, *dl_part;
     double* bpart;  // [nc][BSEG][36] partial border sums
@@ -600,29 +600,17 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
 // One launch per block column k (NB = 32 wide), every launch is a grid of 64x64 tiles of the
 // trailing matrix. A workgroup
 //   * loads W_k = L_kk^-1 (computed by the previous launch) and the RAW panel strips A[i.., k] of its
-//     tile, and forms the factor strips L_ik = A_ik W_k^T itself (a 32-wide GEMM instead of a
+//     tile, and forms the factor strips L_ik = A_ik W_k^T itself (a 32-wide MFMA product instead of a
 //     triangular solve; the tiles of the first tile column also store L_ik into Lm for the
 //     back-substitution) — so panel solve and trailing update share one launch;
 //   * updates its tile A_ij -= L_ik L_jk^T;
-//   * tile (0,0), which holds the next diagonal block, factorises it in LDS and stores W_{k+1}.
+//   * tile (0,0), which holds the next diagonal block, factorises it and stores W_{k+1}.
 // The raw matrix A is never overwritten inside the columns a concurrent workgroup may still read.
-// The serial chain of the whole factorisation is the 32x32 diagonal-block Cholesky (one per launch),
-// so it runs on ONE wave with the block in registers — lane i holds row i, pivots and multipliers are
-// broadcast with v_readlane (compile-time lane ids after full unrolling): no LDS traffic, no
-// workgroup barriers. Only the FACTOR is on the critical path: the panels are solved against it by a
-// per-row triangular solve, and the explicit inverse W_k = L_kk^-1 that the back-substitution wants
-// is produced off the critical path by a spare workgroup of the next launch.
-__device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane is a compile-time constant
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
+// The serial chain of the whole factorisation is, per launch: tile (0,0)'s loads, its panel product, the
+// 32x32 look-ahead update, the diagonal-block factor (ONE wave, the block in MFMA accumulators) and the few
+// hundred cycles the inverting wave trails the factor by. Everything else runs beside that chain.
 
-// Ldiag block layout: [NB][NB] factor (only its strictly lower triangle is defined), then [NB] reciprocals of
-// its diagonal
-constexpr int LDB = NB * NB + NB;
-
-// first wave only; Dn complete. Writes L (lower) and 1/diag.
+// first wave only; Dn complete. Publishes L (strictly lower part) and 1/diag through the FactorImage.
 // The 32x32 block lives in the accumulators of v_mfma_f64_16x16x4_f64 (three 16x16 blocks of the lower
 // triangle; C/D layout col = lane & 15, row = (lane >> 4) + 4 reg) and is factorised four columns at a time:
 //   1. the 16-column slab holding the four pivot columns is dumped to LDS (P) — the only cross-lane step;
@@ -651,8 +639,16 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y * q;
 }
 
+typedef int __attribute__((address_space(3))) LdsInt;
+constexpr int LFS = NB + 2;  // row stride of the factor image in LDS (16-byte aligned rows)
+struct FactorImage {          // what the factorising wave hands to the inverting wave, four columns at a time
+    double L[NB][LFS];        // only the strictly lower triangle is meaningful
+    double dinv[NB];          // reciprocals of the diagonal
+    int progress;             // block columns of four finished so far
+};
+
 __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB * PLD] /* LDS slab image */,
-                                          double* __restrict__ Lout, int* __restrict__ flags) {
+                                          FactorImage& F, int* __restrict__ flags) {
     static_assert(NB == 32, "two 16-row halves");
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     mfma_d4 acc00, acc10, acc11;
@@ -720,20 +716,6 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
                 xr[h][k] = v * y[k];
             }
         }
-        // L and 1/diag of these four columns (lanes 0..15 hold rows c and 16 + c); off the critical path.
-        // Only the STRICTLY LOWER triangle of the stored block is meaningful: its consumers (the panel solve,
-        // invert_32) read nothing else, so the diagonal and what lands above it are left as computed.
-        if (g == 0) {
-#pragma unroll
-            for (int h = jb; h < 2; ++h) {
-                double2* dst = reinterpret_cast<double2*>(&Lout[(16 * h + c) * NB + j0]);
-                dst[0] = double2{xr[h][0], xr[h][1]}, dst[1] = double2{xr[h][2], xr[h][3]};
-            }
-            if (c == 0) {
-                double2* dst = reinterpret_cast<double2*>(&Lout[NB * NB + j0]);
-                dst[0] = double2{y[0], y[1]}, dst[1] = double2{y[2], y[3]};
-            }
-        }
         // 3. rank-4 update of the trailing blocks
         if (s < NB / 4 - 1) {
             // the blocks the next step dumps go first
@@ -745,48 +727,128 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
             }
             acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-b1, b1, acc11, 0, 0, 0);
         }
+        // L and 1/diag of these four columns go to the inverting wave through LDS (lanes 0..15 hold rows c and
+        // 16 + c), behind the MFMAs: the stores ride in their shadow. Only the STRICTLY LOWER triangle of the
+        // image is meaningful — its one consumer reads nothing else — so the diagonal and what lands above
+        // it are left as computed.
+        if (g == 0) {  // one exec region: the sixteen lanes store the same 1/diag values and the same flag
+#pragma unroll
+            for (int h = jb; h < 2; ++h) {
+                double2* dst = reinterpret_cast<double2*>(&F.L[16 * h + c][j0]);
+                dst[0] = double2{xr[h][0], xr[h][1]}, dst[1] = double2{xr[h][2], xr[h][3]};
+            }
+            double2* dd2 = reinterpret_cast<double2*>(&F.dinv[j0]);
+            dd2[0] = double2{y[0], y[1]}, dd2[1] = double2{y[2], y[3]};
+            asm volatile("" ::: "memory");  // LDS executes a wave's operations in order: only the compiler must not reorder
+            *(volatile LdsInt*)&F.progress = s + 1;  // a DS store like the data before it (a flat store is not ordered with them)
+        }
     }
     if (bad && threadIdx.x == 0) atomicOr(flags, 2);
 }
 
-// first wave only: W = L^-1 (lower) from a factor block in LDS; lane c computes column c
-__device__ void invert_32(const double (*Ls)[NB + 1], const double* __restrict__ dinv, double* __restrict__ Wout) {
-    const int c = threadIdx.x & 31;
-    double w[NB];
+// One wave, beside the factorising wave: W = L^-1 (lower), produced four rows at a time as soon as the four
+// columns of L they end in are published (FactorImage::progress), so that it is complete a few hundred cycles
+// after the factor — the next launch turns every panel solve into a product with W (MFMA) instead of a
+// 32-step substitution, and the back-substitution wants W anyway. Lanes c and 32 + c own column c of W.
+// Right-looking: rhs[ii] = [ii == c] - sum_{m done} L[ii][m] w_m is kept for every row; when the block columns
+// 4s..4s+3 arrive, rows 4s..4s+3 are finished by a 4x4 substitution (all that is left behind the factor's
+// last step) and their four w's are then folded into the rows still to come. The two halves of the wave share
+// that folding: row blocks of four alternate between them (block rb belongs to half rb & 1), the finished w's
+// cross with v_permlane32_swap. A lone wave issues one v_fma_f64 per ~8 cycles: on one half-wave the folding
+// alone outlasts the factor.
+__device__ __forceinline__ void invert_behind_factor(const FactorImage& F, double* __restrict__ Wout) {
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    double rhs[NB / 2];  // rhs[4p + a] = row 4 (2p + hh) + a
 #pragma unroll
-    for (int ii = 0; ii < NB; ++ii) {
-        double sacc = (ii == c) ? 1.0 : 0.0;
+    for (int e = 0; e < NB / 2; ++e) rhs[e] = (4 * (2 * (e >> 2) + hh) + (e & 3)) == c ? 1.0 : 0.0;
+    const double* lmine = &F.L[4 * hh][0];  // row 4 (2p + hh) + a starts at lmine + (8p + a) LFS
 #pragma unroll
-        for (int m = 0; m < ii; ++m) sacc -= Ls[ii][m] * w[m];  // same address in every lane: LDS broadcast
-        w[ii] = sacc * dinv[ii];
-    }
-    if (threadIdx.x < NB) {
+    for (int s = 0; s < NB / 4; ++s) {
+        for (int spins = 0; *(const volatile LdsInt*)&F.progress <= s && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const double2 dv01 = *reinterpret_cast<const double2*>(&F.dinv[4 * s]), dv23 = *reinterpret_cast<const double2*>(&F.dinv[4 * s + 2]);
+        const double l10 = F.L[4 * s + 1][4 * s];
+        const double2 l2x = *reinterpret_cast<const double2*>(&F.L[4 * s + 2][4 * s]);   // l20 l21
+        const double2 l3x = *reinterpret_cast<const double2*>(&F.L[4 * s + 3][4 * s]);   // l30 l31
+        const double l32 = F.L[4 * s + 3][4 * s + 2];
+        // the substitution, meaningful in the half that owns row block s
+        double w[4];
+        w[0] = rhs[4 * (s >> 1)] * dv01.x;
+        w[1] = __builtin_fma(-l10, w[0], rhs[4 * (s >> 1) + 1]) * dv01.y;
+        w[2] = __builtin_fma(-l2x.y, w[1], __builtin_fma(-l2x.x, w[0], rhs[4 * (s >> 1) + 2])) * dv23.x;
+        w[3] = __builtin_fma(-l32, w[2], __builtin_fma(-l3x.y, w[1], __builtin_fma(-l3x.x, w[0], rhs[4 * (s >> 1) + 3]))) * dv23.y;
+        if (hh == (s & 1)) {
 #pragma unroll
-        for (int ii = 0; ii < NB; ++ii) Wout[ii * NB + c] = w[ii];
+            for (int a2 = 0; a2 < 4; ++a2) Wout[(4 * s + a2) * NB + c] = w[a2];
+        }
+        if (s == NB / 4 - 1) break;
+#pragma unroll
+        for (int a2 = 0; a2 < 4; ++a2) {  // the owner's w's to both halves
+            const auto wl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(w[a2]), (unsigned)__double2loint(w[a2]), false, false);
+            const auto wh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(w[a2]), (unsigned)__double2hiint(w[a2]), false, false);
+            w[a2] = __hiloint2double((int)wh[s & 1], (int)wl[s & 1]);
+        }
+        // fold them into the rows still to come: row blocks 2p + hh, p >= (s + 1) / 2 (for even s the lower
+        // half's first block is the finished one itself: dead values, harmless), two blocks = eight rows at a
+        // time with every read of a group issued before its arithmetic
+#pragma unroll
+        for (int p0 = (s + 1) >> 1; p0 < NB / 8; p0 += 2) {
+            double2 la[8], lb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + (u >> 2) < NB / 8) {
+                    const double* row = lmine + (8 * (p0 + (u >> 2)) + (u & 3)) * LFS + 4 * s;
+                    la[u] = *reinterpret_cast<const double2*>(row);
+                    lb[u] = *reinterpret_cast<const double2*>(row + 2);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + (u >> 2) < NB / 8) {
+                    double& r = rhs[4 * (p0 + (u >> 2)) + (u & 3)];
+                    r = __builtin_fma(-lb[u].y, w[3], __builtin_fma(-lb[u].x, w[2], __builtin_fma(-la[u].y, w[1], __builtin_fma(-la[u].x, w[0], r))));
+                }
+            // the next group's reads stay behind this group's arithmetic (hoisted together they spill): a memory
+            // clobber alone lets the compiler sink the FMAs below it, so the results are pinned as operands
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + (u >> 2) < NB / 8) asm volatile("" : "+v"(rhs[4 * (p0 + (u >> 2)) + (u & 3)]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
-// L_0 of the first diagonal block
-__global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Ldiag,
+// W_0 = L_0^-1 of the first diagonal block
+__global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Winv,
                                                   int* __restrict__ flags) {
     __shared__ double Dn[NB][NB + 1];
     __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
-    for (int idx = threadIdx.x; idx < NB * NB; idx += TPB) {
-        const int i = idx / NB, j = idx % NB;
-        Dn[i][j] = (i < n && j < n) ? (j <= i ? A[(size_t)i * ld + j] : 0.0) : (i == j ? 1.0 : 0.0);
+    __shared__ __attribute__((aligned(16))) FactorImage Fimg;
+    double raw[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // all four loads in flight together (S is zero-padded: no bounds tests)
+        const int idx = threadIdx.x + TPB * m;
+        raw[m] = A[(size_t)(idx / NB) * ld + idx % NB];
     }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int idx = threadIdx.x + TPB * m, i = idx / NB, j = idx % NB;
+        Dn[i][j] = (i < n && j < n) ? raw[m] : (i == j ? 1.0 : 0.0);
+    }
+    if (threadIdx.x == 0) Fimg.progress = 0;
     __syncthreads();
-    if (threadIdx.x < 64) factor_32(Dn, Pslab, Ldiag, flags);
+    if (threadIdx.x < 64) factor_32(Dn, Pslab, Fimg, flags);
+    else if (threadIdx.x < 128) invert_behind_factor(Fimg, Winv);
 }
 
-// K-E step k. Grid = lower-triangular 64x64 tiles of the trailing matrix + ONE spare workgroup.
-//   * every tile workgroup loads L_kk and the RAW strips A[i.., k] of its tile and solves them
-//     against L_kk itself (thread = row; the first tile column also stores L_ik into Lm) — panel
-//     solve and trailing update share one launch; the raw matrix A is never overwritten inside the
-//     columns a concurrent workgroup may still read;
+// K-E step k. Grid = lower-triangular 64x64 tiles of the trailing matrix.
+//   * every tile workgroup loads W_k = L_kk^-1 and the RAW strips A[i.., k] of its tile and forms the factor
+//     strips L_ik = A_ik W_k^T itself with v_mfma_f64_16x16x4_f64 (the first tile column also stores L_ik into
+//     Lm) — panel solve and trailing update share one launch; the raw matrix A is never overwritten inside
+//     the columns a concurrent workgroup may still read;
 //   * updates its tile A_ij -= L_ik L_jk^T;
-//   * tile (0,0), which holds the next diagonal block, factorises it on its first wave -> Ldiag[k+1];
-//   * the spare workgroup inverts L_kk -> Winv[k] for the back-substitution (off the critical path).
+//   * tile (0,0), which holds the next diagonal block, factorises it on its first wave while its fourth wave
+//     inverts the factor right behind it -> Winv[k+1], for the next launch and for the back-substitution.
 #ifdef EXP_BA_STAMPS
 __device__ unsigned long long g_ba_dbg[16];
 #define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_ba_dbg[i], now_ - st_prev); st_prev = now_; } } while (0)
@@ -794,48 +856,39 @@ __device__ unsigned long long g_ba_dbg[16];
 #define BSTAMP(i) do {} while (0)
 #endif
 __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr,
-                                                 int k0, int ntiles, const double* __restrict__ Ldiag_in,
-                                                 double* __restrict__ Ldiag, double* __restrict__ Winv,
-                                                 int* __restrict__ flags) {
+                                                 int k0, double* __restrict__ Winv, int* __restrict__ flags) {
 #ifdef EXP_BA_STAMPS
     unsigned long long st_prev = __builtin_readcyclecounter();
+    const unsigned long long st_start = st_prev;
 #endif
-    constexpr int LS = NB + 2;  // even row stride: 16-byte aligned pairs for ds_read_b128, still conflict-free
-    __shared__ double Lk[NB][NB + 1];
-    __shared__ double dinv_s[NB];
-    __shared__ double dtab[NB][2];  // [j][half]: 1/diag_j for the half that owns column j, 1.0 for the other
+    constexpr int LS = NB + 2;   // even row stride: 16-byte aligned pairs for ds_read_b128, still conflict-free
+    constexpr int WLD = NB + 4;  // row stride of W_k in LDS: the MFMA operand reads (16 rows x 4 columns) stay 2-way
+    __shared__ double Wk[NB][WLD];
+    __shared__ double Dn[NB][NB + 1];
     __shared__ __attribute__((aligned(16))) double Li[64][LS], Lj[64][LS];
     __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
+    __shared__ __attribute__((aligned(16))) FactorImage Fimg;
     const int tid = threadIdx.x;
-    const double* __restrict__ Lsrc = Ldiag_in + (size_t)(k0 / NB) * LDB;
-    // L_kk goes through registers so that its loads are in flight together with the panel and tile loads
+    const double* __restrict__ Wsrc = Winv + (size_t)(k0 / NB) * NB * NB;
+    // W_k goes through registers so that its loads are in flight together with the panel and tile loads
     // below: a load -> LDS-store loop costs one full memory round trip per trip, on the critical path
-    static_assert(NB * NB == 4 * TPB, "L_kk is four values per thread");
-    double lkraw[4];
+    static_assert(NB * NB == 4 * TPB, "W_k is four values per thread");
+    double wraw[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) lkraw[m] = Lsrc[tid + TPB * m];
-    const double dinv_raw = Lsrc[NB * NB + ((tid >> 1) & (NB - 1))];  // pivot reciprocal of column tid / 2
-    if ((int)blockIdx.x == ntiles) {  // spare workgroup
-#pragma unroll
-        for (int m = 0; m < 4; ++m) Lk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = lkraw[m];
-        if (tid < 2 * NB && !(tid & 1)) dinv_s[tid >> 1] = dinv_raw;
-        __syncthreads();
-        if (tid < 64) invert_32(Lk, dinv_s, Winv + (size_t)(k0 / NB) * NB * NB);
-        return;
-    }
-    const int k1 = k0 + NB;  // columns >= n inside the block are zero padding, rows are masked below
+    for (int m = 0; m < 4; ++m) wraw[m] = Wsrc[tid + TPB * m];
+    const int k1 = k0 + NB;  // columns >= n inside the block are zero padding
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
     const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
-    // every global read of this workgroup is issued up front: the panel strip of this thread's row and
-    // the 4x4 outputs it will update, so their latencies overlap each other and the solve
-    // the two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes, fetched as 16-byte
-    // pairs) and are handed to their row's thread through LDS: a thread reading its own row directly touches
-    // 64 lines per load. No load of this kernel is predicated: S is allocated with 64 rows and columns of
-    // zero padding beyond the rhs row / the last block (ba_prepare), rows n..nr-1 and columns >= n stay zero,
-    // and values read outside the lower triangle only feed outputs that are never stored. That keeps the
-    // ~750 instructions of address arithmetic and branches off the front of the critical path.
+    const bool same = ti == tj;  // a diagonal tile: both strips are the same rows, one is computed
+    double (*LjE)[LS] = same ? Li : Lj;
+    // Every global read of this workgroup is issued up front so that the latencies overlap each other.
+    // The two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes, fetched as 16-byte pairs).
+    // No load of this kernel is predicated: S is allocated with 64 rows and columns of zero padding beyond the
+    // rhs row / the last block (ba_prepare), rows n..nr-1 and columns >= n stay zero, and values read
+    // outside the lower triangle only feed outputs that are never stored. That keeps the ~750 instructions
+    // of address arithmetic and branches off the front of the critical path.
     double2 praw[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -848,8 +901,8 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     // other three quarters of the tile beside it. The block itself is not written back to A: nothing reads
     // rows k1..k1+31 of A after this step.
     const bool first = t == 0;
-    const int wv = tid >> 6, mc = tid & 15, mg = (tid >> 4) & 3;                  // mini: MFMA column / row group
-    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;                     // block (0,0), (1,0), (1,1)
+    const int wv = tid >> 6, mc = tid & 15, mg = (tid >> 4) & 3;                  // MFMA column / row group
+    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;                     // mini: block (0,0), (1,0), (1,1)
     const int rest_idx = tid - 64;                                                // waves 1-2: 128 blocks of 4x4 below
     const bool rest_thread = first && rest_idx >= 0 && rest_idx < 128;
     const int tr = first ? 32 + (rest_idx / 16) * 4 : (tid / 16) * 4, tc = first ? (rest_idx % 16) * 4 : (tid % 16) * 4;
@@ -868,68 +921,46 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(size_t)(i0 + mbi + mg + 4 * reg) * ld + j0 + mbj + mc];
     }
-    // the solve below never reads the diagonal of L_kk (it multiplies by 1/diag): a zero there turns the one
-    // update per step that only half of the lanes need into a no-op for the other half
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int rr = (tid + TPB * m) / NB, cc = (tid + TPB * m) % NB;
-        Lk[rr][cc] = rr == cc ? 0.0 : lkraw[m];
-    }
-    if (tid < 2 * NB) dtab[tid >> 1][tid & 1] = (tid & 1) == ((tid >> 1) & 1) ? dinv_raw : 1.0;
+    for (int m = 0; m < 4; ++m) Wk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = wraw[m];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;
-        *reinterpret_cast<double2*>(&(m < 4 ? Li : Lj)[rr][lp]) = praw[m];
+        *reinterpret_cast<double2*>(&(m < 4 ? Li : Lj)[rr][lp]) = praw[m];  // (a diagonal tile loads the same rows twice)
     }
+    if (tid == 0) Fimg.progress = 0;
     __syncthreads();
     BSTAMP(0);
-    {   // triangular solve x L_kk^T = a, column-oriented (the 31-j updates of a step are independent; the
-        // row-oriented form is one 496-long FMA chain). A wave takes 32 rows, and the two halves of the wave
-        // share each row: lanes 0-31 own its even columns, lanes 32-63 its odd ones, so a step costs half the
-        // v_fma_f64 (8 issue cycles each for a lone wave) and half the L_kk reads. The pivot entry x_j is
-        // scaled by its owner (the other half multiplies its own entry by 1.0: dtab) and handed across with
-        // v_permlane32_swap — pure VALU, no LDS on the chain.
-        const int wv4 = tid >> 6, hh = (tid >> 5) & 1, r2 = 32 * (wv4 & 1) + (tid & 31);
-        double (*strip)[LS] = wv4 < 2 ? Li : Lj;
-        double xo[NB / 2];
+    {   // L_ik = A_ik W_k^T: wave w takes rows 16w..16w+15 of each strip. A operand: lane (i, kk) holds
+        // A[i][4t + kk]; B operand: lane (j, kk) holds W[j][4t + kk]; W is lower triangular, so the first 16
+        // columns only need the first four k-steps: 12 MFMAs per 16 rows instead of a 32-step substitution
+        // (6.4k cycles per step of the chain as a substitution shared by the two halves of a wave).
 #pragma unroll
-        for (int m = 0; m < NB / 2; ++m) xo[m] = strip[r2][2 * m + hh];
-        const double* lkh = &Lk[hh][0];  // row 2m + hh of L_kk starts at lkh + 2m (NB + 1)
-        // Left to itself the compiler turns this back into per-entry dot-product chains with the LDS reads
-        // just in time (fewest registers; every FMA then waits for its predecessor and its read). So the
-        // order is pinned: the multipliers of step j + 1 are read while step j computes, and nothing crosses
-        // a step boundary.
-        double lcur[NB / 2], lnxt[NB / 2], dcur, dnxt;
+        for (int st = 0; st < 2; ++st) {
+            if (st == 1 && same) break;
+            double (*strip)[LS] = st == 0 ? Li : Lj;
+            double av[NB / 4];
 #pragma unroll
-        for (int m = 0; m < NB / 2; ++m) lnxt[m] = lkh[2 * m * (NB + 1)];
-        dnxt = dtab[0][hh];
+            for (int ks = 0; ks < NB / 4; ++ks) av[ks] = strip[16 * wv + mc][4 * ks + mg];
+            mfma_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-#pragma unroll
-            for (int m = (j + 1) >> 1; m < NB / 2; ++m) lcur[m] = lnxt[m];
-            dcur = dnxt;
-            if (j + 1 < NB) {
-#pragma unroll
-                for (int m = (j + 2) >> 1; m < NB / 2; ++m) lnxt[m] = lkh[2 * m * (NB + 1) + j + 1];
-                dnxt = dtab[j + 1][hh];
+            for (int ks = 0; ks < 4; ++ks) {  // three independent accumulation chains
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], Wk[mc][4 * ks + mg], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], Wk[16 + mc][4 * ks + mg], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks + 4], Wk[16 + mc][4 * ks + 16 + mg], x2, 0, 0, 0);
             }
-            const double cand = xo[j >> 1] * dcur;
-            xo[j >> 1] = cand;
-            const auto wl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(cand), (unsigned)__double2loint(cand), false, false);
-            const auto wh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(cand), (unsigned)__double2hiint(cand), false, false);
-            const double xj = __hiloint2double((int)wh[j & 1], (int)wl[j & 1]);
+            // the wave's own 16 rows: every read above precedes these writes in the wave's LDS order
 #pragma unroll
-            for (int m = (j + 1) >> 1; m < NB / 2; ++m) xo[m] -= xj * lcur[m];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int reg = 0; reg < 4; ++reg) {
+                strip[16 * wv + mg + 4 * reg][mc] = x0[reg];
+                strip[16 * wv + mg + 4 * reg][16 + mc] = x1[reg] + x2[reg];
+            }
         }
-#pragma unroll
-        for (int m = 0; m < NB / 2; ++m) strip[r2][2 * m + hh] = xo[m];
     }
     __syncthreads();
     BSTAMP(1);
     // the tiles of the first tile column keep L_ik for the back-substitution. The store is made from LDS,
-    // coalesced, after the barrier — by the idle fourth wave in tile 0, by everybody elsewhere — instead of
-    // 32 row-strided stores on the wave that has just finished the solve.
+    // coalesced, after the barrier — by the fourth wave in tile 0, by everybody elsewhere.
     auto store_panel = [&](int lane, int nlanes) {
         for (int e = lane; e < 64 * (NB / 2); e += nlanes) {
             const int rr = e / (NB / 2), lp = (e % (NB / 2)) * 2, grow = i0 + rr;
@@ -939,7 +970,6 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     };
     if (tj == 0 && t != 0) store_panel(tid, TPB);
     const bool next_diag = first && (k1 < n);
-    double (*Dn)[NB + 1] = Lk;  // L_kk is not read after the solve
     if (first) {
         if (wv < 3 && next_diag) {
             mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};  // two accumulators: two independent MFMA chains
@@ -959,15 +989,20 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         __syncthreads();
         BSTAMP(2);
         if (tid < 64) {
-            if (next_diag) factor_32(Dn, Pslab, Ldiag + (size_t)(k1 / NB) * LDB, flags);
+            if (next_diag) factor_32(Dn, Pslab, Fimg, flags);
             BSTAMP(4);
 #ifdef EXP_BA_STAMPS
             if (tid == 0 && next_diag) atomicAdd(&g_ba_dbg[8], 1ull);
+            if (tid == 0 && next_diag) atomicAdd(&g_ba_dbg[6], __builtin_readcyclecounter() - st_start);
 #endif
             return;
         }
         if (!rest_thread) {
             store_panel(tid - 192, 64);
+            if (next_diag) invert_behind_factor(Fimg, Winv + (size_t)(k1 / NB) * NB * NB);
+#ifdef EXP_BA_STAMPS
+            if (tid == 192 && next_diag) atomicAdd(&g_ba_dbg[5], __builtin_readcyclecounter() - st_start);
+#endif
             return;
         }
     }
@@ -982,7 +1017,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             xi[a] = *reinterpret_cast<const double2*>(&Li[tr + a][l]);
-            xj[a] = *reinterpret_cast<const double2*>(&Lj[tc + a][l]);
+            xj[a] = *reinterpret_cast<const double2*>(&LjE[tc + a][l]);
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -1683,7 +1718,6 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
-    TRY(dev_alloc(ctx, h, &D.Ldiag, (size_t)((D.n + NB - 1) / NB + 1) * LDB));
     TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
     TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
     TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
@@ -1772,12 +1806,11 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
-        chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Ldiag, D.flags);
+        chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int k1 = k0 + NB;
             const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-            chol_step<<<nt * (nt + 1) / 2 + 1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, nt * (nt + 1) / 2, D.Ldiag, D.Ldiag,
-                                                                      D.Winv, D.flags);
+            chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
         }
         EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
                                            hipMemcpyDeviceToDevice, ctx->stream));

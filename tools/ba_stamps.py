@@ -17,3 +17,4 @@ names = ["loads + sync", "panel solve + sync", "32x32 update + sync", "(unused)"
 print("steps", v[8])
 for i in range(5): print(f"{names[i]:24s} {v[i] / v[8]:9.0f} cycles/step")
 print("sum", v[:5].sum() / v[8])
+print(f"factor wave done at {v[6] / v[8]:.0f}, inverting wave done at {v[5] / v[8]:.0f} cycles after kernel entry")
