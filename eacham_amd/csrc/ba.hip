@@ -960,7 +960,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     __syncthreads();
     BSTAMP(1);
     // the tiles of the first tile column keep L_ik for the back-substitution. The store is made from LDS,
-    // coalesced, after the barrier — by the fourth wave in tile 0, by everybody elsewhere.
+    // coalesced, after the barrier — by everybody, except in tile 0 where waves 1-2 do it after their update.
     auto store_panel = [&](int lane, int nlanes) {
         for (int e = lane; e < 64 * (NB / 2); e += nlanes) {
             const int rr = e / (NB / 2), lp = (e % (NB / 2)) * 2, grow = i0 + rr;
@@ -997,8 +997,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 #endif
             return;
         }
-        if (!rest_thread) {
-            store_panel(tid - 192, 64);
+        if (!rest_thread) {  // the inverting wave starts with the factor; L_ik is stored by waves 1-2, which idle early
             if (next_diag) invert_behind_factor(Fimg, Winv + (size_t)(k1 / NB) * NB * NB);
 #ifdef EXP_BA_STAMPS
             if (tid == 192 && next_diag) atomicAdd(&g_ba_dbg[5], __builtin_readcyclecounter() - st_start);
@@ -1035,6 +1034,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             const bool inside = (i < n || i == nr) && j < n && j <= i;
             if (inside) A[(size_t)i * ld + j] = old[a][b] - acc[a][b];
         }
+    if (first) store_panel(rest_idx, 128);
 }
 
 // back substitution L^T x = y (y = row nr of Lm) in super-blocks of SB = 4 x NB columns, one launch per
