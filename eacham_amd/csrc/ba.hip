@@ -187,6 +187,8 @@ struct BaDev {
     const double* lmprior;  // [nl][2] sigma, k
     // structure
     const int *lm_ptr, *cam_ptr, *cam_obs;
+    const int* cam_lm;      // landmark of cam_obs[p], camera order: one hop less in the per-camera gathers
+    const double* cam_uv;   // measurement of cam_obs[p], camera order
     const unsigned *obs_cam, *obs_lm;
     const double* obs_uv;
     const int2* pair_entries;
@@ -288,29 +290,48 @@ __global__ __launch_bounds__(TPB) void ba_linearize_cameras(BaDev D, double* __r
     for (int k = 0; k < 15; ++k) hkk[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) gk[k] = 0.0;
-    for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
-        const int o = D.cam_obs[p];
-        const double* lp = D.pt + 3 * (size_t)D.obs_lm[o];
-        const double l[3] = {lp[0], lp[1], lp[2]};
-        double Ap[12], Al[6], Ak[10], b[2];
-        obs_factor(x, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
-        int q = 0;
+    // The loop is a chain of dependent gathers (landmark id -> point) on four waves per CU: its latency is
+    // the kernel. Ids and measurements come from camera-ordered copies (one hop instead of three), and four
+    // trips are fetched together before any of them computes. Accumulation order per thread is unchanged.
+    constexpr int UB = 4;
+    for (int pb = p0 + threadIdx.x; pb < p1; pb += UB * TPB) {
+        int lm[UB];
+        double2 uv[UB];
+        double l[UB][3];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int bb = a; bb < 6; ++bb) hcc[q++] += Ap[a] * Ap[bb] + Ap[6 + a] * Ap[6 + bb];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int bb = 0; bb < 5; ++bb) hck[5 * a + bb] += Ap[a] * Ak[bb] + Ap[6 + a] * Ak[5 + bb];
-            gc[a] += Ap[a] * b[0] + Ap[6 + a] * b[1];
+        for (int u = 0; u < UB; ++u) {
+            const int p = pb + u * TPB;
+            lm[u] = p < p1 ? D.cam_lm[p] : 0;
+            uv[u] = p < p1 ? *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]) : double2{0.0, 0.0};
         }
-        q = 0;
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
+        for (int u = 0; u < UB; ++u) {
+            const double* lp = D.pt + 3 * (size_t)lm[u];
+            l[u][0] = lp[0], l[u][1] = lp[1], l[u][2] = lp[2];
+        }
 #pragma unroll
-            for (int bb = a; bb < 5; ++bb) hkk[q++] += Ak[a] * Ak[bb] + Ak[5 + a] * Ak[5 + bb];
-            gk[a] += Ak[a] * b[0] + Ak[5 + a] * b[1];
+        for (int u = 0; u < UB; ++u) {
+            if (pb + u * TPB >= p1) break;
+            double Ap[12], Al[6], Ak[10], b[2];
+            obs_factor(x, l[u], K, uv[u].x, uv[u].y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int bb = a; bb < 6; ++bb) hcc[q++] += Ap[a] * Ap[bb] + Ap[6 + a] * Ap[6 + bb];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int bb = 0; bb < 5; ++bb) hck[5 * a + bb] += Ap[a] * Ak[bb] + Ap[6 + a] * Ak[5 + bb];
+                gc[a] += Ap[a] * b[0] + Ap[6 + a] * b[1];
+            }
+            q = 0;
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+#pragma unroll
+                for (int bb = a; bb < 5; ++bb) hkk[q++] += Ak[a] * Ak[bb] + Ak[5 + a] * Ak[5 + bb];
+                gk[a] += Ak[a] * b[0] + Ak[5 + a] * b[1];
+            }
         }
     }
     // reduce in three batches to bound LDS (51 values at most per batch)
@@ -1629,6 +1650,13 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         std::vector<int> f2(cam_ptr.begin(), cam_ptr.end() - 1);
         for (int p = 0; p < no; ++p) cam_obs[f2[obs_cam[p]]++] = p;
     }
+    std::vector<int> cam_lm(no);
+    std::vector<double> cam_uv(2 * (size_t)no);
+    for (int p = 0; p < no; ++p) {
+        cam_lm[p] = (int)obs_lm[cam_obs[p]];
+        cam_uv[2 * (size_t)p] = obs_uv[2 * (size_t)cam_obs[p]];
+        cam_uv[2 * (size_t)p + 1] = obs_uv[2 * (size_t)cam_obs[p] + 1];
+    }
     // ---- camera-pair lists of the Schur complement: block (c <= c') -> (o, o') pairs, landmark order ----
     const long long nblk_all = (long long)nc * (nc + 1) / 2;
     auto bid = [nc](int c, int c2) { return (long long)c * nc - (long long)c * (c - 1) / 2 + (c2 - c); };
@@ -1702,6 +1730,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_upload(ctx, h, &D.lm_ptr, lm_ptr));
     TRY(dev_upload(ctx, h, &D.cam_ptr, cam_ptr));
     TRY(dev_upload(ctx, h, &D.cam_obs, cam_obs));
+    TRY(dev_upload(ctx, h, &D.cam_lm, cam_lm));
+    TRY(dev_upload(ctx, h, &D.cam_uv, cam_uv));
     TRY(dev_upload(ctx, h, &D.obs_cam, obs_cam));
     TRY(dev_upload(ctx, h, &D.obs_lm, obs_lm));
     TRY(dev_upload(ctx, h, &D.pair_entries, entries));
