@@ -567,16 +567,33 @@ __global__ __launch_bounds__(TPB) void ba_border_partials(BaDev D) {
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int p = q0 + threadIdx.x; p < q1; p += TPB) {
-        const int o = D.cam_obs[p];
-        const double* Et = D.Et + 18 * (size_t)o;
-        const double* lt = D.lmtry + (size_t)LMLIN * D.obs_lm[o];
+    // two trips of gathers in flight, ids from the camera-ordered copies (one hop to each record, not two or three)
+    constexpr int UB = 2;
+    for (int pb = q0 + threadIdx.x; pb < q1; pb += UB * TPB) {
+        double et[UB][18], lv[UB][18];
+        int o[UB], lm[UB];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double e0 = Et[3 * a], e1 = Et[3 * a + 1], e2 = Et[3 * a + 2];
+        for (int u = 0; u < UB; ++u) {
+            const int p = min(pb + u * TPB, q1 - 1);
+            o[u] = D.cam_obs[p], lm[u] = D.cam_lm[p];
+        }
 #pragma unroll
-            for (int bb = 0; bb < 5; ++bb) acc[5 * a + bb] += e0 * lt[9 + 3 * bb] + e1 * lt[10 + 3 * bb] + e2 * lt[11 + 3 * bb];
-            acc[30 + a] += e0 * lt[6] + e1 * lt[7] + e2 * lt[8];
+        for (int u = 0; u < UB; ++u) {
+            const double* Et = D.Et + 18 * (size_t)o[u];
+            const double* lt = D.lmtry + (size_t)LMLIN * lm[u] + 6;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) et[u][k] = Et[k], lv[u][k] = lt[k];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (pb + u * TPB >= q1) break;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double e0 = et[u][3 * a], e1 = et[u][3 * a + 1], e2 = et[u][3 * a + 2];
+#pragma unroll
+                for (int bb = 0; bb < 5; ++bb) acc[5 * a + bb] += e0 * lv[u][3 + 3 * bb] + e1 * lv[u][4 + 3 * bb] + e2 * lv[u][5 + 3 * bb];
+                acc[30 + a] += e0 * lv[u][0] + e1 * lv[u][1] + e2 * lv[u][2];
+            }
         }
     }
     block_sum<36>(acc, sm);
