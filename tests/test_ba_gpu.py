@@ -56,6 +56,21 @@ def test_step_with_repeated_camera_and_cheirality(hip_ctx):
     assert np.isclose(err, erro, rtol=1e-12) and not dl[-1].any()
 
 
+@pytest.mark.parametrize("lam", [-1e-3, -0.05, -0.5, -1.5])  # the first two: landmark blocks fine, reduced system indefinite
+def test_indefinite_system_is_reported_like_the_oracle(hip_ctx, lam):
+    """A negative damping makes the damped blocks indefinite at some stage. The diagonal-block factor tests one
+    pivot per 32 (a bad pivot poisons every later one with NaN), the oracle tests each: both must agree on
+    whether the step exists, and a failed step must surface as an error, never as numbers."""
+    sc, A = scene_arrays(seed=8, n_cams=12, n_lm=200, k=6)
+    ok = O.ba_step(A, lam, 0)[-1]
+    if ok:
+        _, _, dc, dl, _, _ = ba.debug_step(hip_ctx, A, lam)
+        assert np.isfinite(dc).all() and np.isfinite(dl).all()
+    else:
+        with pytest.raises(EachamError, match="positive definite"):
+            ba.debug_step(hip_ctx, A, lam)
+
+
 @pytest.mark.parametrize("name", ["ba_golden.npz", "ba_golden_hard.npz"])
 def test_golden_fixture(hip_ctx, name):
     g = np.load(os.path.join(GOLD_DIR, name))
