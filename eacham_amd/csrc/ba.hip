@@ -946,18 +946,19 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     const bool first = t == 0;
     const int wv = tid >> 6, mc = tid & 15, mg = (tid >> 4) & 3;                  // MFMA column / row group
     const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;                     // mini: block (0,0), (1,0), (1,1)
-    const int rest_idx = tid - 64;                                                // waves 1-2: 128 blocks of 4x4 below
+    // trailing update: a wave owns 16 rows of the tile (row block urb) and its four 16-column blocks, in the
+    // MFMA accumulator layout. In tile 0 only waves 1-2 update (rows 32..63): wave 0 factors, wave 3 inverts.
+    const int rest_idx = tid - 64;
     const bool rest_thread = first && rest_idx >= 0 && rest_idx < 128;
-    const int tr = first ? 32 + (rest_idx / 16) * 4 : (tid / 16) * 4, tc = first ? (rest_idx % 16) * 4 : (tid % 16) * 4;
     const bool block_thread = first ? rest_thread : true;
-    double old[4][4];
+    const int urb = first ? (wv == 1 ? 2 : 3) : wv;
+    mfma_d4 old[4];
     if (block_thread) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const double2* src = reinterpret_cast<const double2*>(&A[(size_t)(i0 + tr + a) * ld + j0 + tc]);
-            const double2 lo = src[0], hi = src[1];
-            old[a][0] = lo.x, old[a][1] = lo.y, old[a][2] = hi.x, old[a][3] = hi.y;
-        }
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                old[cb][reg] = (same && cb > urb) ? 0.0 : A[(size_t)(i0 + 16 * urb + mg + 4 * reg) * ld + j0 + 16 * cb + mc];
     }
     mfma_d4 mold = {0.0, 0.0, 0.0, 0.0};
     if (first && wv < 3) {
@@ -1048,35 +1049,25 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             return;
         }
     }
-    double acc[4][4];
+    {   // A_ij -= L_ik L_jk^T on v_mfma_f64_16x16x4_f64: eight k-steps per 16x16 block, the four blocks of the
+        // wave's rows as four independent accumulation chains (a diagonal tile skips the blocks above it)
+        double av[NB / 4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int ks = 0; ks < NB / 4; ++ks) av[ks] = -Li[16 * urb + mc][4 * ks + mg];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 4
-    for (int l = 0; l < NB; l += 2) {
-        double2 xi[4], xj[4];
+        for (int ks = 0; ks < NB / 4; ++ks)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            xi[a] = *reinterpret_cast<const double2*>(&Li[tr + a][l]);
-            xj[a] = *reinterpret_cast<const double2*>(&LjE[tc + a][l]);
-        }
+            for (int cb = 0; cb < 4; ++cb)
+                if (!(same && cb > urb)) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], LjE[16 * cb + mc][4 * ks + mg], old[cb], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                acc[a][b] += xi[a].x * xj[b].x;
-                acc[a][b] += xi[a].y * xj[b].y;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = i0 + 16 * urb + mg + 4 * reg, j = j0 + 16 * cb + mc;
+                const bool inside = (i < n || i == nr) && j < n && j <= i;
+                if (inside && !(same && cb > urb)) A[(size_t)i * ld + j] = old[cb][reg];
             }
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = i0 + tr + a, j = j0 + tc + b;
-            const bool inside = (i < n || i == nr) && j < n && j <= i;
-            if (inside) A[(size_t)i * ld + j] = old[a][b] - acc[a][b];
-        }
     if (first) store_panel(rest_idx, 128);
 }
 
