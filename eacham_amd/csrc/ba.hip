@@ -188,6 +188,7 @@ struct BaDev {
     // structure
     const int *lm_ptr, *cam_ptr, *cam_obs;
     const int* cam_lm;      // landmark of cam_obs[p], camera order: one hop less in the per-camera gathers
+    const int* obs_pos;     // inverse of cam_obs: Et is stored in CAMERA order (record of observation o at obs_pos[o])
     const double* cam_uv;   // measurement of cam_obs[p], camera order
     const unsigned *obs_cam, *obs_lm;
     const double* obs_uv;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations(BaDev D) {
     const int o = (int)(idx / 6);
     const double* m = D.lmtry + (size_t)LMLIN * D.obs_lm[o];  // Linv (lower): m00; m10 m11; m20 m21 m22
     const double* E = D.E + 3 * (size_t)idx;
-    double* Et = D.Et + 3 * (size_t)idx;
+    double* Et = D.Et + 18 * (size_t)D.obs_pos[o] + 3 * (int)(idx % 6);  // camera-major: see ba_schur_pairs
     const double e0 = E[0], e1 = E[1], e2 = E[2];
     Et[0] = m[0] * e0;
     Et[1] = m[1] * e0 + m[2] * e1;
@@ -488,6 +489,8 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations(BaDev D) {
 __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
     constexpr int ROW = 65;  // odd stride in doubles: the row reads of the 36 summing lanes spread over the banks
     __shared__ double tr[TPB / 64][36 * ROW];
+    // Et is stored in CAMERA order: the two sides of a block's entries walk two cameras' contiguous regions in
+    // ascending order (landmark-ordered records put every gather in a different page of 72 MB).
     // Workgroups go to the 8 XCDs round-robin, each XCD has its own 4 MB L2, and the chunk list is ordered by
     // camera block (ci, cj): every XCD takes one contiguous eighth of it, so that the rows Et of the few cameras
     // ci it is working on stay in ITS L2 (dealt round-robin every XCD sees every camera and the 2 x 144-byte
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(TPB) void ba_border_partials(BaDev D) {
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const double* Et = D.Et + 18 * (size_t)o[u];
+            const double* Et = D.Et + 18 * (size_t)min(pb + u * TPB, q1 - 1);  // camera order: contiguous
             const double* lt = D.lmtry + (size_t)LMLIN * lm[u] + 6;
 #pragma unroll
             for (int k = 0; k < 18; ++k) et[u][k] = Et[k], lv[u][k] = lt[k];
@@ -1301,7 +1304,7 @@ __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lamb
                 t2 -= lt[11 + 3 * a] * dK[a];
             }
             for (int o = o0; o < o1; ++o) {
-                const double* Et = D.Et + 18 * (size_t)o;
+                const double* Et = D.Et + 18 * (size_t)D.obs_pos[o];
                 const double* dc = D.delta_c + 6 * (size_t)D.obs_cam[o];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
@@ -1658,6 +1661,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         std::vector<int> f2(cam_ptr.begin(), cam_ptr.end() - 1);
         for (int p = 0; p < no; ++p) cam_obs[f2[obs_cam[p]]++] = p;
     }
+    std::vector<int> obs_pos(no);
+    for (int p = 0; p < no; ++p) obs_pos[cam_obs[p]] = p;
     std::vector<int> cam_lm(no);
     std::vector<double> cam_uv(2 * (size_t)no);
     for (int p = 0; p < no; ++p) {
@@ -1697,6 +1702,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
                     }
                 }
     }
+    for (auto& e : entries) e = make_int2(obs_pos[e.x], obs_pos[e.y]);  // Et records live in camera order
     std::vector<int4> chunks, blocks;
     for (int c = 0; c < nc; ++c)
         for (int c2 = c; c2 < nc; ++c2) {
@@ -1739,6 +1745,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_upload(ctx, h, &D.cam_ptr, cam_ptr));
     TRY(dev_upload(ctx, h, &D.cam_obs, cam_obs));
     TRY(dev_upload(ctx, h, &D.cam_lm, cam_lm));
+    TRY(dev_upload(ctx, h, &D.obs_pos, obs_pos));
     TRY(dev_upload(ctx, h, &D.cam_uv, cam_uv));
     TRY(dev_upload(ctx, h, &D.obs_cam, obs_cam));
     TRY(dev_upload(ctx, h, &D.obs_lm, obs_lm));
