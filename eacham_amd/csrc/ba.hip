@@ -241,7 +241,7 @@ __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
         for (int a = 0; a < 5; ++a)
 #pragma unroll
             for (int c = 0; c < 3; ++c) EK[3 * a + c] += Ak[a] * Al[c] + Ak[5 + a] * Al[3 + c];
-        double* E = D.E + 18 * (size_t)o;
+        double* E = D.E + 18 * (size_t)D.obs_pos[o];  // camera order
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -470,10 +470,10 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
 __global__ __launch_bounds__(TPB) void ba_eliminate_observations(BaDev D) {
     const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
     if (idx >= 6ll * D.no) return;
-    const int o = (int)(idx / 6);
-    const double* m = D.lmtry + (size_t)LMLIN * D.obs_lm[o];  // Linv (lower): m00; m10 m11; m20 m21 m22
+    // E and Et are both stored in CAMERA order (ba_schur_pairs): idx walks them contiguously
+    const double* m = D.lmtry + (size_t)LMLIN * D.cam_lm[idx / 6];  // Linv (lower): m00; m10 m11; m20 m21 m22
     const double* E = D.E + 3 * (size_t)idx;
-    double* Et = D.Et + 18 * (size_t)D.obs_pos[o] + 3 * (int)(idx % 6);  // camera-major: see ba_schur_pairs
+    double* Et = D.Et + 3 * (size_t)idx;
     const double e0 = E[0], e1 = E[1], e2 = E[2];
     Et[0] = m[0] * e0;
     Et[1] = m[1] * e0 + m[2] * e1;
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(TPB) void ba_dl_forms_landmarks(BaDev D) {
                     an[c] += in[9 + 3 * a + c] * nK[a];
                 }
             for (int o = o0; o < o1; ++o) {
-                const double* E = D.E + 18 * (size_t)o;
+                const double* E = D.E + 18 * (size_t)D.obs_pos[o];
                 const int cam = (int)D.obs_cam[o];
                 const double* gc = D.camlin + (size_t)CAMLIN * cam + 66;
                 const double* nc = D.dl_nc + 6 * (size_t)cam;
