@@ -56,6 +56,17 @@ def test_step_with_repeated_camera_and_cheirality(hip_ctx):
     assert np.isclose(err, erro, rtol=1e-12) and not dl[-1].any()
 
 
+def test_launch_chain_back_substitution_agrees_with_the_single_launch(hip_ctx, monkeypatch):
+    """The back-substitution normally runs as one launch with in-kernel hand-offs; systems with more than 64
+    super-blocks (n > 8192) and the EACHAM_BA_BACKSTEP_LAUNCHES switch take one launch per super-block."""
+    sc, A = scene_arrays(seed=5, n_cams=60, n_lm=400, k=8)  # n = 365: three super-blocks
+    one = ba.debug_step(hip_ctx, A, 1e-3)
+    monkeypatch.setenv("EACHAM_BA_BACKSTEP_LAUNCHES", "1")
+    chain = ba.debug_step(hip_ctx, A, 1e-3)
+    assert rel(chain[2], one[2]) < 1e-10 and rel(chain[3], one[3]) < 1e-10
+    assert rel(one[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
+
+
 @pytest.mark.parametrize("lam", [-1e-3, -0.05, -0.5, -1.5])  # the first two: landmark blocks fine, reduced system indefinite
 def test_indefinite_system_is_reported_like_the_oracle(hip_ctx, lam):
     """A negative damping makes the damped blocks indefinite at some stage. The diagonal-block factor tests one
