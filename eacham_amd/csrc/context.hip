@@ -1,6 +1,7 @@
 // context.hip — context lifetime, workspace, profiling: the non-kernel part of the C-ABI
 // declared in include/eacham_hip.h.
 #include "context.hpp"
+#include <algorithm>
 
 #include <cstring>
 #include <new>
@@ -164,6 +165,22 @@ using namespace eacham;
 extern "C" {
 
 const char* eacham_version(void) { return "eacham_hip 0.1 gfx950"; }
+
+int eacham_order_pairs(int32_t* pairs, int npairs) {
+    if (npairs < 0 || (npairs > 0 && !pairs)) return EACHAM_ERR_INVALID;
+    struct P2 { int32_t q, t; };
+    P2* p = reinterpret_cast<P2*>(pairs);
+    std::stable_sort(p, p + npairs, [](const P2& a, const P2& b) { return a.t != b.t ? a.t < b.t : a.q < b.q; });
+    return EACHAM_OK;
+}
+
+int eacham_shard_bounds(int npairs, int world, int rank, int* begin, int* end) {
+    if (npairs < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end) return EACHAM_ERR_INVALID;
+    const int base = npairs / world, rem = npairs % world;
+    *begin = rank * base + std::min(rank, rem);
+    *end = *begin + base + (rank < rem ? 1 : 0);
+    return EACHAM_OK;
+}
 
 int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     if (!out_ctx) return EACHAM_ERR_INVALID;

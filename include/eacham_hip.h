@@ -287,6 +287,17 @@ int eacham_profile_reset(eacham_ctx* ctx);
 /* Synchronises, then returns launches and total milliseconds recorded for `kernel_id`. */
 int eacham_profile_get(eacham_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 
+/* ---- multi-GPU sharding of the pair loop (host-side helpers, no device needed) ---------------------
+ * One process per GPU, one context each: every rank orders the pair list the same
+ * way, takes its contiguous shard, runs eacham_match_all_pairs(_dev) on it and all-gathers counts + edges with
+ * RCCL (the collective stays with the host: bench.py / eacham_amd/shard.py show the torch.distributed form).
+ * Replaces the std::for_each(par_unseq) over pairs of apps/sfm/main.cpp:98-109 across devices. */
+/* Sorts [npairs][2] in place by train frame (second column), then query frame: consecutive workgroups stream
+ * the same train frame, which keeps it in the XCD's L2. */
+int eacham_order_pairs(int32_t* pairs, int npairs);
+/* Contiguous shard of rank `rank` of `world`: [*begin, *end), sizes differ by at most one. */
+int eacham_shard_bounds(int npairs, int world, int rank, int* begin, int* end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,28 @@ def _worker(rank, world, port, descs, pairs, out_dir):
     dist.destroy_process_group()
 
 
+def test_c_abi_sharding_helpers_agree_with_the_python_mirror():
+    """eacham_order_pairs / eacham_shard_bounds (host-side, no device) against eacham_amd/shard.py."""
+    import ctypes as C
+    from eacham_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(7)
+    pairs = rng.integers(0, 40, size=(997, 2)).astype(np.int32)
+    mine = np.ascontiguousarray(pairs.copy())
+    assert L.eacham_order_pairs(mine.ctypes.data, len(mine)) == 0
+    assert np.array_equal(mine, shard.order_pairs(pairs))
+    for world in (1, 2, 3, 8, 1000):
+        b = shard.shard_bounds(len(pairs), world)
+        for rank in range(world):
+            lo, hi = C.c_int32(-1), C.c_int32(-1)
+            assert L.eacham_shard_bounds(len(pairs), world, rank, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == (b[rank], b[rank + 1])
+    lo, hi = C.c_int32(), C.c_int32()
+    assert L.eacham_shard_bounds(10, 0, 0, C.byref(lo), C.byref(hi)) < 0
+    assert L.eacham_shard_bounds(10, 2, 2, C.byref(lo), C.byref(hi)) < 0
+    assert L.eacham_order_pairs(None, 0) == 0
+
+
 def test_two_rank_all_gather_reproduces_the_single_process_graph(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as O
