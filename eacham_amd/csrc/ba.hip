@@ -9,15 +9,17 @@
 //   cameras   pose[nc][12] = R (camera->world, row-major) | t          prior means pose0
 //   points    pt[nl][3], prior means pt0, lmprior[nl][2] = {sigma, huber k}
 //   obs       grouped by landmark (CSR lm_ptr): obs_cam[no], obs_uv[no][2]; a second CSR
-//             (cam_ptr, cam_obs) lists each camera's observations
+//             (cam_ptr, cam_obs) lists each camera's observations, with camera-ordered copies of their
+//             landmark ids / measurements (cam_lm, cam_uv) and the inverse map obs_pos; the per-observation
+//             blocks E and Et are stored in CAMERA order (a camera's records are contiguous)
 //   pairs     for every camera block (c <= c') the list of observation pairs (o, o') of one landmark
 //             seen by both: the sparsity structure of the Schur complement, built once per problem
 // Linear algebra of one damped step (H + lambda diag(clamp(diag H))) delta = g:
 //   landmarks are eliminated first (3x3 blocks, one thread each), the reduced camera system
 //   S (n = 6 nc + 5, the 5 shared-calibration columns are a dense border) is assembled WITHOUT
 //   atomics — every block is a deterministic sequential sum over its pair list — factorised by a
-//   blocked right-looking Cholesky with the right-hand side carried as an extra row, and the
-//   landmark steps follow by back-substitution.
+//   blocked right-looking Cholesky on v_mfma_f64_16x16x4_f64 with the right-hand side carried as an
+//   extra row, and the landmark steps follow by back-substitution.
 // Roofline: every kernel except the dense factorisation streams observation-sized arrays once
 // (HBM-bound); see DESIGN.md for the per-kernel byte counts.
 #include "context.hpp"
