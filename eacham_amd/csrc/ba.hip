@@ -190,6 +190,8 @@ struct BaDev {
     // structure
     const int *lm_ptr, *cam_ptr, *cam_obs;
     const int* cam_lm;      // landmark of cam_obs[p], camera order: one hop less in the per-camera gathers
+    const int* pos_cam;     // camera of position p (camera order)
+    int store_E;            // 1: the linearisation keeps E (DogLeg reads it); 0: the E -> Et kernel recomputes it
     const int* obs_pos;     // inverse of cam_obs: Et is stored in CAMERA order (record of observation o at obs_pos[o])
     const double* cam_uv;   // measurement of cam_obs[p], camera order
     const unsigned *obs_cam, *obs_lm;
@@ -243,11 +245,13 @@ __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
         for (int a = 0; a < 5; ++a)
 #pragma unroll
             for (int c = 0; c < 3; ++c) EK[3 * a + c] += Ak[a] * Al[c] + Ak[5 + a] * Al[3 + c];
-        double* E = D.E + 18 * (size_t)D.obs_pos[o];  // camera order
+        if (D.store_E) {
+            double* E = D.E + 18 * (size_t)D.obs_pos[o];  // camera order
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) E[3 * a + c] = Ap[a] * Al[c] + Ap[6 + a] * Al[3 + c];
+                for (int c = 0; c < 3; ++c) E[3 * a + c] = Ap[a] * Al[c] + Ap[6 + a] * Al[3 + c];
+        }
     }
     if (o1 > o0) {  // PriorFactor<Point3>, Robust(Huber(3/obs), Isotropic(1/obs))
         const double sg = D.lmprior[2 * j], kh = D.lmprior[2 * j + 1];
@@ -480,6 +484,40 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations(BaDev D) {
     Et[0] = m[0] * e0;
     Et[1] = m[1] * e0 + m[2] * e1;
     Et[2] = m[3] * e0 + m[4] * e1 + m[5] * e2;
+}
+
+// ---- K-C2': the same Et without a stored E (thread = observation, camera order). Levenberg-Marquardt never
+// reads E again, so writing its 144 bytes per observation in the linearisation and reading them back here is
+// 2 x 72 MB of traffic for ~450 flops per observation: the Jacobians are recomputed at the linearisation point
+// (pose / pt / Kc do not change inside the lambda loop) from camera-ordered ids and measurements. ---------
+__global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev D) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= D.no) return;
+    const int lm = D.cam_lm[p];
+    const double* x = D.pose + 12 * (size_t)D.pos_cam[p];
+    const double* lp = D.pt + 3 * (size_t)lm;
+    const double2 uv = *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]);
+    const double* m = D.lmtry + (size_t)LMLIN * lm;  // Linv (lower): m00; m10 m11; m20 m21 m22
+    double xr[12], K[5];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) xr[k] = x[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
+    const double l[3] = {lp[0], lp[1], lp[2]};
+    const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
+    double Ap[12], Al[6], Ak[10], b[2];
+    obs_factor(xr, l, K, uv.x, uv.y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+    double et[18];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double e0 = Ap[a] * Al[0] + Ap[6 + a] * Al[3], e1 = Ap[a] * Al[1] + Ap[6 + a] * Al[4], e2 = Ap[a] * Al[2] + Ap[6 + a] * Al[5];
+        et[3 * a] = m0 * e0;
+        et[3 * a + 1] = m1 * e0 + m2 * e1;
+        et[3 * a + 2] = m3 * e0 + m4 * e1 + m5 * e2;
+    }
+    double2* out = reinterpret_cast<double2*>(D.Et + 18 * (size_t)p);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k] = double2{et[2 * k], et[2 * k + 1]};
 }
 
 // ---- K-D1: Schur pair products (wave = chunk of <= 64 entries of one camera block's pair list) ------
@@ -1663,8 +1701,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         std::vector<int> f2(cam_ptr.begin(), cam_ptr.end() - 1);
         for (int p = 0; p < no; ++p) cam_obs[f2[obs_cam[p]]++] = p;
     }
-    std::vector<int> obs_pos(no);
-    for (int p = 0; p < no; ++p) obs_pos[cam_obs[p]] = p;
+    std::vector<int> obs_pos(no), pos_cam(no);
+    for (int p = 0; p < no; ++p) obs_pos[cam_obs[p]] = p, pos_cam[p] = (int)obs_cam[cam_obs[p]];
     std::vector<int> cam_lm(no);
     std::vector<double> cam_uv(2 * (size_t)no);
     for (int p = 0; p < no; ++p) {
@@ -1748,6 +1786,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_upload(ctx, h, &D.cam_obs, cam_obs));
     TRY(dev_upload(ctx, h, &D.cam_lm, cam_lm));
     TRY(dev_upload(ctx, h, &D.obs_pos, obs_pos));
+    TRY(dev_upload(ctx, h, &D.pos_cam, pos_cam));
     TRY(dev_upload(ctx, h, &D.cam_uv, cam_uv));
     TRY(dev_upload(ctx, h, &D.obs_cam, obs_cam));
     TRY(dev_upload(ctx, h, &D.obs_lm, obs_lm));
@@ -1843,7 +1882,10 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
         EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
-        if (D.no > 0) ba_eliminate_observations<<<(unsigned)((6ll * D.no + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D);
+        if (D.no > 0) {
+            if (D.store_E) ba_eliminate_observations<<<(unsigned)((6ll * D.no + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D);
+            else ba_eliminate_observations_recompute<<<(D.no + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D);
+        }
         if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
         if (D.n_blocks > 0) ba_assemble_blocks<<<(unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D, lambda);
         if (D.nc > 0) ba_border_partials<<<D.nc * BSEG, TPB, 0, ctx->stream>>>(D);
@@ -1919,6 +1961,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
         return download();
     }
     if (O->method != EACHAM_BA_LM && O->method != EACHAM_BA_DOGLEG) return ctx->fail(EACHAM_ERR_INVALID, "unknown BA method %d", O->method);
+    D.store_E = O->method == EACHAM_BA_DOGLEG ? 1 : 0;  // only the dog-leg forms read E after the linearisation
     // use_preconditioner (PCG + block-Jacobi at 1e-10) asks GTSAM for an iterative solve of the same
     // system; the direct Schur/Cholesky solve here is its limit, so the flag needs no separate path.
 
