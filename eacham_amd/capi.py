@@ -74,8 +74,9 @@ def lib() -> C.CDLL:
     L.eacham_profile_enable.argtypes = [vp, i32]
     L.eacham_profile_reset.argtypes = [vp]
     L.eacham_profile_get.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(dbl)]
-    L.eacham_order_pairs.argtypes = [vp, i32]
-    L.eacham_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    if hasattr(L, "eacham_order_pairs"):  # (absent from older diagnostic builds selected with EACHAM_HIP_LIB)
+        L.eacham_order_pairs.argtypes = [vp, i32]
+        L.eacham_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
 
