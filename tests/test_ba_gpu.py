@@ -56,6 +56,19 @@ def test_step_with_repeated_camera_and_cheirality(hip_ctx):
     assert np.isclose(err, erro, rtol=1e-12) and not dl[-1].any()
 
 
+@pytest.mark.parametrize("n_cams", [2, 3, 5, 10, 11, 16, 21, 22, 43])
+def test_block_boundaries_of_the_reduced_system(hip_ctx, n_cams):
+    """n = 6 n_cams + 5 against the 32-column Cholesky blocks, the 64-row tiles and the 128-column
+    back-substitution super-blocks: a single partial block (17, 23), one real column in the last block (65),
+    exact multiples nearby (131 = 4 x 32 + 3, 137, 263 = two super-blocks + 7)."""
+    sc, A = scene_arrays(seed=20 + n_cams, n_cams=n_cams, n_lm=60 + 12 * n_cams, k=min(n_cams, 5))
+    S, g, dc, dl, err, lin = ba.debug_step(hip_ctx, A, 1e-3)
+    So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
+    assert ok and rel(S, So) < 1e-11 and rel(g, go) < 1e-11
+    assert rel(dc, dco) < 1e-8 and rel(dl, dlo) < 1e-8
+    assert np.isclose(err, erro, rtol=1e-12) and np.isclose(lin, lino, rtol=1e-9)
+
+
 def test_launch_chain_back_substitution_agrees_with_the_single_launch(hip_ctx, monkeypatch):
     """The back-substitution normally runs as one launch with in-kernel hand-offs; systems with more than 64
     super-blocks (n > 8192) and the EACHAM_BA_BACKSTEP_LAUNCHES switch take one launch per super-block."""
