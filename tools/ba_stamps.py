@@ -13,7 +13,7 @@ cfg = ba.OptimizerConfig.refine_ba()
 P.run(cfg); L.eacham_ba_debug_read(buf, 16)
 P.run(cfg); L.eacham_ba_debug_read(buf, 16)
 v = np.array(list(buf), dtype=np.float64)
-names = ["loads + sync", "panel solve + sync", "32x32 update + sync", "(unused)", "factor_32"]
+names = ["loads + sync", "panel product + sync", "32x32 update + sync", "(unused)", "factor_32"]
 print("steps", v[8])
 for i in range(5): print(f"{names[i]:24s} {v[i] / v[8]:9.0f} cycles/step")
 print("sum", v[:5].sum() / v[8])
