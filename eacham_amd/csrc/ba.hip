@@ -842,7 +842,7 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
 // that folding: row blocks of four alternate between them (block rb belongs to half rb & 1), the finished w's
 // cross with v_permlane32_swap. A lone wave issues one v_fma_f64 per ~8 cycles: on one half-wave the folding
 // alone outlasts the factor.
-__device__ __forceinline__ void invert_behind_factor(const FactorImage& F, double* __restrict__ Wout) {
+__device__ __forceinline__ void invert_behind_factor(const FactorImage& F, double* __restrict__ Wout, int* __restrict__ flags) {
     const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
     double rhs[NB / 2];  // rhs[4p + a] = row 4 (2p + hh) + a
 #pragma unroll
@@ -850,7 +850,14 @@ __device__ __forceinline__ void invert_behind_factor(const FactorImage& F, doubl
     const double* lmine = &F.L[4 * hh][0];  // row 4 (2p + hh) + a starts at lmine + (8p + a) LFS
 #pragma unroll
     for (int s = 0; s < NB / 4; ++s) {
-        for (int spins = 0; *(const volatile LdsInt*)&F.progress <= s && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+        // bounded wait (the factorising wave never waits for anybody, so this cannot expire while it runs);
+        // an expired wait marks the solve failed like a hand-off time-out of the back-substitution
+        int spins = 0;
+        while (*(const volatile LdsInt*)&F.progress <= s && spins < (1 << 24)) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+        }
+        if (spins >= (1 << 24) && lane == 0) atomicOr(flags, 4);
         asm volatile("" ::: "memory");
         const double2 dv01 = *reinterpret_cast<const double2*>(&F.dinv[4 * s]), dv23 = *reinterpret_cast<const double2*>(&F.dinv[4 * s + 2]);
         const double l10 = F.L[4 * s + 1][4 * s];
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, 
     if (threadIdx.x == 0) Fimg.progress = 0;
     __syncthreads();
     if (threadIdx.x < 64) factor_32(Dn, Pslab, Fimg, flags);
-    else if (threadIdx.x < 128) invert_behind_factor(Fimg, Winv);
+    else if (threadIdx.x < 128) invert_behind_factor(Fimg, Winv, flags);
 }
 
 // K-E step k. Grid = lower-triangular 64x64 tiles of the trailing matrix.
@@ -1085,7 +1092,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             return;
         }
         if (!rest_thread) {  // the inverting wave starts with the factor; L_ik is stored by waves 1-2, which idle early
-            if (next_diag) invert_behind_factor(Fimg, Winv + (size_t)(k1 / NB) * NB * NB);
+            if (next_diag) invert_behind_factor(Fimg, Winv + (size_t)(k1 / NB) * NB * NB, flags);
 #ifdef EXP_BA_STAMPS
             if (tid == 192 && next_diag) atomicAdd(&g_ba_dbg[5], __builtin_readcyclecounter() - st_start);
 #endif
