@@ -93,17 +93,24 @@ class BaOutcome:
     trace: np.ndarray  # rows: lambda, new_error, lin_change, accepted, outer
 
 
-def c_options(cfg: OptimizerConfig, min_landmarks: int = 50) -> capi.BaOptions:
+LM_FACTOR_POLICIES = {"reset": capi.BA_LM_FACTOR_RESET, "double": capi.BA_LM_FACTOR_DOUBLE}
+
+
+def c_options(cfg: OptimizerConfig, min_landmarks: int = 50, lm_factor: str = "reset") -> capi.BaOptions:
+    """`lm_factor` is not a field of the reference's OptimizerConfig: it names the reading of GTSAM's
+    LevenbergMarquardtState::decreaseLambda to follow (EACHAM_BA_LM_FACTOR_* in include/eacham_hip.h)."""
     o = capi.BaOptions()
     o.method = {"LM": capi.BA_LM, "DogLeg": capi.BA_DOGLEG}[cfg.method]
     o.max_iter, o.max_tolerance, o.delta = int(cfg.maxIter), float(cfg.maxTolerance), float(cfg.delta)
     o.use_preconditioner, o.min_landmarks = int(bool(cfg.usePreconditioner)), int(min_landmarks)
+    o.lm_factor_policy = LM_FACTOR_POLICIES[lm_factor]
     return o
 
 
-def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024, extra=()):
+def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024, extra=(),
+               lm_factor: str = "reset"):
     """Shared marshalling for any function with the eacham_ba_solve result contract."""
-    prob, opt = arrays.c_problem(), c_options(cfg, min_landmarks)
+    prob, opt = arrays.c_problem(), c_options(cfg, min_landmarks, lm_factor)
     T = np.zeros((prob.n_cams, 16), np.float64)
     pts = np.zeros((prob.n_points, 3), np.float64)
     trace = (capi.BaTraceRow * max(trace_cap, 1))()
@@ -118,10 +125,12 @@ def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 
     return rc, out
 
 
-def RefineBA(ctx, arrays: BaArrays, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024) -> BaOutcome:
+def RefineBA(ctx, arrays: BaArrays, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024,
+             lm_factor: str = "reset") -> BaOutcome:
     """RefineBA on the device (eacham_ba_solve). `ctx` is a HipContext."""
     L = capi.lib()
-    rc, out = run_solver(lambda p, o, r: L.eacham_ba_solve(ctx.handle, p, o, r), arrays, config, min_landmarks, trace_cap)
+    rc, out = run_solver(lambda p, o, r: L.eacham_ba_solve(ctx.handle, p, o, r), arrays, config, min_landmarks, trace_cap,
+                         lm_factor=lm_factor)
     ctx._check(rc)
     return out
 
@@ -148,9 +157,9 @@ class PreparedBA:
         ctx._check(self._L.eacham_ba_prepare(ctx.handle, C.byref(self._prob), C.byref(h)))
         self._h = h
 
-    def run(self, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024) -> BaOutcome:
+    def run(self, config: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024, lm_factor: str = "reset") -> BaOutcome:
         rc, out = run_solver(lambda p, o, r: self._L.eacham_ba_run(self.ctx.handle, self._h, o, r), self.arrays,
-                             config, min_landmarks, trace_cap)
+                             config, min_landmarks, trace_cap, lm_factor=lm_factor)
         self.ctx._check(rc)
         return out
 

@@ -83,7 +83,8 @@ def lib() -> C.CDLL:
 
 # ---- bundle adjustment structs (include/eacham_hip.h) ---------------------------------------------
 BA_LM, BA_DOGLEG = 0, 1
-BA_DONE, BA_SKIPPED = 0, 1
+BA_DONE, BA_SKIPPED, BA_INDETERMINATE = 0, 1, 2
+BA_LM_FACTOR_RESET, BA_LM_FACTOR_DOUBLE = 0, 1
 
 
 class BaProblem(C.Structure):
@@ -95,7 +96,8 @@ class BaProblem(C.Structure):
 
 class BaOptions(C.Structure):
     _fields_ = [("method", C.c_int32), ("max_iter", C.c_int32), ("max_tolerance", C.c_float),
-                ("delta", C.c_float), ("use_preconditioner", C.c_int32), ("min_landmarks", C.c_int32)]
+                ("delta", C.c_float), ("use_preconditioner", C.c_int32), ("min_landmarks", C.c_int32),
+                ("lm_factor_policy", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BaTraceRow(C.Structure):

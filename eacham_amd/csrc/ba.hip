@@ -725,6 +725,16 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y * q;
 }
 
+// Fault injection for the time-out branches of the two in-kernel hand-offs (diagnostic build -DEXP_BA_FAULT,
+// `make fault`; tests/test_ba_gpu.py). The product build compiles the hooks away.
+#ifdef EXP_BA_FAULT
+__device__ int g_ba_fault;  // 1: the last super-block of the back-substitution never raises its flag
+                            // 2: the first diagonal-block factor drops one progress store
+#define BA_FAULT(k) (g_ba_fault == (k))
+#else
+#define BA_FAULT(k) false
+#endif
+
 typedef int __attribute__((address_space(3))) LdsInt;
 constexpr int LFS = NB + 2;  // row stride of the factor image in LDS (16-byte aligned rows)
 struct FactorImage {          // what the factorising wave hands to the inverting wave, four columns at a time
@@ -734,7 +744,7 @@ struct FactorImage {          // what the factorising wave hands to the invertin
 };
 
 __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB * PLD] /* LDS slab image */,
-                                          FactorImage& F, int* __restrict__ flags) {
+                                          FactorImage& F, int* __restrict__ flags, bool inject_fault = false) {
     static_assert(NB == 32, "two 16-row halves");
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     mfma_d4 acc00, acc10, acc11;
@@ -826,7 +836,8 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
             double2* dd2 = reinterpret_cast<double2*>(&F.dinv[j0]);
             dd2[0] = double2{y[0], y[1]}, dd2[1] = double2{y[2], y[3]};
             asm volatile("" ::: "memory");  // LDS executes a wave's operations in order: only the compiler must not reorder
-            *(volatile LdsInt*)&F.progress = s + 1;  // a DS store like the data before it (a flat store is not ordered with them)
+            if (!(inject_fault && BA_FAULT(2) && s == 3))
+                *(volatile LdsInt*)&F.progress = s + 1;  // a DS store like the data before it (a flat store is not ordered with them)
         }
     }
     if (bad && threadIdx.x == 0) atomicOr(flags, 2);
@@ -930,7 +941,7 @@ __global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, 
     }
     if (threadIdx.x == 0) Fimg.progress = 0;
     __syncthreads();
-    if (threadIdx.x < 64) factor_32(Dn, Pslab, Fimg, flags);
+    if (threadIdx.x < 64) factor_32(Dn, Pslab, Fimg, flags, true);
     else if (threadIdx.x < 128) invert_behind_factor(Fimg, Winv, flags);
 }
 
@@ -1238,7 +1249,11 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
     __shared__ double Lin[SB][SB - NB + 1];
     __shared__ int timed_out;
     const int tid = threadIdx.x;
-    const int s = blockIdx.x;
+    // Workgroup s waits for the super-blocks K > s. The hardware hands out workgroup ids in ascending order, so
+    // the producers take the low ids: the only workgroup that waits for nobody (s = nsb - 1) is dispatched first
+    // and a consumer never occupies a CU its producer still needs (with the chip shared by another context or
+    // stream the grid need not be co-resident). Every wait stays bounded all the same.
+    const int s = nsb - 1 - (int)blockIdx.x;
     const int c0 = s * SB;
     int* handoff = flags + 4;
     if (tid == 0) timed_out = 0;
@@ -1327,7 +1342,7 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
     __syncthreads();
     if (tid == 0) {
         if (timed_out) atomicOr(flags, 4);
-        __hip_atomic_store(&handoff[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(BA_FAULT(1) && s == nsb - 1)) __hip_atomic_store(&handoff[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1905,6 +1920,14 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         EACHAM_HIP_TRY(ctx, hipMemcpy(S_copy + (size_t)n * n, D.S + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
                                       hipMemcpyDeviceToHost));
     }
+#ifdef EXP_BA_FAULT
+    {
+        const char* f = getenv("EACHAM_FAULT");
+        const int kind = !f ? 0 : (!strcmp(f, "handoff") ? 1 : (!strcmp(f, "progress") ? 2 : 0));
+        EACHAM_HIP_TRY(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(eacham::g_ba_fault), &kind, sizeof(int), 0, hipMemcpyHostToDevice, ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+#endif
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
         chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
@@ -1968,13 +1991,16 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
         return download();
     }
     if (O->method != EACHAM_BA_LM && O->method != EACHAM_BA_DOGLEG) return ctx->fail(EACHAM_ERR_INVALID, "unknown BA method %d", O->method);
+    if (O->lm_factor_policy != EACHAM_BA_LM_FACTOR_RESET && O->lm_factor_policy != EACHAM_BA_LM_FACTOR_DOUBLE)
+        return ctx->fail(EACHAM_ERR_INVALID, "unknown lm_factor_policy %d", O->lm_factor_policy);
     D.store_E = O->method == EACHAM_BA_DOGLEG ? 1 : 0;  // only the dog-leg forms read E after the linearisation
     // use_preconditioner (PCG + block-Jacobi at 1e-10) asks GTSAM for an iterative solve of the same
     // system; the direct Schur/Cholesky solve here is its limit, so the flag needs no separate path.
 
     const double lambdaUpper = 1e32, lambdaLower = 1e-16, minModelFidelity = 1e-3;
     const double relTol = (double)O->max_tolerance, absTol = (double)O->max_tolerance, errorTol = 0.0;
-    double lambda = 1e-4, factor = 2.0;
+    const double lambdaFactor = 2.0;  // SetCeresDefaults
+    double lambda = 1e-4, factor = lambdaFactor;
     int iterations = 0, inner = 0;
     double sc[3];
     launch_error(ctx, h, D.pose, D.pt, D.Kc);
@@ -1983,6 +2009,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
     double error = sc[0];
     R->initial_error = error;
     double newErrorOuter = error, currentError = error;
+    bool indeterminate = false;
     if (O->method == EACHAM_BA_DOGLEG) {
         // DoglegOptimizer (BundleAdjuster.cpp:204-214; GTSAM 4.1.1 DoglegOptimizer.cpp, DoglegOptimizerImpl.h):
         // per iterate() one linearisation, the Gauss-Newton step n (the LM pipeline at lambda = 0), the
@@ -2006,7 +2033,11 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
                 double s10[10];
                 EACHAM_HIP_TRY(ctx, hipMemcpyAsync(s10, D.scal, sizeof(s10), hipMemcpyDeviceToHost, ctx->stream));
                 EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                if (!(s10[2] == 0.0) || !std::isfinite(s10[1])) break;  // GTSAM would throw IndeterminantLinearSystemException
+                if (((int)s10[2] & 4) != 0) return ctx->fail(EACHAM_ERR_HIP, "BA solve: an in-kernel hand-off timed out (flags %d)", (int)s10[2]);
+                if (!(s10[2] == 0.0) || !std::isfinite(s10[1])) {  // GTSAM throws IndeterminantLinearSystemException here
+                    indeterminate = true;
+                    break;
+                }
                 const double gg = s10[4], gn0 = s10[5], nn = s10[6], gHg = s10[7], gHn = s10[8], nHn = s10[9];
                 const double alpha = gg / gHg;  // u = alpha g
                 const double uu = alpha * alpha * gg, un = alpha * gn0, uHu = alpha * alpha * gHg, uHn = alpha * gHn;
@@ -2096,6 +2127,9 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
                 if (rc) return rc;
                 rc = read_scal(ctx, h, sc);
                 if (rc) return rc;
+                // a hand-off time-out (flags bit 2) is a failure of the machine, not of the matrix: it must not
+                // be taken for "not positive definite" and silently raise lambda
+                if (((int)sc[2] & 4) != 0) return ctx->fail(EACHAM_ERR_HIP, "BA solve: an in-kernel hand-off timed out (flags %d)", (int)sc[2]);
                 const bool solved = sc[2] == 0.0 && std::isfinite(sc[1]);
                 if (solved) {
                     linChange = sc[1];
@@ -2121,7 +2155,8 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
                     double m = 1.0 - std::pow(2.0 * fidelity - 1.0, 3);
                     if (m < 1.0 / 3.0) m = 1.0 / 3.0;
                     lambda *= m;
-                    factor = 2.0 * factor;
+                    // LevenbergMarquardtState::decreaseLambda: see EACHAM_BA_LM_FACTOR_* in eacham_hip.h
+                    factor = O->lm_factor_policy == EACHAM_BA_LM_FACTOR_DOUBLE ? 2.0 * factor : 2.0 * lambdaFactor;
                     if (lambda < lambdaLower) lambda = lambdaLower;
                     std::swap(D.pose, D.pose_new);
                     std::swap(D.pt, D.pt_new);
@@ -2144,7 +2179,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
             if (!(iterations < O->max_iter) || converged || !std::isfinite(currentError)) break;
         }
     }
-    R->status = EACHAM_BA_DONE;
+    R->status = indeterminate ? EACHAM_BA_INDETERMINATE : EACHAM_BA_DONE;
     R->final_error = error;
     R->final_lambda = lambda;
     R->outer_iterations = iterations;
@@ -2231,6 +2266,7 @@ int eacham_ba_debug_step(eacham_ctx* ctx, const eacham_ba_problem* problem, doub
         hipError_t e1 = delta_cams ? hipMemcpy(delta_cams, D.delta_c, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) : hipSuccess;
         hipError_t e2 = (delta_points && D.nl) ? hipMemcpy(delta_points, D.delta_l, sizeof(double) * 3 * (size_t)D.nl, hipMemcpyDeviceToHost) : hipSuccess;
         if (e1 != hipSuccess || e2 != hipSuccess) rc = ctx->fail(EACHAM_ERR_HIP, "debug_step download failed");
+        if (!rc && ((int)sc[2] & 4) != 0) rc = ctx->fail(EACHAM_ERR_HIP, "BA solve: an in-kernel hand-off timed out (flags %d)", (int)sc[2]);
         if (!rc && sc[2] != 0.0) rc = ctx->fail(EACHAM_ERR_INVALID, "reduced system not positive definite (flags %d)", (int)sc[2]);
     }
     ba_release(ctx, h);

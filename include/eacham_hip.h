@@ -157,10 +157,26 @@ typedef struct eacham_ba_options {
     float delta;                /* DogLeg deltaInitial (:211)                                        */
     int32_t use_preconditioner; /* usePreconditioner: PCG + block-Jacobi at 1e-10 (:192-200)         */
     int32_t min_landmarks;      /* literal 50 (:166): fewer landmarks -> silently do nothing         */
+    int32_t lm_factor_policy;   /* EACHAM_BA_LM_FACTOR_* below; 0 (zero-initialised options) = RESET */
+    int32_t reserved;
 } eacham_ba_options;
+
+/* What LevenbergMarquardtState::decreaseLambda does to the growth factor after an ACCEPTED step
+ * (GTSAM 4.1.1 gtsam/nonlinear/internal/LevenbergMarquardtState.h, not in the reference tree; the
+ * reference selects it through SetCeresDefaults, BundleAdjuster.cpp:184-190: lambdaFactor = 2,
+ * useFixedLambdaFactor = false). Two readings of that line exist (SURVEY.md Appendix A.4 note):
+ *   RESET  : currentFactor = 2 * params.lambdaFactor  (= 4: Ceres' decrease_factor reset; the default)
+ *   DOUBLE : currentFactor = 2 * currentFactor        (the factor never shrinks)
+ * They give the same lambda schedule until the first rejected step that follows two accepted ones. */
+#define EACHAM_BA_LM_FACTOR_RESET 0
+#define EACHAM_BA_LM_FACTOR_DOUBLE 1
 
 #define EACHAM_BA_DONE 0     /* optimised                                                            */
 #define EACHAM_BA_SKIPPED 1  /* fewer than min_landmarks landmarks: inputs copied through (:166-169) */
+#define EACHAM_BA_INDETERMINATE 2 /* DogLeg only: the Gauss-Newton system is not positive definite. GTSAM's
+                                   * DoglegOptimizer throws IndeterminantLinearSystemException there and
+                                   * RefineBA never reaches its write-back; the values returned are those of
+                                   * the last completed iteration (the inputs if it was the first). */
 
 /* One row per tryLambda() call of the LM loop (for parity tests and reporting). */
 typedef struct eacham_ba_trace_row {

@@ -813,11 +813,13 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
     /* SetCeresDefaults + overrides (BundleAdjuster.cpp:184-190) */
     const double lambdaUpper = 1e32, lambdaLower = 1e-16, minModelFidelity = 1e-3;
     const double relTol = (double)O->max_tolerance, absTol = (double)O->max_tolerance, errorTol = 0.0;
-    double lambda = 1e-4, factor = 2.0;
+    const double lambdaFactor = 2.0; /* SetCeresDefaults */
+    double lambda = 1e-4, factor = lambdaFactor;
     int iterations = 0, inner = 0;
     double error = graph_error(&B, S);
     R->initial_error = error;
     double newErrorOuter = error, currentError = error;
+    int indeterminate = 0;
     if (O->method == EACHAM_BA_DOGLEG) { /* DoglegOptimizer (BundleAdjuster.cpp:204-214): delta0 = config.delta */
         double delta = (double)O->delta;
         double* gc = (double*)calloc((size_t)n, sizeof(double));
@@ -834,7 +836,7 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
                 const double alpha = gg / gHg;                  /* dx_u = -(g.g / |R g|^2) grad = alpha * g */
                 memset(dl, 0, sizeof(double) * (size_t)nl3);
                 const int solved = solve_step(&B, &L, 0.0, 0, dc, dl, 0, 0); /* dx_n: the Gauss-Newton step */
-                if (!solved) break;                             /* GTSAM would throw IndeterminantLinearSystemException */
+                if (!solved) { indeterminate = 1; break; }      /* GTSAM throws IndeterminantLinearSystemException */
                 const double uu = alpha * alpha * gg, un = alpha * dot2(gc, gl, dc, dl, n, nl3), nn = dot2(dc, dl, dc, dl, n, nl3);
                 const double uHu = alpha * alpha * gHg, uHn = alpha * hessian_form(&B, &L, gc, gl, dc, dl),
                              nHn = hessian_form(&B, &L, dc, dl, dc, dl);
@@ -938,7 +940,9 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
                     double m = 1.0 - pow(2.0 * fidelity - 1.0, 3);
                     if (m < 1.0 / 3.0) m = 1.0 / 3.0;
                     lambda *= m;
-                    factor = 2.0 * factor;
+                    /* LevenbergMarquardtState::decreaseLambda, non-fixed-factor branch: two readings of the
+                     * line exist (EACHAM_BA_LM_FACTOR_* in eacham_hip.h); RESET = 2 * params.lambdaFactor */
+                    factor = O->lm_factor_policy == EACHAM_BA_LM_FACTOR_DOUBLE ? 2.0 * factor : 2.0 * lambdaFactor;
                     if (lambda < lambdaLower) lambda = lambdaLower;
                     pose_t* tp = S->pose; S->pose = N.pose; N.pose = tp;
                     double* tq = S->pt; S->pt = N.pt; N.pt = tq;
@@ -962,7 +966,7 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
             if (!(iterations < O->max_iter) || converged || !isfinite(currentError)) break;
         } while (1);
     }
-    R->status = EACHAM_BA_DONE;
+    R->status = indeterminate ? EACHAM_BA_INDETERMINATE : EACHAM_BA_DONE;
     R->final_error = graph_error(&B, S);
     R->final_lambda = lambda;
     R->outer_iterations = iterations;

@@ -24,14 +24,21 @@ def main():
     make("ba_golden.npz", synth.make_scene(6, 90, 4, seed=synth.MASTER_SEED, pixel_noise=1.0))
     # far-off start: the trace contains rejected steps (lambda increases) as well
     make("ba_golden_hard.npz", synth.make_scene(6, 90, 2, seed=0, rot_noise=0.5, trans_noise=0.5, point_noise=0.8))
+    # a far-off start whose trace has reject -> accept -> reject sequences: the two readings of
+    # LevenbergMarquardtState::decreaseLambda (EACHAM_BA_LM_FACTOR_RESET / _DOUBLE) give different lambda
+    # schedules, iterates and iteration counts here; both are recorded
+    make("ba_golden_policy.npz", synth.make_scene(6, 90, 2, seed=1, rot_noise=0.5, trans_noise=0.5, point_noise=0.8),
+         perturb=False)
 
 
-def make(name, sc):
+def make(name, sc, perturb=True):
     A = ba.BaArrays.from_scene(sc)
-    A.obs_uv[::13] += 30.0  # a few outliers so the Huber branch is in the fixture
-    A.point_observers[::5] += 2  # global observer counts exceed the window's (local BA)
+    if perturb:
+        A.obs_uv[::13] += 30.0  # a few outliers so the Huber branch is in the fixture
+        A.point_observers[::5] += 2  # global observer counts exceed the window's (local BA)
     cfg = ba.OptimizerConfig.refine_ba()
-    out = O.ba_solve(A, cfg, nthreads=1)
+    out = O.ba_solve(A, cfg, nthreads=1, lm_factor="reset")    # the default policy: unprefixed keys
+    alt = O.ba_solve(A, cfg, nthreads=1, lm_factor="double")
     rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     np.savez_compressed(
         os.path.join(ROOT, "tests", "golden", name),
@@ -41,9 +48,14 @@ def make(name, sc):
         trace=out.trace, out_T_wc=out.cam_T_wc, out_points=out.points, out_K=out.K,
         initial_error=out.initial_error, final_error=out.final_error,
         outer_iterations=out.outer_iterations, inner_iterations=out.inner_iterations,
-        generator=np.array(f"oracle/ba_oracle.c @ {rev}; LM Ceres defaults, Cayley/first-order Pose3 chart, refine_ba (100, 1e-5)"))
+        double_trace=alt.trace, double_out_T_wc=alt.cam_T_wc, double_out_points=alt.points, double_out_K=alt.K,
+        double_final_error=alt.final_error, double_outer_iterations=alt.outer_iterations,
+        double_inner_iterations=alt.inner_iterations,
+        generator=np.array(f"oracle/ba_oracle.c @ {rev}; LM Ceres defaults, Cayley/first-order Pose3 chart, refine_ba (100, 1e-5); "
+                           "unprefixed keys: lm_factor_policy RESET (2 * lambdaFactor), double_*: DOUBLE (2 * currentFactor)"))
     print(name, out.initial_error, out.final_error, out.outer_iterations, out.inner_iterations,
-          "rejected:", int((out.trace[:, 3] == 0).sum()))
+          "rejected:", int((out.trace[:, 3] == 0).sum()), "| double:", alt.final_error, alt.outer_iterations, alt.inner_iterations,
+          "same trace:", out.trace.shape == alt.trace.shape and bool(np.allclose(out.trace, alt.trace)))
 
 
 if __name__ == "__main__":

@@ -133,12 +133,12 @@ def ba_step(arrays, lam, mode=0):
     return S, g, dc, dl, err.value, lin.value, rc == 0
 
 
-def ba_solve(arrays, cfg, min_landmarks=50, trace_cap=1024, nthreads=0):
+def ba_solve(arrays, cfg, min_landmarks=50, trace_cap=1024, nthreads=0, lm_factor="reset"):
     from eacham_amd import ba
     L = oracle.lib()
     L.oracle_ba_solve.restype = C.c_int
     rc, out = ba.run_solver(lambda p, o, r, nt: L.oracle_ba_solve(p, o, r, nt), arrays, cfg, min_landmarks, trace_cap,
-                            extra=(C.c_int(nthreads),))
+                            extra=(C.c_int(nthreads),), lm_factor=lm_factor)
     assert rc == 0, rc
     return out
 

@@ -95,19 +95,94 @@ def test_indefinite_system_is_reported_like_the_oracle(hip_ctx, lam):
             ba.debug_step(hip_ctx, A, lam)
 
 
-@pytest.mark.parametrize("name", ["ba_golden.npz", "ba_golden_hard.npz"])
-def test_golden_fixture(hip_ctx, name):
+@pytest.mark.parametrize("policy", ["reset", "double"])
+@pytest.mark.parametrize("name", ["ba_golden.npz", "ba_golden_hard.npz", "ba_golden_policy.npz"])
+def test_golden_fixture(hip_ctx, name, policy):
+    """Both readings of LevenbergMarquardtState::decreaseLambda (EACHAM_BA_LM_FACTOR_RESET, the default, and
+    _DOUBLE); ba_golden_policy.npz is the fixture whose two traces differ."""
     g = np.load(os.path.join(GOLD_DIR, name))
+    pre = "" if policy == "reset" else "double_"
     A = ba.BaArrays(g["cam_T_wc"], g["cam_fixed"], g["points"], g["point_observers"], g["obs_cam"], g["obs_point"],
                     g["obs_uv"], g["K"])
-    out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("LM", int(g["max_iter"]), float(g["max_toler"]), 10.0, False))
-    assert out.outer_iterations == int(g["outer_iterations"]) and out.inner_iterations == int(g["inner_iterations"])
-    assert np.array_equal(out.trace[:, 3:], g["trace"][:, 3:])                     # accept/reject decisions
-    assert np.allclose(out.trace[:, 0], g["trace"][:, 0], rtol=1e-6)               # lambda schedule
-    assert np.allclose(out.trace[:, 1], g["trace"][:, 1], rtol=1e-8)               # nonlinear errors
-    assert rel(out.cam_T_wc, g["out_T_wc"]) < POSE_POINT_RTOL and rel(out.points, g["out_points"]) < POSE_POINT_RTOL
-    assert rel(out.cam_T_wc, g["out_T_wc"]) < 1e-7 and rel(out.points, g["out_points"]) < 1e-7
-    assert np.allclose(out.K, g["out_K"], rtol=1e-8) and np.isclose(out.final_error, float(g["final_error"]), rtol=1e-9)
+    out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("LM", int(g["max_iter"]), float(g["max_toler"]), 10.0, False),
+                      lm_factor=policy)
+    assert out.outer_iterations == int(g[pre + "outer_iterations"]) and out.inner_iterations == int(g[pre + "inner_iterations"])
+    assert np.array_equal(out.trace[:, 3:], g[pre + "trace"][:, 3:])                     # accept/reject decisions
+    assert np.allclose(out.trace[:, 0], g[pre + "trace"][:, 0], rtol=1e-6)               # lambda schedule
+    assert np.allclose(out.trace[:, 1], g[pre + "trace"][:, 1], rtol=1e-8)               # nonlinear errors
+    assert rel(out.cam_T_wc, g[pre + "out_T_wc"]) < POSE_POINT_RTOL and rel(out.points, g[pre + "out_points"]) < POSE_POINT_RTOL
+    assert rel(out.cam_T_wc, g[pre + "out_T_wc"]) < 1e-7 and rel(out.points, g[pre + "out_points"]) < 1e-7
+    assert np.allclose(out.K, g[pre + "out_K"], rtol=1e-8) and np.isclose(out.final_error, float(g[pre + "final_error"]), rtol=1e-9)
+
+
+FAULT_LIB = os.path.join(os.path.dirname(capi.LIB_PATH), "exp", "libeacham_hip_fault.so")
+FAULT_SCRIPT = """
+import sys, numpy as np
+from eacham_amd import ba, synth, capi, HipContext, EachamError
+A = ba.BaArrays.from_scene(synth.make_scene(60, 400, 8, seed=5))      # n = 365: three super-blocks
+with HipContext(0) as ctx:
+    try:
+        ba.RefineBA(ctx, A, ba.OptimizerConfig(sys.argv[1], 100, 1e-5, 10.0, False))
+    except EachamError as e:
+        print("code", e.code, e)
+        sys.exit(0 if e.code == capi.ERR_HIP and "timed out" in str(e) else 3)
+sys.exit(4)
+"""
+
+
+@pytest.mark.parametrize("fault", ["handoff", "progress"])
+@pytest.mark.parametrize("method", ["LM", "DogLeg"])
+def test_an_expired_in_kernel_wait_is_an_error_not_a_rejected_step(fault, method):
+    """The two in-kernel hand-offs of the dense solve (super-block to super-block in chol_backsolve, factorising
+    wave to inverting wave in the diagonal-block factor) have bounded waits. The diagnostic build
+    (-DEXP_BA_FAULT, `make fault`) withholds one signal: the wait must expire, the launch must end, and the solve
+    must come back as EACHAM_ERR_HIP — not as 'not positive definite', which LM would answer by silently raising
+    lambda. Runs in a child process because the library to load is chosen at import time."""
+    import subprocess
+    import sys
+    assert os.path.exists(FAULT_LIB), "build the diagnostic library with `make -C eacham_amd/csrc fault`"
+    env = dict(os.environ, EACHAM_HIP_LIB=FAULT_LIB, EACHAM_FAULT=fault,
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", FAULT_SCRIPT, method], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_dogleg_on_an_unfactorisable_system_reports_indeterminate(hip_ctx):
+    """GTSAM's DoglegOptimizer throws IndeterminantLinearSystemException when the Gauss-Newton system cannot be
+    factorised; RefineBA would not reach its write-back. Here: status EACHAM_BA_INDETERMINATE and the input values,
+    in the oracle and on the device alike. The case: a landmark 1e-160 in front of a camera centre — finite error
+    (Huber), Jacobians of 1e163, a landmark block that overflows — with LM on the same window as the contrast
+    (every try fails, lambda climbs to its bound, status DONE with zero iterations)."""
+    sc, A = scene_arrays(seed=8, n_cams=12, n_lm=200, k=6, outliers=False)
+    c, j = int(A.obs_cam[0]), int(A.obs_point[0])
+    A.cam_T_wc = A.cam_T_wc.copy()
+    A.cam_T_wc[c] = np.eye(4)
+    A.points = A.points.copy()
+    A.points[j] = [1e-161, 0.0, 1e-160]
+    A.obs_uv = A.obs_uv.copy()
+    A.obs_uv[0] = [A.K[0] * 0.1 + A.K[2], A.K[3]]
+    cfg = ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, False)
+    out = ba.RefineBA(hip_ctx, A, cfg)
+    ref = O.ba_solve(A, cfg)
+    assert out.status == ref.status == capi.BA_INDETERMINATE
+    assert out.outer_iterations == ref.outer_iterations == 0 and np.isfinite(out.initial_error)
+    assert np.isclose(out.initial_error, ref.initial_error, rtol=1e-12)
+    assert np.array_equal(out.points, A.points) and rel(out.cam_T_wc.reshape(-1, 16), A.cam_T_wc.reshape(-1, 16)) < 1e-15
+    lm, lm_ref = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba()), O.ba_solve(A, ba.OptimizerConfig.refine_ba())
+    assert lm.status == lm_ref.status == capi.BA_DONE and lm.outer_iterations == lm_ref.outer_iterations == 0
+    assert lm.inner_iterations == lm_ref.inner_iterations and not lm.trace[:, 3].any()
+
+
+def test_unknown_factor_policy_is_rejected(hip_ctx):
+    sc, A = scene_arrays(n_cams=4, n_lm=60, k=3)
+    L = capi.lib()
+    import ctypes as C
+    prob, opt = A.c_problem(), ba.c_options(ba.OptimizerConfig.refine_ba())
+    opt.lm_factor_policy = 7
+    res = capi.BaResult()
+    T = np.zeros((prob.n_cams, 16)); P = np.zeros((prob.n_points, 3))
+    res.cam_T_wc, res.points = T.ctypes.data, P.ctypes.data
+    assert L.eacham_ba_solve(hip_ctx.handle, C.byref(prob), C.byref(opt), C.byref(res)) == capi.ERR_INVALID
 
 
 @pytest.mark.parametrize("cfg", [ba.OptimizerConfig.refine_ba(), ba.OptimizerConfig.global_ba(),

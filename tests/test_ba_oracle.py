@@ -9,7 +9,7 @@ import np_reference as R
 import oracle_api as O
 
 GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
-GOLDEN = ["ba_golden.npz", "ba_golden_hard.npz"]
+GOLDEN = ["ba_golden.npz", "ba_golden_hard.npz", "ba_golden_policy.npz"]
 
 
 def small_scene(seed=3, n_cams=6, n_lm=200, k=4, **kw):
@@ -90,30 +90,54 @@ def test_schur_complement_equals_dense_solve(lam):
     assert np.allclose(np.linalg.solve(S, g), dc, rtol=1e-7, atol=1e-10)
 
 
-def test_lm_follows_the_ceres_default_policy():
-    sc = small_scene(seed=5, n_cams=8, n_lm=300, k=4)
-    A = ba.BaArrays.from_scene(sc)
-    out = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
-    tr = out.trace
-    assert out.status == 0 and tr.shape[0] == out.inner_iterations >= out.outer_iterations >= 2
-    assert tr[0, 0] == 1e-4  # lambdaInitial
+def replay_lambda_policy(out, policy):
+    """Replays the lambda schedule of a trace under one reading of decreaseLambda."""
     lam, factor, err = 1e-4, 2.0, out.initial_error
-    for lam_i, new_err, lin, acc, outer in tr:
+    for lam_i, new_err, lin, acc, outer in out.trace:
         assert np.isclose(lam_i, lam, rtol=1e-12)
         if acc:
             rho = (err - new_err) / lin
             assert rho > 1e-3
             lam = max(1e-16, lam * max(1 / 3, 1 - (2 * rho - 1) ** 3))
-            factor *= 2
+            factor = 2 * factor if policy == "double" else 2 * 2.0   # 2 * currentFactor | 2 * params.lambdaFactor
             err = new_err
         else:
             lam *= factor
             factor *= 2
+    return err
+
+
+@pytest.mark.parametrize("policy", ["reset", "double"])
+def test_lm_follows_the_ceres_default_policy(policy):
+    sc = small_scene(seed=5, n_cams=8, n_lm=300, k=4)
+    A = ba.BaArrays.from_scene(sc)
+    out = O.ba_solve(A, ba.OptimizerConfig.refine_ba(), lm_factor=policy)
+    tr = out.trace
+    assert out.status == 0 and tr.shape[0] == out.inner_iterations >= out.outer_iterations >= 2
+    assert tr[0, 0] == 1e-4  # lambdaInitial
+    err = replay_lambda_policy(out, policy)
     assert np.isclose(out.final_error, err, rtol=1e-12) and out.final_error < 0.1 * out.initial_error
     # converged: last accepted decrease below the tolerances or max_iter reached
     assert out.outer_iterations <= 100
     # truth is recovered up to noise
     assert np.abs(out.points - sc["points_true"]).max() < 0.05
+
+
+def test_the_two_factor_policies_part_after_reject_accept_reject():
+    """EACHAM_BA_LM_FACTOR_RESET (default: currentFactor = 2 * lambdaFactor after an accepted step) against
+    _DOUBLE (2 * currentFactor): identical until a rejected step follows two accepted ones, different after."""
+    sc = synth.make_scene(6, 90, 2, seed=1, rot_noise=0.5, trans_noise=0.5, point_noise=0.8)
+    A = ba.BaArrays.from_scene(sc)
+    a = O.ba_solve(A, ba.OptimizerConfig.refine_ba(), nthreads=1, lm_factor="reset")
+    b = O.ba_solve(A, ba.OptimizerConfig.refine_ba(), nthreads=1, lm_factor="double")
+    replay_lambda_policy(a, "reset")
+    replay_lambda_policy(b, "double")
+    k = int(np.argmax(~np.isclose(a.trace[:min(len(a.trace), len(b.trace)), 0], b.trace[:min(len(a.trace), len(b.trace)), 0])))
+    assert k > 0 and a.trace[k - 1, 3] == 0                      # the first different lambda follows a rejected step ...
+    assert (a.trace[:k - 1, 3] == 1).sum() >= 2                  # ... that came after at least two accepted ones
+    assert np.allclose(a.trace[:k], b.trace[:k])
+    assert a.trace[k, 0] < b.trace[k, 0]                         # RESET grows lambda by 4, DOUBLE by more
+    assert (a.inner_iterations, a.final_error) != (b.inner_iterations, b.final_error)
 
 
 def test_result_is_a_stationary_point_of_the_numpy_objective():
@@ -147,19 +171,23 @@ def test_fewer_than_50_landmarks_is_a_silent_no_op():
     assert O.ba_solve(ba.BaArrays.from_scene(sc), ba.OptimizerConfig.refine_ba()).status == 0
 
 
+@pytest.mark.parametrize("policy", ["reset", "double"])
 @pytest.mark.parametrize("name", GOLDEN)
-def test_golden_fixture(name):
+def test_golden_fixture(name, policy):
     g = np.load(os.path.join(GOLD_DIR, name))
-    if "hard" in name:
-        assert (g["trace"][:, 3] == 0).sum() >= 1  # the fixture covers the increaseLambda branch
+    pre = "" if policy == "reset" else "double_"   # unprefixed keys: the default policy
+    if "hard" in name or "policy" in name:
+        assert (g[pre + "trace"][:, 3] == 0).sum() >= 1  # the fixture covers the increaseLambda branch
+    if "policy" in name:
+        assert g["trace"].shape != g["double_trace"].shape  # ... and this one tells the two policies apart
     A = ba.BaArrays(g["cam_T_wc"], g["cam_fixed"], g["points"], g["point_observers"], g["obs_cam"], g["obs_point"],
                     g["obs_uv"], g["K"])
-    out = O.ba_solve(A, ba.OptimizerConfig("LM", int(g["max_iter"]), float(g["max_toler"]), 10.0, False))
-    assert out.outer_iterations == int(g["outer_iterations"]) and out.inner_iterations == int(g["inner_iterations"])
-    assert np.allclose(out.trace, g["trace"], rtol=1e-7, atol=0)
-    assert np.allclose(out.cam_T_wc, g["out_T_wc"], rtol=0, atol=1e-9)
-    assert np.allclose(out.points, g["out_points"], rtol=0, atol=1e-9) and np.allclose(out.K, g["out_K"], rtol=1e-10)
-    assert np.isclose(out.final_error, float(g["final_error"]), rtol=1e-9)
+    out = O.ba_solve(A, ba.OptimizerConfig("LM", int(g["max_iter"]), float(g["max_toler"]), 10.0, False), lm_factor=policy)
+    assert out.outer_iterations == int(g[pre + "outer_iterations"]) and out.inner_iterations == int(g[pre + "inner_iterations"])
+    assert np.allclose(out.trace, g[pre + "trace"], rtol=1e-7, atol=0)
+    assert np.allclose(out.cam_T_wc, g[pre + "out_T_wc"], rtol=0, atol=1e-9)
+    assert np.allclose(out.points, g[pre + "out_points"], rtol=0, atol=1e-9) and np.allclose(out.K, g[pre + "out_K"], rtol=1e-10)
+    assert np.isclose(out.final_error, float(g[pre + "final_error"]), rtol=1e-9)
 
 
 def test_dogleg_reaches_the_lm_optimum_and_adapts_the_region():
