@@ -11,11 +11,24 @@ all-gather of the match graph. Inputs are resident in HBM before the timed regio
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+Besides the headline line the JSON carries `lines`: the other BASELINE.json configurations and the real
+descriptor shapes as sub-objects, each with its own roofline against the peak of the arithmetic it runs on
+(SURVEY.md §8(d) "Other configs as inputs"):
+  s200_d128_i8   S200 with 128-D integer descriptors (what eacham's SIFT extractor produces)
+  s200_d256_f32  S200 with 256-D unit-norm float descriptors (SuperPoint / LightGlue style), fp32 MFMA
+  c2             configs[1]: 100 frames x 2000 x 256-D
+  c3_tum         configs[2] stand-in: 500 frames x 600 x 128-D all pairs + a sequence of local-window RefineBA
+  c4_ba          configs[3]: 500 cams / 100k landmarks / 1M observations, LM inner loop
+  c5_kitti       configs[4] stand-in: 100 frames x 1500 x 128-D through the shard path (+ RCCL all-gather, N > 1)
+With N > 1 only the headline and c5_kitti run (the lines that shard); `--lines` selects explicitly.
+
 The CPU oracle (oracle/) is used here only for the `cpu_baseline` leg (rank 0, N=1, bounded sample).
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the ~2.5 PF bf16 dense rate (MI355X_MICROARCH.md, Matrix cores)
+F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = the fp32 vector rate (same guide)
+HBM_PEAK_GBS = 8000.0
+FP64_PEAK_TFLOPS = 78.6
+ALL_LINES = ["s200_d128_i8", "s200_d256_f32", "c2", "c3_tum", "c4_ba", "c5_kitti"]
 
 
 def parse():
@@ -38,71 +55,142 @@ def parse():
     ap.add_argument("--kpts", type=int, default=2000)
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--landmarks", type=int, default=50_000)
-    ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (-1 = 4 per core, 0 = skip)")
-    ap.add_argument("--ba-solves", type=int, default=5, help="timed RefineBA solves of the S200 window (0 = skip BA)")
+    ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (-1 = 400 per core, 0 = skip)")
+    ap.add_argument("--ba-solves", type=int, default=50, help="timed RefineBA solves of the S200 window per option set (0 = skip BA)")
+    ap.add_argument("--lines", default="auto", help="comma list of sub-lines (see the module docstring), 'all', 'none', or "
+                                                    "'auto' = all at N=1, c5_kitti at N>1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--all-on-device", type=int, default=-1, help="rehearsal: put every rank on this device index")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+def kernel_source_sha() -> str:
+    """Identity of the kernels a profile was taken with: sha256 over the HIP sources of the library."""
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hpp"))):
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if args.all_on_device >= 0:
-        local = args.all_on_device
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
 
+def measured_traffic(kernel_prefix: str, grid: int | None = None):
+    """(HBM bytes per launch, source note) of a kernel from the committed rocprofv3 --pmc passes
+    (profiles/r02_pmc_hbm_traffic.json, written by tools/pmc_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate
+    passes, KB units, FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md). The file records the sha of
+    the kernel sources it was taken with; a figure from other sources is NOT reported (None + the reason)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, "no PMC profile committed"
+    meta = tab.get("__meta__", {})
+    if meta.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"stale: profile taken with kernel sources {meta.get('kernel_source_sha')}, running {kernel_source_sha()}"
+    keys = [k for k in tab if k.startswith(kernel_prefix) and " grid=" in k]
+    if grid is not None:
+        keys = [k for k in keys if int(k.rsplit("=", 1)[1]) == grid] or keys
+    if not keys:
+        return None, "kernel not in the PMC profile"
+    try:
+        d = tab[max(keys, key=lambda k: int(k.rsplit("=", 1)[1]))]
+        return (2.0 * d["FETCH_SIZE_KB_mean_per_dispatch"] + d["WRITE_SIZE_KB_mean_per_dispatch"]) * 1024.0, \
+            f"profiles/r02_pmc_hbm_traffic.json ({meta.get('command', 'tools/prof.sh')})"
+    except (KeyError, TypeError, ValueError):
+        return None, "malformed PMC profile entry"
+
+
+def host_cores() -> int:
+    """Usable host cores: the affinity mask capped by the cgroup CPU quota (the GPU box grants a
+    share of a large host)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+class Dist:
+    """rank/world + the torch handles every leg needs."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        if args.all_on_device >= 0:
+            local = args.all_on_device
+        self.local = local
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        if self.world > 1:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(args.backend)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_f(self, x: float) -> float:
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_f(self, x: float) -> float:
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
+    """The matching hot path over all unordered pairs of `descs` (list of N x dim fp32 matrices), sharded over
+    the ranks: pairs ordered by train frame, contiguous shard per rank, one eacham_match_all_pairs_dev per step
+    and (N > 1) the asynchronous RCCL all-gather of the match graph, double-buffered against the next step.
+    kind: "i8" (integer descriptors, exact int8 MFMA path) or "f32" (float descriptors, fp32 MFMA path).
+    Returns the timing of exactly `steps` steps bracketed by barrier + synchronize, max over ranks."""
+    torch, dist = D.torch, D.dist
     from eacham_amd import HipContext, synth, capi, shard
-
-    # ---- synthetic S200 inputs, identical on every rank ------------------------------------
-    t_gen = time.time()
-    scene = synth.make_scene(args.frames, args.landmarks, 10)
-    descs, _ = synth.make_frame_descriptors(scene, args.kpts, args.dim)
-    pairs_all = synth.all_pairs(args.frames)
+    world, rank, dev = D.world, D.rank, D.dev
+    pairs_all = shard.order_pairs(synth.all_pairs(len(descs)))
     npairs_total = len(pairs_all)
-    # pairs ordered by train frame (L2 reuse of the B operand), contiguous shard per rank
-    pairs_all = shard.order_pairs(pairs_all)
     pairs = shard.shard_pairs(pairs_all, world, rank)
     npairs = len(pairs)
     shard_max = shard.shard_capacity(npairs_total, world)
-    t_gen = time.time() - t_gen
+    kmax = max(d.shape[0] for d in descs)
 
-    ctx = HipContext(local)
-    for f, d in enumerate(descs):  # replicated descriptor store: 200 x 2000 x 256 B = 102 MB int8
-        ctx.upload_descriptors(f, d)
+    ctx = HipContext(D.local)
+    for f, d in enumerate(descs):  # replicated descriptor store (S200: 200 x 2000 x 256 B = 102 MB int8)
+        (ctx.upload_descriptors if kind == "i8" else ctx.upload_descriptors_f32)(f, d)
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-
     with torch.cuda.stream(ext):
         pairs_dev = torch.from_numpy(pairs).to(dev)
-        counts = torch.zeros(shard_max, dtype=torch.int32, device=dev)
         offsets = torch.zeros(npairs + 1, dtype=torch.int64, device=dev)
         total = torch.zeros(1, dtype=torch.int64, device=dev)
         # size the edge buffer from one untimed pass (deterministic inputs -> exact)
-        probe_cap = npairs * args.kpts
-        edges = torch.zeros(max(probe_cap, 1) * 2, dtype=torch.int32, device=dev)
-        ctx.match_all_pairs_dev(pairs_dev.data_ptr(), npairs, counts.data_ptr(), offsets.data_ptr(),
-                                edges.data_ptr(), probe_cap, total.data_ptr())
+        probe_cap = max(npairs * kmax, 1)
+        counts0 = torch.zeros(shard_max, dtype=torch.int32, device=dev)
+        edges0 = torch.zeros(probe_cap * 2, dtype=torch.int32, device=dev)
+        ctx.match_all_pairs_dev(pairs_dev.data_ptr(), npairs, counts0.data_ptr(), offsets.data_ptr(),
+                                edges0.data_ptr(), probe_cap, total.data_ptr())
         ctx.sync()
-        my_total = int(total.item())
-        cap_t = torch.tensor([my_total], dtype=torch.int64, device=dev)
+        cap_t = torch.tensor([int(total.item())], dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
         edge_cap = max(int(cap_t.item()), 1)
+        del edges0, counts0
         # two output sets: the all-gather of step i (its own RCCL stream) overlaps the matching of step i+1
         sets = []
         for _ in range(2 if world > 1 else 1):
@@ -133,121 +221,66 @@ def main():
                 for w in st["pending"]:
                     w.wait()
                 st["pending"] = []
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     ctx.profile_reset()
     ctx.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = D.max_f(time.perf_counter() - t0)
     ctx.profile_enable(False)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
     launches, tile_ms = ctx.profile_get(capi.KERNEL_MATCH_TILE)
     _, fin_ms = ctx.profile_get(capi.KERNEL_MATCH_FINALIZE)
-    n_matches = int(total.item())
-
-    ba_out = bench_ba(ctx, scene, args, rank, world, dev) if args.ba_solves > 0 else None
-
-    if rank == 0:
-        ops_per_pair = 2.0 * args.kpts * args.kpts * args.dim  # 2*N1*N2*D per unordered pair
-        achieved = ops_per_pair * npairs * args.steps / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0
-        out = {
-            "metric": "image-pairs matched/s + BA iters/s, 200-frame/50k-landmark synthetic",
-            "value": npairs_total * args.steps / elapsed,
-            "unit": "image-pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "i8",
-            "data": "synthetic",
-            "config": {"workload": f"S200 matching: {args.frames} frames x {args.kpts} kpts x {args.dim}-D, "
-                                   f"{npairs_total} unordered pairs (both directions + mutual check)",
-                       "pairs_per_rank": npairs, "mutual_matches_rank0": n_matches,
-                       "parallelism": f"pairs sharded over {world} GPU(s)" + (" + RCCL all-gather" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
-                         "frac": achieved / I8_MFMA_PEAK_TOPS,
-                         # HBM bytes of one full-batch launch (1872 pairs x 8 workgroups x 256 threads)
-                         "traffic": measured_traffic("eacham::match_tile_kernel<8, 2>") if args.kpts == 2000 and args.dim == 256 else None,
-                         "kernel": "match_tile_kernel<8, 2>", "launches": launches,
-                         "avg_launch_ms": tile_ms / max(launches, 1),
-                         "finalize_ms_per_step": fin_ms / args.steps},
-        }
-        if ba_out is not None:
-            out["ba"] = ba_out
-        if world == 1 and args.cpu_pairs != 0:
-            out["cpu_baseline"] = cpu_baseline(descs, pairs_all, args)
-            if ba_out is not None:
-                out["ba"]["cpu_baseline"] = cpu_baseline_ba(scene)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms,
+           "fin_ms": fin_ms, "matches": int(total.item()), "pairs_all": pairs_all, "edge_cap": edge_cap}
     ctx.close()
+    return out
 
 
-def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_hbm_traffic.json, written by tools/pmc_traffic_json.py; FETCH_SIZE and WRITE_SIZE in
-    separate passes, KB units, FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md). The entry
-    of the largest grid = the full-batch launch the roofline line is about. None if not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            tab = json.load(f)
-        keys = [k for k in tab if k.startswith(kernel + " grid=")]
-        d = tab[max(keys, key=lambda k: int(k.rsplit("=", 1)[1]))]
-        return (2.0 * d["FETCH_SIZE_KB_mean_per_dispatch"] + d["WRITE_SIZE_KB_mean_per_dispatch"]) * 1024.0
-    except (OSError, KeyError, TypeError, ValueError):
-        return None
+def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str):
+    """One matching sub-line: value + roofline against the MFMA peak of the arithmetic used."""
+    r = run_matching(D, descs, kind, steps, warmup)
+    n = np.array([d.shape[0] for d in descs], dtype=np.float64)
+    # algorithmic work of this rank's launches: 2 * N1 * N2 * D per unordered pair (SURVEY.md §8(d))
+    ops = 2.0 * dim * float(np.mean(n)) ** 2 * r["npairs"] * steps
+    achieved = ops / (r["tile_ms"] * 1e-3) / 1e12 if r["tile_ms"] > 0 else 0.0
+    peak = I8_MFMA_PEAK_TOPS if kind == "i8" else F32_MFMA_PEAK_TFLOPS
+    return {"workload": workload, "value": r["npairs_total"] * steps / r["elapsed"], "unit": "image-pairs/s",
+            "dtype": kind, "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3, "pairs": r["npairs_total"],
+            "pairs_per_rank": r["npairs"], "mutual_matches_rank0": r["matches"],
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "kernel": kernel, "launches": r["launches"],
+                         "avg_launch_ms": r["tile_ms"] / max(r["launches"], 1),
+                         "finalize_ms_per_step": r["fin_ms"] / steps}}, r
 
 
-def host_cores() -> int:
-    """Usable host cores: the affinity mask capped by the cgroup CPU quota (the GPU box grants a
-    share of a large host)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
+def ba_bytes_flops(nc, nl, no):
+    n = 6 * nc + 5
+    return 48 * no + 3 * (96 * nc + 24 * nl + 40) + 144 * nl + 8 * n * (n + 1), n  # SURVEY.md §8(d)
 
 
-def bench_ba(ctx, scene, args, rank, world, dev):
-    """BA iters/s: K timed RefineBA solves (config/SfmConfigNerf.json `refine_ba`: LM, 100 it, 1e-5) of
-    the whole S200 window, values resident on the device, each solve restarting from the same
-    perturbed initial guess. BA does not shard at these sizes: with N > 1 every
-    rank runs an independent replica and the rates are summed ("replicas")."""
-    import torch
-    import torch.distributed as dist
+def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=True):
+    """BA iters/s: `solves` timed RefineBA solves of one window, values resident on the device, each solve restarting
+    from the same perturbed initial guess. BA does not shard at these sizes: with N > 1 every rank
+    runs an independent replica and the rates are summed ("replicas")."""
+    torch = D.torch
     from eacham_amd import ba, capi
 
     arrays = ba.BaArrays.from_scene(scene)
-    cfg = ba.OptimizerConfig.refine_ba()
     solver = ba.PreparedBA(ctx, arrays)
     first = solver.run(cfg)  # warm-up (allocations, code objects)
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     outer = inner = 0
-    for _ in range(args.ba_solves):  # the rate: no instrumentation inside the timed region
-        o = solver.run(cfg)
+    for _ in range(solves):  # the rate: no instrumentation inside the timed region
+        o = solver.run(cfg, trace_cap=0)
         outer += o.outer_iterations
         inner += o.inner_iterations
     torch.cuda.synchronize()
@@ -262,36 +295,81 @@ def bench_ba(ctx, scene, args, rank, world, dev):
     stage = {}
     for name, kid in [("linearize", capi.KERNEL_BA_LINEARIZE), ("schur", capi.KERNEL_BA_SCHUR),
                       ("solve", capi.KERNEL_BA_SOLVE), ("error", capi.KERNEL_BA_ERROR)]:
-        n, ms = ctx.profile_get(kid)
+        _, ms = ctx.profile_get(kid)
         stage[name + "_ms_per_inner_iter"] = ms / max(prof.inner_iterations, 1)
     solver.close()
-    rate = torch.tensor([outer / dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(rate, op=dist.ReduceOp.SUM)
+    rate = D.sum_f(outer / dt)
     nc, nl, no = arrays.cam_T_wc.shape[0], arrays.points.shape[0], arrays.obs_cam.shape[0]
-    n = 6 * nc + 5
-    bytes_iter = 48 * no + 3 * (96 * nc + 24 * nl + 40) + 144 * nl + 8 * n * (n + 1)
+    bytes_iter, n = ba_bytes_flops(nc, nl, no)
     dev_ms = sum(stage.values())
     achieved = bytes_iter / (dev_ms * 1e-3) / 1e9 if dev_ms > 0 else 0.0
-    return {"value": float(rate.item()), "unit": "LM outer iters/s", "replicas": world, "solves": args.ba_solves,
-            "outer_iters_per_solve": outer / args.ba_solves, "inner_iters_per_solve": inner / args.ba_solves,
+    solve_ms = stage["solve_ms_per_inner_iter"]
+    solve_tf = (n ** 3 / 3.0) / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
+    traffic, src = (None, "not collected for this window")
+    if with_traffic:
+        traffic, src = ba_measured_traffic()
+    return {"value": rate, "unit": "LM outer iters/s", "replicas": D.world, "solves": solves,
+            "outer_iters_per_solve": outer / solves, "inner_iters_per_solve": inner / solves,
+            "inner_iters_per_s": D.sum_f(inner / dt), "timed_region_s": dt,
             "ms_per_inner_iter": dt / max(inner, 1) * 1e3, "dtype": "f64",
-            "workload": f"S200 RefineBA: {nc} cams / {nl} landmarks / {no} obs, refine_ba (LM, 100, 1e-5)",
+            "workload": f"{label}: {nc} cams / {nl} landmarks / {no} obs, {cfg.method} ({cfg.maxIter}, {cfg.maxTolerance:g})",
             "final_error": first.final_error, "initial_error": first.initial_error, **stage,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                         "algorithmic_bytes_per_inner_iter": bytes_iter,
                          "note": "algorithmic bytes of one inner iteration (SURVEY.md §8(d)) / summed kernel time",
                          # the dense reduced solve against the fp64 vector peak (SURVEY.md §8(d) asks for both)
-                         "solve": {"bound": "fp64", "achieved": (n ** 3 / 3.0) / (stage["solve_ms_per_inner_iter"] * 1e-3) / 1e12
-                                   if stage["solve_ms_per_inner_iter"] > 0 else 0.0,
-                                   "peak": 78.6, "unit": "TFLOP/s",
-                                   "frac": ((n ** 3 / 3.0) / (stage["solve_ms_per_inner_iter"] * 1e-3) / 1e12 / 78.6)
-                                   if stage["solve_ms_per_inner_iter"] > 0 else 0.0,
-                                   "note": "n^3/3 flops of the Cholesky factorisation / solve time; the chain of 38 dependent block steps is latency-bound"}}}
+                         "solve": {"bound": "fp64", "achieved": solve_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": solve_tf / FP64_PEAK_TFLOPS,
+                                   "note": f"n^3/3 flops of the Cholesky factorisation / solve time; the chain of {(n + 31) // 32} "
+                                           "dependent block steps is latency-bound"}}}
+
+
+def ba_measured_traffic():
+    """HBM bytes of ONE LM inner iteration of the S200 window: sum over the BA kernels of (2 FETCH + WRITE) per
+    dispatch x dispatches per inner iteration, from profiles/r02_pmc_ba_traffic.json (tools/pmc_ba_traffic_json.py)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_ba_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, "no PMC profile committed"
+    if tab.get("__meta__", {}).get("kernel_source_sha") != kernel_source_sha():
+        return None, f"stale: profile taken with kernel sources {tab.get('__meta__', {}).get('kernel_source_sha')}, running {kernel_source_sha()}"
+    try:
+        return float(tab["per_inner_iteration"]["hbm_bytes"]), "profiles/r02_pmc_ba_traffic.json"
+    except (KeyError, TypeError, ValueError):
+        return None, "malformed PMC profile"
+
+
+def bench_local_windows(D: Dist, ctx, scene, frames, cfg):
+    """configs[2] stand-in, BA part: a sequence of local-window RefineBA calls as apps/sfm/main.cpp:207 issues them —
+    every window is a NEW problem (eacham_ba_solve = structure build + upload + LM + read-back), so the timed region
+    holds all of it."""
+    torch = D.torch
+    from eacham_amd import ba, synth
+    wins = [ba.BaArrays.from_scene(synth.local_window(scene, f)) for f in frames]
+    ba.RefineBA(ctx, wins[0], cfg)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outer = inner = 0
+    for A in wins:
+        o = ba.RefineBA(ctx, A, cfg, trace_cap=0)
+        outer += o.outer_iterations
+        inner += o.inner_iterations
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cams = np.mean([A.cam_T_wc.shape[0] for A in wins])
+    lms = np.mean([A.points.shape[0] for A in wins])
+    obs = np.mean([A.obs_cam.shape[0] for A in wins])
+    return {"value": outer / dt, "unit": "LM outer iters/s", "windows": len(wins), "windows_per_s": len(wins) / dt,
+            "inner_iters_per_s": inner / dt, "timed_region_s": dt, "dtype": "f64",
+            "workload": f"{len(wins)} local windows (current frame + covisible neighbours): mean {cams:.0f} cams / {lms:.0f} "
+                        f"landmarks / {obs:.0f} obs, refine_ba (LM, 100, 1e-5), prepare + solve + read-back per window"}
 
 
 def cpu_baseline_ba(scene):
-    """oracle/ba_oracle.c (kind "port"): two LM iterations of the same S200 window on the host cores."""
+    """oracle/ba_oracle.c (kind "port"): LM iterations of the same S200 window on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as O
     from eacham_amd import ba
@@ -320,6 +398,128 @@ def cpu_baseline(descs, pairs_all, args):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "image-pairs/s", "cores": int(res[5]), "kind": "port",
             "sample": f"{n} of {len(pairs_all)} pairs of the same workload, exact brute-force 2-NN + ratio + mutual check, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    D = Dist(args)
+    from eacham_amd import HipContext, synth, ba
+
+    if args.lines == "auto":
+        lines = list(ALL_LINES) if D.world == 1 else ["c5_kitti"]
+    elif args.lines in ("none", ""):
+        lines = []
+    elif args.lines == "all":
+        lines = list(ALL_LINES)
+    else:
+        lines = [x for x in args.lines.split(",") if x]
+        bad = [x for x in lines if x not in ALL_LINES]
+        if bad:
+            raise SystemExit(f"unknown --lines {bad}; known: {ALL_LINES}")
+
+    # ---- headline: S200 matching, identical inputs on every rank ----------------------------
+    scene = synth.make_scene(args.frames, args.landmarks, 10)
+    descs, _ = synth.make_frame_descriptors(scene, args.kpts, args.dim)
+    head, r = matching_line(D, descs, "i8", args.dim, args.steps, args.warmup,
+                            f"S200 matching: {args.frames} frames x {args.kpts} kpts x {args.dim}-D, "
+                            f"{len(synth.all_pairs(args.frames))} unordered pairs (both directions + mutual check)",
+                            "match_tile_kernel<8, 2>" if args.dim > 128 else "match_tile_kernel<4, 2>")
+    if args.kpts == 2000 and args.dim == 256:
+        head["roofline"]["traffic"], head["roofline"]["traffic_source"] = measured_traffic("eacham::match_tile_kernel<8, 2>")
+    else:
+        head["roofline"]["traffic_source"] = "not the profiled workload"
+
+    sub = {}
+    ctx = HipContext(D.local)  # BA legs
+    ba_out = None
+    if args.ba_solves > 0:
+        ba_out = bench_ba(D, ctx, scene, args.ba_solves, ba.OptimizerConfig.refine_ba(), "S200 RefineBA")
+        ba_out["global_ba"] = bench_ba(D, ctx, scene, args.ba_solves, ba.OptimizerConfig.global_ba(), "S200 RefineBA(-1)",
+                                       with_traffic=False)
+
+    def leg(name, fn):
+        if name in lines:
+            t0 = time.time()
+            sub[name] = fn()
+            sub[name]["wall_s_incl_setup"] = round(time.time() - t0, 2)
+
+    sub_steps = max(1, min(args.steps, 3))
+    leg("s200_d128_i8", lambda: matching_line(
+        D, synth.make_frame_descriptors(scene, args.kpts, 128)[0], "i8", 128, sub_steps, 1,
+        f"S200 matching with SIFT-shaped descriptors: {args.frames} frames x {args.kpts} kpts x 128-D integers "
+        "(FeatureExtractorSift.cpp:8)", "match_tile_kernel<4, 2>")[0])
+
+    def f32_line():
+        base = synth.unit_float_descriptors(args.kpts, 256, 1, 99)
+        fd = [synth.unit_float_descriptors(args.kpts, 256, 1, f, shared=base[:args.kpts // 2]) for f in range(args.frames)]
+        return matching_line(D, fd, "f32", 256, 1, 1,
+                             f"S200-sized matching with float descriptors: {args.frames} frames x {args.kpts} kpts x 256-D unit-norm fp32 "
+                             "(SuperPoint / LightGlue, modules/onnx/lightglue/feature/Types.h:11-14)", "match_tile_f32_kernel")[0]
+    leg("s200_d256_f32", f32_line)
+    leg("c2", lambda: matching_line(
+        D, descs[:100] if args.frames >= 100 else descs, "i8", args.dim, sub_steps, 1,
+        "BASELINE configs[1]: brute-force 256-D descriptor match, 2k kpts x 100 synthetic frames (4950 pairs)",
+        "match_tile_kernel<8, 2>")[0])
+
+    def tum_line():
+        # config/ConfigTUM.json:3,28: <= 500 frames x 600 features (it asks for ORB/Hamming; the path stays L2 on
+        # SIFT-shaped 128-D integers); 30 000 landmarks x 10 observers = 600 per frame
+        tum = synth.make_scene(500, 30_000, 10, seed=3)
+        td, _ = synth.make_frame_descriptors(tum, 600, 128, seed=3)
+        out, _r = matching_line(D, td, "i8", 128, sub_steps, 1,
+                                "BASELINE configs[2] stand-in (TUM fr1/desk sizes): 500 frames x 600 kpts x 128-D, 124750 pairs",
+                                "match_tile_kernel<4, 2>")
+        out["ba"] = bench_local_windows(D, ctx, tum, range(100, 140), ba.OptimizerConfig.refine_ba())
+        return out
+    leg("c3_tum", tum_line)
+    leg("c4_ba", lambda: bench_ba(D, ctx, synth.make_scene(500, 100_000, 10, seed=4), max(3, args.ba_solves // 10),
+                                  ba.OptimizerConfig.refine_ba(), "BASELINE configs[3]", with_traffic=False))
+
+    def kitti_line():
+        # config/ConfigKITTI.json:3,29: 100 frames x 1500 features; sharded over the ranks + all-gather
+        kit = synth.make_scene(100, 15_000, 10, seed=5)
+        kd, _ = synth.make_frame_descriptors(kit, 1500, 128, seed=5)
+        out, _r = matching_line(D, kd, "i8", 128, sub_steps, 1,
+                                f"BASELINE configs[4] stand-in (KITTI seq-00 sizes): 100 frames x 1500 kpts x 128-D, 4950 pairs sharded "
+                                f"over {D.world} GPU(s)" + (" + RCCL all-gather of the match graph" if D.world > 1 else ""),
+                                "match_tile_kernel<4, 2>")
+        out["scaling"] = "strong"
+        return out
+    leg("c5_kitti", kitti_line)
+
+    if D.rank == 0:
+        out = {
+            "metric": "image-pairs matched/s + BA iters/s, 200-frame/50k-landmark synthetic",
+            "value": head["value"],
+            "unit": "image-pairs/s",
+            "n_gpus": D.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "i8",
+            "data": "synthetic",
+            "config": {"workload": head["workload"], "pairs_per_rank": head["pairs_per_rank"],
+                       "mutual_matches_rank0": head["mutual_matches_rank0"],
+                       "parallelism": f"pairs sharded over {D.world} GPU(s)" + (" + RCCL all-gather" if D.world > 1 else "")},
+            "roofline": head["roofline"],
+            "kernel_source_sha": kernel_source_sha(),
+        }
+        if ba_out is not None:
+            out["ba"] = ba_out
+        if sub:
+            out["lines"] = sub
+        if D.world == 1 and args.cpu_pairs != 0:
+            out["cpu_baseline"] = cpu_baseline(descs, r["pairs_all"], args)
+            if ba_out is not None:
+                out["ba"]["cpu_baseline"] = cpu_baseline_ba(scene)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if D.world > 1:
+        D.dist.barrier()
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -882,7 +882,8 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
         }
         EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_tile[slot], st1));
         EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_tile[slot], 0));
-        int* cnt = mode == 1 ? counts_dev : counts_dev + first;
+        const bool csr = offsets_dev != nullptr;  // mode 1 without offsets: the single directed pair of eacham_match_pair
+        int* cnt = csr ? counts_dev + first : counts_dev;
         {
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE, st2);
             match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(
@@ -890,7 +891,7 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
                 (const uint2*)(ws + pl.off_colpart), pl.col_chunks, pl.wb_stride, pl.row_stride, ratio, min_dir,
                 min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt,
                 stats_dev ? stats_dev + first : nullptr);
-            if (mode == 0) {
+            if (csr) {
                 scan_counts_kernel<<<1, 1024, 0, st2>>>(cnt, nb, offsets_dev, total_dev, first, first + nb == npairs);
                 compact_edges_kernel<<<nb, 256, 0, st2>>>((const uint2*)(ws + pl.off_matches), cnt, offsets_dev + first,
                                                           pl.row_stride, edges_dev, edge_cap);
@@ -1020,13 +1021,11 @@ int eacham_match_all_pairs_dev(eacham_ctx* ctx, const int32_t* pairs_dev, int np
                      (int4*)stats_dev);
 }
 
-int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio, int min_dir,
-                           int min_mutual, int32_t* counts, int64_t* offsets, uint32_t* out_q,
-                           uint32_t* out_t, int64_t cap, int64_t* out_total, int32_t* stats) {
-    if (!ctx) return EACHAM_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
-    if (npairs < 0 || (npairs > 0 && (!pairs || !counts || !offsets)) || !out_total || cap < 0)
+// host pointers in, CSR over the pairs out: mode 0 = mutual + thresholds, mode 1 = directed lists
+static int match_pairs_host(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio, int min_dir,
+                            int min_mutual, int mode, int32_t* counts, int64_t* offsets, uint32_t* out_q,
+                            uint32_t* out_t, int64_t cap, int64_t* out_total, int32_t* stats) {
+    if (npairs < 0 || (npairs > 0 && (!pairs || !counts || !offsets)) || !out_total || cap < 0 || (cap > 0 && (!out_q || !out_t)))
         return ctx->fail(EACHAM_ERR_INVALID, "bad arguments to match_all_pairs");
     int rc = check_pairs_host(ctx, pairs, npairs);
     if (rc) return rc;
@@ -1050,9 +1049,9 @@ int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, do
     char* io = (char*)ctx->io;
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(io + o_pairs, pairs, (size_t)npairs * 2 * sizeof(int32_t),
                                        hipMemcpyHostToDevice, ctx->stream));
-    rc = run_match(ctx, (const int2*)(io + o_pairs), npairs, ratio, min_dir, min_mutual, 0,
+    rc = run_match(ctx, (const int2*)(io + o_pairs), npairs, ratio, min_dir, min_mutual, mode,
                    (int*)(io + o_counts), (long long*)(io + o_offsets), (uint2*)(io + o_edges), cap,
-                   (long long*)(io + o_total), (int4*)(io + o_stats));
+                   (long long*)(io + o_total), stats ? (int4*)(io + o_stats) : nullptr);
     if (rc) return rc;
     long long total = 0;
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(&total, io + o_total, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
@@ -1075,6 +1074,23 @@ int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, do
         }
     }
     return EACHAM_OK;
+}
+
+int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio, int min_dir,
+                           int min_mutual, int32_t* counts, int64_t* offsets, uint32_t* out_q,
+                           uint32_t* out_t, int64_t cap, int64_t* out_total, int32_t* stats) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return match_pairs_host(ctx, pairs, npairs, ratio, min_dir, min_mutual, 0, counts, offsets, out_q, out_t, cap, out_total, stats);
+}
+
+int eacham_match_pairs_directed(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio, int32_t* counts,
+                                int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    return match_pairs_host(ctx, pairs, npairs, ratio, 0, 0, 1, counts, offsets, out_q, out_t, cap, out_total, nullptr);
 }
 
 }  // extern "C"

@@ -333,13 +333,14 @@ int run_match_f32(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double rat
                 default: match_tile_f32_kernel<128><<<nb * wgs_per_pair, F_THREADS, 0, ctx->stream>>>(ctx->frame_table_dev, pb, wgs_per_pair, rr, cp, wb_stride, row_stride); break;
             }
         }
-        int* cnt = mode == 1 ? counts_dev : counts_dev + first;
+        const bool csr = offsets_dev != nullptr;  // mode 1 without offsets: the single directed pair of eacham_match_pair
+        int* cnt = csr ? counts_dev + first : counts_dev;
         {
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE);
             match_finalize_f32_kernel<<<nb, FIN_T, fin_smem, ctx->stream>>>(
                 ctx->frame_table_dev, pb, (const int4*)(ws + off_rowres), (const int4*)(ws + off_colpart), wb_stride, row_stride,
                 ratio, min_dir, min_mutual, mode, (uint2*)(ws + off_matches), cnt, stats_dev ? stats_dev + first : nullptr);
-            if (mode == 0) {
+            if (csr) {
                 launch_scan_counts(ctx, cnt, nb, offsets_dev, total_dev, first, first + nb == npairs);
                 launch_compact_edges(ctx, nb, (const uint2*)(ws + off_matches), cnt, offsets_dev + first, row_stride, edges_dev, edge_cap);
             }

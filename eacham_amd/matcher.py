@@ -118,6 +118,24 @@ class HipContext:
             offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total), stats.ctypes.data))
         return counts, offsets, q[:total.value].copy(), t[:total.value].copy(), stats
 
+    def match_pairs_directed(self, frames, ordered_pairs, ratio: float = RATIO, f32: bool = False) -> list:
+        """Uploads `frames` (list of N x D matrices) as frames 0.. and runs every ordered pair (i, j) as one directed
+        Match(frames[i], frames[j]) in ONE launch sequence; returns a list of {queryIdx: trainIdx} dicts."""
+        self.clear_descriptors()
+        for f, d in enumerate(frames):
+            (self.upload_descriptors_f32 if f32 else self.upload_descriptors)(f, d)
+        pairs = np.ascontiguousarray(ordered_pairs, dtype=np.int32).reshape(-1, 2)
+        npairs = pairs.shape[0]
+        cap = int(sum(frames[int(p[0])].shape[0] for p in pairs))
+        counts = np.zeros(npairs, dtype=np.int32)
+        offsets = np.zeros(npairs + 1, dtype=np.int64)
+        q = np.empty(max(cap, 1), dtype=np.uint32)
+        t = np.empty(max(cap, 1), dtype=np.uint32)
+        total = C.c_int64(0)
+        self._check(self._L.eacham_match_pairs_directed(self._h, pairs.ctypes.data, npairs, ratio, counts.ctypes.data,
+                                                        offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total)))
+        return [dict(zip(q[offsets[p]:offsets[p + 1]].tolist(), t[offsets[p]:offsets[p + 1]].tolist())) for p in range(npairs)]
+
     def match_all_pairs_dev(self, pairs_dev: int, npairs: int, counts_dev: int, offsets_dev: int,
                             edges_dev: int, edge_cap: int, total_dev: int, stats_dev: int = 0,
                             ratio: float = RATIO, min_dir: int = MIN_DIRECTED, min_mutual: int = MIN_MUTUAL):
@@ -151,19 +169,28 @@ class FeatureMatcherHip:
         self.inliersRatio = inliersRatio
         self.ratio = ratio
         self.ctx = context or HipContext()
-        self._scratch = (1 << 16) - 2  # two frame slots reserved for ad-hoc Match() calls
+        self._f32 = False  # the first non-integer frame switches the instance to the fp32 path for good
 
     def Match(self, descriptor1: np.ndarray, descriptor2: np.ndarray) -> dict:
-        a, b = self._scratch, self._scratch + 1
-        self.ctx.clear_descriptors()
-        try:  # SIFT-style integers: exact int8 path; other floats: fp32 MFMA path
-            self.ctx.upload_descriptors(a, descriptor1)
-            self.ctx.upload_descriptors(b, descriptor2)
-        except capi.EachamError as e:
-            if e.code not in (capi.ERR_NOT_INTEGER, capi.ERR_UNSUPPORTED):
-                raise
-            self.ctx.clear_descriptors()
-            self.ctx.upload_descriptors_f32(a, descriptor1)
-            self.ctx.upload_descriptors_f32(b, descriptor2)
-        q, t = self.ctx.match_pair(a, b, self.ratio)
+        """Two frame slots (0 and 1) of the context's store are rewritten per call; the store is cleared only
+        when the descriptor kind changes. (The C++ adapter include/eacham/FeatureMatcherHip.hpp additionally
+        caches uploads by buffer address and combines concurrent callers; numpy temporaries reuse addresses too
+        freely for that to be safe here, and this class only drives tests.)"""
+        if not self._f32:
+            try:  # SIFT-style integers: exact int8 path
+                self.ctx.upload_descriptors(0, descriptor1)
+                self.ctx.upload_descriptors(1, descriptor2)
+            except capi.EachamError as e:
+                if e.code not in (capi.ERR_NOT_INTEGER, capi.ERR_UNSUPPORTED):
+                    raise
+                self._f32 = True  # other floats: fp32 MFMA path; all resident frames must be of one kind
+                self.ctx.clear_descriptors()
+        if self._f32:
+            self.ctx.upload_descriptors_f32(0, descriptor1)
+            self.ctx.upload_descriptors_f32(1, descriptor2)
+        q, t = self.ctx.match_pair(0, 1, self.ratio)
         return dict(zip(q.tolist(), t.tolist()))
+
+    def MatchPairs(self, frames, ordered_pairs) -> list:
+        """eacham_match_pairs_directed: every (i, j) of `ordered_pairs` is one Match(frames[i], frames[j])."""
+        return self.ctx.match_pairs_directed(frames, ordered_pairs, self.ratio, f32=self._f32)

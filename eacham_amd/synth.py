@@ -145,6 +145,43 @@ def make_scene(n_cams: int = 200, n_landmarks: int = 50_000, k_obs: int = 10,
     }
 
 
+def local_window(scene, frame: int, min_shared: int = 31, max_neighbours: int | None = None):
+    """The local BA window RefineBA(currentFrameId >= 0) builds (BundleAdjuster.cpp:123-145): the current
+    frame first, then its valid neighbours in the view graph in ascending id — here the frames that share at
+    least `min_shared` landmarks with it (an edge of the match graph needs more than 30 mutual matches,
+    apps/sfm/main.cpp:142). Landmarks = every map point a window frame observes (first-seen order, :100-117);
+    `observers` keeps the GLOBAL observer counts (:109). Returns a scene-shaped dict (BaArrays.from_scene works)
+    plus "frames" (window index -> frame id) and "landmarks" (window index -> landmark id)."""
+    obs_cam, obs_lm = scene["obs_cam"].astype(np.int64), scene["obs_lm"].astype(np.int64)
+    n_cams = scene["T_true"].shape[0]
+    mine = obs_lm[obs_cam == frame]
+    seen = np.zeros(scene["points_true"].shape[0], dtype=bool)
+    seen[mine] = True
+    shared = np.bincount(obs_cam[seen[obs_lm]], minlength=n_cams)
+    nb = [int(c) for c in np.nonzero(shared >= min_shared)[0] if c != frame]
+    if max_neighbours is not None:
+        nb = sorted(sorted(nb, key=lambda c: -shared[c])[:max_neighbours])
+    frames = np.array([frame] + nb, dtype=np.int64)
+    cam_new = np.full(n_cams, -1, dtype=np.int64)
+    cam_new[frames] = np.arange(frames.size)
+    sel = np.nonzero(cam_new[obs_cam] >= 0)[0]
+    # frameAdder visits the window frames in order, each frame's points in ascending keypoint (= observation) order
+    sel = sel[np.lexsort((sel, cam_new[obs_cam[sel]]))]
+    lm_ids, first = np.unique(obs_lm[sel], return_index=True)
+    lm_ids = lm_ids[np.argsort(first, kind="stable")]  # first-seen order
+    lm_new = np.full(scene["points_true"].shape[0], -1, dtype=np.int64)
+    lm_new[lm_ids] = np.arange(lm_ids.size)
+    return {
+        "K": scene["K"].copy(),
+        "T_true": scene["T_true"][frames], "T_init": scene["T_init"][frames],
+        "points_true": scene["points_true"][lm_ids], "points_init": scene["points_init"][lm_ids],
+        "fixed": scene["fixed"][frames].copy(),
+        "obs_cam": cam_new[obs_cam[sel]].astype(np.uint32), "obs_lm": lm_new[obs_lm[sel]].astype(np.uint32),
+        "obs_uv": scene["obs_uv"][sel], "observers": scene["observers"][lm_ids].copy(),
+        "frames": frames, "landmarks": lm_ids,
+    }
+
+
 # --------------------------------------------------------------------------------------------
 # descriptors
 # --------------------------------------------------------------------------------------------

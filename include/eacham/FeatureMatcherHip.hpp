@@ -7,10 +7,15 @@
 //
 // Header-only; link against libeacham_hip.so. Errors become std::runtime_error like the reference's
 // own accessors (Node.h:78-98); the C-ABI itself never throws. Thread-safe: one shared instance may
-// be called from many threads (apps/sfm/main.cpp:98-109) — calls serialise on the context.
+// be called from many threads (apps/sfm/main.cpp:98-109) — concurrent calls are combined into batches.
 #pragma once
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstring>
+#include <exception>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -58,39 +63,66 @@ public:
     void check(int rc) const {
         if (rc != EACHAM_OK) throw std::runtime_error(std::string("eacham_hip: ") + eacham_last_error(ctx_));
     }
+    // Bumped by whoever rewrites the context's descriptor store wholesale (MatchAllPairs): a FeatureMatcherHip
+    // that caches uploads on the same context then knows its slots are gone.
+    unsigned store_generation() const { return generation_.load(); }
+    void store_rewritten() { generation_.fetch_add(1); }
 
 private:
     eacham_ctx* ctx_ = nullptr;
+    std::atomic<unsigned> generation_{0};
 };
 
+// Drop-in for eacham::FeatureMatcherFlann. The reference calls Match(d1, d2) once per ORDERED frame pair, from many
+// threads at once on one shared instance, always with the descriptor matrices the Nodes own
+// (apps/sfm/main.cpp:98-109: `std::async(&FeatureMatcherFlann::Match, &matcher, node1->GetDescriptors(), ...)`).
+// Two things keep that call pattern off the PCIe bus and the launch latency:
+//   * uploads are cached by (data pointer, rows, dim) + a sampled fingerprint of the values: F frames are uploaded
+//     once and serve all F (F - 1) calls (LRU over `cacheCapacity` device-resident frames);
+//   * concurrent callers are combined: one of the waiting threads takes every request queued so far and runs them as
+//     ONE eacham_match_pairs_directed launch sequence, the others sleep until their result is ready.
+// Integer-valued descriptors (SIFT) take the exact int8 path; the first frame that is not integer-valued switches
+// the instance to the fp32 MFMA path for good (one extractor feeds one matcher in the reference).
 class FeatureMatcherHip : public IFeatureMatcher<DescriptorView> {
 public:
     // `inliersRatio` is kept for signature parity; as in the reference it is NOT the ratio of the
     // test, which is the literal 0.8 (FeatureMatcherFlann.cpp:23) unless `ratio` overrides it.
-    explicit FeatureMatcherHip(float inliersRatio = 0.8f, int device = 0, double ratio = 0.8)
-        : inliersRatio_(inliersRatio), ratio_(ratio), ctx_(device) {}
+    explicit FeatureMatcherHip(float inliersRatio = 0.8f, int device = 0, double ratio = 0.8, int cacheCapacity = 4096)
+        : inliersRatio_(inliersRatio), ratio_(ratio), ctx_(device),
+          capacity_(cacheCapacity < 2 * kMaxBatch ? 2 * kMaxBatch : cacheCapacity) {}
 
     MatchType Match(const DescriptorView& d1, const DescriptorView& d2) override {
-        std::lock_guard<std::mutex> lock(mu_);  // the two scratch frame slots are shared
-        // SIFT-style integer descriptors take the exact int8 path; anything else (SuperPoint /
-        // LightGlue floats, modules/onnx/lightglue/feature/Types.h:11-14) the fp32 MFMA path.
-        ctx_.check(eacham_clear_descriptors(ctx_.get()));
-        int rc = eacham_upload_descriptors(ctx_.get(), kSlotA, d1.data, d1.rows, d1.dim);
-        if (rc == EACHAM_OK) rc = eacham_upload_descriptors(ctx_.get(), kSlotB, d2.data, d2.rows, d2.dim);
-        if (rc == EACHAM_ERR_NOT_INTEGER || rc == EACHAM_ERR_UNSUPPORTED) {
-            ctx_.check(eacham_clear_descriptors(ctx_.get()));
-            ctx_.check(eacham_upload_descriptors_f32(ctx_.get(), kSlotA, d1.data, d1.rows, d1.dim));
-            ctx_.check(eacham_upload_descriptors_f32(ctx_.get(), kSlotB, d2.data, d2.rows, d2.dim));
-        } else {
-            ctx_.check(rc);
+        Request req;
+        req.d1 = d1;
+        req.d2 = d2;
+        std::unique_lock<std::mutex> lk(mu_);
+        queue_.push_back(&req);
+        while (!req.done) {
+            if (leader_active_) {
+                cv_.wait(lk);
+                continue;
+            }
+            // this thread serves everything queued so far (its own request included unless an earlier leader took it)
+            leader_active_ = true;
+            std::vector<Request*> batch;
+            const size_t take = queue_.size() < (size_t)kMaxBatch ? queue_.size() : (size_t)kMaxBatch;
+            batch.assign(queue_.begin(), queue_.begin() + take);
+            queue_.erase(queue_.begin(), queue_.begin() + take);
+            lk.unlock();
+            try {
+                run_batch(batch);
+            } catch (...) {  // a failure of the batch as a whole: every member sees it
+                for (Request* r : batch)
+                    if (!r->error) r->error = std::current_exception();
+            }
+            lk.lock();
+            for (Request* r : batch) r->done = true;
+            leader_active_ = false;
+            cv_.notify_all();
         }
-        std::vector<uint32_t> q(d1.rows > 0 ? d1.rows : 1), t(q.size());
-        int count = 0;
-        ctx_.check(eacham_match_pair(ctx_.get(), kSlotA, kSlotB, ratio_, q.data(), t.data(), (int)q.size(), &count));
-        MatchType out;
-        out.reserve(count);
-        for (int k = 0; k < count; ++k) out.insert({q[k], t[k]});
-        return out;
+        lk.unlock();
+        if (req.error) std::rethrow_exception(req.error);
+        return std::move(req.result);
     }
 
 #ifdef EACHAM_HIP_HAVE_OPENCV
@@ -102,14 +134,181 @@ public:
     }
 #endif
 
+    // Forgets every cached upload (call it when descriptor buffers have been freed and their addresses may be
+    // reused with other values of the same shape; the sampled fingerprint catches most such reuse, not all).
+    void ClearCache() {
+        std::unique_lock<std::mutex> lk(mu_);
+        while (leader_active_) cv_.wait(lk);
+        drop_cache(true);
+    }
+    struct Stats {
+        uint64_t calls = 0, batches = 0, uploads = 0, cache_hits = 0;
+    };
+    Stats stats() {
+        std::lock_guard<std::mutex> lk(mu_);
+        return stats_;
+    }
+
     Context& context() { return ctx_; }
 
 private:
-    static constexpr int kSlotA = 65534, kSlotB = 65535;
+    static constexpr int kMaxBatch = 256;  // requests combined into one launch sequence
+    struct Request {
+        DescriptorView d1, d2;
+        MatchType result;
+        std::exception_ptr error;
+        bool done = false;
+    };
+    struct Key {
+        const float* data;
+        int rows, dim;
+        bool operator==(const Key& o) const { return data == o.data && rows == o.rows && dim == o.dim; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key& k) const {
+            return std::hash<const void*>()(k.data) ^ (std::hash<int>()(k.rows) * 0x9E3779B97F4A7C15ull) ^ ((size_t)k.dim << 48);
+        }
+    };
+    struct Entry {
+        int slot;
+        uint64_t fingerprint, last_use;
+    };
+
+    // FNV-1a over <= 1024 words spread evenly over the matrix, plus its last word
+    static uint64_t fingerprint(const DescriptorView& v) {
+        const size_t total = (size_t)(v.rows > 0 ? v.rows : 0) * (size_t)(v.dim > 0 ? v.dim : 0);
+        uint64_t h = 1469598103934665603ull ^ total;
+        if (!total) return h;
+        const size_t step = total / 1024 ? total / 1024 : 1;
+        auto mix = [&](size_t i) {
+            uint32_t w;
+            std::memcpy(&w, v.data + i, sizeof(w));
+            h = (h ^ w) * 1099511628211ull;
+        };
+        for (size_t i = 0; i < total; i += step) mix(i);
+        mix(total - 1);
+        return h;
+    }
+
+    void drop_cache(bool clear_device) {
+        cache_.clear();
+        free_slots_.clear();
+        next_slot_ = 0;
+        if (clear_device) ctx_.check(eacham_clear_descriptors(ctx_.get()));
+        generation_seen_ = ctx_.store_generation();
+    }
+
+    // device slot holding `v`, uploading it when it is not resident. Returns -1 with *rc set when the upload fails.
+    int slot_for(const DescriptorView& v, uint64_t tick, int* rc) {
+        const Key key{v.data, v.rows, v.dim};
+        const uint64_t fp = fingerprint(v);
+        auto it = cache_.find(key);
+        if (it != cache_.end() && it->second.fingerprint == fp) {
+            it->second.last_use = tick;
+            ++hits_;
+            return it->second.slot;
+        }
+        int slot;
+        if (it != cache_.end()) {
+            slot = it->second.slot;  // same buffer, new values: re-upload in place
+        } else if (!free_slots_.empty()) {
+            slot = free_slots_.back();
+            free_slots_.pop_back();
+        } else if (next_slot_ < capacity_) {
+            slot = next_slot_++;
+        } else {  // evict the least recently used frame that this batch does not use
+            auto victim = cache_.end();
+            for (auto c = cache_.begin(); c != cache_.end(); ++c)
+                if (c->second.last_use != tick && (victim == cache_.end() || c->second.last_use < victim->second.last_use)) victim = c;
+            if (victim == cache_.end()) {
+                *rc = EACHAM_ERR_CAPACITY;
+                return -1;
+            }
+            slot = victim->second.slot;
+            cache_.erase(victim);
+        }
+        *rc = f32_ ? eacham_upload_descriptors_f32(ctx_.get(), slot, v.data, v.rows, v.dim)
+                   : eacham_upload_descriptors(ctx_.get(), slot, v.data, v.rows, v.dim);
+        ++uploads_;
+        if (*rc != EACHAM_OK) {
+            if (it != cache_.end()) cache_.erase(it);
+            free_slots_.push_back(slot);
+            return -1;
+        }
+        cache_[key] = Entry{slot, fp, tick};
+        return slot;
+    }
+
+    // Only one thread at a time runs this (the leader): the cache and the context's store are its own.
+    void run_batch(const std::vector<Request*>& batch) {
+        if (generation_seen_ != ctx_.store_generation()) drop_cache(true);  // somebody rewrote the store (MatchAllPairs)
+        hits_ = uploads_ = 0;
+        std::vector<int32_t> pairs;
+        std::vector<Request*> live;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const uint64_t tick = ++tick_;
+            pairs.clear();
+            live.clear();
+            bool switch_to_f32 = false;
+            for (Request* r : batch) {
+                if (r->error) continue;
+                int rc = EACHAM_OK;
+                const int a = slot_for(r->d1, tick, &rc);
+                const int b = a >= 0 ? slot_for(r->d2, tick, &rc) : -1;
+                if (a < 0 || b < 0) {
+                    if (!f32_ && (rc == EACHAM_ERR_NOT_INTEGER || rc == EACHAM_ERR_UNSUPPORTED)) {
+                        switch_to_f32 = true;  // SuperPoint / LightGlue style floats (or a dim the int8 path lacks)
+                        break;
+                    }
+                    r->error = std::make_exception_ptr(std::runtime_error(std::string("eacham_hip: ") + eacham_last_error(ctx_.get())));
+                    continue;
+                }
+                pairs.push_back(a);
+                pairs.push_back(b);
+                live.push_back(r);
+            }
+            if (!switch_to_f32) break;
+            f32_ = true;  // all resident frames must be of one kind: start over on the fp32 path
+            drop_cache(true);
+        }
+        int64_t cap = 0;
+        for (Request* r : live) cap += r->d1.rows > 0 ? r->d1.rows : 0;
+        if (!live.empty()) {
+            std::vector<int32_t> counts(live.size());
+            std::vector<int64_t> offsets(live.size() + 1);
+            std::vector<uint32_t> q((size_t)(cap > 0 ? cap : 1)), t(q.size());
+            int64_t total = 0;
+            ctx_.check(eacham_match_pairs_directed(ctx_.get(), pairs.data(), (int)live.size(), ratio_, counts.data(), offsets.data(),
+                                                   q.data(), t.data(), cap, &total));
+            for (size_t p = 0; p < live.size(); ++p) {
+                MatchType& out = live[p]->result;
+                out.reserve((size_t)counts[p]);
+                for (int64_t k = offsets[p]; k < offsets[p + 1]; ++k) out.insert({q[k], t[k]});
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        stats_.calls += batch.size();
+        stats_.batches += 1;
+        stats_.uploads += uploads_;
+        stats_.cache_hits += hits_;
+    }
+
     float inliersRatio_;
     double ratio_;
     Context ctx_;
+    const int capacity_;
     std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Request*> queue_;
+    bool leader_active_ = false;
+    Stats stats_;
+    // owned by the leader
+    std::unordered_map<Key, Entry, KeyHash> cache_;
+    std::vector<int> free_slots_;
+    int next_slot_ = 0;
+    bool f32_ = false;
+    uint64_t tick_ = 0, hits_ = 0, uploads_ = 0;
+    unsigned generation_seen_ = 0;
 };
 
 // The pair loop of apps/sfm/main.cpp:84-147 as one call: frames are uploaded once, every unordered
@@ -120,11 +319,23 @@ struct MatchGraph {
     std::vector<uint32_t> q, t;    // Graph::Connect(n1, n2, {q -> t}); the reverse edge is the inverse map
 };
 
+// Rewrites the context's descriptor store (frame f -> id f). Integer-valued descriptors take the exact int8 path,
+// anything else the fp32 MFMA path, like FeatureMatcherHip::Match.
 inline MatchGraph MatchAllPairs(Context& ctx, const std::vector<DescriptorView>& frames,
                                 const std::vector<std::pair<unsigned, unsigned>>& pairs, double ratio = 0.8,
                                 int min_directed = 30, int min_mutual = 30) {
-    for (size_t f = 0; f < frames.size(); ++f)
-        ctx.check(eacham_upload_descriptors(ctx.get(), (int)f, frames[f].data, frames[f].rows, frames[f].dim));
+    ctx.store_rewritten();
+    ctx.check(eacham_clear_descriptors(ctx.get()));
+    int rc = EACHAM_OK;
+    for (size_t f = 0; f < frames.size() && rc == EACHAM_OK; ++f)
+        rc = eacham_upload_descriptors(ctx.get(), (int)f, frames[f].data, frames[f].rows, frames[f].dim);
+    if (rc == EACHAM_ERR_NOT_INTEGER || rc == EACHAM_ERR_UNSUPPORTED) {
+        ctx.check(eacham_clear_descriptors(ctx.get()));
+        for (size_t f = 0; f < frames.size(); ++f)
+            ctx.check(eacham_upload_descriptors_f32(ctx.get(), (int)f, frames[f].data, frames[f].rows, frames[f].dim));
+    } else {
+        ctx.check(rc);
+    }
     std::vector<int32_t> flat(2 * pairs.size());
     int64_t cap = 0;
     for (size_t p = 0; p < pairs.size(); ++p) {

@@ -87,6 +87,16 @@ int eacham_clear_descriptors(eacham_ctx* ctx);
 int eacham_match_pair(eacham_ctx* ctx, int f1, int f2, double ratio,
                       uint32_t* out_q, uint32_t* out_t, int cap, int* out_count);
 
+/* Batched form: npairs ORDERED pairs {f1, f2}, each one FeatureMatcherFlann::Match(d[f1], d[f2]) call, in one
+ * launch sequence — what the reference's std::for_each(par_unseq) + std::async issues concurrently on its shared
+ * matcher (apps/sfm/main.cpp:98-109); the C++ adapter funnels concurrent Match() callers into this entry point.
+ * No thresholds, no mutual check. Result in CSR form over the pairs: counts[p], offsets (npairs + 1), and for
+ * k in [offsets[p], offsets[p+1]) the match q[k] -> t[k] of pair p, sorted by q. cap = capacity of out_q / out_t
+ * (sum of the query frames' rows always suffices); *out_total = matches found (EACHAM_ERR_CAPACITY if > cap). */
+int eacham_match_pairs_directed(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio,
+                                int32_t* counts, int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap,
+                                int64_t* out_total);
+
 /* ---- all-pairs match + mutual check: apps/sfm/main.cpp:84-147 -------------------------------
  * pairs = npairs x {f1, f2} (unordered pairs; both directions are evaluated from one distance
  * tile). For each pair: directed matches m12, m21 as above; if |m12| < min_dir or |m21| < min_dir

@@ -40,8 +40,17 @@ def build(force: bool = False) -> str:
     return so
 
 
+def build_sanitized() -> str:
+    """ASAN + UBSAN build of the same sources (oracle/Makefile target liboracle-san.so)."""
+    r = subprocess.run(["make", "-C", _HERE, "-B", "liboracle-san.so"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("sanitized oracle build failed:\n" + r.stdout + r.stderr)
+    return os.path.join(_HERE, "liboracle-san.so")
+
+
 def lib() -> ctypes.CDLL:
+    """EACHAM_ORACLE_LIB selects another build of the same sources (the sanitizer run)."""
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
+        _LIB = ctypes.CDLL(os.environ.get("EACHAM_ORACLE_LIB") or build())
     return _LIB

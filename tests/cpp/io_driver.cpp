@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
             }
             f << "ui " << (c.ui ? 1 : 0) << "\n";
         }
+        if (argc > 2 && std::string(argv[2]) == "config-only") return 0;
         {
             std::ifstream in(dir + "positions.txt");
             int n = 0;

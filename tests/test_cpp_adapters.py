@@ -28,9 +28,9 @@ def _vec(f, dtype):
     return np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype).copy()
 
 
-def test_cpp_adapters_against_oracle(tmp_path):
-    tmp = str(tmp_path)
-    exe = _build(tmp)
+def write_adapter_fixture(tmp):
+    """Inputs of tests/cpp/adapter_driver.cpp (also used, with a stub of the C-ABI, by tests/test_sanitizers.py)."""
+    import types
     # ---- matcher inputs ----
     sc = synth.make_scene(4, 300, 3, seed=17)
     descs, _ = synth.make_frame_descriptors(sc, 200, 128, seed=17)
@@ -72,6 +72,15 @@ def test_cpp_adapters_against_oracle(tmp_path):
             f.write(struct.pack("I", j + 100)); f.write(bsc["points_init"][j].astype(np.float64).tobytes())
             f.write(struct.pack("iI", int(status[j]), int(observers[j])))
         f.write(K9.tobytes()); f.write(struct.pack("i", current))
+    return types.SimpleNamespace(**locals())
+
+
+def test_cpp_adapters_against_oracle(tmp_path):
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    fx = write_adapter_fixture(tmp)
+    (fin, fout, descs, bsc, ids, valid, fixed, neighbours, n_lm, status, observers, kp, p3) = (
+        fx.fin, fx.fout, fx.descs, fx.bsc, fx.ids, fx.valid, fx.fixed, fx.neighbours, fx.n_lm, fx.status, fx.observers, fx.kp, fx.p3)
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -121,10 +130,9 @@ def test_cpp_adapters_against_oracle(tmp_path):
     assert np.array_equal(Ps[untouched], bsc["points_init"][untouched]) and np.array_equal(st_out[untouched], status[untouched].astype(np.int32))
 
 
-def test_cpp_triangulate_frame_against_oracle_walk(tmp_path):
-    """TriangulatorHip.hpp: TriangulatePointRansac + TriangulateFrame (Triangulator.cpp:96-300)."""
-    tmp = str(tmp_path)
-    exe = _build(tmp, "tri_driver")
+def write_tri_fixture(tmp):
+    """Inputs of tests/cpp/tri_driver.cpp (also used, with a stub of the C-ABI, by tests/test_sanitizers.py)."""
+    import types
     sc = synth.make_scene(8, 300, 5, seed=31, pixel_noise=1.0)
     ids = [3, 4, 7, 9, 12, 15, 16, 20]
     valid = [1, 1, 1, 0, 1, 1, 1, 1]
@@ -191,6 +199,17 @@ def test_cpp_triangulate_frame_against_oracle_walk(tmp_path):
         f.write(struct.pack("i", len(single)))
         for n, k in single:
             f.write(T[ids.index(n)].astype(np.float64).tobytes()); f.write(kp[n][k].astype(np.float64).tobytes())
+    return types.SimpleNamespace(**locals())
+
+
+def test_cpp_triangulate_frame_against_oracle_walk(tmp_path):
+    """TriangulatorHip.hpp: TriangulatePointRansac + TriangulateFrame (Triangulator.cpp:96-300)."""
+    tmp = str(tmp_path)
+    exe = _build(tmp, "tri_driver")
+    fx = write_tri_fixture(tmp)
+    (fin, fout, sc, ids, valid, frame_id, K, T, max_err, min_angle, min_obs, kp, p3, mpts, factors, single) = (
+        fx.fin, fx.fout, fx.sc, fx.ids, fx.valid, fx.frame_id, fx.K, fx.T, fx.max_err, fx.min_angle, fx.min_obs, fx.kp, fx.p3, fx.mpts,
+        fx.factors, fx.single)
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -256,3 +275,46 @@ def test_cpp_triangulate_frame_against_oracle_walk(tmp_path):
         assert np.allclose(gP[j], mpts[pid]["p"], rtol=1e-9, atol=1e-12), pid
         cnt = int(gobs[pos]); flat = gobs[pos + 1:pos + 1 + 2 * cnt].reshape(-1, 2); pos += 1 + 2 * cnt
         assert dict(map(tuple, flat.tolist())) == mpts[pid]["obs"], pid
+
+
+def _write_frames(path, descs, dim):
+    with open(path, "wb") as f:
+        f.write(struct.pack("ii", len(descs), dim))
+        for d in descs:
+            f.write(struct.pack("i", d.shape[0])); f.write(np.ascontiguousarray(d, np.float32).tobytes())
+
+
+@pytest.mark.parametrize("kind", ["u8", "f32"])
+def test_drop_in_match_under_the_reference_call_pattern(tmp_path, kind):
+    """apps/sfm/main.cpp:84-109 on the drop-in: one std::async(&Match) per ORDERED pair from a pool of threads on one
+    shared instance. Every result must equal the oracle's directed match; every frame is uploaded exactly once (the
+    cache by buffer address) and concurrent callers are served in batches (fewer launches than calls)."""
+    tmp = str(tmp_path)
+    exe = _build(tmp, "match_async_driver")
+    sc = synth.make_scene(7, 500, 4, seed=29)
+    if kind == "u8":
+        descs, _ = synth.make_frame_descriptors(sc, 240, 128, seed=29)
+        descs[3] = descs[3][:97]
+        descs[5] = descs[5][:1]            # a single-row train frame: nothing passes the ratio test against it
+    else:
+        base = synth.unit_float_descriptors(240, 64, 1, 99)
+        descs = [synth.unit_float_descriptors(240, 64, 1, f, shared=base[:150]) for f in range(7)]
+        descs[3] = descs[3][:97]
+    dim = descs[0].shape[1]
+    fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+    _write_frames(fin, descs, dim)
+    r = subprocess.run([exe, fin, fout, "8", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    F = len(descs)
+    with open(fout, "rb") as f:
+        for i in range(F):
+            for j in range(F):
+                if i == j:
+                    continue
+                got = _vec(f, np.uint32).reshape(-1, 2)
+                qo, to = O.match_directed(descs[i], descs[j], force_f32=2 if kind == "f32" else 0)
+                assert np.array_equal(got[:, 0], qo) and np.array_equal(got[:, 1], to), (i, j)
+        seconds, calls, batches, uploads, hits = np.frombuffer(f.read(40), dtype=np.float64)
+    assert calls == 2 * F * (F - 1)                    # two repeats
+    assert uploads == (F if kind == "u8" else F + 1)   # f32: the first frame is tried on the int8 path once
+    assert hits >= 2 * calls - uploads - 1 and batches < calls and seconds > 0

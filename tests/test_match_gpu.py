@@ -358,3 +358,23 @@ def test_f32_ties_and_kind_mixing(hip_ctx):
     with pytest.raises(EachamError):
         hip_ctx.upload_descriptors_f32(1, A)
     hip_ctx.clear_descriptors()
+
+
+def test_batched_directed_matches_equal_single_calls(hip_ctx):
+    """eacham_match_pairs_directed: many ordered pairs in one launch sequence = that many FeatureMatcherFlann::Match
+    calls (what the C++ adapter funnels concurrent callers into). Ragged, empty and single-row frames included."""
+    sc = synth.make_scene(6, 500, 4, seed=31)
+    descs, _ = synth.make_frame_descriptors(sc, 300, 128, seed=31)
+    descs[1] = descs[1][:37]
+    descs[2] = descs[2][:0]
+    descs[3] = descs[3][:1]
+    pairs = [(i, j) for i in range(6) for j in range(6) if i != j] + [(0, 0)]
+    got = hip_ctx.match_pairs_directed(descs, pairs)
+    for (i, j), m in zip(pairs, got):
+        qo, to = O.match_directed(descs[i], descs[j])
+        assert m == dict(zip(qo.tolist(), to.tolist())), (i, j)
+        q1, t1 = hip_ctx.match_pair(i, j)
+        assert np.array_equal(q1, qo) and np.array_equal(t1, to)
+    assert sum(len(m) for m in got) > 200
+    assert got[-1] == {q: q for q in range(300)}                 # a frame against itself: d0 = 0 < 0.8 d1 always passes
+    assert hip_ctx.match_pairs_directed(descs, []) == []

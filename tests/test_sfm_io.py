@@ -26,6 +26,84 @@ CONFIG = {  # the schema of config/SfmConfigNerf.json
 }
 
 
+# The reference's own config files, copied as DATA (tests/golden/ref_*.json = /root/reference/config/SfmConfig.json
+# and SfmConfigNerf.json, byte for byte): the only files the reference holds for any row of SURVEY.md §8.
+# Expected values are what SfmConfig::Parse (modules/sfm/config/SfmConfig.h:27-71) makes of them, derived by hand.
+REF_CONFIGS = {
+    "ref_SfmConfig.json": dict(initial_min_inliers=450, initial_max_repr_error=4.0, initial_angle_deg=3.0, angle_deg=2.0,
+                               global_iter=150, global_tol=1e-7),
+    "ref_SfmConfigNerf.json": dict(initial_min_inliers=350, initial_max_repr_error=3.5, initial_angle_deg=3.0, angle_deg=3.0,
+                                   global_iter=50, global_tol=1e-4),
+}
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+def _check_reference_config(get, name):
+    """`get(field)` reads a parsed field by its reference (C++) name."""
+    e = REF_CONFIGS[name]
+    assert get("imagesPath") == "path.../images" and get("outputTransformPath") == "path.../transform.json"  # root + path (:30-34)
+    assert int(get("maxDataSize")) == 0 and int(get("ui")) == 0          # "ui": true is a boolean, never == "true" (:36)
+    assert int(get("minFeaturesCount")) == 100 and int(get("maxFeaturesCount")) == 15000
+    assert float(get("inliersRatio")) == _f32(0.8)
+    assert int(get("initialMinInliers")) == e["initial_min_inliers"]
+    assert float(get("initialMaxReprError")) == _f32(e["initial_max_repr_error"])
+    # `float x = deg; x *= 3.141592 / 180.0;` : the product is formed in double and rounded to float (:47-48, :52-53)
+    assert float(get("initialMinTriAngle")) == _f32(_f32(e["initial_angle_deg"]) * (3.141592 / 180.0))
+    assert float(get("minTriAngle")) == _f32(_f32(e["angle_deg"]) * (3.141592 / 180.0))
+    assert float(get("maxReprError")) == _f32(8.0) and int(get("minPnpInliers")) == 15
+    assert (get("refine.method"), int(get("refine.maxIter"))) == ("LM", 100)
+    assert float(get("refine.maxTolerance")) == _f32(1e-5) and float(get("refine.delta")) == 10.0
+    assert int(get("refine.usePreconditioner")) == 0
+    assert (get("global.method"), int(get("global.maxIter"))) == ("LM", e["global_iter"])
+    assert float(get("global.maxTolerance")) == _f32(e["global_tol"])
+    assert float(get("global.delta")) == 10.0 and int(get("global.usePreconditioner")) == 0   # read from refine_ba (:67-68)
+
+
+@pytest.mark.parametrize("name", sorted(REF_CONFIGS))
+def test_python_mirror_parses_the_reference_config_files(name):
+    c = sfm_io.SfmConfig.parse(json.load(open(os.path.join(ROOT, "tests", "golden", name))))
+    fields = {"imagesPath": c.images_path, "outputTransformPath": c.output_transform_path, "maxDataSize": c.max_data_size,
+              "ui": c.ui, "minFeaturesCount": c.min_features_count, "maxFeaturesCount": c.max_features_count,
+              "inliersRatio": c.inliers_ratio, "initialMinInliers": c.initial_min_inliers,
+              "initialMaxReprError": c.initial_max_repr_error, "initialMinTriAngle": c.initial_min_tri_angle,
+              "maxReprError": c.max_repr_error, "minTriAngle": c.min_tri_angle, "minPnpInliers": c.min_pnp_inliers}
+    for pre, o in (("refine", c.refine_opt), ("global", c.global_opt)):
+        fields.update({pre + ".method": o.method, pre + ".maxIter": o.max_iter, pre + ".maxTolerance": o.max_tolerance,
+                       pre + ".delta": o.delta, pre + ".usePreconditioner": o.use_preconditioner})
+    _check_reference_config(fields.__getitem__, name)
+    # the OptimizerConfig the BA boundary receives (SfmConfig.h:15-22 -> eacham_ba_options)
+    from eacham_amd import ba
+    o = ba.c_options(ba.OptimizerConfig(c.global_opt.method, c.global_opt.max_iter, c.global_opt.max_tolerance,
+                                        c.global_opt.delta, c.global_opt.use_preconditioner))
+    assert (o.method, o.max_iter, o.use_preconditioner) == (0, REF_CONFIGS[name]["global_iter"], 0)
+    assert o.max_tolerance == _f32(REF_CONFIGS[name]["global_tol"])
+
+
+@pytest.mark.parametrize("name", sorted(REF_CONFIGS))
+def test_cpp_header_parses_the_reference_config_files(tmp_path, name):
+    import shutil
+    exe = str(tmp_path / "io_driver")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "io_driver.cpp"), "-o", exe], check=True, capture_output=True)
+    d = tmp_path / "case"
+    d.mkdir()
+    shutil.copy(os.path.join(ROOT, "tests", "golden", name), d / "config.json")
+    r = subprocess.run([exe, str(d), "config-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split(" ", 1) for ln in open(d / "config.out").read().splitlines()]
+    flat, seen = {}, 0
+    for k, v in rows:   # the five OptimizerConfig names appear twice: refine first, then global
+        if k in ("method", "maxIter", "maxTolerance", "delta", "usePreconditioner"):
+            flat[("refine." if seen < 5 else "global.") + k] = v
+            seen += 1
+        else:
+            flat[k] = v
+    _check_reference_config(flat.__getitem__, name)
+
+
 def _poses(n, seed=3):
     rng = np.random.default_rng(seed)
     out = {}
