@@ -729,7 +729,7 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 // `make fault`; tests/test_ba_gpu.py). The product build compiles the hooks away.
 #ifdef EXP_BA_FAULT
 __device__ int g_ba_fault;  // 1: the last super-block of the back-substitution never raises its flag
-                            // 2: the first diagonal-block factor drops one progress store
+                            // 2: the first diagonal-block factor drops its last progress store
 #define BA_FAULT(k) (g_ba_fault == (k))
 #else
 #define BA_FAULT(k) false
@@ -836,7 +836,7 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
             double2* dd2 = reinterpret_cast<double2*>(&F.dinv[j0]);
             dd2[0] = double2{y[0], y[1]}, dd2[1] = double2{y[2], y[3]};
             asm volatile("" ::: "memory");  // LDS executes a wave's operations in order: only the compiler must not reorder
-            if (!(inject_fault && BA_FAULT(2) && s == 3))
+            if (!(inject_fault && BA_FAULT(2) && s == NB / 4 - 1))  // the LAST store: an earlier one is made up for by the next
                 *(volatile LdsInt*)&F.progress = s + 1;  // a DS store like the data before it (a flat store is not ordered with them)
         }
     }
