@@ -91,6 +91,7 @@ class BaOutcome:
     outer_iterations: int
     inner_iterations: int
     trace: np.ndarray  # rows: lambda, new_error, lin_change, accepted, outer
+    reserved: int = 0  # eacham_ba_result.reserved (the CPU oracle reports its PCG iteration total here)
 
 
 LM_FACTOR_POLICIES = {"reset": capi.BA_LM_FACTOR_RESET, "double": capi.BA_LM_FACTOR_DOUBLE}
@@ -108,9 +109,12 @@ def c_options(cfg: OptimizerConfig, min_landmarks: int = 50, lm_factor: str = "r
 
 
 def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 50, trace_cap: int = 1024, extra=(),
-               lm_factor: str = "reset"):
-    """Shared marshalling for any function with the eacham_ba_solve result contract."""
+               lm_factor: str = "reset", tweak=None):
+    """Shared marshalling for any function with the eacham_ba_solve result contract. `tweak(options)` may edit
+    the eacham_ba_options before the call (test hooks)."""
     prob, opt = arrays.c_problem(), c_options(cfg, min_landmarks, lm_factor)
+    if tweak is not None:
+        tweak(opt)
     T = np.zeros((prob.n_cams, 16), np.float64)
     pts = np.zeros((prob.n_points, 3), np.float64)
     trace = (capi.BaTraceRow * max(trace_cap, 1))()
@@ -121,7 +125,7 @@ def run_solver(fn, arrays: BaArrays, cfg: OptimizerConfig, min_landmarks: int = 
     tr = np.array([[r.lambda_, r.new_error, r.lin_change, r.accepted, r.outer] for r in trace[:res.trace_len]],
                   dtype=np.float64).reshape(-1, 5)
     out = BaOutcome(T.reshape(-1, 4, 4), pts, np.array(list(res.K)), res.initial_error, res.final_error,
-                    res.final_lambda, res.status, res.outer_iterations, res.inner_iterations, tr)
+                    res.final_lambda, res.status, res.outer_iterations, res.inner_iterations, tr, int(res.reserved))
     return rc, out
 
 

@@ -733,6 +733,173 @@ static double dot2(const double* ac, const double* al, const double* bc, const d
     return t;
 }
 
+/* ---- the iterative solve the reference can select: PCG + block-Jacobi (BundleAdjuster.cpp:192-200) -------------
+ * params.linearSolverType = Iterative with gtsam::PCGSolverParameters{preconditioner = BlockJacobi, epsilon_abs =
+ * epsilon_rel = 1e-10}. GTSAM 4.1.1 (gtsam/linear/PCGSolver.cpp, iterative-inl.h preconditionedConjugateGradient,
+ * Preconditioner.cpp BlockJacobiPreconditioner; not in the reference tree, restated from memory like Appendix A):
+ *   the system is the DAMPED Gauss-Newton system over ALL variables (poses, landmarks, calibration); the
+ *   preconditioner is the Cholesky factor of its diagonal blocks (6x6, 3x3, 5x5), applied split (L^-1 . L^-T);
+ *   x0 = 0; gamma = |L^-1 r|^2; stop when gamma <= max(epsilon_abs, epsilon_rel^2 * gamma0) or after
+ *   maxIterations = 500 (ConjugateGradientParameters defaults: minIterations 1, reset 501).
+ * The split form and the textbook form z = M^-1 r, M = L L^T generate the same iterates; the latter is coded.
+ * Returns the number of iterations (0 if a diagonal block is not positive definite). */
+typedef struct { double* c; double* l; } vec_t; /* [6 nc + 5] cameras + K, [3 nl] landmarks */
+
+static void hess_apply(const ba_t* B, const lin_t* L, double lambda, const double* Dc, const double* Dl, const vec_t x, vec_t y) {
+    const eacham_ba_problem* P = B->P;
+    const state_t* S = &B->S;
+    const int nc = S->nc, n = 6 * nc + 5;
+    memset(y.c, 0, sizeof(double) * (size_t)n);
+    memset(y.l, 0, sizeof(double) * 3 * (size_t)S->nl);
+    for (int o = 0; o < S->no; ++o) { /* y += A_o^T (A_o x) */
+        const int c = (int)P->obs_cam[o], j = (int)P->obs_point[o];
+        const double *Ap = L->Ap + 12 * (size_t)o, *Al = L->Al + 6 * (size_t)o, *Ak = L->Ak + 10 * (size_t)o;
+        double r0 = 0, r1 = 0;
+        for (int a = 0; a < 6; ++a) { r0 += Ap[a] * x.c[6 * c + a]; r1 += Ap[6 + a] * x.c[6 * c + a]; }
+        for (int a = 0; a < 3; ++a) { r0 += Al[a] * x.l[3 * j + a]; r1 += Al[3 + a] * x.l[3 * j + a]; }
+        for (int a = 0; a < 5; ++a) { r0 += Ak[a] * x.c[6 * nc + a]; r1 += Ak[5 + a] * x.c[6 * nc + a]; }
+        for (int a = 0; a < 6; ++a) y.c[6 * c + a] += Ap[a] * r0 + Ap[6 + a] * r1;
+        for (int a = 0; a < 3; ++a) y.l[3 * j + a] += Al[a] * r0 + Al[3 + a] * r1;
+        for (int a = 0; a < 5; ++a) y.c[6 * nc + a] += Ak[a] * r0 + Ak[5 + a] * r1;
+    }
+    for (int i = 0; i < nc; ++i)
+        for (int a = 0; a < 6; ++a) y.c[6 * i + a] += L->Pw[6 * i + a] * L->Pw[6 * i + a] * x.c[6 * i + a];
+    for (int j = 0; j < S->nl; ++j) {
+        if (B->lm_ptr[j + 1] == B->lm_ptr[j]) { for (int a = 0; a < 3; ++a) y.l[3 * j + a] = x.l[3 * j + a]; continue; } /* unused: identity */
+        for (int a = 0; a < 3; ++a) y.l[3 * j + a] += L->Lw[j] * L->Lw[j] * x.l[3 * j + a];
+    }
+    for (int a = 0; a < 5; ++a) y.c[6 * nc + a] += L->Kw[a] * L->Kw[a] * x.c[6 * nc + a];
+    for (int k = 0; k < n; ++k) y.c[k] += lambda * Dc[k] * x.c[k];
+    for (int k = 0; k < 3 * S->nl; ++k) y.l[k] += lambda * Dl[k] * x.l[k];
+}
+
+static int chol_small(double* A, int m) { /* in place, lower; 0 if not positive definite */
+    for (int j = 0; j < m; ++j) {
+        double d = A[j * m + j];
+        for (int k = 0; k < j; ++k) d -= A[j * m + k] * A[j * m + k];
+        if (!(d > 0.0) || !isfinite(d)) return 0;
+        d = sqrt(d);
+        A[j * m + j] = d;
+        for (int i = j + 1; i < m; ++i) {
+            double v = A[i * m + j];
+            for (int k = 0; k < j; ++k) v -= A[i * m + k] * A[j * m + k];
+            A[i * m + j] = v / d;
+        }
+    }
+    return 1;
+}
+static void chol_small_solve(const double* Lf, int m, const double* r, double* z) { /* z = (L L^T)^-1 r */
+    double t[6];
+    for (int i = 0; i < m; ++i) {
+        double v = r[i];
+        for (int k = 0; k < i; ++k) v -= Lf[i * m + k] * t[k];
+        t[i] = v / Lf[i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double v = t[i];
+        for (int k = i + 1; k < m; ++k) v -= Lf[k * m + i] * z[k];
+        z[i] = v / Lf[i * m + i];
+    }
+}
+
+static int solve_step_pcg(const ba_t* B, const lin_t* L, double lambda, double* dc, double* dl, int* iterations) {
+    const eacham_ba_problem* P = B->P;
+    const state_t* S = &B->S;
+    const int nc = S->nc, nl = S->nl, n = 6 * nc + 5, nl3 = 3 * nl;
+    const double eps_abs = 1e-10, eps_rel = 1e-10; /* BundleAdjuster.cpp:197-198 */
+    const int max_it = 500, min_it = 1, reset = 501;
+    /* undamped diagonal blocks, the damping diagonal D = clamp(diag H), the right-hand side g = A^T b */
+    double* Hcc = (double*)calloc((size_t)36 * (nc > 0 ? nc : 1), sizeof(double));
+    double* Hll = (double*)calloc((size_t)9 * (nl > 0 ? nl : 1), sizeof(double));
+    double HKK[25] = {0};
+    for (int o = 0; o < S->no; ++o) {
+        const int c = (int)P->obs_cam[o], j = (int)P->obs_point[o];
+        const double *Ap = L->Ap + 12 * (size_t)o, *Al = L->Al + 6 * (size_t)o, *Ak = L->Ak + 10 * (size_t)o;
+        for (int a = 0; a < 6; ++a)
+            for (int bb = 0; bb < 6; ++bb) Hcc[36 * c + 6 * a + bb] += Ap[a] * Ap[bb] + Ap[6 + a] * Ap[6 + bb];
+        for (int a = 0; a < 3; ++a)
+            for (int bb = 0; bb < 3; ++bb) Hll[9 * j + 3 * a + bb] += Al[a] * Al[bb] + Al[3 + a] * Al[3 + bb];
+        for (int a = 0; a < 5; ++a)
+            for (int bb = 0; bb < 5; ++bb) HKK[5 * a + bb] += Ak[a] * Ak[bb] + Ak[5 + a] * Ak[5 + bb];
+    }
+    for (int i = 0; i < nc; ++i)
+        for (int a = 0; a < 6; ++a) Hcc[36 * i + 7 * a] += L->Pw[6 * i + a] * L->Pw[6 * i + a];
+    for (int j = 0; j < nl; ++j) {
+        if (B->lm_ptr[j + 1] == B->lm_ptr[j]) { Hll[9 * j] = Hll[9 * j + 4] = Hll[9 * j + 8] = 1.0; continue; }
+        for (int a = 0; a < 3; ++a) Hll[9 * j + 4 * a] += L->Lw[j] * L->Lw[j];
+    }
+    for (int a = 0; a < 5; ++a) HKK[6 * a] += L->Kw[a] * L->Kw[a];
+    double* Dc = (double*)malloc(sizeof(double) * (size_t)n);
+    double* Dl = (double*)malloc(sizeof(double) * (size_t)(nl3 > 0 ? nl3 : 1));
+    for (int i = 0; i < nc; ++i)
+        for (int a = 0; a < 6; ++a) Dc[6 * i + a] = clampd(Hcc[36 * i + 7 * a], 1e-6, 1e32);
+    for (int a = 0; a < 5; ++a) Dc[6 * nc + a] = clampd(HKK[6 * a], 1e-6, 1e32);
+    for (int j = 0; j < nl; ++j)
+        for (int a = 0; a < 3; ++a) Dl[3 * j + a] = B->lm_ptr[j + 1] == B->lm_ptr[j] ? 0.0 : clampd(Hll[9 * j + 4 * a], 1e-6, 1e32);
+    int ok = 1;
+    for (int i = 0; i < nc; ++i) { /* block-Jacobi: Cholesky factors of the damped diagonal blocks */
+        for (int a = 0; a < 6; ++a) Hcc[36 * i + 7 * a] += lambda * Dc[6 * i + a];
+        ok &= chol_small(Hcc + 36 * i, 6);
+    }
+    for (int j = 0; j < nl; ++j) {
+        for (int a = 0; a < 3; ++a) Hll[9 * j + 4 * a] += lambda * Dl[3 * j + a];
+        ok &= chol_small(Hll + 9 * j, 3);
+    }
+    for (int a = 0; a < 5; ++a) HKK[6 * a] += lambda * Dc[6 * nc + a];
+    ok &= chol_small(HKK, 5);
+    int k = 0;
+    if (ok) {
+        vec_t x = {dc, dl}, r, z, p, q;
+        double* buf = (double*)calloc((size_t)4 * (n + (nl3 > 0 ? nl3 : 1)), sizeof(double));
+        r.c = buf; r.l = r.c + n; z.c = r.l + (nl3 > 0 ? nl3 : 1); z.l = z.c + n;
+        p.c = z.l + (nl3 > 0 ? nl3 : 1); p.l = p.c + n; q.c = p.l + (nl3 > 0 ? nl3 : 1); q.l = q.c + n;
+        memset(dc, 0, sizeof(double) * (size_t)n);
+        memset(dl, 0, sizeof(double) * (size_t)nl3);
+        gradient(B, L, r.c, r.l); /* r = b - A 0 = g */
+#define PRECOND()                                                                                       \
+        do {                                                                                            \
+            for (int i = 0; i < nc; ++i) chol_small_solve(Hcc + 36 * i, 6, r.c + 6 * i, z.c + 6 * i);     \
+            chol_small_solve(HKK, 5, r.c + 6 * nc, z.c + 6 * nc);                                       \
+            for (int j = 0; j < nl; ++j) chol_small_solve(Hll + 9 * j, 3, r.l + 3 * j, z.l + 3 * j);      \
+        } while (0)
+        PRECOND();
+        memcpy(p.c, z.c, sizeof(double) * (size_t)n);
+        memcpy(p.l, z.l, sizeof(double) * (size_t)nl3);
+        double gamma = dot2(r.c, r.l, z.c, z.l, n, nl3);
+        const double thr = fmax(eps_abs, eps_rel * eps_rel * gamma);
+        for (k = 1; k <= max_it && (gamma > thr || k <= min_it); ++k) {
+            if (k % reset == 0) { /* (never reached with maxIterations 500 < reset 501; kept for the record) */
+                hess_apply(B, L, lambda, Dc, Dl, x, q);
+                gradient(B, L, r.c, r.l);
+                for (int i = 0; i < n; ++i) r.c[i] -= q.c[i];
+                for (int i = 0; i < nl3; ++i) r.l[i] -= q.l[i];
+                PRECOND();
+                memcpy(p.c, z.c, sizeof(double) * (size_t)n);
+                memcpy(p.l, z.l, sizeof(double) * (size_t)nl3);
+                gamma = dot2(r.c, r.l, z.c, z.l, n, nl3);
+            }
+            hess_apply(B, L, lambda, Dc, Dl, p, q);
+            const double alpha = gamma / dot2(p.c, p.l, q.c, q.l, n, nl3);
+            for (int i = 0; i < n; ++i) { dc[i] += alpha * p.c[i]; r.c[i] -= alpha * q.c[i]; }
+            for (int i = 0; i < nl3; ++i) { dl[i] += alpha * p.l[i]; r.l[i] -= alpha * q.l[i]; }
+            PRECOND();
+            const double prev = gamma;
+            gamma = dot2(r.c, r.l, z.c, z.l, n, nl3);
+            const double beta = gamma / prev;
+            for (int i = 0; i < n; ++i) p.c[i] = z.c[i] + beta * p.c[i];
+            for (int i = 0; i < nl3; ++i) p.l[i] = z.l[i] + beta * p.l[i];
+        }
+#undef PRECOND
+        --k;
+        for (int j = 0; j < nl; ++j) /* landmarks without observations take no step */
+            if (B->lm_ptr[j + 1] == B->lm_ptr[j]) dl[3 * j] = dl[3 * j + 1] = dl[3 * j + 2] = 0.0;
+        free(buf);
+    }
+    if (iterations) *iterations = k;
+    free(Hcc); free(Hll); free(Dc); free(Dl);
+    return ok ? (k > 0 ? k : 1) : 0;
+}
+
 /* DoglegOptimizerImpl::ComputeDoglegPoint / ComputeBlend: x_d = cu * x_u + cn * x_n */
 static void dogleg_point(double delta, double uu, double un, double nn, double* cu, double* cn) {
     const double DeltaSq = delta * delta;
@@ -770,7 +937,8 @@ int oracle_ba_step(const eacham_ba_problem* P, double lambda, int mode, double* 
     lin_alloc(&L, &B.S);
     linearize(&B, &B.S, &L);
     memset(dl, 0, sizeof(double) * 3 * (size_t)P->n_points);
-    const int ok = solve_step(&B, &L, lambda, mode, dc, dl, Sout, gout);
+    /* mode 0 = Schur complement, 1 = dense over all variables, 2 = PCG + block-Jacobi (no Sout / gout) */
+    const int ok = mode == 2 ? solve_step_pcg(&B, &L, lambda, dc, dl, 0) : solve_step(&B, &L, lambda, mode, dc, dl, Sout, gout);
     if (error) *error = graph_error(&B, &B.S);
     if (lin_change) *lin_change = ok ? linear_error(&B, &L, 0, 0) - linear_error(&B, &L, dc, dl) : NAN;
     lin_free(&L);
@@ -820,6 +988,7 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
     R->initial_error = error;
     double newErrorOuter = error, currentError = error;
     int indeterminate = 0;
+    long pcg_total = 0;
     if (O->method == EACHAM_BA_DOGLEG) { /* DoglegOptimizer (BundleAdjuster.cpp:204-214): delta0 = config.delta */
         double delta = (double)O->delta;
         double* gc = (double*)calloc((size_t)n, sizeof(double));
@@ -915,7 +1084,13 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
                 int success = 0, stop = 0;
                 double newError = INFINITY, linChange = NAN, fidelity = 0.0;
                 memset(dl, 0, sizeof(double) * 3 * (size_t)S->nl);
-                const int solved = solve_step(&B, &L, lambda, 0, dc, dl, 0, 0);
+                /* use_preconditioner = 2 (oracle only): solve with the PCG + block-Jacobi the reference would
+                 * configure (BundleAdjuster.cpp:192-200) instead of the direct solve; 1 = the direct solve, as the
+                 * product library does (the two are compared in tests/test_ba_oracle.py) */
+                int pcg_it = 0;
+                const int solved = O->use_preconditioner == 2 ? solve_step_pcg(&B, &L, lambda, dc, dl, &pcg_it)
+                                                              : solve_step(&B, &L, lambda, 0, dc, dl, 0, 0);
+                pcg_total += pcg_it;
                 if (solved) {
                     const double oldLin = linear_error(&B, &L, 0, 0), newLin = linear_error(&B, &L, dc, dl);
                     linChange = oldLin - newLin;
@@ -971,6 +1146,7 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
     R->final_lambda = lambda;
     R->outer_iterations = iterations;
     R->inner_iterations = inner;
+    R->reserved = (int32_t)(pcg_total > 0x7fffffff ? 0x7fffffff : pcg_total); /* oracle only: PCG iterations in total */
     for (int i = 0; i < S->nc; ++i) pose_to_Twc(&S->pose[i], R->cam_T_wc + 16 * (size_t)i);
     memcpy(R->points, S->pt, sizeof(double) * 3 * (size_t)S->nl);
     R->K[0] = S->K[0]; R->K[1] = S->K[1]; R->K[2] = S->K[3]; R->K[3] = S->K[4]; /* fx fy px py (:224-227) */
