@@ -109,6 +109,46 @@ inline int BestTwoViewSolution(const std::vector<TwoViewSolution>& sols) {
     return bestSize > 20 ? best : -1;
 }
 
+// ---- hypothesis scoring for the robust estimators (ReconstructionManager.cpp:57-61, :75, :227-228) -------------
+// One call scores every candidate model against every correspondence: inlier counts under `threshold` (RANSAC,
+// err <= threshold with the SQUARED pixel threshold, as OpenCV's findInliers compares) and medians (LMedS).
+//   kind EACHAM_SCORE_ESSENTIAL : a, b = x0 y0 x1 y1 ... pixels of view 1 / 2, models = 9 doubles per E, K4 = fx fy cx cy
+//                                 (nullptr: the points are already normalised)
+//   kind EACHAM_SCORE_HOMOGRAPHY: the same points, models = 9 doubles per H (H[8] taken as 1), K4 unused
+//   kind EACHAM_SCORE_PNP       : a = X0 Y0 Z0 ... object points, b = pixels, models = 12 doubles per pose (R row-major | t)
+// The caller keeps OpenCV's sampling + minimal solvers (cv::findEssentialMat's five-point, EPnP) and hands over the
+// candidates; `best_by_inliers()` / `best_by_median()` give the RANSAC / LMedS choice (first best on ties).
+struct HypothesisScores {
+    std::vector<int32_t> inliers;
+    std::vector<float> medians;
+    int best_by_inliers() const {
+        int best = -1;
+        for (size_t m = 0; m < inliers.size(); ++m)
+            if (best < 0 || inliers[m] > inliers[best]) best = (int)m;
+        return best;
+    }
+    int best_by_median() const {
+        int best = -1;
+        for (size_t m = 0; m < medians.size(); ++m)
+            if (medians[m] == medians[m] && (best < 0 || medians[m] < medians[best])) best = (int)m;
+        return best;
+    }
+};
+
+inline HypothesisScores ScoreHypotheses(Context& ctx, int kind, const std::vector<double>& a, const std::vector<double>& b,
+                                        const std::vector<double>& models, const double* K4, float threshold) {
+    const int stride_a = kind == EACHAM_SCORE_PNP ? 3 : 2, stride_m = kind == EACHAM_SCORE_PNP ? 12 : 9;
+    const int n = (int)(b.size() / 2), nm = (int)(models.size() / stride_m);
+    if ((size_t)n * stride_a != a.size() || (size_t)n * 2 != b.size() || (size_t)nm * stride_m != models.size())
+        throw std::runtime_error("ScoreHypotheses: array sizes disagree");
+    HypothesisScores out;
+    out.inliers.resize(nm);
+    out.medians.resize(nm);
+    ctx.check(eacham_score_hypotheses(ctx.get(), kind, n, a.data(), b.data(), nm, models.data(), K4, threshold, nullptr,
+                                      out.inliers.data(), out.medians.data()));
+    return out;
+}
+
 // ---- views for TriangulateFrame ---------------------------------------------------------------
 
 struct TriNodeView {

@@ -279,6 +279,31 @@ int eacham_two_view_points(eacham_ctx* ctx, int n_matches, const double* uv1, co
                            int n_transforms, const double* transforms, float max_repr_error, float min_tri_angle,
                            int angle_strict, double* points, uint8_t* keep, int32_t* counts);
 
+/* ---- hypothesis scoring for the robust estimators (rest of SURVEY.md §8(f) rank 3) -----------------------------
+ * The part of cv::findEssentialMat / cv::findHomography (LMEDS) and cv::solvePnPRansac (EPNP, 10 000 iterations,
+ * 4 px) — /root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:57-61, :75, :227-228 — that is
+ * data-parallel over (hypothesis, correspondence): the error every candidate model assigns to every point, as
+ * OpenCV 4.5.5's estimator callbacks define it (EMEstimatorCallback / HomographyEstimatorCallback /
+ * PnPRansacCallback ::computeError), its inlier count under a
+ * threshold (RANSAC: err <= threshold, the caller passes the squared pixel threshold as OpenCV does) and its median
+ * (LMedS). One call scores all candidates; drawing the minimal samples and solving them stays with the caller.
+ *   kind ESSENTIAL   a, b = n x 2 image points of view 1 / view 2; models = n_models x 9 row-major E. With K
+ *                    (fx, fy, cx, cy) the points are normalised first, (u - cx) / fx, as findEssentialMat does;
+ *                    K = NULL takes them as already normalised. err = Sampson distance (x2' E x1)^2 / (...), float.
+ *   kind HOMOGRAPHY  a, b = n x 2; models = n_models x 9 row-major H (H[8] is taken as 1, as OpenCV's callback does);
+ *                    err = |H a - b|^2 in float arithmetic. K unused.
+ *   kind PNP         a = n x 3 object points, b = n x 2 image points; models = n_models x 12 = R (row-major) | t
+ *                    (cv::Rodrigues of the candidate rvec is the caller's); K required; err = squared reprojection
+ *                    error, projection in double, difference in float.
+ * Outputs (each optional): errors n_models x n_points, inlier_counts n_models, medians n_models (sorted middle, or
+ * the mean of the two middle values for even n; NaN for n = 0). */
+#define EACHAM_SCORE_ESSENTIAL 0
+#define EACHAM_SCORE_HOMOGRAPHY 1
+#define EACHAM_SCORE_PNP 2
+int eacham_score_hypotheses(eacham_ctx* ctx, int kind, int n_points, const double* a, const double* b, int n_models,
+                            const double* models, const double* K, float threshold, float* errors,
+                            int32_t* inlier_counts, float* medians);
+
 /* ---- view-graph query on the CSR match graph --------------------------
  * Graph::GetBestPairForValid (/root/reference/modules/sfm/data/Graph.h:59-106) evaluated directly on the
  * wire format of eacham_match_all_pairs: pair p with counts[p] > 0 is the factor f1 -> f2 with matches
@@ -305,6 +330,7 @@ int eacham_graph_best_pair(eacham_ctx* ctx, int n_frames, const int32_t* pairs, 
 #define EACHAM_KERNEL_BA_SOLVE 4
 #define EACHAM_KERNEL_BA_ERROR 5
 #define EACHAM_KERNEL_TRIANGULATE 6     /* pair DLT + scoring and the per-track selection          */
+#define EACHAM_KERNEL_SCORE 7           /* hypothesis scoring (errors, inlier counts, medians)      */
 #define EACHAM_KERNEL_COUNT 8
 
 /* Enables (1) / disables (0) per-launch HIP-event timing of the kernels above. */

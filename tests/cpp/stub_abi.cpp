@@ -177,4 +177,19 @@ int eacham_two_view_points(eacham_ctx*, int n, const double* uv1, const double* 
     return EACHAM_OK;
 }
 
+int eacham_score_hypotheses(eacham_ctx*, int kind, int n, const double* a, const double* b, int nm, const double* models, const double* K,
+                            float, float* errors, int32_t* counts, float* medians) {
+    const int sa = kind == EACHAM_SCORE_PNP ? 3 : 2, sm = kind == EACHAM_SCORE_PNP ? 12 : 9;
+    double acc = K ? K[0] + K[3] : 0.0;
+    for (int i = 0; i < n * sa; ++i) acc += a[i];
+    for (int i = 0; i < n * 2; ++i) acc += b[i];
+    for (int m = 0; m < nm; ++m) {
+        for (int k = 0; k < sm; ++k) acc += models[(size_t)sm * m + k];
+        if (counts) counts[m] = n;
+        if (medians) medians[m] = (float)(1e-300 * acc);
+        if (errors) for (int i = 0; i < n; ++i) errors[(size_t)m * n + i] = 0.f;
+    }
+    return EACHAM_OK;
+}
+
 }  // extern "C"

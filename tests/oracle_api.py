@@ -243,3 +243,20 @@ def two_view_points(uv1, uv2, K4, transforms, max_err, min_angle, angle_strict):
                              C.c_float(max_err), C.c_float(min_angle), C.c_int(int(bool(angle_strict))), vp(pts.ctypes.data),
                              vp(keep.ctypes.data), vp(counts.ctypes.data))
     return pts, keep, counts
+
+
+def score_hypotheses(kind, a, b, models, K=None, threshold=16.0):
+    """oracle/score_oracle.c: (errors [nm, n] float32, inlier counts, medians)."""
+    from eacham_amd import score
+    L = oracle.lib()
+    k, a, b, models, K4 = score.marshal(kind, a, b, models, K)
+    n, nm = a.shape[0], models.shape[0]
+    err = np.zeros((nm, n), dtype=np.float32)
+    counts = np.zeros(nm, dtype=np.int32)
+    med = np.zeros(nm, dtype=np.float32)
+    vp = C.c_void_p
+    L.oracle_score_hypotheses.restype = None
+    L.oracle_score_hypotheses(C.c_int(k), C.c_int(n), vp(a.ctypes.data), vp(b.ctypes.data), C.c_int(nm), vp(models.ctypes.data),
+                              vp(K4.ctypes.data) if K4 is not None else None, C.c_float(threshold), vp(err.ctypes.data),
+                              vp(counts.ctypes.data), vp(med.ctypes.data))
+    return err, counts, med
