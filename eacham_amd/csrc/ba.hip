@@ -63,7 +63,14 @@ constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) E
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
 constexpr int KLIN = 30;           // HKK(25) gK(5)
 constexpr int SCAL = 16;           // scalar block read back per try
-constexpr int BSEG = 4;            // segments a camera's observations are cut into by the border kernel
+
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64: D[(lane >> 4) + 4 reg][lane & 15]
+
+__device__ __forceinline__ void wave_lds_sync() {  // a wave's own LDS region: order its writes before its reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ double huber_weight(double n, double k) { return n <= k ? 1.0 : k / n; }
 __device__ __forceinline__ double huber_loss(double n, double k) { return n <= k ? 0.5 * n * n : k * (n - 0.5 * k); }
@@ -189,6 +196,9 @@ struct BaDev {
     const double* lmprior;  // [nl][2] sigma, k
     // structure
     const int *lm_ptr, *cam_ptr, *cam_obs;
+    const int2* cam_chunks; // camera-aligned chunks of <= TPB positions {first, count}; cam_chunk_ptr[c] .. [c+1] = camera c's
+    const int* cam_chunk_ptr;
+    int n_cam_chunks;
     const int* cam_lm;      // landmark of cam_obs[p], camera order: one hop less in the per-camera gathers
     const int* pos_cam;     // camera of position p (camera order)
     int store_E;            // 1: the linearisation keeps E (DogLeg reads it); 0: the E -> Et kernel recomputes it
@@ -206,7 +216,7 @@ struct BaDev {
     double *Et, *lmtry, *S, *Lm, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
     double *dl_nc, *dl_nl, *dl_part;
-    double* bpart;  // [nc][BSEG][36] partial border sums
+    double* bpart;  // [n_cam_chunks][36] partial border sums
     int* flags;
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
@@ -274,134 +284,149 @@ __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
     for (int k = 0; k < 15; ++k) out[9 + k] = EK[k];
 }
 
-// ---- K-B: per-camera linearisation (block = camera) -----------------------------------------------
-// Hcc (6x6), HcK (6x5), gc (6) of the camera incl. its pose prior, and the camera's share of
-// HKK (5x5) / gK (5), written per camera and summed in fixed order by ba_assemble_border.
-__global__ __launch_bounds__(TPB) void ba_linearize_cameras(BaDev D, double* __restrict__ kpart /* [nc][KLIN] */) {
-    __shared__ double sm[(TPB / 64) * 51];
-    const int c = blockIdx.x;
-    const int p0 = D.cam_ptr[c], p1 = D.cam_ptr[c + 1];
+// ---- K-B: per-camera linearisation (block = one of LSEG segments of a camera's observations) ----------
+// Every observation contributes two whitened Jacobian rows r = [Ap (6) | Ak (5) | b] (12 entries) and the camera's
+// blocks are the 12 x 12 Gram matrix sum_rows r^T r: Hcc = [0:6, 0:6], HcK = [0:6, 6:11], gc = [0:6, 11],
+// the camera's share of HKK = [6:11, 6:11] and of gK = [6:11, 11]. The sum over observations is the K dimension of
+// v_mfma_f64_16x16x4_f64 (D += R^T R, four rows per instruction; the same register is the A and the B operand), so
+// there is no block-wide reduction of 77 per-thread sums any more — those shuffle trees, not the arithmetic or the
+// gathers, were the kernel's time (35 us on S200 with one block per camera, more with four). A wave stages the
+// rows of 32 observations at a time in its own LDS region as 64 rows x 16 doubles (padding columns zero): the
+// operand of step t is then lds[64 t + lane], one conflict-free 512-byte read.
+// -> clpart[(c * LSEG + seg)][256] = the block's 16 x 16 accumulator (waves added in order).
+constexpr int LSEG = 4;     // segments per camera
+constexpr int CLP = 256;    // 16 x 16 accumulator image per (camera, segment)
+__global__ __launch_bounds__(TPB) void ba_linearize_cameras(BaDev D, double* __restrict__ clpart) {
+    __shared__ __attribute__((aligned(16))) double stage[TPB / 64][64 * 16];  // 8 KB per wave
+    __shared__ double wsum[TPB / 64][4][64];
+    const int c = blockIdx.x / LSEG, seg = blockIdx.x % LSEG;
+    const int q0c = D.cam_ptr[c], q1c = D.cam_ptr[c + 1];
+    const int len = (q1c - q0c + LSEG - 1) / LSEG;
+    const int p0 = q0c + seg * len, p1 = min(p0 + len, q1c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* st = stage[wave];
     double x[12], K[5];
 #pragma unroll
     for (int k = 0; k < 12; ++k) x[k] = D.pose[12 * (size_t)c + k];
 #pragma unroll
     for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
-    double hcc[21], hck[30], gc[6], hkk[15], gk[5];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) hcc[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 30; ++k) hck[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) gc[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) hkk[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) gk[k] = 0.0;
-    // The loop is a chain of dependent gathers (landmark id -> point) on four waves per CU: its latency is
-    // the kernel. Ids and measurements come from camera-ordered copies (one hop instead of three), and four
-    // trips are fetched together before any of them computes. Accumulation order per thread is unchanged.
-    constexpr int UB = 4;
-    for (int pb = p0 + threadIdx.x; pb < p1; pb += UB * TPB) {
-        int lm[UB];
-        double2 uv[UB];
-        double l[UB][3];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int p = pb + u * TPB;
-            lm[u] = p < p1 ? D.cam_lm[p] : 0;
-            uv[u] = p < p1 ? *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]) : double2{0.0, 0.0};
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const double* lp = D.pt + 3 * (size_t)lm[u];
-            l[u][0] = lp[0], l[u][1] = lp[1], l[u][2] = lp[2];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (pb + u * TPB >= p1) break;
+    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int base = p0; base < p1; base += TPB) {  // block-uniform trip count
+        const int p = base + (int)threadIdx.x;
+        const bool valid = p < p1;
+        double row[2][12];
+        {
+            const int lm = valid ? D.cam_lm[p] : 0;
+            const double2 uv = valid ? *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]) : double2{0.0, 0.0};
+            const double* lp = D.pt + 3 * (size_t)lm;
+            const double l[3] = {lp[0], lp[1], lp[2]};
             double Ap[12], Al[6], Ak[10], b[2];
-            obs_factor(x, l[u], K, uv[u].x, uv[u].y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
-            int q = 0;
+            obs_factor(x, l, K, uv.x, uv.y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int bb = a; bb < 6; ++bb) hcc[q++] += Ap[a] * Ap[bb] + Ap[6 + a] * Ap[6 + bb];
+                for (int k = 0; k < 6; ++k) row[h][k] = valid ? Ap[6 * h + k] : 0.0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int bb = 0; bb < 5; ++bb) hck[5 * a + bb] += Ap[a] * Ak[bb] + Ap[6 + a] * Ak[5 + bb];
-                gc[a] += Ap[a] * b[0] + Ap[6 + a] * b[1];
+                for (int k = 0; k < 5; ++k) row[h][6 + k] = valid ? Ak[5 * h + k] : 0.0;
+                row[h][11] = valid ? b[h] : 0.0;
             }
-            q = 0;
+        }
 #pragma unroll
-            for (int a = 0; a < 5; ++a) {
+        for (int half = 0; half < 2; ++half) {
+            if ((lane >> 5) == half) {
+                // rows 2 (lane & 31) and + 1; the 16-byte slots of a row are XOR-swizzled with the observation's low
+                // bits so that the eight lanes of a store group hit eight different slots (stride 256 bytes otherwise)
+                const int o = lane & 31;
 #pragma unroll
-                for (int bb = a; bb < 5; ++bb) hkk[q++] += Ak[a] * Ak[bb] + Ak[5 + a] * Ak[5 + bb];
-                gk[a] += Ak[a] * b[0] + Ak[5 + a] * b[1];
+                for (int h = 0; h < 2; ++h) {
+                    double2* dst = reinterpret_cast<double2*>(st + (2 * o + h) * 16);
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl)
+                        dst[sl ^ (o & 7)] = sl < 6 ? double2{row[h][2 * sl], row[h][2 * sl + 1]} : double2{0.0, 0.0};
+                }
             }
+            wave_lds_sync();
+            {   // operand of step t: lane (i = lane & 15, kk = lane >> 4) <- row 4 t + kk, entry i
+                const int i = lane & 15, kk = lane >> 4;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int r = 4 * t + kk, o = r >> 1;
+                    const double v = st[r * 16 + ((((i >> 1) ^ (o & 7)) << 1) | (i & 1))];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+                }
+            }
+            wave_lds_sync();
         }
     }
-    // reduce in three batches to bound LDS (51 values at most per batch)
-    block_sum<21>(hcc, sm);
-    block_sum<30>(hck, sm);
-    double rest[26];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) rest[k] = gc[k];
+    for (int r = 0; r < 4; ++r) wsum[wave][r][lane] = acc[r];
+    __syncthreads();
+    {   // thread -> (reg, lane) of the accumulator image: D[(lane >> 4) + 4 reg][lane & 15]
+        const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
+        double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) rest[6 + k] = hkk[k];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) rest[21 + k] = gk[k];
-    block_sum<26>(rest, sm);
-    if (threadIdx.x == 0) {
-        // PriorFactor<Pose3>: e = -Local(x, prior), H = I; Robust(Huber 2.5) unless the node is fixed
-        double xi[6], e[6], n2 = 0.0;
-        pose_local(x, D.pose0 + 12 * (size_t)c, xi);
-        const bool fx = D.fixed[c] != 0;
-        const double* sg = fx ? D.nz.fixed_sigma : D.nz.pose_sigma;
-        for (int k = 0; k < 6; ++k) {
-            e[k] = -xi[k] / sg[k];
-            n2 += e[k] * e[k];
-        }
-        const double sw = fx ? 1.0 : sqrt(huber_weight(sqrt(n2), D.nz.pose_huber));
-        double* out = D.camlin + (size_t)CAMLIN * c;
-        int q = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int bb = a; bb < 6; ++bb) {
-                double v = hcc[q++];
-                if (a == bb) v += (sw / sg[a]) * (sw / sg[a]);
-                out[6 * a + bb] = v;
-                out[6 * bb + a] = v;
-            }
-        for (int k = 0; k < 30; ++k) out[36 + k] = hck[k];
-        for (int a = 0; a < 6; ++a) out[66 + a] = rest[a] + (sw / sg[a]) * (-sw * e[a]);
-        double* kp = kpart + (size_t)KLIN * c;
-        q = 0;
-        for (int a = 0; a < 5; ++a)
-            for (int bb = a; bb < 5; ++bb) {
-                kp[5 * a + bb] = rest[6 + q];
-                kp[5 * bb + a] = rest[6 + q];
-                ++q;
-            }
-        for (int a = 0; a < 5; ++a) kp[25 + a] = rest[21 + a];
+        for (int w = 0; w < TPB / 64; ++w) v += wsum[w][r][l];
+        clpart[(size_t)CLP * blockIdx.x + 16 * ((l >> 4) + 4 * r) + (l & 15)] = v;
     }
 }
 
-// sums the per-camera K parts (fixed order: strided partial sums, then a shuffle tree) and adds the
-// Cal3_S2 prior -> klin. One wave per entry of [HKK | gK].
-__global__ __launch_bounds__(64) void ba_finish_klin(BaDev D, const double* __restrict__ kpart) {
-    const int i = blockIdx.x, lane = threadIdx.x;
-    double s = 0.0;
-    for (int c = lane; c < D.nc; c += 64) s += kpart[(size_t)KLIN * c + i];
+// Second stage, one launch: blocks [0, KLIN) sum the calibration parts over every (camera, segment) in fixed order
+// (strided partial sums, then a shuffle tree) and add the Cal3_S2 prior -> klin; blocks [KLIN, KLIN + nc) add a
+// camera's segments in order and its pose prior -> camlin.
+__global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double* __restrict__ clpart) {
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x < KLIN) {
+        const int i = blockIdx.x;
+        const int src = i < 25 ? 16 * (6 + min(i / 5, i % 5)) + 6 + max(i / 5, i % 5) : 16 * (6 + (i - 25)) + 11;  // upper triangle
+        double s = 0.0;
+        for (int e = lane; e < D.nc * LSEG; e += 64) s += clpart[(size_t)CLP * e + src];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) {
-        if (i < 25) {
-            if (i / 5 == i % 5) s += 1.0 / (D.nz.k_sigma[i / 5] * D.nz.k_sigma[i / 5]);
-        } else {
-            const int a = i - 25;
-            s += (1.0 / D.nz.k_sigma[a]) * (-(D.Kc[a] - D.K0[a]) / D.nz.k_sigma[a]);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) {
+            if (i < 25) {
+                if (i / 5 == i % 5) s += 1.0 / (D.nz.k_sigma[i / 5] * D.nz.k_sigma[i / 5]);
+            } else {
+                const int a = i - 25;
+                s += (1.0 / D.nz.k_sigma[a]) * (-(D.Kc[a] - D.K0[a]) / D.nz.k_sigma[a]);
+            }
+            D.klin[i] = s;
         }
-        D.klin[i] = s;
+        return;
+    }
+    const int c = blockIdx.x - KLIN;
+    if (lane >= 57) return;
+    int a, bb;  // entry of the accumulator image this lane finishes: Hcc upper triangle (21), HcK (30), gc (6)
+    if (lane < 21) {
+        a = 0;
+        int rem = lane;
+        while (rem >= 6 - a) rem -= 6 - a, ++a;
+        bb = a + rem;
+    } else if (lane < 51) {
+        a = (lane - 21) / 5, bb = 6 + (lane - 21) % 5;
+    } else {
+        a = lane - 51, bb = 11;
+    }
+    double v = 0.0;
+    for (int seg = 0; seg < LSEG; ++seg) v += clpart[(size_t)CLP * (c * LSEG + seg) + 16 * a + bb];
+    // PriorFactor<Pose3>: e = -Local(x, prior), H = I; Robust(Huber 2.5) unless the node is fixed
+    double x[12], xi[6], n2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) x[k] = D.pose[12 * (size_t)c + k];
+    pose_local(x, D.pose0 + 12 * (size_t)c, xi);
+    const bool fx = D.fixed[c] != 0;
+    const double* sg = fx ? D.nz.fixed_sigma : D.nz.pose_sigma;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n2 += (xi[k] / sg[k]) * (xi[k] / sg[k]);
+    const double sw = fx ? 1.0 : sqrt(huber_weight(sqrt(n2), D.nz.pose_huber));
+    double* out = D.camlin + (size_t)CAMLIN * c;
+    if (lane < 21) {
+        if (a == bb) v += (sw / sg[a]) * (sw / sg[a]);
+        out[6 * a + bb] = v;
+        out[6 * bb + a] = v;
+    } else if (lane < 51) {
+        out[36 + (lane - 21)] = v;
+    } else {
+        out[66 + a] = v + (sw / sg[a]) * (-sw * (-xi[a] / sg[a]));
     }
 }
 
@@ -470,54 +495,104 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
         for (int k = 0; k < 30; ++k) D.kk_part[(size_t)30 * blockIdx.x + k] = kk[k];
 }
 
-// ---- K-C2: Et_o = E_o Linv^T (thread = one 3-vector row of one observation: consecutive threads touch
-// consecutive 24 bytes, and half a million observations give the launch its parallelism; inside K-C the
-// same work was a per-landmark loop of strided 144-byte records) ------------------------------------
-__global__ __launch_bounds__(TPB) void ba_eliminate_observations(BaDev D) {
-    const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (idx >= 6ll * D.no) return;
-    // E and Et are both stored in CAMERA order (ba_schur_pairs): idx walks them contiguously
-    const double* m = D.lmtry + (size_t)LMLIN * D.cam_lm[idx / 6];  // Linv (lower): m00; m10 m11; m20 m21 m22
-    const double* E = D.E + 3 * (size_t)idx;
-    double* Et = D.Et + 3 * (size_t)idx;
-    const double e0 = E[0], e1 = E[1], e2 = E[2];
-    Et[0] = m[0] * e0;
-    Et[1] = m[1] * e0 + m[2] * e1;
-    Et[2] = m[3] * e0 + m[4] * e1 + m[5] * e2;
-}
-
-// ---- K-C2': the same Et without a stored E (thread = observation, camera order). Levenberg-Marquardt never
-// reads E again, so writing its 144 bytes per observation in the linearisation and reading them back here is
-// 2 x 72 MB of traffic for ~450 flops per observation: the Jacobians are recomputed at the linearisation point
-// (pose / pt / Kc do not change inside the lambda loop) from camera-ordered ids and measurements. ---------
+// ---- K-C2: Et_o = E_o Linv^T and the calibration border, fused (thread = observation, camera order) -------------
+// Levenberg-Marquardt never reads E after the linearisation, so writing its 144 bytes per observation there and
+// reading them back here would be 2 x 72 MB of traffic for ~450 flops per observation: the Jacobians are recomputed
+// at the linearisation point (pose / pt / Kc do not change inside the lambda loop) from camera-ordered ids and
+// measurements. The same thread holds Et_o and has its landmark's record in reach, so it also forms the
+// observation's share of the border, Et_o [gt | EKt^T] (6 x 6 = 36 products), which used to be a second pass over
+// Et with the same gathers (ba_border_partials, 36 us on S200). Workgroups are CAMERA-ALIGNED chunks of <= 256
+// observations (cam_chunks, built once per problem): a block sum per chunk -> bpart[chunk][36], added per camera in
+// chunk order by ba_assemble_border. Fixed order, no atomics.
 __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev D) {
-    const int p = blockIdx.x * TPB + threadIdx.x;
-    if (p >= D.no) return;
-    const int lm = D.cam_lm[p];
-    const double* x = D.pose + 12 * (size_t)D.pos_cam[p];
-    const double* lp = D.pt + 3 * (size_t)lm;
-    const double2 uv = *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]);
-    const double* m = D.lmtry + (size_t)LMLIN * lm;  // Linv (lower): m00; m10 m11; m20 m21 m22
-    double xr[12], K[5];
+    // The border share of an observation is Et_o (6 x 3) M_o (3 x 6), M_o = [EKt^T | gt]; its sum over the chunk runs
+    // on v_mfma_f64_16x16x4_f64 with TWO observations per instruction: rows 0..5 / 8..13 of the A operand hold Et of
+    // the even / odd observation of a pair, columns 0..5 / 8..13 of the B operand their M, the K index (3 used of 4)
+    // is shared, so the diagonal 6 x 6 blocks of D accumulate Et M of the two observations and the off-diagonal
+    // blocks are discarded. A wave stages 32 observations at a time in its own LDS region, pair t as 3 x 16 doubles
+    // per operand: the operands of step t are lds[48 t + lane] for the lanes of k = lane >> 4 < 3, zero otherwise.
+    __shared__ __attribute__((aligned(16))) double stA[TPB / 64][16 * 48], stB[TPB / 64][16 * 48];  // 2 x 6 KB per wave
+    __shared__ double wsum[TPB / 64][4][64];
+    const int2 ch = D.cam_chunks[blockIdx.x];  // {first position, count}
+    const int p = ch.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = (int)threadIdx.x < ch.y;
+    double et[18], lv[18];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) xr[k] = x[k];
+    for (int k = 0; k < 18; ++k) et[k] = 0.0, lv[k] = 0.0;
+    if (valid) {
+        const int lm = D.cam_lm[p];
+        const double* x = D.pose + 12 * (size_t)D.pos_cam[p];
+        const double* lp = D.pt + 3 * (size_t)lm;
+        const double2 uv = *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]);
+        const double* m = D.lmtry + (size_t)LMLIN * lm;  // Linv (lower): m00; m10 m11; m20 m21 m22 | gt (3) | EKt (5 x 3)
+        double xr[12], K[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
-    const double l[3] = {lp[0], lp[1], lp[2]};
-    const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
-    double Ap[12], Al[6], Ak[10], b[2];
-    obs_factor(xr, l, K, uv.x, uv.y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
-    double et[18];
+        for (int k = 0; k < 12; ++k) xr[k] = x[k];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const double e0 = Ap[a] * Al[0] + Ap[6 + a] * Al[3], e1 = Ap[a] * Al[1] + Ap[6 + a] * Al[4], e2 = Ap[a] * Al[2] + Ap[6 + a] * Al[5];
-        et[3 * a] = m0 * e0;
-        et[3 * a + 1] = m1 * e0 + m2 * e1;
-        et[3 * a + 2] = m3 * e0 + m4 * e1 + m5 * e2;
+        for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
+        const double l[3] = {lp[0], lp[1], lp[2]};
+        const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) lv[k] = m[6 + k];
+        double Ap[12], Al[6], Ak[10], b[2];
+        obs_factor(xr, l, K, uv.x, uv.y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double e0 = Ap[a] * Al[0] + Ap[6 + a] * Al[3], e1 = Ap[a] * Al[1] + Ap[6 + a] * Al[4], e2 = Ap[a] * Al[2] + Ap[6 + a] * Al[5];
+            et[3 * a] = m0 * e0;
+            et[3 * a + 1] = m1 * e0 + m2 * e1;
+            et[3 * a + 2] = m3 * e0 + m4 * e1 + m5 * e2;
+        }
+        double2* out = reinterpret_cast<double2*>(D.Et + 18 * (size_t)p);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = double2{et[2 * k], et[2 * k + 1]};
     }
-    double2* out = reinterpret_cast<double2*>(D.Et + 18 * (size_t)p);
+    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double *sa = stA[wave], *sb = stB[wave];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) out[k] = double2{et[2 * k], et[2 * k + 1]};
+    for (int half = 0; half < 2; ++half) {
+        if ((lane >> 5) == half) {
+            const int o = lane & 31, t = o >> 1, sub = o & 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // A: Et[a][k] = et[3 a + k], a = 0..5 (+ two zero rows); B: M[k][j] = EKt[j][k] = lv[3 + 3 j + k] (j < 5), gt[k] = lv[k] (j = 5)
+                double2* da = reinterpret_cast<double2*>(sa + 48 * t + 16 * k + 8 * sub);
+                double2* db = reinterpret_cast<double2*>(sb + 48 * t + 16 * k + 8 * sub);
+                da[0] = double2{et[k], et[3 + k]};
+                da[1] = double2{et[6 + k], et[9 + k]};
+                da[2] = double2{et[12 + k], et[15 + k]};
+                da[3] = double2{0.0, 0.0};
+                db[0] = double2{lv[3 + k], lv[6 + k]};
+                db[1] = double2{lv[9 + k], lv[12 + k]};
+                db[2] = double2{lv[15 + k], lv[k]};
+                db[3] = double2{0.0, 0.0};
+            }
+        }
+        wave_lds_sync();
+        {
+            const bool live = lane < 48;  // k = lane >> 4 < 3
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const double a = live ? sa[48 * t + lane] : 0.0, b = live ? sb[48 * t + lane] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+        }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wsum[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        // bpart entry k: k < 30 -> (a, bb) = (k / 5, k % 5), else (k - 30, 5); D[a][b] + D[8 + a][8 + b] with
+        // D[row][col] in register row >> 2 of lane (col + 16 (row & 3)); the waves are added in order
+        const int k = threadIdx.x, a = k < 30 ? k / 5 : k - 30, b = k < 30 ? k % 5 : 5;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w)
+            v += wsum[w][a >> 2][b + 16 * (a & 3)] + wsum[w][2 + (a >> 2)][8 + b + 16 * (a & 3)];
+        D.bpart[(size_t)36 * blockIdx.x + k] = v;
+    }
 }
 
 // ---- K-D1: Schur pair products (wave = chunk of <= 64 entries of one camera block's pair list) ------
@@ -598,59 +673,15 @@ __global__ __launch_bounds__(TPB) void ba_assemble_blocks(BaDev D, double lambda
 }
 
 // ---- K-D3: the calibration border and the right-hand side -------------------------------------------
-// Stage 1 (block = one of BSEG segments of a camera's observations): partial sums of Et EKt^T (6x5) and
-// Et gt (6) -> bpart. Stage 2 (thread = border entry): adds a camera's segments in order and writes S;
-// its last block reduces the (K,K) corner. Two stages because 200 cameras alone do not fill the chip.
-__global__ __launch_bounds__(TPB) void ba_border_partials(BaDev D) {
-    __shared__ double sm[(TPB / 64) * 36];
-    const int c = blockIdx.x / BSEG, seg = blockIdx.x % BSEG;
-    const int p0 = D.cam_ptr[c], p1 = D.cam_ptr[c + 1];
-    const int len = (p1 - p0 + BSEG - 1) / BSEG;
-    const int q0 = p0 + seg * len, q1 = min(q0 + len, p1);
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    // two trips of gathers in flight, ids from the camera-ordered copies (one hop to each record, not two or three)
-    constexpr int UB = 2;
-    for (int pb = q0 + threadIdx.x; pb < q1; pb += UB * TPB) {
-        double et[UB][18], lv[UB][18];
-        int o[UB], lm[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int p = min(pb + u * TPB, q1 - 1);
-            o[u] = D.cam_obs[p], lm[u] = D.cam_lm[p];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const double* Et = D.Et + 18 * (size_t)min(pb + u * TPB, q1 - 1);  // camera order: contiguous
-            const double* lt = D.lmtry + (size_t)LMLIN * lm[u] + 6;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) et[u][k] = Et[k], lv[u][k] = lt[k];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (pb + u * TPB >= q1) break;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const double e0 = et[u][3 * a], e1 = et[u][3 * a + 1], e2 = et[u][3 * a + 2];
-#pragma unroll
-                for (int bb = 0; bb < 5; ++bb) acc[5 * a + bb] += e0 * lv[u][3 + 3 * bb] + e1 * lv[u][4 + 3 * bb] + e2 * lv[u][5 + 3 * bb];
-                acc[30 + a] += e0 * lv[u][0] + e1 * lv[u][1] + e2 * lv[u][2];
-            }
-        }
-    }
-    block_sum<36>(acc, sm);
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 36; ++k) D.bpart[(size_t)36 * blockIdx.x + k] = acc[k];
-}
-
+// thread = border entry: adds the chunk partials of its camera (written by K-C2) in chunk order and writes S;
+// the last block reduces the (K,K) corner.
 __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda) {
     const int c = blockIdx.x;
     if (c < D.nc) {
         if (threadIdx.x < 36) {
             const int k = threadIdx.x;
             double s = 0.0;
-            for (int seg = 0; seg < BSEG; ++seg) s += D.bpart[(size_t)36 * (c * BSEG + seg) + k];
+            for (int ch = D.cam_chunk_ptr[c]; ch < D.cam_chunk_ptr[c + 1]; ++ch) s += D.bpart[(size_t)36 * ch + k];
             const double* cl = D.camlin + (size_t)CAMLIN * c;
             if (k < 30) {
                 const int a = k / 5, bb = k % 5;
@@ -710,18 +741,17 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
 // The non-positive-pivot test stays off the critical path: a bad pivot is only recorded (flags bit 1, the
 // solve then counts as failed and its NaNs are never used), it is not replaced. Rows and columns that are
 // already factorised keep dead values in the accumulators; they only ever feed other dead elements.
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 constexpr int PLD = 18;  // row stride of the slab image P[32][PLD]: 16 columns + padding, 16-byte aligned rows
 
 __device__ __forceinline__ double rsqrt_newton(double d) {
-    // 1/sqrt(d): hardware estimate + two Newton steps y <- y (1.5 - (d/2) y^2) (fp64 sqrt and divide are
-    // ~30-instruction sequences each)
+    // 1/sqrt(d): hardware estimate (~2^-26 relative, like v_rcp_f64: the compiler's own fp64 division refines it
+    // with two Newton steps only to round correctly) + ONE Newton step y <- y (1.5 - (d/2) y^2): the error after
+    // the step is ~1.5 e0^2 = a few 1e-16, one or two units in the last place — far inside what a Cholesky factor
+    // carries anyway (tests/test_ba_gpu.py holds the step against the oracle at 1e-8). The second step cost three
+    // dependent fp64 operations per pivot on the one-wave chain of the diagonal-block factor.
     const double h = 0.5 * d;
     double y = __builtin_amdgcn_rsq(d);
-    double p = h * y, q = __builtin_fma(-p, y, 1.5);
-    y = y * q;
-    p = h * y;
-    q = __builtin_fma(-p, y, 1.5);
+    const double p = h * y, q = __builtin_fma(-p, y, 1.5);
     return y * q;
 }
 
@@ -1725,6 +1755,13 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     }
     std::vector<int> obs_pos(no), pos_cam(no);
     for (int p = 0; p < no; ++p) obs_pos[cam_obs[p]] = p, pos_cam[p] = (int)obs_cam[cam_obs[p]];
+    std::vector<int2> cam_chunks;
+    std::vector<int> cam_chunk_ptr(nc + 1, 0);
+    for (int c = 0; c < nc; ++c) {
+        for (int q = cam_ptr[c]; q < cam_ptr[c + 1]; q += TPB) cam_chunks.push_back(make_int2(q, std::min(TPB, cam_ptr[c + 1] - q)));
+        cam_chunk_ptr[c + 1] = (int)cam_chunks.size();
+    }
+    D.n_cam_chunks = (int)cam_chunks.size();
     std::vector<int> cam_lm(no);
     std::vector<double> cam_uv(2 * (size_t)no);
     for (int p = 0; p < no; ++p) {
@@ -1807,6 +1844,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_upload(ctx, h, &D.cam_ptr, cam_ptr));
     TRY(dev_upload(ctx, h, &D.cam_obs, cam_obs));
     TRY(dev_upload(ctx, h, &D.cam_lm, cam_lm));
+    TRY(dev_upload(ctx, h, &D.cam_chunks, cam_chunks));
+    TRY(dev_upload(ctx, h, &D.cam_chunk_ptr, cam_chunk_ptr));
     TRY(dev_upload(ctx, h, &D.obs_pos, obs_pos));
     TRY(dev_upload(ctx, h, &D.pos_cam, pos_cam));
     TRY(dev_upload(ctx, h, &D.cam_uv, cam_uv));
@@ -1827,7 +1866,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.lmtry, (size_t)LMLIN * nl));
     TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
     TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
-    TRY(dev_alloc(ctx, h, &h->kpart, (size_t)KLIN * nc));
+    TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
     TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
@@ -1840,7 +1879,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
     TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
     TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
-    TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * BSEG * std::max(D.nc, 1)));
+    TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * std::max(D.n_cam_chunks, 1)));
     TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
     TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
     TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
@@ -1890,8 +1929,8 @@ static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
     ba_linearize_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D);
-    if (D.nc > 0) ba_linearize_cameras<<<D.nc, TPB, 0, ctx->stream>>>(D, h->kpart);
-    ba_finish_klin<<<KLIN, 64, 0, ctx->stream>>>(D, h->kpart);
+    if (D.nc > 0) ba_linearize_cameras<<<D.nc * LSEG, TPB, 0, ctx->stream>>>(D, h->kpart);
+    ba_finish_linearize<<<KLIN + D.nc, 64, 0, ctx->stream>>>(D, h->kpart);
 }
 
 // one tryLambda(): builds and solves the damped system, writes tentative values and
@@ -1904,13 +1943,9 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
         EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
-        if (D.no > 0) {
-            if (D.store_E) ba_eliminate_observations<<<(unsigned)((6ll * D.no + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D);
-            else ba_eliminate_observations_recompute<<<(D.no + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D);
-        }
+        if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
         if (D.n_blocks > 0) ba_assemble_blocks<<<(unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D, lambda);
-        if (D.nc > 0) ba_border_partials<<<D.nc * BSEG, TPB, 0, ctx->stream>>>(D);
         ba_assemble_border<<<D.nc + 1, TPB, 0, ctx->stream>>>(D, lambda);
     }
     if (S_copy) {
