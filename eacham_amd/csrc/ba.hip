@@ -217,6 +217,12 @@ struct BaDev {
     // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
     double *dl_nc, *dl_nl, *dl_part;
     double* bpart;  // [n_cam_chunks][36] partial border sums
+    // PCG + block-Jacobi (use_preconditioner): x = delta_c | delta_l; r, z, p, q over [cameras + K | landmarks];
+    // inverse diagonal blocks Mc (36 per camera), MK (25), Ml (9 per landmark); damping diagonals Dc, Dl;
+    // pcg_p1 [n_lm_blocks][6], pcg_p2 [n_cam_chunks][6], pcg_p3 [n_lm_blocks + 1] partial sums;
+    // pcg_s = {gamma, threshold, alpha, beta, done, iterations, p.q}
+    double *pcg_rc, *pcg_rl, *pcg_zc, *pcg_zl, *pcg_pc, *pcg_pl, *pcg_qc, *pcg_ql, *pcg_Mc, *pcg_MK, *pcg_Ml, *pcg_Dc, *pcg_Dl,
+        *pcg_p1, *pcg_p2, *pcg_p3, *pcg_s;
     int* flags;
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
@@ -1525,6 +1531,395 @@ __global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_
     }
 }
 
+// ---- the iterative solve the reference can select: PCG + block-Jacobi (BundleAdjuster.cpp:192-200) -----------------
+// params.linearSolverType = Iterative, PCGSolverParameters{BlockJacobi, epsilon_abs = epsilon_rel = 1e-10}: GTSAM 4.1.1
+// runs preconditioned conjugate gradients on the DAMPED system over ALL variables (poses, calibration, landmarks),
+// preconditioned by the Cholesky factors of its diagonal blocks, from x0 = 0, until gamma = r^T M^-1 r <=
+// max(epsilon_abs, epsilon_rel^2 gamma0) or 500 iterations (gtsam/linear/PCGSolver.cpp, iterative-inl.h; restated from
+// memory like SURVEY.md Appendix A). Here the operator is applied in block form on the linearisation that is already
+// resident — y_c = (Hcc + lambda Dc) x_c + HcK x_K + sum_o E_o x_l(o), y_l = (Hll + lambda Dl) x_l + ElK^T x_K +
+// sum_o E_o^T x_c(o), y_K likewise — with E kept by the linearisation (store_E). Five launches per iteration, every sum
+// in a fixed order (no atomics), the scalars (gamma, alpha, beta, the stop flag) stay on the device and the host looks
+// at the flag once per batch of iterations: after convergence the remaining launches of a batch return at once.
+constexpr int PCG_MAX_IT = 500;
+constexpr int PCG_BATCH = 25;
+
+template <int M>
+__device__ __forceinline__ bool spd_inverse(const double* A /* M x M, lower used */, double* inv /* M x M full */) {
+    double L[M][M], W[M][M];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        double d = A[j * M + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && d > 0.0;
+        const double sd = sqrt(d > 0.0 ? d : 1.0);
+        L[j][j] = sd;
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            double v = A[i * M + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+            L[i][j] = v / sd;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < M; ++c)  // W = L^-1, column by column
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i < c) { W[i][c] = 0.0; continue; }
+            double v = i == c ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = c; k < i; ++k) v -= L[i][k] * W[k][c];
+            W[i][c] = v / L[i][i];
+        }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {  // inv = W^T W
+            double v = 0.0;
+#pragma unroll
+            for (int k = (i > j ? i : j); k < M; ++k) v += W[k][i] * W[k][j];
+            inv[i * M + j] = v;
+        }
+    return ok;
+}
+
+// x = 0, r = g, z = M^-1 r, p = z; partial gamma. thread = landmark
+__global__ __launch_bounds__(TPB) void pcg_setup_landmarks(BaDev D, double lambda) {
+    __shared__ double sm[(TPB / 64) * 1];
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    double g[1] = {0.0};
+    if (j < D.nl) {
+        double r[3] = {0, 0, 0}, z[3] = {0, 0, 0}, Mi[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, dd[3] = {0, 0, 0};
+        if (D.lm_ptr[j + 1] > D.lm_ptr[j]) {
+            const double* in = D.lmlin + (size_t)LMLIN * j;
+            dd[0] = clampd(in[0], 1e-6, 1e32), dd[1] = clampd(in[3], 1e-6, 1e32), dd[2] = clampd(in[5], 1e-6, 1e32);
+            const double A[9] = {in[0] + lambda * dd[0], in[1], in[2], in[1], in[3] + lambda * dd[1], in[4], in[2], in[4], in[5] + lambda * dd[2]};
+            if (!spd_inverse<3>(A, Mi)) atomicOr(D.flags, 1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) r[a] = in[6 + a];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) z[a] = Mi[3 * a] * r[0] + Mi[3 * a + 1] * r[1] + Mi[3 * a + 2] * r[2];
+            g[0] = r[0] * z[0] + r[1] * z[1] + r[2] * z[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            D.pcg_Dl[3 * (size_t)j + a] = dd[a];
+            D.pcg_rl[3 * (size_t)j + a] = r[a];
+            D.pcg_zl[3 * (size_t)j + a] = z[a];
+            D.pcg_pl[3 * (size_t)j + a] = z[a];
+            D.delta_l[3 * (size_t)j + a] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) D.pcg_Ml[9 * (size_t)j + k] = Mi[k];
+    }
+    block_sum<1>(g, sm);
+    if (threadIdx.x == 0) D.pcg_p3[blockIdx.x] = g[0];
+}
+
+// the same for the cameras (thread = camera) and the calibration (thread nc); one block: also the scalars
+__global__ __launch_bounds__(1024) void pcg_setup_cameras(BaDev D, double lambda) {
+    __shared__ double red[1024 / 64];
+    double g = 0.0;
+    for (int c = threadIdx.x; c <= D.nc; c += blockDim.x) {
+        if (c < D.nc) {
+            const double* cl = D.camlin + (size_t)CAMLIN * c;
+            double A[36], Mi[36], r[6], z[6];
+#pragma unroll
+            for (int k = 0; k < 36; ++k) A[k] = cl[k];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double dd = clampd(cl[7 * a], 1e-6, 1e32);
+                D.pcg_Dc[6 * (size_t)c + a] = dd;
+                A[7 * a] += lambda * dd;
+                r[a] = cl[66 + a];
+            }
+            if (!spd_inverse<6>(A, Mi)) atomicOr(D.flags, 2);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) v += Mi[6 * a + b] * r[b];
+                z[a] = v;
+                g += r[a] * v;
+            }
+#pragma unroll
+            for (int k = 0; k < 36; ++k) D.pcg_Mc[36 * (size_t)c + k] = Mi[k];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                D.pcg_rc[6 * (size_t)c + a] = r[a];
+                D.pcg_zc[6 * (size_t)c + a] = z[a];
+                D.pcg_pc[6 * (size_t)c + a] = z[a];
+                D.delta_c[6 * (size_t)c + a] = 0.0;
+            }
+        } else {
+            double A[25], Mi[25], r[5];
+#pragma unroll
+            for (int k = 0; k < 25; ++k) A[k] = D.klin[k];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const double dd = clampd(D.klin[6 * a], 1e-6, 1e32);
+                D.pcg_Dc[6 * (size_t)D.nc + a] = dd;
+                A[6 * a] += lambda * dd;
+                r[a] = D.klin[25 + a];
+            }
+            if (!spd_inverse<5>(A, Mi)) atomicOr(D.flags, 2);
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) v += Mi[5 * a + b] * r[b];
+                g += r[a] * v;
+                D.pcg_rc[6 * (size_t)D.nc + a] = r[a];
+                D.pcg_zc[6 * (size_t)D.nc + a] = v;
+                D.pcg_pc[6 * (size_t)D.nc + a] = v;
+                D.delta_c[6 * (size_t)D.nc + a] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 25; ++k) D.pcg_MK[k] = Mi[k];
+        }
+    }
+    for (int i = threadIdx.x; i < D.n_lm_blocks; i += blockDim.x) g += D.pcg_p3[i];  // the landmarks' partial gammas
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 1024 / 64; ++w) tot += red[w];
+        D.pcg_s[0] = tot;                                   // gamma
+        D.pcg_s[1] = fmax(1e-10, 1e-10 * 1e-10 * tot);      // max(epsilon_abs, epsilon_rel^2 gamma0)
+        D.pcg_s[2] = D.pcg_s[3] = 0.0;
+        D.pcg_s[4] = 0.0;                                   // done
+        D.pcg_s[5] = 0.0;                                   // iterations
+    }
+}
+
+// 1/5: p_l <- z_l + beta p_l (not in the first iteration); q_l = A_ll p_l + ElK^T p_K + sum_o E_o^T p_c(o); partials of p_l.q_l and ElK p_l
+__global__ __launch_bounds__(TPB) void pcg_apply_landmarks(BaDev D, double lambda) {
+    __shared__ double sm[(TPB / 64) * 6];
+    if (D.pcg_s[4] != 0.0) return;
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    const double beta = D.pcg_s[3];
+    const bool first = D.pcg_s[5] == 0.0;
+    double part[6] = {0, 0, 0, 0, 0, 0};
+    if (j < D.nl) {
+        const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
+        double pl[3], q[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double pv = D.pcg_pl[3 * (size_t)j + a];
+            pl[a] = first ? pv : D.pcg_zl[3 * (size_t)j + a] + beta * pv;
+            D.pcg_pl[3 * (size_t)j + a] = pl[a];
+        }
+        if (o1 > o0) {
+            const double* in = D.lmlin + (size_t)LMLIN * j;
+            const double* pK = D.pcg_pc + 6 * (size_t)D.nc;
+            const double* dd = D.pcg_Dl + 3 * (size_t)j;
+            q[0] = (in[0] + lambda * dd[0]) * pl[0] + in[1] * pl[1] + in[2] * pl[2];
+            q[1] = in[1] * pl[0] + (in[3] + lambda * dd[1]) * pl[1] + in[4] * pl[2];
+            q[2] = in[2] * pl[0] + in[4] * pl[1] + (in[5] + lambda * dd[2]) * pl[2];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const double e0 = in[9 + 3 * a], e1 = in[10 + 3 * a], e2 = in[11 + 3 * a];
+                q[0] += e0 * pK[a], q[1] += e1 * pK[a], q[2] += e2 * pK[a];
+                part[1 + a] = e0 * pl[0] + e1 * pl[1] + e2 * pl[2];  // (ElK p_l)[a]
+            }
+            for (int o = o0; o < o1; ++o) {
+                const double* E = D.E + 18 * (size_t)D.obs_pos[o];
+                const double* pc = D.pcg_pc + 6 * (size_t)D.obs_cam[o];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    q[0] += E[3 * a] * pc[a];
+                    q[1] += E[3 * a + 1] * pc[a];
+                    q[2] += E[3 * a + 2] * pc[a];
+                }
+            }
+            part[0] = pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) D.pcg_ql[3 * (size_t)j + a] = q[a];
+    }
+    block_sum<6>(part, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) D.pcg_p1[6 * (size_t)blockIdx.x + k] = part[k];
+}
+
+// 2/5: per camera-aligned chunk: sum_o E_o p_l(o) (6 values)
+__global__ __launch_bounds__(TPB) void pcg_apply_cam_chunks(BaDev D) {
+    __shared__ double sm[(TPB / 64) * 6];
+    if (D.pcg_s[4] != 0.0) return;
+    const int2 ch = D.cam_chunks[blockIdx.x];
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if ((int)threadIdx.x < ch.y) {
+        const int p = ch.x + threadIdx.x;
+        const double* E = D.E + 18 * (size_t)p;
+        const double* pl = D.pcg_pl + 3 * (size_t)D.cam_lm[p];
+        const double p0 = pl[0], p1 = pl[1], p2 = pl[2];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = E[3 * a] * p0 + E[3 * a + 1] * p1 + E[3 * a + 2] * p2;
+    }
+    block_sum<6>(v, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) D.pcg_p2[6 * (size_t)blockIdx.x + k] = v[k];
+}
+
+// 3/5 (one block): q_c, q_K, p.q and alpha = gamma / p.q
+__global__ __launch_bounds__(1024) void pcg_apply_finish(BaDev D, double lambda) {
+    __shared__ double red[1024 / 64][6];
+    if (D.pcg_s[4] != 0.0) return;
+    const double* pK = D.pcg_pc + 6 * (size_t)D.nc;
+    double acc[6] = {0, 0, 0, 0, 0, 0};  // p.q | HcK^T p_c + ElK p_l partials (5)
+    for (int c = threadIdx.x; c < D.nc; c += blockDim.x) {
+        const double* cl = D.camlin + (size_t)CAMLIN * c;
+        const double* pc = D.pcg_pc + 6 * (size_t)c;
+        double q[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double v = lambda * D.pcg_Dc[6 * (size_t)c + a] * pc[a];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) v += cl[6 * a + b] * pc[b];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) v += cl[36 + 5 * a + b] * pK[b];
+            q[a] = v;
+        }
+        for (int chn = D.cam_chunk_ptr[c]; chn < D.cam_chunk_ptr[c + 1]; ++chn)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) q[a] += D.pcg_p2[6 * (size_t)chn + a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            D.pcg_qc[6 * (size_t)c + a] = q[a];
+            acc[0] += pc[a] * q[a];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[1 + b] += cl[36 + 5 * a + b] * pc[a];
+        }
+    }
+    for (int i = threadIdx.x; i < D.n_lm_blocks; i += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += D.pcg_p1[6 * (size_t)i + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double x = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 1024 / 64; ++w)
+            for (int k = 0; k < 6; ++k) tot[k] += red[w][k];
+        double pq = tot[0];
+        for (int a = 0; a < 5; ++a) {
+            double v = lambda * D.pcg_Dc[6 * (size_t)D.nc + a] * pK[a] + tot[1 + a];
+            for (int b = 0; b < 5; ++b) v += D.klin[5 * a + b] * pK[b];
+            D.pcg_qc[6 * (size_t)D.nc + a] = v;
+            pq += pK[a] * v;
+        }
+        D.pcg_s[6] = pq;
+        D.pcg_s[2] = D.pcg_s[0] / pq;  // alpha
+    }
+}
+
+// 4/5: x += alpha p, r -= alpha q, z = M^-1 r, partial r.z; threads [0, nl) landmarks, then cameras + K
+__global__ __launch_bounds__(TPB) void pcg_update(BaDev D) {
+    __shared__ double sm[(TPB / 64) * 1];
+    if (D.pcg_s[4] != 0.0) return;
+    const double alpha = D.pcg_s[2];
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    double g[1] = {0.0};
+    if (idx < D.nl) {
+        const size_t b = 3 * (size_t)idx;
+        double r[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            D.delta_l[b + a] += alpha * D.pcg_pl[b + a];
+            r[a] = D.pcg_rl[b + a] - alpha * D.pcg_ql[b + a];
+            D.pcg_rl[b + a] = r[a];
+        }
+        const double* Mi = D.pcg_Ml + 9 * (size_t)idx;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double z = Mi[3 * a] * r[0] + Mi[3 * a + 1] * r[1] + Mi[3 * a + 2] * r[2];
+            D.pcg_zl[b + a] = z;
+            g[0] += r[a] * z;
+        }
+    } else if (idx - D.nl <= D.nc) {
+        const int c = idx - D.nl, m = c < D.nc ? 6 : 5;
+        const size_t b = 6 * (size_t)c;
+        const double* Mi = c < D.nc ? D.pcg_Mc + 36 * (size_t)c : D.pcg_MK;
+        double r[6] = {0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < m; ++a) {
+            D.delta_c[b + a] += alpha * D.pcg_pc[b + a];
+            r[a] = D.pcg_rc[b + a] - alpha * D.pcg_qc[b + a];
+            D.pcg_rc[b + a] = r[a];
+        }
+        for (int a = 0; a < m; ++a) {
+            double z = 0.0;
+            for (int k = 0; k < m; ++k) z += Mi[m * a + k] * r[k];
+            D.pcg_zc[b + a] = z;
+            g[0] += r[a] * z;
+        }
+    }
+    block_sum<1>(g, sm);
+    if (threadIdx.x == 0) D.pcg_p3[blockIdx.x] = g[0];
+}
+
+// 5/5 (one block): gamma', beta, the stop test, p_c <- z_c + beta p_c (p_l follows in 1/5 of the next iteration)
+__global__ __launch_bounds__(1024) void pcg_update_finish(BaDev D, int n_update_blocks) {
+    __shared__ double red[1024 / 64];
+    __shared__ double s_beta;
+    if (D.pcg_s[4] != 0.0) return;
+    double g = 0.0;
+    for (int i = threadIdx.x; i < n_update_blocks; i += blockDim.x) g += D.pcg_p3[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 1024 / 64; ++w) tot += red[w];
+        const double beta = tot / D.pcg_s[0];
+        const double it = D.pcg_s[5] + 1.0;
+        D.pcg_s[0] = tot;
+        D.pcg_s[3] = beta;
+        D.pcg_s[5] = it;
+        // for (k = 1; k <= maxIterations && (gamma > threshold || k <= minIterations); ++k), minIterations = 1
+        if (!(tot > D.pcg_s[1]) || it >= (double)PCG_MAX_IT || !(tot == tot)) D.pcg_s[4] = 1.0;
+        s_beta = beta;
+    }
+    __syncthreads();
+    const double beta = s_beta;
+    for (int i = threadIdx.x; i < D.n; i += blockDim.x) D.pcg_pc[i] = D.pcg_zc[i] + beta * D.pcg_pc[i];
+}
+
+// tentative points + the landmarks' linearised-cost terms from the PCG step (the role K-F has for the direct solve)
+__global__ __launch_bounds__(TPB) void pcg_landmark_step(BaDev D, double lambda) {
+    __shared__ double sm[(TPB / 64) * 1];
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    double lin[1] = {0.0};
+    if (j < D.nl) {
+        const bool used = D.lm_ptr[j + 1] > D.lm_ptr[j];
+        double d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            d[a] = used ? D.delta_l[3 * (size_t)j + a] : 0.0;
+            D.delta_l[3 * (size_t)j + a] = d[a];
+            D.pt_new[3 * (size_t)j + a] = D.pt[3 * (size_t)j + a] + d[a];
+        }
+        if (used) {
+            const double* in = D.lmlin + (size_t)LMLIN * j;
+            lin[0] = 0.5 * (d[0] * in[6] + d[1] * in[7] + d[2] * in[8]) +
+                     0.5 * lambda * (clampd(in[0], 1e-6, 1e32) * d[0] * d[0] + clampd(in[3], 1e-6, 1e32) * d[1] * d[1] +
+                                     clampd(in[5], 1e-6, 1e32) * d[2] * d[2]);
+        }
+    }
+    block_sum<1>(lin, sm);
+    if (threadIdx.x == 0) D.lin_part[blockIdx.x] = lin[0];
+}
+
 // ---- DogLeg (GTSAM DoglegOptimizerImpl): scalar forms of the steepest-descent direction g = A^T b and the
 // Gauss-Newton step n on the UNDAMPED linearised system H = A^T A (blocks of K-A/K-B), all sums in
 // fixed order. forms = {g.g, g.n, n.n, g^T H g, g^T H n, n^T H n}; landmark part here, thread = landmark.
@@ -1883,6 +2278,17 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
     TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
     TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
+    {
+        const size_t nn = (size_t)D.n + 8, n3 = 3 * (size_t)std::max(nl, 1);
+        TRY(dev_alloc(ctx, h, &D.pcg_rc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_zc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_pc, nn));
+        TRY(dev_alloc(ctx, h, &D.pcg_qc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_Dc, nn));
+        TRY(dev_alloc(ctx, h, &D.pcg_rl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_zl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_pl, n3));
+        TRY(dev_alloc(ctx, h, &D.pcg_ql, n3)); TRY(dev_alloc(ctx, h, &D.pcg_Dl, n3));
+        TRY(dev_alloc(ctx, h, &D.pcg_Mc, (size_t)36 * std::max(nc, 1))); TRY(dev_alloc(ctx, h, &D.pcg_MK, 32));
+        TRY(dev_alloc(ctx, h, &D.pcg_Ml, 3 * n3));
+        TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks)); TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
+        TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
+    }
     TRY(dev_alloc(ctx, h, &D.flags, 4 + 64));  // [0..3] status, [4..] hand-off flags of the back-substitution
 #undef TRY
     hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
@@ -1992,6 +2398,42 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     return EACHAM_OK;
 }
 
+// tryLambda() with the iterative solve of BundleAdjuster.cpp:192-200: PCG + block-Jacobi on the damped full system
+// (needs E: the linearisation ran with store_E). Same outputs as launch_try. *pcg_iterations (optional) += iterations.
+static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, long long* pcg_iterations) {
+    BaDev& D = h->D;
+    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (4 + 64) * sizeof(int), ctx->stream));
+    const int n_update_blocks = (D.nl + D.nc + 1 + TPB - 1) / TPB;
+    {
+        ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
+        pcg_setup_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
+        pcg_setup_cameras<<<1, 1024, 0, ctx->stream>>>(D, lambda);
+        double st[2] = {0.0, 0.0};
+        for (int done_it = 0; done_it < PCG_MAX_IT; done_it += PCG_BATCH) {
+            for (int k = 0; k < PCG_BATCH; ++k) {
+                pcg_apply_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
+                if (D.n_cam_chunks > 0) pcg_apply_cam_chunks<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
+                pcg_apply_finish<<<1, 1024, 0, ctx->stream>>>(D, lambda);
+                pcg_update<<<n_update_blocks, TPB, 0, ctx->stream>>>(D);
+                pcg_update_finish<<<1, 1024, 0, ctx->stream>>>(D, n_update_blocks);
+            }
+            EACHAM_HIP_TRY(ctx, hipMemcpyAsync(st, D.pcg_s + 4, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+            EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (st[0] != 0.0) break;
+        }
+        if (pcg_iterations) *pcg_iterations += (long long)st[1];
+    }
+    {
+        ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
+        pcg_landmark_step<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
+        ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
+        ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
+        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1);
+    }
+    EACHAM_HIP_TRY(ctx, hipGetLastError());
+    return EACHAM_OK;
+}
+
 static int read_scal(eacham_ctx* ctx, eacham_ba_handle* h, double* out3) {
     if (!h->scal_host) EACHAM_HIP_TRY(ctx, hipHostMalloc((void**)&h->scal_host, SCAL * sizeof(double), hipHostMallocDefault));
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(h->scal_host, h->D.scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2028,9 +2470,11 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
     if (O->method != EACHAM_BA_LM && O->method != EACHAM_BA_DOGLEG) return ctx->fail(EACHAM_ERR_INVALID, "unknown BA method %d", O->method);
     if (O->lm_factor_policy != EACHAM_BA_LM_FACTOR_RESET && O->lm_factor_policy != EACHAM_BA_LM_FACTOR_DOUBLE)
         return ctx->fail(EACHAM_ERR_INVALID, "unknown lm_factor_policy %d", O->lm_factor_policy);
-    D.store_E = O->method == EACHAM_BA_DOGLEG ? 1 : 0;  // only the dog-leg forms read E after the linearisation
-    // use_preconditioner (PCG + block-Jacobi at 1e-10) asks GTSAM for an iterative solve of the same
-    // system; the direct Schur/Cholesky solve here is its limit, so the flag needs no separate path.
+    // use_preconditioner (BundleAdjuster.cpp:192-200) selects GTSAM's iterative solve, PCG + block-Jacobi at 1e-10, for
+    // the LM steps (the option sits inside the LM branch of the reference: DogLeg never sees it)
+    const bool pcg = O->method == EACHAM_BA_LM && O->use_preconditioner != 0;
+    long long pcg_iterations = 0;
+    D.store_E = (O->method == EACHAM_BA_DOGLEG || pcg) ? 1 : 0;  // the dog-leg forms and the PCG operator read E after the linearisation
 
     const double lambdaUpper = 1e32, lambdaLower = 1e-16, minModelFidelity = 1e-3;
     const double relTol = (double)O->max_tolerance, absTol = (double)O->max_tolerance, errorTol = 0.0;
@@ -2158,7 +2602,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
             for (;;) {
                 bool success = false, stop = false;
                 double newError = INFINITY, linChange = NAN, fidelity = 0.0;
-                rc = launch_try(ctx, h, lambda, nullptr);
+                rc = pcg ? launch_try_pcg(ctx, h, lambda, &pcg_iterations) : launch_try(ctx, h, lambda, nullptr);
                 if (rc) return rc;
                 rc = read_scal(ctx, h, sc);
                 if (rc) return rc;
@@ -2219,6 +2663,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
     R->final_lambda = lambda;
     R->outer_iterations = iterations;
     R->inner_iterations = inner;
+    R->reserved = (int32_t)std::min<long long>(pcg_iterations, 0x7fffffff);  // PCG iterations in total (0 for the direct solve)
     return download();
 }
 

@@ -165,7 +165,8 @@ typedef struct eacham_ba_options {
     int32_t max_iter;           /* maxIter                                                           */
     float max_tolerance;        /* maxTolerance: absoluteErrorTol = relativeErrorTol (:187-188)      */
     float delta;                /* DogLeg deltaInitial (:211)                                        */
-    int32_t use_preconditioner; /* usePreconditioner: PCG + block-Jacobi at 1e-10 (:192-200)         */
+    int32_t use_preconditioner; /* usePreconditioner (LM only): solve every damped system with PCG +   */
+                                /* block-Jacobi at 1e-10 / 1e-10 (:192-200) instead of the direct solve */
     int32_t min_landmarks;      /* literal 50 (:166): fewer landmarks -> silently do nothing         */
     int32_t lm_factor_policy;   /* EACHAM_BA_LM_FACTOR_* below; 0 (zero-initialised options) = RESET */
     int32_t reserved;
@@ -209,7 +210,7 @@ typedef struct eacham_ba_result {
     int32_t inner_iterations; /* tryLambda() calls = linear solves                                   */
     int32_t trace_cap;       /* in: capacity of `trace` (may be 0)                                   */
     int32_t trace_len;       /* out: rows written                                                    */
-    int32_t reserved;
+    int32_t reserved;        /* out: PCG iterations in total when use_preconditioner is set, else 0   */
     eacham_ba_trace_row* trace; /* optional                                                          */
 } eacham_ba_result;
 

@@ -1084,11 +1084,10 @@ int oracle_ba_solve(const eacham_ba_problem* P, const eacham_ba_options* O, each
                 int success = 0, stop = 0;
                 double newError = INFINITY, linChange = NAN, fidelity = 0.0;
                 memset(dl, 0, sizeof(double) * 3 * (size_t)S->nl);
-                /* use_preconditioner = 2 (oracle only): solve with the PCG + block-Jacobi the reference would
-                 * configure (BundleAdjuster.cpp:192-200) instead of the direct solve; 1 = the direct solve, as the
-                 * product library does (the two are compared in tests/test_ba_oracle.py) */
+                /* use_preconditioner: the PCG + block-Jacobi the reference configures (BundleAdjuster.cpp:192-200)
+                 * instead of the direct solve (the two are compared in tests/test_ba_oracle.py) */
                 int pcg_it = 0;
-                const int solved = O->use_preconditioner == 2 ? solve_step_pcg(&B, &L, lambda, dc, dl, &pcg_it)
+                const int solved = O->use_preconditioner ? solve_step_pcg(&B, &L, lambda, dc, dl, &pcg_it)
                                                               : solve_step(&B, &L, lambda, 0, dc, dl, 0, 0);
                 pcg_total += pcg_it;
                 if (solved) {

@@ -190,8 +190,32 @@ def test_unknown_factor_policy_is_rejected(hip_ctx):
     assert L.eacham_ba_solve(hip_ctx.handle, C.byref(prob), C.byref(opt), C.byref(res)) == capi.ERR_INVALID
 
 
-@pytest.mark.parametrize("cfg", [ba.OptimizerConfig.refine_ba(), ba.OptimizerConfig.global_ba(),
-                                 ba.OptimizerConfig("LM", 2, 1e-5, 10.0, True)])
+def test_pcg_block_jacobi_parity(hip_ctx):
+    """usePreconditioner (BundleAdjuster.cpp:192-200): every damped system solved by PCG + block-Jacobi at 1e-10, on the
+    device in block form, in the oracle in Jacobian form (different roundings of the same operator, so the CG iterates
+    are not bit-identical). Same LM decisions, poses / points within the north-star tolerance of the oracle's PCG run
+    AND of the direct solve; the iteration counts of the inner solver agree to a few per cent."""
+    for A in (scene_arrays(seed=21, n_cams=12, n_lm=900, k=5)[1],
+              ba.BaArrays.from_scene(synth.local_window(synth.make_scene(120, 7200, 10, seed=3), 60))):
+        cfg = ba.OptimizerConfig("LM", 100, 1e-5, 10.0, True)
+        out = ba.RefineBA(hip_ctx, A, cfg)
+        ref = O.ba_solve(A, cfg)
+        direct = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("LM", 100, 1e-5, 10.0, False))
+        assert out.status == ref.status == 0 and out.reserved > 20 * out.inner_iterations and direct.reserved == 0
+        assert abs(out.reserved - ref.reserved) <= 0.05 * ref.reserved + 5
+        assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+        assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :3], ref.trace[:, :3], rtol=1e-5)
+        for other in (ref, direct):
+            assert rel(out.cam_T_wc, other.cam_T_wc) < POSE_POINT_RTOL and rel(out.points, other.points) < POSE_POINT_RTOL
+            assert np.isclose(out.final_error, other.final_error, rtol=1e-7)
+    # DogLeg ignores the flag (the reference sets it inside its LM branch only)
+    sc, A = scene_arrays(seed=21, n_cams=12, n_lm=900, k=5)
+    a = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, True))
+    b = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig("DogLeg", 100, 1e-5, 10.0, False))
+    assert a.reserved == 0 and np.array_equal(a.points, b.points)
+
+
+@pytest.mark.parametrize("cfg", [ba.OptimizerConfig.refine_ba(), ba.OptimizerConfig.global_ba()])
 def test_refine_ba_parity(hip_ctx, cfg):
     sc, A = scene_arrays(seed=21, n_cams=12, n_lm=900, k=5)
     out = ba.RefineBA(hip_ctx, A, cfg)
@@ -214,8 +238,12 @@ def test_hard_start_with_rejected_steps(hip_ctx):
     A = ba.BaArrays.from_scene(sc)
     out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
     ref = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
-    assert (ref.trace[:, 3] == 0).sum() >= 1  # the case does exercise increaseLambda
-    assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :2], ref.trace[:, :2], rtol=1e-6)
+    assert (ref.trace[:, 3] == 0).sum() >= 3  # the case does exercise increaseLambda, several times
+    # 21 iterations through rejected steps from a far-off start: the decisions are identical, the numbers carry the
+    # amplified rounding differences of the two solvers (lambda follows the step quality: 5e-6; rejected tries: 1e-6)
+    acc = ref.trace[:, 3] == 1
+    assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, 0], ref.trace[:, 0], rtol=1e-4)
+    assert np.allclose(out.trace[acc, 1], ref.trace[acc, 1], rtol=1e-7) and np.allclose(out.trace[~acc, 1], ref.trace[~acc, 1], rtol=1e-4)
     assert rel(out.points, ref.points) < POSE_POINT_RTOL and rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL
 
 

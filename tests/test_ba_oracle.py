@@ -154,15 +154,15 @@ def test_pcg_block_jacobi_step_equals_the_direct_step(lam):
 
 
 def test_lm_with_pcg_follows_the_direct_solve_on_ba_windows():
-    """use_preconditioner: the product library keeps the direct solve (the limit the 1e-10 PCG iterates towards).
-    On windows of the kind RefineBA sees — a perturbed reconstruction, a local window of the TUM stand-in — the LM
+    """use_preconditioner selects the iterative solve (oracle and device alike); the direct solve is the limit it
+    iterates towards. On windows of the kind RefineBA sees — a perturbed reconstruction, a local window of the TUM stand-in — the LM
     trajectories of the two solves take the same decisions and end within 1e-5 relative (measured 3e-7 / 2e-6)."""
     cases = [ba.BaArrays.from_scene(small_scene(seed=21, n_cams=12, n_lm=900, k=5)),
              ba.BaArrays.from_scene(synth.local_window(synth.make_scene(120, 7200, 10, seed=3), 60))]
     for A in cases:
-        cfg = ba.OptimizerConfig("LM", 100, 1e-5, 10.0, True)
-        d, p = O.ba_solve(A, cfg), O.ba_solve(A, cfg, pcg=True)
-        assert p.reserved >= 20 * p.inner_iterations                      # the PCG did iterate (tens of steps per solve)
+        d = O.ba_solve(A, ba.OptimizerConfig("LM", 100, 1e-5, 10.0, False))
+        p = O.ba_solve(A, ba.OptimizerConfig("LM", 100, 1e-5, 10.0, True))
+        assert p.reserved >= 20 * p.inner_iterations and d.reserved == 0   # the PCG did iterate (tens of steps per solve)
         assert (d.outer_iterations, d.inner_iterations) == (p.outer_iterations, p.inner_iterations)
         assert np.array_equal(d.trace[:, 3], p.trace[:, 3]) and np.allclose(d.trace[:, :2], p.trace[:, :2], rtol=1e-6)
         assert np.abs(p.cam_T_wc - d.cam_T_wc).max() < 1e-5 * np.abs(d.cam_T_wc).max()
@@ -175,8 +175,8 @@ def test_lm_with_pcg_on_a_far_off_start_is_a_different_trajectory():
     trajectory amplifies the truncation error of a 1e-10 PCG — the iterative and the direct solve then take
     different decisions and may end in different local minima. Both reduce the error by orders of magnitude."""
     A = ba.BaArrays.from_scene(synth.make_scene(6, 90, 2, seed=1, rot_noise=0.5, trans_noise=0.5, point_noise=0.8))
-    cfg = ba.OptimizerConfig("LM", 100, 1e-5, 10.0, True)
-    d, p = O.ba_solve(A, cfg, nthreads=1), O.ba_solve(A, cfg, nthreads=1, pcg=True)
+    d = O.ba_solve(A, ba.OptimizerConfig("LM", 100, 1e-5, 10.0, False), nthreads=1)
+    p = O.ba_solve(A, ba.OptimizerConfig("LM", 100, 1e-5, 10.0, True), nthreads=1)
     assert d.final_error < 0.01 * d.initial_error and p.final_error < 0.01 * p.initial_error
     assert abs(p.final_error - d.final_error) < 0.01 * d.final_error
 
