@@ -515,9 +515,9 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
     // on v_mfma_f64_16x16x4_f64 with TWO observations per instruction: rows 0..5 / 8..13 of the A operand hold Et of
     // the even / odd observation of a pair, columns 0..5 / 8..13 of the B operand their M, the K index (3 used of 4)
     // is shared, so the diagonal 6 x 6 blocks of D accumulate Et M of the two observations and the off-diagonal
-    // blocks are discarded. A wave stages 32 observations at a time in its own LDS region, pair t as 3 x 16 doubles
+    // blocks are discarded. A wave stages 16 observations at a time in its own LDS region, pair t as 3 x 16 doubles
     // per operand: the operands of step t are lds[48 t + lane] for the lanes of k = lane >> 4 < 3, zero otherwise.
-    __shared__ __attribute__((aligned(16))) double stA[TPB / 64][16 * 48], stB[TPB / 64][16 * 48];  // 2 x 6 KB per wave
+    __shared__ __attribute__((aligned(16))) double stA[TPB / 64][8 * 48], stB[TPB / 64][8 * 48];  // 2 x 3 KB per wave: 16 observations per round
     __shared__ double wsum[TPB / 64][4][64];
     const int2 ch = D.cam_chunks[blockIdx.x];  // {first position, count}
     const int p = ch.x + threadIdx.x;
@@ -557,9 +557,9 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
     mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
     double *sa = stA[wave], *sb = stB[wave];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if ((lane >> 5) == half) {
-            const int o = lane & 31, t = o >> 1, sub = o & 1;
+    for (int round = 0; round < 4; ++round) {  // 16 lanes stage, the whole wave multiplies (small LDS footprint: four workgroups per CU)
+        if ((lane >> 4) == round) {
+            const int o = lane & 15, t = o >> 1, sub = o & 1;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 // A: Et[a][k] = et[3 a + k], a = 0..5 (+ two zero rows); B: M[k][j] = EKt[j][k] = lv[3 + 3 j + k] (j < 5), gt[k] = lv[k] (j = 5)
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
         {
             const bool live = lane < 48;  // k = lane >> 4 < 3
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < 8; ++t) {
                 const double a = live ? sa[48 * t + lane] : 0.0, b = live ? sb[48 * t + lane] : 0.0;
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
