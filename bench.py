@@ -172,8 +172,11 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
     kmax = max(d.shape[0] for d in descs)
 
     ctx = HipContext(D.local)
+    t_up = time.perf_counter()
     for f, d in enumerate(descs):  # replicated descriptor store (S200: 200 x 2000 x 256 B = 102 MB int8)
         (ctx.upload_descriptors if kind == "i8" else ctx.upload_descriptors_f32)(f, d)
+    ctx.sync()
+    t_up = time.perf_counter() - t_up  # once per job, outside the timed steps: PCIe copy of the fp32 matrices + layout kernels
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
     with torch.cuda.stream(ext):
         pairs_dev = torch.from_numpy(pairs).to(dev)
@@ -238,7 +241,8 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
     launches, tile_ms = ctx.profile_get(capi.KERNEL_MATCH_TILE)
     _, fin_ms = ctx.profile_get(capi.KERNEL_MATCH_FINALIZE)
     out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms,
-           "fin_ms": fin_ms, "matches": int(total.item()), "pairs_all": pairs_all, "edge_cap": edge_cap}
+           "fin_ms": fin_ms, "matches": int(total.item()), "pairs_all": pairs_all, "edge_cap": edge_cap, "upload_s": t_up,
+           "upload_bytes": int(sum(d.nbytes for d in descs))}
     ctx.close()
     return out
 
@@ -254,6 +258,9 @@ def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, 
     return {"workload": workload, "value": r["npairs_total"] * steps / r["elapsed"], "unit": "image-pairs/s",
             "dtype": kind, "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3, "pairs": r["npairs_total"],
             "pairs_per_rank": r["npairs"], "mutual_matches_rank0": r["matches"],
+            # the descriptor hand-over happens once per job, before the timed steps (host fp32 -> HBM int8 / fp32 fragments)
+            "upload_once": {"seconds": r["upload_s"], "host_bytes": r["upload_bytes"],
+                            "pairs_per_s_if_paid_every_step": r["npairs_total"] / (r["elapsed"] / steps + r["upload_s"])},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "kernel": kernel, "launches": r["launches"],
                          "avg_launch_ms": r["tile_ms"] / max(r["launches"], 1),
@@ -377,10 +384,14 @@ def cpu_baseline_ba(scene):
     arrays = ba.BaArrays.from_scene(scene)
     O.ba_solve(arrays, ba.OptimizerConfig("LM", 1, 1e-5, 10.0, False), nthreads=cores)  # warm-up
     t0 = time.perf_counter()
-    out = O.ba_solve(arrays, ba.OptimizerConfig("LM", 3, 1e-5, 10.0, False), nthreads=cores)
+    iters = solves = 0
+    while time.perf_counter() - t0 < 8.0:  # whole RefineBA solves of the same window (refine_ba options) for >= 8 s
+        out = O.ba_solve(arrays, ba.OptimizerConfig.refine_ba(), nthreads=cores)
+        iters += out.outer_iterations
+        solves += 1
     dt = time.perf_counter() - t0
-    return {"value": out.outer_iterations / dt, "unit": "LM outer iters/s", "cores": cores, "kind": "port",
-            "sample": f"{out.outer_iterations} LM iterations of the same window (Schur + dense Cholesky, OpenMP), {dt:.1f} s"}
+    return {"value": iters / dt, "unit": "LM outer iters/s", "cores": cores, "kind": "port",
+            "sample": f"{solves} RefineBA solves = {iters} LM iterations of the same window (Schur + dense Cholesky, OpenMP), {dt:.1f} s"}
 
 
 def cpu_baseline(descs, pairs_all, args):
@@ -502,7 +513,7 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": head["workload"], "pairs_per_rank": head["pairs_per_rank"],
-                       "mutual_matches_rank0": head["mutual_matches_rank0"],
+                       "mutual_matches_rank0": head["mutual_matches_rank0"], "upload_once": head["upload_once"],
                        "parallelism": f"pairs sharded over {D.world} GPU(s)" + (" + RCCL all-gather" if D.world > 1 else "")},
             "roofline": head["roofline"],
             "kernel_source_sha": kernel_source_sha(),

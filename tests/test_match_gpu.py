@@ -378,3 +378,26 @@ def test_batched_directed_matches_equal_single_calls(hip_ctx):
     assert sum(len(m) for m in got) > 200
     assert got[-1] == {q: q for q in range(300)}                 # a frame against itself: d0 = 0 < 0.8 d1 always passes
     assert hip_ctx.match_pairs_directed(descs, []) == []
+
+
+def test_documented_limits_are_errors_not_wrong_answers(hip_ctx):
+    """D <= 256, one descriptor kind and one dimension class resident at a time, <= 16384 rows."""
+    hip_ctx.clear_descriptors()
+    for bad_dim in (272, 512):
+        with pytest.raises(EachamError) as e:
+            hip_ctx.upload_descriptors(0, np.zeros((8, bad_dim), np.float32))
+        assert e.value.code == capi.ERR_UNSUPPORTED
+        with pytest.raises(EachamError) as e:
+            hip_ctx.upload_descriptors_f32(0, np.zeros((8, bad_dim), np.float32))
+        assert e.value.code == capi.ERR_UNSUPPORTED
+    hip_ctx.upload_descriptors(0, synth.random_u8_descriptors(40, 128, 1, 0))
+    with pytest.raises(EachamError) as e:   # a 256-D frame beside a 128-D one: another k-step class
+        hip_ctx.upload_descriptors(1, synth.random_u8_descriptors(40, 256, 1, 1))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    hip_ctx.upload_descriptors(1, synth.random_u8_descriptors(40, 112, 1, 1))   # 112 and 128 share the class (zero padding)
+    q, t = hip_ctx.match_pair(0, 0)
+    assert np.array_equal(q, np.arange(40)) and np.array_equal(t, np.arange(40))
+    with pytest.raises(EachamError) as e:
+        hip_ctx.upload_descriptors_f32(2, np.zeros((16385, 32), np.float32))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    hip_ctx.clear_descriptors()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Builds profiles/r02_pmc_hbm_traffic.json and profiles/r02_pmc_ba_traffic.json from the two rocprofv3 --pmc
+"""usage: python3 tools/pmc_traffic_json.py <tag> [round]   (run in the container after `gpurun tools/prof.sh <tag>`)
+Builds profiles/r02_pmc_hbm_traffic.json and profiles/r02_pmc_ba_traffic.json from the two rocprofv3 --pmc
 passes of tools/prof.sh (FETCH_SIZE and WRITE_SIZE collected separately; KB per dispatch, mean per (kernel, grid)).
 Both files record the sha of the kernel sources they were taken with (bench.py kernel_source_sha): bench.py
 reports a traffic figure only when that sha is the one it is running."""
@@ -10,7 +11,9 @@ sys.path.insert(0, root)
 import bench  # noqa: E402
 
 out = collections.defaultdict(dict)
-for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02a"          # gpurun_out/<tag>_fetch, <tag>_write (tools/prof.sh <tag>)
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"           # profiles/<rnd>_pmc_*.json
+for counter, d in (("FETCH_SIZE", tag + "_fetch"), ("WRITE_SIZE", tag + "_write")):
     acc = collections.defaultdict(list)
     for fn in glob.glob(os.path.join(root, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
         with open(fn) as f:
@@ -27,8 +30,7 @@ meta = {"kernel_source_sha": bench.kernel_source_sha(), "head": head,
         "command": "tools/prof.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 "
                    "--cpu-pairs 0 --ba-solves 1 --lines none (separate passes)",
         "units": "KB as reported; HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH correction, MI355X_MICROARCH.md)"}
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-dst = os.path.join(root, "profiles", f"{tag}_pmc_hbm_traffic.json")
+dst = os.path.join(root, "profiles", f"{rnd}_pmc_hbm_traffic.json")
 with open(dst, "w") as f:
     json.dump({"__meta__": meta, **{k: out[k] for k in sorted(out)}}, f, indent=1)
 print(dst, len(out), "kernel/grid entries")
@@ -49,7 +51,7 @@ for k, v in out.items():
         b = (2.0 * v.get("FETCH_SIZE_KB_mean_per_dispatch", 0.0) + v.get("WRITE_SIZE_KB_mean_per_dispatch", 0.0)) * 1024.0 * n
         per_kernel[k] = {"dispatches": n, "hbm_bytes_total": b, "hbm_bytes_per_inner_iteration": b / max(tries, 1)}
         total += b
-dst = os.path.join(root, "profiles", f"{tag}_pmc_ba_traffic.json")
+dst = os.path.join(root, "profiles", f"{rnd}_pmc_ba_traffic.json")
 with open(dst, "w") as f:
     json.dump({"__meta__": meta, "tries": tries,
                "per_inner_iteration": {"hbm_bytes": total / max(tries, 1),
