@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 
 namespace eacham {
 
@@ -358,8 +359,14 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     constexpr bool EPK_ON = true;
 #endif
     constexpr int NSTEP = NSUB * KS;     // (phase, ks) steps per tile
-    int slot_cur = 0, slot_nxt = 1, slot_new = 2;  // t % 3, (t+1) % 3, (t+2) % 3
-    for (int t = 0; t < T; ++t) {
+    // One tile of the sweep. The LDS slot ring (tile t lives in slot t % 3) and the fragment register ring (step i of the
+    // (phase, ks) sequence lives in bq[(i + PH) % 3]; a tile advances it by NSTEP % 3) both have period 3 in t: the body
+    // is instantiated for the three residues and the loop below runs three tiles per trip, so every ring index is a
+    // compile-time constant and no register is moved to rotate a ring (8 v_mov per wave-tile before, 4 % of its VALU
+    // instructions, on a kernel bound by its issue port).
+    auto tile = [&](auto PHc, auto SLc, const int t) {
+        constexpr int PH = decltype(PHc)::value, SL = decltype(SLc)::value;
+        constexpr int slot_cur = SL, slot_nxt = (SL + 1) % 3, slot_new = (SL + 2) % 3;
         // per-column part of this tile's keys: (hb << 8) | pb << 7 | t  (pb is wave-uniform per tile)
         const unsigned lowc = ((unsigned)hb_cur << (KEY_SHIFT + 1)) | (unsigned)((tbeg + t >= B_even ? (1 << KEY_SHIFT) : 0) | t);
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
@@ -387,24 +394,24 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                 // phase NSUB-1 issues chain (t+1, 0) and phase 0 of the next iteration chain (t+1, 1):
                 // tile t+1.
                 const int j = i + 2;
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[i % 3]));  // step i landed (i+1 may be in flight)
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[(i + PH) % 3]));  // step i landed (i+1 may be in flight)
 #ifndef EXP_NO_LDSREAD
-                lds_read_frag(bq[j % 3], (j / KS < NSUB - 1) ? curB : nxtB, (j % KS) * 1024);
+                lds_read_frag(bq[(j + PH) % 3], (j / KS < NSUB - 1) ? curB : nxtB, (j % KS) * 1024);
 #endif
                 const int q = (ph + 1) % NSUB;       // accumulator of the chain being issued
                 // (the last iteration recomputes tile T-1 into acc[0]; it is never read)
 #if defined(EXP_SHAPE16)
                 {   // diagnostic build (wrong results): same MACs issued as two 16x16x64 MFMAs per 32x32x32
                     v4i lo = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]}, hi = {acc[q][4], acc[q][5], acc[q][6], acc[q][7]};
-                    lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[i % 3], lo, 0, 0, 0);
-                    hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[i % 3], hi, 0, 0, 0);
+                    lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[(i + PH) % 3], lo, 0, 0, 0);
+                    hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[(i + PH) % 3], hi, 0, 0, 0);
                     acc[q][0] = lo[0]; acc[q][1] = lo[1]; acc[q][2] = lo[2]; acc[q][3] = lo[3];
                     acc[q][4] = hi[0]; acc[q][5] = hi[1]; acc[q][6] = hi[2]; acc[q][7] = hi[3];
                 }
 #elif !defined(EXP_NO_MFMA)
-                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q][ks], bq[i % 3], ks ? acc[q] : cinit[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q][ks], bq[(i + PH) % 3], ks ? acc[q] : cinit[q], 0, 0, 0);
 #else
-                acc[q][ks] += bq[i % 3][0] + a[q][ks][0];
+                acc[q][ks] += bq[(i + PH) % 3][0] + a[q][ks][0];
 #endif
 #pragma unroll
                 for (int e = 0; e < (EPK_ON ? EPK : 0); ++e) {
@@ -436,13 +443,9 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                 if (i == KS - 1) STAMP(1);
             }
             STAMP(2);
-            // steps NSTEP and NSTEP+1 (= steps 0, 1 of the next iteration) sit in bq[NSTEP % 3], ...
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));  // before any register move
-            {
-                v4i s0 = bq[NSTEP % 3], s1 = bq[(NSTEP + 1) % 3];
-                bq[0] = s0;
-                bq[1] = s1;
-            }
+            // steps NSTEP and NSTEP + 1 (= steps 0, 1 of the next tile, whose ring phase is PH + NSTEP) are in flight:
+            // they have landed before the barrier below lets anybody overwrite their slot
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));
             // Merge the sub-tiles that share a parity: all of them, except in the workgroup that
             // straddles the even/odd boundary of frame A, which keeps the two parities apart.
             unsigned g1[2] = {0xffffffffu, 0xffffffffu}, g2[2] = {0xffffffffu, 0xffffffffu};
@@ -479,14 +482,28 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         }
         STAMP(3);
         STAMP(4);
-        const int tmp = slot_cur;
-        slot_cur = slot_nxt;
-        slot_nxt = slot_new;
-        slot_new = tmp;
 #ifndef EXP_NO_BARRIER
         __syncthreads();
 #endif
         STAMP(5);
+    };
+    {
+        constexpr int ADV = NSTEP % 3;  // ring advance per tile
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, ADV % 3>;
+        using P2 = std::integral_constant<int, (2 * ADV) % 3>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        int t = 0;
+        for (; t + 3 <= T; t += 3) {
+            tile(P0{}, P0{}, t);
+            tile(P1{}, S1{}, t + 1);
+            tile(P2{}, S2{}, t + 2);
+        }
+        if (t < T) {
+            tile(P0{}, P0{}, t);
+            if (t + 1 < T) tile(P1{}, S1{}, t + 1);
+        }
     }
 #ifdef EXP_CLOCK
     if (lane == 0 && active && blockIdx.x % 61 == 0) {
