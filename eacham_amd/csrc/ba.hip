@@ -1003,11 +1003,21 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 #endif
     constexpr int LS = NB + 2;   // even row stride: 16-byte aligned pairs for ds_read_b128, still conflict-free
     constexpr int WLD = NB + 4;  // row stride of W_k in LDS: the MFMA operand reads (16 rows x 4 columns) stay 2-way
-    __shared__ double Wk[NB][WLD];
-    __shared__ double Dn[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double Li[64][LS], Lj[64][LS];
-    __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
-    __shared__ __attribute__((aligned(16))) FactorImage Fimg;
+    // 44 KB of LDS per workgroup: three workgroups per CU (the structures only tile 0 needs for the next diagonal block
+    // live in regions that are dead by then: Dn / Pslab over Lj — a diagonal tile never reads its second strip —, the
+    // factor image over W_k, which nobody reads after the panel product). With 66 KB the steps of a large system ran
+    // their tile grids (1128 tiles at n = 3005) in two and a half rounds of 512 resident workgroups.
+    struct NextDiag { double Dn[NB][NB + 1]; double Pslab[NB * PLD]; };
+    static_assert(sizeof(double) * NB * (NB + 1) % 16 == 0, "Pslab stays 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) union { double Wk[NB][WLD]; FactorImage F; } uW;
+    __shared__ __attribute__((aligned(16))) double Li[64][LS];
+    __shared__ __attribute__((aligned(16))) union { double Lj[64][LS]; NextDiag nd; } uJ;
+    static_assert(sizeof(FactorImage) <= sizeof(double) * NB * WLD && sizeof(NextDiag) <= sizeof(double) * 64 * LS, "aliases fit");
+    double (&Wk)[NB][WLD] = uW.Wk;
+    FactorImage& Fimg = uW.F;
+    double (&Lj)[64][LS] = uJ.Lj;
+    double (&Dn)[NB][NB + 1] = uJ.nd.Dn;
+    double (&Pslab)[NB * PLD] = uJ.nd.Pslab;
     const int tid = threadIdx.x;
     const double* __restrict__ Wsrc = Winv + (size_t)(k0 / NB) * NB * NB;
     // W_k goes through registers so that its loads are in flight together with the panel and tile loads
@@ -1069,7 +1079,6 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
         const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;
         *reinterpret_cast<double2*>(&(m < 4 ? Li : Lj)[rr][lp]) = praw[m];  // (a diagonal tile loads the same rows twice)
     }
-    if (tid == 0) Fimg.progress = 0;
     __syncthreads();
     BSTAMP(0);
     {   // L_ik = A_ik W_k^T: wave w takes rows 16w..16w+15 of each strip. A operand: lane (i, kk) holds
@@ -1112,6 +1121,7 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
     if (tj == 0 && t != 0) store_panel(tid, TPB);
     const bool next_diag = first && (k1 < n);
     if (first) {
+        if (tid == 0) Fimg.progress = 0;  // (W_k's region: free since the barrier behind the panel product)
         if (wv < 3 && next_diag) {
             mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};  // two accumulators: two independent MFMA chains
 #pragma unroll
