@@ -1411,17 +1411,38 @@ __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lamb
                 t1 -= lt[10 + 3 * a] * dK[a];
                 t2 -= lt[11 + 3 * a] * dK[a];
             }
+            // sum_o Et_o^T dc = Linv sum_o E_o^T dc and E_o^T dc = Al^T (Ap dc): the Jacobians are recomputed at the
+            // linearisation point (pose / pt / Kc do not change inside the lambda loop) from this landmark's own
+            // observation records instead of gathering its ten 144-byte Et rows out of the camera-ordered array
+            // (137 MB of HBM traffic per try, profiles/r02_pmc_ba_traffic.json of the first round-2 build)
+            const double l[3] = {D.pt[3 * (size_t)j], D.pt[3 * (size_t)j + 1], D.pt[3 * (size_t)j + 2]};
+            double K[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0;
             for (int o = o0; o < o1; ++o) {
-                const double* Et = D.Et + 18 * (size_t)D.obs_pos[o];
-                const double* dc = D.delta_c + 6 * (size_t)D.obs_cam[o];
+                const int cam = (int)D.obs_cam[o];
+                const double* x = D.pose + 12 * (size_t)cam;
+                const double* dc = D.delta_c + 6 * (size_t)cam;
+                double xr[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) xr[k] = x[k];
+                double Ap[12], Al[6], Ak[10], b[2];
+                obs_factor(xr, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+                double u0 = 0.0, u1 = 0.0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
-                    t0 -= Et[3 * a] * dc[a];
-                    t1 -= Et[3 * a + 1] * dc[a];
-                    t2 -= Et[3 * a + 2] * dc[a];
+                    u0 += Ap[a] * dc[a];
+                    u1 += Ap[6 + a] * dc[a];
                 }
+                w0 += Al[0] * u0 + Al[3] * u1;
+                w1 += Al[1] * u0 + Al[4] * u1;
+                w2 += Al[2] * u0 + Al[5] * u1;
             }
             const double m00 = lt[0], m10 = lt[1], m11 = lt[2], m20 = lt[3], m21 = lt[4], m22 = lt[5];
+            t0 -= m00 * w0;
+            t1 -= m10 * w0 + m11 * w1;
+            t2 -= m20 * w0 + m21 * w1 + m22 * w2;
             d0 = m00 * t0 + m10 * t1 + m20 * t2;
             d1 = m11 * t1 + m21 * t2;
             d2 = m22 * t2;

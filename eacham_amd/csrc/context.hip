@@ -3,7 +3,9 @@
 #include "context.hpp"
 #include <algorithm>
 
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 
 namespace eacham {
@@ -127,7 +129,35 @@ int sync_frame_table(eacham_ctx* ctx) {
     return EACHAM_OK;
 }
 
+// Optional ROCTx ranges around the stages ("roctx ranges"): EACHAM_ROCTX=1 in the environment loads
+// the marker library at run time (no link-time dependency) and every ProfileScope pushes / pops a named range, visible
+// to `rocprofv3 --marker-trace` (never together with --pmc).
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+const char* const kStageNames[EACHAM_KERNEL_COUNT] = {"eacham.match.tile", "eacham.match.finalize", "eacham.ba.linearize", "eacham.ba.schur",
+                                                      "eacham.ba.solve", "eacham.ba.error", "eacham.triangulate", "eacham.score"};
+void roctx_init() {
+    const char* e = getenv("EACHAM_ROCTX");
+    if (!e || !*e || *e == '0') return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+    if (!g_roctx_push || !g_roctx_pop) g_roctx_push = nullptr, g_roctx_pop = nullptr;
+}
+}  // namespace
+
 ProfileScope::ProfileScope(eacham_ctx* c, int kernel_id, hipStream_t on) : ctx(c), id(kernel_id), stream(on ? on : c->stream) {
+    std::call_once(g_roctx_once, roctx_init);
+    if (g_roctx_push) {
+        (void)g_roctx_push(kStageNames[id]);
+        range = true;
+    }
     if (!ctx->profile) return;
     ProfileSlot& s = ctx->prof[id];
     if (s.used == s.events.size()) {
@@ -142,6 +172,7 @@ ProfileScope::ProfileScope(eacham_ctx* c, int kernel_id, hipStream_t on) : ctx(c
 
 ProfileScope::~ProfileScope() {
     if (stop) (void)hipEventRecord(stop, stream);
+    if (range && g_roctx_pop) (void)g_roctx_pop();
 }
 
 static void profile_drain(eacham_ctx* ctx) {

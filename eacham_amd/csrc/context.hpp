@@ -132,6 +132,7 @@ struct ProfileScope {
     int id;
     hipEvent_t stop = nullptr;
     hipStream_t stream;
+    bool range = false;  // a ROCTx range is open (EACHAM_ROCTX=1)
     ProfileScope(eacham_ctx* c, int kernel_id, hipStream_t on = nullptr);
     ~ProfileScope();
 };
