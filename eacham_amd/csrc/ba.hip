@@ -601,15 +601,20 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
     }
 }
 
-// ---- K-D1: Schur pair products (wave = chunk of <= 64 entries of one camera block's pair list) ------
-// lane e computes the 6x6 product Et[o_e] Et[o'_e]^T of its entry (all loads independent: the
-// gathers of a whole chunk are in flight together). The 36 sums over the wave's entries go through a
-// wave-private LDS transpose: lane e writes its 36 products as column e, lane v < 36 then adds row v in
-// entry order — 36 writes + 64 reads + 64 adds per wave instead of the 36 x 6 x (2 bpermute + add) of a
-// shuffle tree. Fixed order, no atomics: deterministic.
+// ---- K-D1: Schur pair products (wave = chunk of <= 256 entries of one camera block's pair list) ------
+// lane e computes the 6x6 product Et[o_e] Et[o'_e]^T of its entry. The two 144-byte rows of an entry are NOT gathered
+// by the lane that multiplies them (64 lanes x 16 bytes out of 64 different rows per instruction: 64 memory sectors
+// per wave-instruction, nine instructions per row): the 128 rows of a group of 64 entries are copied into the wave's
+// LDS region by LDS-DMA with per-lane source addresses, 16-byte piece c = 64 it + lane of the row-major image coming
+// from row c / 9 — a wave-instruction then covers seven rows end to end (21 sectors) — and every lane reads its two
+// rows back from LDS. The 36 sums over the wave's entries go through a wave-private LDS transpose (the same
+// region): lane e writes its 36 products as column e, lane v < 36 then adds row v in entry order — 36 writes +
+// 64 reads + 64 adds per wave instead of the 36 x 6 x (2 bpermute + add) of a shuffle tree. Fixed order, no atomics.
 __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
     constexpr int ROW = 65;  // odd stride in doubles: the row reads of the 36 summing lanes spread over the banks
-    __shared__ double tr[TPB / 64][36 * ROW];
+    constexpr int WBUF = 36 * ROW;  // 2340 doubles per wave: >= the 128 x 18 doubles of a staged group
+    static_assert(WBUF >= 128 * 18, "the staging image fits the reduction image");
+    __shared__ __attribute__((aligned(16))) double tr[TPB / 64][WBUF];
     // Et is stored in CAMERA order: the two sides of a block's entries walk two cameras' contiguous regions in
     // ascending order (landmark-ordered records put every gather in a different page of 72 MB).
     // Workgroups go to the 8 XCDs round-robin, each XCD has its own 4 MB L2, and the chunk list is ordered by
@@ -625,26 +630,49 @@ __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int e = lane; e < ch.z; e += 64) {  // entries e, e+64, ... in order: a fixed summation order per lane
-        const int2 pr = D.pair_entries[ch.y + e];
-        const double* xp = D.Et + 18 * (size_t)pr.x;
-        const double* yp = D.Et + 18 * (size_t)pr.y;
+    // groups of 64 entries, in order (a fixed summation order per lane); the copy of group g + 1 is issued as soon as
+    // the rows of group g sit in registers and flies while they are multiplied. Measured on S200 (per launch): the
+    // per-lane gathers 85 us, this staging 79 us, with the copy in flight under the products 76 us; the same image
+    // staged through registers (16-byte loads + ds_write_b128) 81 us, and with the next group's pieces held in
+    // registers across the products it spills.
+    auto stage = [&](int g) {
+        const int e = g + lane;
+        const int2 pr = D.pair_entries[ch.y + (e < ch.z ? e : 0)];  // (a dead lane stages rows nobody multiplies)
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {
+            const int c = 64 * it + lane, r = c / 9, piece = c - 9 * r;  // piece of row r = side (r & 1) of entry r >> 1
+            const int rx = __shfl(pr.x, r >> 1), ry = __shfl(pr.y, r >> 1);
+            const double* src = D.Et + 18 * (size_t)((r & 1) ? ry : rx) + 2 * piece;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + 128 * it), 16, 0, 0);
+        }
+    };
+    stage(0);
+    for (int g = 0; g < ch.z; g += 64) {
+        __builtin_amdgcn_s_waitcnt(0);  // the DMA pieces have landed (vmcnt) before any lane reads them
+        wave_lds_sync();
+        const double2* xp = reinterpret_cast<const double2*>(buf + 36 * lane);
         double x[18], y[18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            x[k] = xp[k];
-            y[k] = yp[k];
+        for (int k = 0; k < 9; ++k) {
+            const double2 a = xp[k], b = xp[9 + k];
+            x[2 * k] = a.x, x[2 * k + 1] = a.y, y[2 * k] = b.x, y[2 * k + 1] = b.y;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are in registers: LDS-DMA is not ordered behind ds_read
+        wave_lds_sync();
+        if (g + 64 < ch.z) stage(g + 64);
+        if (g + lane < ch.z) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) acc[6 * a + b] += x[3 * a] * y[3 * b] + x[3 * a + 1] * y[3 * b + 1] + x[3 * a + 2] * y[3 * b + 2];
+                for (int b = 0; b < 6; ++b) acc[6 * a + b] += x[3 * a] * y[3 * b] + x[3 * a + 1] * y[3 * b + 1] + x[3 * a + 2] * y[3 * b + 2];
+        }
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 36; ++k) buf[k * ROW + lane] = acc[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
     if (lane < 36) {
         const double* rowp = buf + lane * ROW;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four interleaved partial sums, combined in a fixed order
