@@ -63,6 +63,7 @@ constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) E
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
 constexpr int KLIN = 30;           // HKK(25) gK(5)
 constexpr int SCAL = 16;           // scalar block read back per try
+constexpr int N_FLAGS = 4 + 64;    // flags[0..3] status, [4..] hand-off flags of the back-substitution
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64: D[(lane >> 4) + 4 reg][lane & 15]
 
@@ -224,6 +225,7 @@ struct BaDev {
     double *pcg_rc, *pcg_rl, *pcg_zc, *pcg_zl, *pcg_pc, *pcg_pl, *pcg_qc, *pcg_ql, *pcg_Mc, *pcg_MK, *pcg_Ml, *pcg_Dc, *pcg_Dl,
         *pcg_p1, *pcg_p2, *pcg_p3, *pcg_s;
     int* flags;
+    double* scal_pinned;  // device view of the pinned host copy of scal[0..2] (ba_final_sums)
     int n_lm_blocks;  // grid of the per-landmark kernels
     Noise nz;
 };
@@ -439,9 +441,16 @@ __global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double*
 // ---- K-C: per-landmark elimination for one lambda (thread = landmark) -------------------------------
 // Hd = Hll + lambda clamp(diag), Hd = L L^T, Linv; EKt = ElK Linv^T, gt = Linv gl (Et_o = E_o Linv^T: K-C2).
 // Also this block's share of the (K,K) Schur term: sum EKt EKt^T (25) and EKt gt (5) -> kk_part.
+// The launch also clears S for the assembly kernels behind it (the factorisation works in place, so S is rebuilt for
+// every lambda): the stores are issued first and drain under the arithmetic — a 12 MB fill node less per try on S200.
 __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double lambda) {
     __shared__ double sm[(TPB / 64) * 30];
     const int j = blockIdx.x * TPB + threadIdx.x;
+    {
+        double2* S2 = reinterpret_cast<double2*>(D.S);  // ld is a multiple of 32: whole double2s
+        const size_t total = (size_t)(D.nr + 64) * D.ld / 2;
+        for (size_t e = (size_t)j; e < total; e += (size_t)gridDim.x * TPB) S2[e] = make_double2(0.0, 0.0);
+    }
     double kk[30];
 #pragma unroll
     for (int k = 0; k < 30; ++k) kk[k] = 0.0;
@@ -1314,8 +1323,8 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
 // so no acquire fence either — every other load of the kernel reads bytes no workgroup writes in this launch.
 // The two fences cost ~3 us per hand-off, on a chain of nsb - 1 hand-offs.
 __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nsb,
-                                                                const double* __restrict__ Winv, double* __restrict__ xv,
-                                                                int* __restrict__ flags) {
+                                                                const double* __restrict__ Winv, const double* __restrict__ y0,
+                                                                double* __restrict__ xv, int* __restrict__ flags) {
     __shared__ double xK[SB];
     __shared__ double ys[SB];
     __shared__ double part[BSTEP_THREADS / SB][SB];
@@ -1340,7 +1349,7 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
         const int r = idx / (SB - NB), c = idx % (SB - NB);
         Lin[r][c] = (c < (r / NB) * NB && c0 + r < n) ? Lm[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
     }
-    if (tid < SB) ys[tid] = (c0 + tid < n) ? xv[c0 + tid] : 0.0;
+    if (tid < SB) ys[tid] = (c0 + tid < n) ? y0[c0 + tid] : 0.0;  // xv only ever holds solutions
     // 8 threads per column, 16 rows each (rows are contiguous along columns: coalesced)
     const int cl = tid & (SB - 1), pr = tid / SB, col = c0 + cl;
     constexpr int RP = SB / (BSTEP_THREADS / SB);
@@ -1583,11 +1592,21 @@ __global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_
         if (with_lin) v[1] += lin_cam[i];
     }
     block_sum<2>(v, sm);
+    // The status word and the hand-off flags of the back-substitution are consumed here, so this kernel also clears
+    // them for the next tryLambda(), and it stores the three scalars a second time into pinned host memory: a memset
+    // node and a device-to-host copy less on the chain of every LM inner iteration.
     if (threadIdx.x == 0) {
+        const double st = (double)D.flags[0];
         D.scal[0] = v[0];
         D.scal[1] = v[1];
-        D.scal[2] = (double)D.flags[0];
+        D.scal[2] = st;
+        if (D.scal_pinned) {
+            D.scal_pinned[0] = v[0];
+            D.scal_pinned[1] = v[1];
+            D.scal_pinned[2] = st;
+        }
     }
+    if (threadIdx.x < N_FLAGS) D.flags[threadIdx.x] = 0;  // (thread 0 read flags[0] above, in program order)
 }
 
 // ---- the iterative solve the reference can select: PCG + block-Jacobi (BundleAdjuster.cpp:192-200) -----------------
@@ -2348,7 +2367,10 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks)); TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
         TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
     }
-    TRY(dev_alloc(ctx, h, &D.flags, 4 + 64));  // [0..3] status, [4..] hand-off flags of the back-substitution
+    TRY(dev_alloc(ctx, h, &D.flags, N_FLAGS));  // [0..3] status, [4..] hand-off flags of the back-substitution
+    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, N_FLAGS * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
+    EACHAM_HIP_TRY(ctx, hipHostMalloc((void**)&h->scal_host, SCAL * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
 #undef TRY
     hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
     if (e != hipSuccess) {
@@ -2403,10 +2425,8 @@ static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
 static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, double* S_copy /* host, optional */) {
     BaDev& D = h->D;
     const int n = D.n;
-    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (4 + 64) * sizeof(int), ctx->stream));
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
-        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
@@ -2436,12 +2456,12 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
             const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
             chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
         }
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
-                                           hipMemcpyDeviceToDevice, ctx->stream));
         const int nsb = (n + SB - 1) / SB;
-        if (nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES")) {
-            chol_backsolve<<<nsb, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, D.Winv, D.delta_c, D.flags);
+        if (nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES")) {  // (y = row nr of Lm is read in place)
+            chol_backsolve<<<nsb, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, D.Winv, D.Lm + (size_t)D.nr * D.ld, D.delta_c, D.flags);
         } else {  // more super-blocks than hand-off flags (n > 8192), or the diagnostic switch: one launch per super-block
+            EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
+                                               hipMemcpyDeviceToDevice, ctx->stream));
             chol_backstep<<<1, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, nsb - 1, 1, D.Winv, D.delta_c);
             for (int K = nsb - 1; K >= 1; --K) chol_backstep<<<K, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, K, 0, 0, D.Winv, D.delta_c);
         }
@@ -2461,7 +2481,6 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
 // (needs E: the linearisation ran with store_E). Same outputs as launch_try. *pcg_iterations (optional) += iterations.
 static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, long long* pcg_iterations) {
     BaDev& D = h->D;
-    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (4 + 64) * sizeof(int), ctx->stream));
     const int n_update_blocks = (D.nl + D.nc + 1 + TPB - 1) / TPB;
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
@@ -2494,9 +2513,7 @@ static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, l
 }
 
 static int read_scal(eacham_ctx* ctx, eacham_ba_handle* h, double* out3) {
-    if (!h->scal_host) EACHAM_HIP_TRY(ctx, hipHostMalloc((void**)&h->scal_host, SCAL * sizeof(double), hipHostMallocDefault));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(h->scal_host, h->D.scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // ba_final_sums stored them into the pinned block itself
     for (int k = 0; k < 3; ++k) out3[k] = h->scal_host[k];
     return EACHAM_OK;
 }
