@@ -518,7 +518,7 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
 // observation's share of the border, Et_o [gt | EKt^T] (6 x 6 = 36 products), which used to be a second pass over
 // Et with the same gathers (ba_border_partials, 36 us on S200). Workgroups are CAMERA-ALIGNED chunks of <= 256
 // observations (cam_chunks, built once per problem): a block sum per chunk -> bpart[chunk][36], added per camera in
-// chunk order by ba_assemble_border. Fixed order, no atomics.
+// chunk order by assemble_border (ba_assemble). Fixed order, no atomics.
 __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev D) {
     // The border share of an observation is Et_o (6 x 3) M_o (3 x 6), M_o = [EKt^T | gt]; its sum over the chunk runs
     // on v_mfma_f64_16x16x4_f64 with TWO observations per instruction: rows 0..5 / 8..13 of the A operand hold Et of
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
 }
 
 // ---- K-D2: assemble the camera blocks of S (thread = block element) ---------------------------------
-__global__ __launch_bounds__(TPB) void ba_assemble_blocks(BaDev D, double lambda) {
-    const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+__device__ __forceinline__ void assemble_blocks(const BaDev& D, double lambda, unsigned block) {
+    const long long idx = (long long)block * TPB + threadIdx.x;
     const int blk = (int)(idx / 36), el = (int)(idx % 36);
     if (blk >= D.n_blocks) return;
     const int4 B = D.blocks[blk];
@@ -718,8 +718,7 @@ __global__ __launch_bounds__(TPB) void ba_assemble_blocks(BaDev D, double lambda
 // ---- K-D3: the calibration border and the right-hand side -------------------------------------------
 // thread = border entry: adds the chunk partials of its camera (written by K-C2) in chunk order and writes S;
 // the last block reduces the (K,K) corner.
-__global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda) {
-    const int c = blockIdx.x;
+__device__ __forceinline__ void assemble_border(const BaDev& D, double lambda, int c) {
     if (c < D.nc) {
         if (threadIdx.x < 36) {
             const int k = threadIdx.x;
@@ -754,6 +753,13 @@ __global__ __launch_bounds__(TPB) void ba_assemble_border(BaDev D, double lambda
             D.S[(size_t)D.nr * D.ld + 6 * D.nc + (i - 25)] = D.klin[i] - s;
         }
     }
+}
+
+// K-D2 and K-D3 write disjoint parts of S from the same inputs: one launch, the block range decides the role
+// (two launches of a few microseconds each cost the chain a launch gap more).
+__global__ __launch_bounds__(TPB) void ba_assemble(BaDev D, double lambda, unsigned n_block_groups) {
+    if (blockIdx.x < n_block_groups) assemble_blocks(D, lambda, blockIdx.x);
+    else assemble_border(D, lambda, (int)(blockIdx.x - n_block_groups));
 }
 
 // ---- K-E: blocked right-looking Cholesky of S (lower triangle), rhs carried as row n ------------------
@@ -1431,8 +1437,17 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
 
 // ---- K-F: landmark back-substitution + tentative points + linearised-cost terms (thread = landmark) ----
 // delta_l = Linv^T (gt - sum_o Et_o^T dc[c_o] - EKt^T dK);  lin += 1/2 (dl.gl + lambda dl.D dl)
-__global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lambda) {
+__device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lambda, const double* pose_in, double* pose_out,
+                                               const double* K_in, double* K_out, int apply_delta, double* err_cam,
+                                               double* lin_cam);
+// The workgroups behind the landmarks' (blockIdx.x >= n_lm_blocks) retract the cameras and K (K-G1, thread = camera):
+// both read delta_c and nothing of each other, and a launch of one workgroup costs the chain as much as this one.
+__global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lambda, double* err_cam, double* lin_cam) {
     __shared__ double sm[(TPB / 64) * 1];
+    if ((int)blockIdx.x >= D.n_lm_blocks) {
+        retract_camera(D, ((int)blockIdx.x - D.n_lm_blocks) * TPB + threadIdx.x, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, err_cam, lin_cam);
+        return;
+    }
     const int j = blockIdx.x * TPB + threadIdx.x;
     double lin[1] = {0.0};
     if (j < D.nl) {
@@ -1501,10 +1516,9 @@ __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lamb
 
 // ---- K-G1: retract cameras + K, pose/K prior errors and their linearised-cost terms (thread = camera) --
 // err_cam[c] = prior error at the NEW pose; lin_cam[c] = 1/2 (dc.gc + lambda dc.D dc); slot nc = K.
-__global__ void ba_retract_cameras(BaDev D, double lambda, const double* pose_in, double* pose_out,
-                                   const double* K_in, double* K_out, int apply_delta, double* err_cam,
-                                   double* lin_cam) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lambda, const double* pose_in, double* pose_out,
+                                               const double* K_in, double* K_out, int apply_delta, double* err_cam,
+                                               double* lin_cam) {
     if (c < D.nc) {
         const double* x = pose_in + 12 * (size_t)c;
         double y[12];
@@ -1542,6 +1556,11 @@ __global__ void ba_retract_cameras(BaDev D, double lambda, const double* pose_in
         err_cam[D.nc] = e;
         lin_cam[D.nc] = lin;
     }
+}
+__global__ void ba_retract_cameras(BaDev D, double lambda, const double* pose_in, double* pose_out,
+                                   const double* K_in, double* K_out, int apply_delta, double* err_cam,
+                                   double* lin_cam) {
+    retract_camera(D, blockIdx.x * blockDim.x + threadIdx.x, lambda, pose_in, pose_out, K_in, K_out, apply_delta, err_cam, lin_cam);
 }
 
 // ---- K-G2: nonlinear error of the reprojection + landmark-prior factors (thread = landmark) -----------
@@ -2430,8 +2449,8 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
-        if (D.n_blocks > 0) ba_assemble_blocks<<<(unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB), TPB, 0, ctx->stream>>>(D, lambda);
-        ba_assemble_border<<<D.nc + 1, TPB, 0, ctx->stream>>>(D, lambda);
+        const unsigned nbg = (unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB);
+        ba_assemble<<<nbg + D.nc + 1, TPB, 0, ctx->stream>>>(D, lambda, nbg);
     }
     if (S_copy) {
         EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2468,8 +2487,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
-        ba_backsub_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
-        ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
+        ba_backsub_landmarks<<<D.n_lm_blocks + (D.nc + 1 + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam);
         ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
         ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1);
     }
