@@ -27,6 +27,8 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -1599,7 +1601,7 @@ __global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double*
 }
 
 // ---- K-G3: fixed-order final sums -> scal[0] = error, scal[1] = linearised cost change -----------------
-__global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_cam, const double* lin_cam, int with_lin) {
+__global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_cam, const double* lin_cam, int with_lin, double ticket) {
     __shared__ double sm[(TPB / 64) * 2];
     double v[2] = {0.0, 0.0};
     for (int i = threadIdx.x; i < D.n_lm_blocks; i += TPB) {
@@ -1619,10 +1621,12 @@ __global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_
         D.scal[0] = v[0];
         D.scal[1] = v[1];
         D.scal[2] = st;
-        if (D.scal_pinned) {
+        if (D.scal_pinned) {  // the host polls slot 3 for this launch's ticket (read_scal): the values first, fenced
             D.scal_pinned[0] = v[0];
             D.scal_pinned[1] = v[1];
             D.scal_pinned[2] = st;
+            __threadfence_system();
+            *(volatile double*)&D.scal_pinned[3] = ticket;
         }
     }
     if (threadIdx.x < N_FLAGS) D.flags[threadIdx.x] = 0;  // (thread 0 read flags[0] above, in program order)
@@ -2158,6 +2162,7 @@ struct eacham_ba_handle {
     std::vector<int> lm_order;  // landmark-sorted observation index -> caller's observation index
     double *kpart = nullptr, *err_cam = nullptr, *lin_cam = nullptr;
     double* scal_host = nullptr;  // pinned: the per-try scalar read-back sits on the LM loop's critical path
+    long long ticket = 0;         // number of the last ba_final_sums launch (it stores it behind the scalars)
     double *pose_init = nullptr, *pt_init = nullptr, *K_init = nullptr;
     int n_landmarks_used = 0;
     size_t bytes_linearize = 0, bytes_try = 0;
@@ -2390,6 +2395,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, N_FLAGS * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
     EACHAM_HIP_TRY(ctx, hipHostMalloc((void**)&h->scal_host, SCAL * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
+    for (int k = 0; k < SCAL; ++k) h->scal_host[k] = 0.0;  // (tickets start at 1)
 #undef TRY
     hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
     if (e != hipSuccess) {
@@ -2428,7 +2434,7 @@ static void launch_error(eacham_ctx* ctx, eacham_ba_handle* h, const double* pos
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
     ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, pose, D.pose_new, Kc, D.K_new, 0, h->err_cam, h->lin_cam);
     ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
-    ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0);
+    ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0, (double)++h->ticket);
 }
 
 static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
@@ -2489,7 +2495,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
         ba_backsub_landmarks<<<D.n_lm_blocks + (D.nc + 1 + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam);
         ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
-        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1);
+        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1, (double)++h->ticket);
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     return EACHAM_OK;
@@ -2524,14 +2530,29 @@ static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, l
         pcg_landmark_step<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
         ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
-        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1);
+        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1, (double)++h->ticket);
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     return EACHAM_OK;
 }
 
 static int read_scal(eacham_ctx* ctx, eacham_ba_handle* h, double* out3) {
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // ba_final_sums stored them into the pinned block itself
+    // ba_final_sums stored them into the pinned block itself, its ticket last. The LM loop is one host round trip per
+    // tryLambda(): waking up from hipStreamSynchronize and only then deciding and launching left the device idle for
+    // ~25 us per inner iteration on S200, so the host first watches the ticket for a bounded while (the stream is
+    // still in order: what is launched next runs behind that kernel) and only then falls back to the blocking wait.
+    {
+        volatile double* sh = h->scal_host;
+        const double want = (double)h->ticket;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (int spin = 0;; ++spin) {
+            if (sh[3] == want) { seen = true; break; }
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        }
+        if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+        else EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     for (int k = 0; k < 3; ++k) out3[k] = h->scal_host[k];
     return EACHAM_OK;
 }
@@ -2641,7 +2662,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
                         ba_dl_apply<<<(na + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, cu * alpha, cn);
                         ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
                         ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
-                        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0);
+                        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0, (double)++h->ticket);
                     }
                     rc = read_scal(ctx, h, sc);
                     if (rc) return rc;
