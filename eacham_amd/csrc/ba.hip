@@ -61,6 +61,7 @@ static Noise make_noise() {
 constexpr int TPB = 256;           // threads per block of the streaming kernels
 constexpr int PAIR_CHUNK = 256;    // pair-list entries summed by one wave (lane e takes entries e, e+64, ...)
 constexpr int NB = 32;             // Cholesky block size
+constexpr int PB = 2 * NB;         // columns retired per launch of the factorisation (chol_step64)
 constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) ElK(15)
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
 constexpr int KLIN = 30;           // HKK(25) gK(5)
@@ -216,7 +217,7 @@ struct BaDev {
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
-    double *Et, *lmtry, *S, *Lm, *Winv, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
+    double *Et, *lmtry, *S, *Lm, *Winv, *Wops, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
     double *dl_nc, *dl_nl, *dl_part;
     double* bpart;  // [n_cam_chunks][36] partial border sums
@@ -934,7 +935,34 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
 // that folding: row blocks of four alternate between them (block rb belongs to half rb & 1), the finished w's
 // cross with v_permlane32_swap. A lone wave issues one v_fma_f64 per ~8 cycles: on one half-wave the folding
 // alone outlasts the factor.
-__device__ __forceinline__ void invert_behind_factor(const FactorImage& F, double* __restrict__ Wout, int* __restrict__ flags) {
+// A lower-triangular 32x32 inverse W as the B operand of the panel product L = A W^T: lane (j = lane & 15, kk = lane >> 4)
+// of k-step t holds W[j][4t + kk] (rows 0..15, t < 4: slots 0..3) or W[16 + j][4t + kk] (t < 8: slots 4..11). Stored in
+// that order — two slots per 16-byte lane element, op_index — a consumer wave fetches a slot pair with ONE coalesced 1 KB load; read from the
+// row-major image, 64 lanes x 8 bytes out of 16 different rows, the operand fetches of chol_step64 (40 per wave) took
+// most of 19k cycles per launch. X (a full 32x32 block) uses slots 0..7 for its rows 0..15 and 8..15 for rows 16..31.
+constexpr int WOP = 12 * 64, XOP = 16 * 64, TILE_OPS = 2 * WOP + XOP;  // per 64x64 diagonal tile: W_a | W_b | X
+__device__ __forceinline__ int op_index(int slot, int lane) { return (slot >> 1) * 128 + 2 * lane + (slot & 1); }  // slot pairs: 16-byte loads
+__device__ __forceinline__ int wop_index(int row, int col) {
+    return row < 16 ? op_index(col >> 2, (col & 3) * 16 + row) : op_index(4 + (col >> 2), (col & 3) * 16 + row - 16);
+}
+__device__ __forceinline__ int xop_index(int row, int col) {
+    return row < 16 ? op_index(col >> 2, (col & 3) * 16 + row) : op_index(8 + (col >> 2), (col & 3) * 16 + row - 16);
+}
+// W (LDS image, row stride wls) -> global memory, row-major (back-substitution) and in operand order, by `nthreads` threads
+template <int NT>
+__device__ __forceinline__ void publish_w(const double* Wl, int wls, double* __restrict__ Wout, double* __restrict__ Wop, int thread) {
+    double v[NB * NB / NT];
+#pragma unroll
+    for (int m = 0; m < NB * NB / NT; ++m) v[m] = Wl[((thread + NT * m) / NB) * wls + (thread + NT * m) % NB];  // every read first
+#pragma unroll
+    for (int m = 0; m < NB * NB / NT; ++m) {
+        const int e = thread + NT * m, row = e / NB, col = e % NB;
+        Wout[e] = v[m];
+        if (row >= 16 || col < 16) Wop[wop_index(row, col)] = v[m];
+    }
+}
+__device__ __forceinline__ void invert_behind_factor(const FactorImage& F, double* __restrict__ Wout, int* __restrict__ flags,
+                                                     double* Wlds = nullptr, int wls = 0 /* LDS copy, row stride; Wout may then be null */) {
     const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
     double rhs[NB / 2];  // rhs[4p + a] = row 4 (2p + hh) + a
 #pragma unroll
@@ -964,7 +992,10 @@ __device__ __forceinline__ void invert_behind_factor(const FactorImage& F, doubl
         w[3] = __builtin_fma(-l32, w[2], __builtin_fma(-l3x.y, w[1], __builtin_fma(-l3x.x, w[0], rhs[4 * (s >> 1) + 3]))) * dv23.y;
         if (hh == (s & 1)) {
 #pragma unroll
-            for (int a2 = 0; a2 < 4; ++a2) Wout[(4 * s + a2) * NB + c] = w[a2];
+            for (int a2 = 0; a2 < 4; ++a2) {
+                if (Wout) Wout[(4 * s + a2) * NB + c] = w[a2];
+                if (Wlds) Wlds[(4 * s + a2) * wls + c] = w[a2];
+            }
         }
         if (s == NB / 4 - 1) break;
 #pragma unroll
@@ -1221,6 +1252,389 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
             }
     }
     if (first) store_panel(rest_idx, 128);
+}
+
+// ---- K-E in steps of 64 columns ---------------------------------------------------------------------------------
+// The chain of a 32-column step is launch + loads (6k cycles) + panel product + look-ahead update (3.6k) + the
+// one-wave factor (10k): a third of it is paid per LAUNCH, not per column. A 64x64 diagonal tile holds two diagonal
+// blocks a, b, and everything the second one needs — L_ba = A'_ba W_a^T and D_b = A'_bb - L_ba L_ba^T — comes from
+// the tile itself, so one workgroup can factorise both without a launch in between. chol_step64 therefore retires
+// 64 columns per launch:
+//   * the panel of a tile row is ONE product with the inverse of the 64x64 factor, [L_ia L_ib] = [A_ia A_ib] W64^T,
+//     W64 = [[W_a, 0], [X, W_b]], X = -W_b L_ba W_a (stored by the producer next to W_a, W_b). Both operands come
+//     straight from global memory in MFMA operand layout (lane (i, kk) holds element [i][4t + kk]): 40 MFMAs per 16
+//     rows, no LDS staging, no barrier before the product;
+//   * the trailing update is rank 64 (half the reads and writes of the trailing matrix per retired column: the first
+//     steps of a 3005-column system are bound by that traffic);
+//   * tile (0,0) updates its first quadrant first (waves 0-2), then wave 0 factorises it, wave 1 inverts behind it and
+//     waves 2-3 update the other quadrants (kept in registers); after a barrier waves 0-1 form L_ba, waves 0-2 D_b,
+//     then wave 0 factorises D_b, wave 1 inverts, waves 2-3 form L_ba W_a, and all four waves finish X.
+// LDS: two 64 x 66 strips (67.6 KB, two workgroups per CU). Tile (0,0) is a diagonal tile — it never uses the second
+// strip — and its first strip is dead once the quadrants are updated: the factor images live in the second strip's
+// region, the four 32 x 33 images of the second half in the first's.
+constexpr int LS2 = PB + 2;  // row stride of the strips
+constexpr int TS = NB + 1;   // row stride of the 32x32 images of the second half (8-byte accesses only)
+constexpr int WLS = NB + 2;  // row stride of the LDS copy of W_a
+
+// L = A W^T for 16 rows whose A operand a[0..7] (columns 0..31) sits in registers, W (lower triangular, row stride ws)
+// in LDS or global memory: columns 0..15 -> x0, 16..31 -> x1 + x2
+__device__ __forceinline__ void panel32(const double (&a)[8], const double* __restrict__ W, int ws, int mc, int mg, mfma_d4& lo,
+                                        mfma_d4& hi) {
+    mfma_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], W[mc * ws + 4 * t + mg], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], W[(16 + mc) * ws + 4 * t + mg], x1, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t + 4], W[(16 + mc) * ws + 4 * t + 16 + mg], x2, 0, 0, 0);
+    }
+    lo = x0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) hi[reg] = x1[reg] + x2[reg];
+}
+
+struct DiagImages {  // LDS views of a 64x64 diagonal tile being factorised
+    double (*Dn)[NB + 1];
+    double* Pslab;    // [NB * PLD], 16-byte aligned
+    FactorImage* F;
+    double* Wa;       // [NB][WLS] copy of W_a (written by the inverting wave of the first half)
+    double* T10;      // [NB][TS] A'_ba, then L_ba
+    double* T11;      // [NB][TS] A'_bb
+    double* P1;       // [NB][TS] L_ba W_a
+    double* Wb;       // [NB][TS] copy of W_b
+};
+
+// Second half of a diagonal tile: every thread of the workgroup, after a barrier behind which W_a (LDS copy), T10 and
+// T11 are complete. kb = global index of block b's first row. Stores L_ba -> Lm, W_b -> Wout_b (row-major, for the
+// back-substitution) and Wop_b, X -> Xop (operand order, for the next launch's panel products).
+__device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, int n, int ld, double* __restrict__ Lm,
+                                                 double* __restrict__ Wout_b, double* __restrict__ Wop_b, double* __restrict__ Xop,
+                                                 int* __restrict__ flags, int w0 = 0, unsigned long long st_prev = 0) {
+    const int tid = threadIdx.x, mc = tid & 15, mg = (tid >> 4) & 3;
+    int wv = (tid >> 6) - w0;  // waves w0, w0 + 1 form L_ba (in chol_step64 the two that just wrote those rows of T10)
+    if (wv >= 0 && wv < 2) {  // L_ba = A'_ba W_a^T, 16 rows per wave, in place (the wave's own rows: reads before writes, in LDS order)
+        double a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = I.T10[(16 * wv + mc) * TS + 4 * t + mg];
+        mfma_d4 lo, hi;
+        panel32(a, I.Wa, WLS, mc, mg, lo, hi);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * wv + mg + 4 * reg;
+            I.T10[row * TS + mc] = lo[reg];
+            I.T10[row * TS + 16 + mc] = hi[reg];
+            if (kb + row < n) {  // (columns kb - 32 .. kb - 1 are inside the matrix whenever block b has a real row)
+                Lm[(size_t)(kb + row) * ld + kb - NB + mc] = lo[reg];
+                Lm[(size_t)(kb + row) * ld + kb - NB + 16 + mc] = hi[reg];
+            }
+        }
+    }
+    if (tid == 0) I.F->progress = 0;
+    wv = tid >> 6;
+    __syncthreads();
+    if (st_prev) BSTAMP(5);
+    if (wv < 3) {  // D_b = A'_bb - L_ba L_ba^T, one 16x16 block of the lower triangle per wave
+        const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;
+        mfma_d4 m0, m1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) m0[reg] = I.T11[(mbi + mg + 4 * reg) * TS + mbj + mc];
+#pragma unroll
+        for (int t = 0; t < NB / 4; t += 2) {
+            const double a0 = I.T10[(mbi + mc) * TS + 4 * t + mg], b0 = I.T10[(mbj + mc) * TS + 4 * t + mg];
+            const double a1 = I.T10[(mbi + mc) * TS + 4 * t + 4 + mg], b1 = I.T10[(mbj + mc) * TS + 4 * t + 4 + mg];
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rr = mbi + mg + 4 * reg, cc = mbj + mc;  // rows / columns past n: identity padding
+            I.Dn[rr][cc] = (kb + rr < n && kb + cc < n) ? m0[reg] + m1[reg] : (rr == cc ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    if (st_prev) BSTAMP(6);
+    if (wv == 0) {
+        factor_32(I.Dn, *reinterpret_cast<double (*)[NB * PLD]>(I.Pslab), *I.F, flags);
+        if (st_prev) BSTAMP(7);
+    } else if (wv == 1) {
+        invert_behind_factor(*I.F, nullptr, flags, I.Wb, TS);
+    } else {  // P1 = L_ba W_a beside the factor: rows 16 (wv - 2) .., W_a[k][j] = 0 for k < j
+        const int bi = wv - 2;
+        mfma_d4 p0 = {0.0, 0.0, 0.0, 0.0}, p1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double a = I.T10[(16 * bi + mc) * TS + 4 * t + mg];
+            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, I.Wa[(4 * t + mg) * WLS + mc], p0, 0, 0, 0);
+            if (t >= 4) p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, I.Wa[(4 * t + mg) * WLS + 16 + mc], p1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            I.P1[(16 * bi + mg + 4 * reg) * TS + mc] = p0[reg];
+            I.P1[(16 * bi + mg + 4 * reg) * TS + 16 + mc] = p1[reg];
+        }
+    }
+    __syncthreads();
+    if (st_prev) BSTAMP(9);
+    {   // X = -W_b P1: one 16x16 block per wave, W_b[i][k] = 0 for k > i; W_b is published in the shadow of the chain
+        const int bi = wv >> 1, bj = wv & 1;
+        mfma_d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < 4 * (bi + 1))
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(-I.Wb[(16 * bi + mc) * TS + 4 * t + mg], I.P1[(4 * t + mg) * TS + 16 * bj + mc], x, 0, 0, 0);
+        publish_w<TPB>(I.Wb, TS, Wout_b, Wop_b, tid);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Xop[xop_index(16 * bi + mg + 4 * reg, 16 * bj + mc)] = x[reg];
+    }
+    if (st_prev) BSTAMP(10);
+}
+
+// the first diagonal tile: W_0, W_1, L_10 and X_0
+__global__ __launch_bounds__(TPB) void chol_diag64(const double* __restrict__ A, double* __restrict__ Lm, int ld, int n,
+                                                   double* __restrict__ Winv, double* __restrict__ Wops, int* __restrict__ flags) {
+    __shared__ double Dn[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
+    __shared__ __attribute__((aligned(16))) FactorImage Fimg;
+    __shared__ double Wa[NB * WLS], T10[NB * TS], T11[NB * TS], P1[NB * TS], Wb[NB * TS];
+    const int tid = threadIdx.x;
+    double raw[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {  // the three quadrants of the lower triangle, all loads in flight together (S is zero-padded)
+        const int q = m >> 2, idx = tid + TPB * (m & 3), i = idx / NB + (q > 0 ? NB : 0), j = idx % NB + (q == 2 ? NB : 0);
+        raw[m] = A[(size_t)i * ld + j];
+    }
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+        const int q = m >> 2, idx = tid + TPB * (m & 3), i = idx / NB, j = idx % NB;
+        const int gi = i + (q > 0 ? NB : 0), gj = j + (q == 2 ? NB : 0);
+        const bool in = gi < n && gj < n;
+        if (q == 0) Dn[i][j] = in ? raw[m] : (i == j ? 1.0 : 0.0);
+        else if (q == 1) T10[i * TS + j] = in ? raw[m] : 0.0;
+        else T11[i * TS + j] = in ? raw[m] : (i == j ? 1.0 : 0.0);
+    }
+    if (tid == 0) Fimg.progress = 0;
+    __syncthreads();
+    if (tid < 64) factor_32(Dn, Pslab, Fimg, flags, true);
+    else if (tid < 128) invert_behind_factor(Fimg, nullptr, flags, Wa, WLS);
+    __syncthreads();
+    if (tid >= 128) publish_w<128>(Wa, WLS, Winv, Wops, tid - 128);  // (waves 0-1 form L_ba next)
+    DiagImages I{Dn, Pslab, &Fimg, Wa, T10, T11, P1, Wb};
+    diag_second_half(I, NB, n, ld, Lm, Winv + NB * NB, Wops + WOP, Wops + 2 * WOP, flags);
+}
+
+// [L_a L_b] = [A_a A_b] W64^T for the wave's 16 rows of a strip, in place: every operand read of the strip precedes the
+// writes in the wave's LDS order. wa / wb: W_a / W_b in operand order (wop_index), xp: X (xop_index).
+__device__ __forceinline__ void panel64(double (*strip)[LS2], int wv, int mc, int mg, const double (&wa)[12], const double (&wb)[12],
+                                        const double (&xp)[16]) {
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = strip[16 * wv + mc][4 * q + mg];
+    mfma_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, y0 = x0, y1 = x0, y2 = x0, y3 = x0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], wa[q], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], wa[4 + q], x1, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 + q], wa[8 + q], x2, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 + q], wb[q], y1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xp[q], y0, 0, 0, 0);
+        y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xp[8 + q], y2, 0, 0, 0);
+        y3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 + q], wb[4 + q], y3, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        double* row = strip[16 * wv + mg + 4 * reg];
+        row[mc] = x0[reg];
+        row[16 + mc] = x1[reg] + x2[reg];
+        row[32 + mc] = y0[reg] + y1[reg];
+        row[48 + mc] = y2[reg] + y3[reg];
+    }
+}
+
+// the 64 x 64 panel of a tile row: LDS -> Lm, coalesced, every LDS read in flight before the first store
+template <int NT>
+__device__ __forceinline__ void store_panel64(double (*Li)[LS2], double* __restrict__ Lm, int ld, int n, int nr, int i0, int k0, int thread) {
+    constexpr int PER = 64 * (PB / 2) / NT;
+#pragma unroll
+    for (int h = 0; h < PER; h += 8) {  // eight 16-byte pieces at a time (sixteen registers)
+        double2 v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int e = thread + NT * (h + m);
+            v[m] = *reinterpret_cast<const double2*>(&Li[e / (PB / 2)][(e % (PB / 2)) * 2]);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int e = thread + NT * (h + m), rr = e / (PB / 2), lp = (e % (PB / 2)) * 2, grow = i0 + rr;
+            if ((grow < n || grow == nr) && k0 + lp < n) *reinterpret_cast<double2*>(&Lm[(size_t)grow * ld + k0 + lp]) = v[m];
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr, int k0,
+                                                      double* __restrict__ Winv, double* __restrict__ Wops, int* __restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 64 * LS2];
+    double (*Li)[LS2] = reinterpret_cast<double (*)[LS2]>(lds);
+    double (*Lj)[LS2] = reinterpret_cast<double (*)[LS2]>(lds + 64 * LS2);
+#ifdef EXP_BA_STAMPS
+    unsigned long long st_prev = __builtin_readcyclecounter();
+#else
+    const unsigned long long st_prev = 0;
+#endif
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mc = tid & 15, mg = (tid >> 4) & 3;
+    const int k1 = k0 + PB;
+    int t = blockIdx.x, ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
+    const bool same = ti == tj;
+    const bool first = t == 0 && k1 < n;  // the tile that holds the next two diagonal blocks
+    // Every global read is issued up front, none is predicated (see chol_step: S has 64 rows and columns of padding).
+    // A wave fetches ITS 16 rows of each raw strip, two whole rows (2 x 512 bytes) per instruction, and is the only
+    // reader of their LDS image: no workgroup barrier before the panel product.
+    double2 pi[8], pj[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) pi[m] = *reinterpret_cast<const double2*>(&A[(size_t)(i0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)  // (a diagonal tile fetches the same rows twice: the second strip is then never used)
+        pj[m] = *reinterpret_cast<const double2*>(&A[(size_t)(j0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
+    // the B operands of the panel product, stored in operand order by the producer: one coalesced load per k-step
+    const double* __restrict__ ops = Wops + (size_t)(k0 / PB) * TILE_OPS;
+    double wa[12], wb[12], xp[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (q < 6) {
+            const double2 u = *reinterpret_cast<const double2*>(&ops[op_index(2 * q, lane)]), v = *reinterpret_cast<const double2*>(&ops[WOP + op_index(2 * q, lane)]);
+            wa[2 * q] = u.x, wa[2 * q + 1] = u.y, wb[2 * q] = v.x, wb[2 * q + 1] = v.y;
+        }
+        const double2 u = *reinterpret_cast<const double2*>(&ops[2 * WOP + op_index(2 * q, lane)]);
+        xp[2 * q] = u.x, xp[2 * q + 1] = u.y;
+    }
+    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;  // first quadrant of tile 0: blocks (0,0), (1,0), (1,1)
+    const bool block_thread = !first || wv >= 2;             // a wave owns 16 rows of the tile and its four 16-column blocks
+    mfma_d4 old[4];
+    if (block_thread) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                old[cb][reg] = (same && cb > wv) ? 0.0 : A[(size_t)(i0 + 16 * wv + mg + 4 * reg) * ld + j0 + 16 * cb + mc];
+    }
+    mfma_d4 mold = {0.0, 0.0, 0.0, 0.0};
+    if (first && wv < 3) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(size_t)(i0 + mbi + mg + 4 * reg) * ld + j0 + mbj + mc];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        *reinterpret_cast<double2*>(&Li[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pi[m];
+        *reinterpret_cast<double2*>(&Lj[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pj[m];
+    }
+    wave_lds_sync();
+    panel64(Li, wv, mc, mg, wa, wb, xp);
+    if (!same) panel64(Lj, wv, mc, mg, wa, wb, xp);
+    __syncthreads();
+    BSTAMP(0);
+    double (*LjE)[LS2] = same ? Li : Lj;
+    // the tiles of the first tile column keep the panel for the back-substitution (coalesced, from LDS)
+    if (tj == 0 && !first) store_panel64<TPB>(Li, Lm, ld, n, nr, i0, k0, tid);
+    if (first) {
+        // images of the factorisation: second strip's region (a diagonal tile never writes it)
+        double* base = lds + 64 * LS2;
+        double (*Dn)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(base);
+        double* Pslab = base + NB * (NB + 1);  // 1056 doubles in: 16-byte aligned
+        FactorImage* F = reinterpret_cast<FactorImage*>(Pslab + NB * PLD);
+        double* Wal = reinterpret_cast<double*>(F) + (sizeof(FactorImage) + 7) / 8 + 1;
+        static_assert(NB * (NB + 1) % 2 == 0 && (NB * PLD) % 2 == 0, "Pslab and the factor image stay 16-byte aligned");
+        static_assert(NB * (NB + 1) + NB * PLD + (sizeof(FactorImage) + 7) / 8 + 1 + NB * WLS <= 64 * LS2, "the images fit the second strip");
+        static_assert(4 * NB * TS <= 64 * LS2, "the images of the second half fit the first strip");
+        DiagImages I{Dn, Pslab, F, Wal, lds, lds + NB * TS, lds + 2 * NB * TS, lds + 3 * NB * TS};
+        if (tid == 0) F->progress = 0;
+        if (wv < 3) {  // first quadrant: A_00 - L_0 L_0^T over the 64 panel columns
+            mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < PB / 4; q += 2) {
+                const double a0 = Li[mbi + mc][4 * q + mg], b0 = Li[mbj + mc][4 * q + mg];
+                const double a1 = Li[mbi + mc][4 * q + 4 + mg], b1 = Li[mbj + mc][4 * q + 4 + mg];
+                m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
+                m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = mbi + mg + 4 * reg, cc = mbj + mc;
+                Dn[rr][cc] = (k1 + rr < n && k1 + cc < n) ? m0[reg] + m1[reg] : (rr == cc ? 1.0 : 0.0);
+            }
+        }
+        __syncthreads();
+        BSTAMP(1);
+#ifdef EXP_BA_STAMPS
+        const unsigned long long st_q = __builtin_readcyclecounter();
+#endif
+        if (wv == 0) {
+            factor_32(Dn, *reinterpret_cast<double (*)[NB * PLD]>(Pslab), *F, flags);
+            BSTAMP(2);
+        } else if (wv == 1) {
+            invert_behind_factor(*F, nullptr, flags, Wal, WLS);
+#ifdef EXP_BA_STAMPS
+            if (lane == 0) atomicAdd(&g_ba_dbg[12], __builtin_readcyclecounter() - st_q);
+#endif
+        } else {  // rows 32..63 of the tile beside the factor; the results stay in registers until the strip is dead
+#pragma unroll
+            for (int q = 0; q < PB / 4; ++q) {
+                const double av = -Li[16 * wv + mc][4 * q + mg];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    if (cb <= wv) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
+            }
+#ifdef EXP_BA_STAMPS
+            if (lane == 0) atomicAdd(&g_ba_dbg[wv == 2 ? 13 : 11], __builtin_readcyclecounter() - st_q);
+#endif
+            store_panel64<128>(Li, Lm, ld, n, nr, i0, k0, tid - 128);
+#ifdef EXP_BA_STAMPS
+            if (lane == 0 && wv == 3) atomicAdd(&g_ba_dbg[14], __builtin_readcyclecounter() - st_q);
+#endif
+        }
+        __syncthreads();  // the strip is dead: W_a's copy, the factor of block a and every read of Li are complete
+        BSTAMP(3);
+        if (wv >= 2) {  // the wave's 16 rows of A'_ba (own rows of T10: wave-local) and of A'_bb
+            const int r0 = 16 * (wv - 2);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = r0 + mg + 4 * reg, col = 16 * (cb & 1) + mc;
+                    const bool rin = k1 + NB + row < n;
+                    if (cb < 2) I.T10[row * TS + col] = (rin && k1 + col < n) ? old[cb][reg] : 0.0;
+                    else I.T11[row * TS + col] = (rin && k1 + NB + col < n) ? old[cb][reg] : (row == col ? 1.0 : 0.0);
+                }
+            wave_lds_sync();
+        } else {  // waves 0-1 are idle until D_b: they publish W_a
+            publish_w<128>(Wal, WLS, Winv + (size_t)(k1 / NB) * NB * NB, Wops + (size_t)(k1 / PB) * TILE_OPS, tid);
+        }
+#ifdef EXP_BA_STAMPS
+        if (tid == 0) atomicAdd(&g_ba_dbg[15], 1ull);
+#endif
+        diag_second_half(I, k1 + NB, n, ld, Lm, Winv + (size_t)(k1 / NB + 1) * NB * NB, Wops + (size_t)(k1 / PB) * TILE_OPS + WOP,
+                         Wops + (size_t)(k1 / PB) * TILE_OPS + 2 * WOP, flags, 2, st_prev);
+        return;
+    }
+    // A_ij -= L_i L_j^T over the 64 panel columns: the four 16-column blocks of the wave's rows as four chains
+#pragma unroll
+    for (int q = 0; q < PB / 4; ++q) {
+        const double av = -Li[16 * wv + mc][4 * q + mg];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+            if (!(same && cb > wv)) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LjE[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = i0 + 16 * wv + mg + 4 * reg, j = j0 + 16 * cb + mc;
+            const bool inside = (i < n || i == nr) && j < n && j <= i;
+            if (inside && !(same && cb > wv)) A[(size_t)i * ld + j] = old[cb][reg];
+        }
 }
 
 // back substitution L^T x = y (y = row nr of Lm) in super-blocks of SB = 4 x NB columns, one launch per
@@ -2215,7 +2629,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     BaDev& D = h->D;
     memset(&D, 0, sizeof(D));
     D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
-    D.nr = ((D.n + NB - 1) / NB) * NB;
+    D.nr = ((D.n + PB - 1) / PB) * PB;  // whole 64-column steps (chol_step64); rows / columns n..nr-1 are identity padding
     // 64 columns (and, for S, 64 rows) of zero padding beyond the last 64x64 tile a Cholesky step can touch:
     // chol_step reads its tiles without bounds tests. An odd multiple of 256 bytes as the row stride keeps
     // a column of S from landing on one memory channel.
@@ -2367,6 +2781,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
     TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
+    TRY(dev_alloc(ctx, h, &D.Wops, (size_t)(D.nr / PB) * TILE_OPS));  // W_a, W_b, X = -W_b L_ba W_a of every 64x64 diagonal tile in operand order
     TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
     TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
     TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
@@ -2475,11 +2890,20 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
 #endif
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
-        chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
-        for (int k0 = 0; k0 < n; k0 += NB) {
-            const int k1 = k0 + NB;
-            const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-            chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
+        if (getenv("EACHAM_BA_CHOL32")) {  // diagnostic switch: one launch per 32 columns
+            chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
+            for (int k0 = 0; k0 < n; k0 += NB) {
+                const int k1 = k0 + NB;
+                const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
+                chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
+            }
+        } else {
+            chol_diag64<<<1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.Winv, D.Wops, D.flags);
+            for (int k0 = 0; k0 < D.nr; k0 += PB) {
+                const int k1 = k0 + PB;
+                const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
+                chol_step64<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
+            }
         }
         const int nsb = (n + SB - 1) / SB;
         if (nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES")) {  // (y = row nr of Lm is read in place)
