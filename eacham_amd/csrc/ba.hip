@@ -1376,14 +1376,16 @@ __device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, in
     if (st_prev) BSTAMP(9);
     {   // X = -W_b P1: one 16x16 block per wave, W_b[i][k] = 0 for k > i; W_b is published in the shadow of the chain
         const int bi = wv >> 1, bj = wv & 1;
-        mfma_d4 x = {0.0, 0.0, 0.0, 0.0};
+        mfma_d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = x;  // two chains: a dependent f64 MFMA waits out the full 64-cycle pass
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (t < 4 * (bi + 1))
+        for (int t = 0; t < 8; t += 2)
+            if (t < 4 * (bi + 1)) {
                 x = __builtin_amdgcn_mfma_f64_16x16x4f64(-I.Wb[(16 * bi + mc) * TS + 4 * t + mg], I.P1[(4 * t + mg) * TS + 16 * bj + mc], x, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-I.Wb[(16 * bi + mc) * TS + 4 * t + 4 + mg], I.P1[(4 * t + 4 + mg) * TS + 16 * bj + mc], x2, 0, 0, 0);
+            }
         publish_w<TPB>(I.Wb, TS, Wout_b, Wop_b, tid);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Xop[xop_index(16 * bi + mg + 4 * reg, 16 * bj + mc)] = x[reg];
+        for (int reg = 0; reg < 4; ++reg) Xop[xop_index(16 * bi + mg + 4 * reg, 16 * bj + mc)] = x[reg] + x2[reg];
     }
     if (st_prev) BSTAMP(10);
 }
@@ -1599,14 +1601,15 @@ __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, do
         BSTAMP(3);
         if (wv >= 2) {  // the wave's 16 rows of A'_ba (own rows of T10: wave-local) and of A'_bb
             const int r0 = 16 * (wv - 2);
+            const bool interior = k1 + PB <= n;
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int row = r0 + mg + 4 * reg, col = 16 * (cb & 1) + mc;
-                    const bool rin = k1 + NB + row < n;
-                    if (cb < 2) I.T10[row * TS + col] = (rin && k1 + col < n) ? old[cb][reg] : 0.0;
-                    else I.T11[row * TS + col] = (rin && k1 + NB + col < n) ? old[cb][reg] : (row == col ? 1.0 : 0.0);
+                    const bool rin = interior || k1 + NB + row < n;  // (a tile inside the matrix takes no padding)
+                    if (cb < 2) I.T10[row * TS + col] = (rin && (interior || k1 + col < n)) ? old[cb][reg] : 0.0;
+                    else I.T11[row * TS + col] = (rin && (interior || k1 + NB + col < n)) ? old[cb][reg] : (row == col ? 1.0 : 0.0);
                 }
             wave_lds_sync();
         } else {  // waves 0-1 are idle until D_b: they publish W_a

@@ -56,7 +56,7 @@ def test_step_with_repeated_camera_and_cheirality(hip_ctx):
     assert np.isclose(err, erro, rtol=1e-12) and not dl[-1].any()
 
 
-@pytest.mark.parametrize("n_cams", [2, 3, 5, 10, 11, 16, 21, 22, 43])
+@pytest.mark.parametrize("n_cams", [2, 3, 5, 10, 11, 15, 16, 21, 22, 26, 31, 43])  # n = 6 cams + 5 around the 32- and 64-column edges
 def test_block_boundaries_of_the_reduced_system(hip_ctx, n_cams):
     """n = 6 n_cams + 5 against the 32-column Cholesky blocks, the 64-row tiles and the 128-column
     back-substitution super-blocks: a single partial block (17, 23), one real column in the last block (65),
@@ -78,6 +78,17 @@ def test_launch_chain_back_substitution_agrees_with_the_single_launch(hip_ctx, m
     chain = ba.debug_step(hip_ctx, A, 1e-3)
     assert rel(chain[2], one[2]) < 1e-10 and rel(chain[3], one[3]) < 1e-10
     assert rel(one[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
+
+
+def test_32_column_steps_agree_with_the_64_column_steps(hip_ctx, monkeypatch):
+    """The factorisation retires 64 columns per launch (chol_step64); EACHAM_BA_CHOL32 selects the older chain of
+    one launch per 32 columns (kept for A/B measurements): same factor, same step."""
+    sc, A = scene_arrays(seed=6, n_cams=60, n_lm=400, k=8)  # n = 365
+    wide = ba.debug_step(hip_ctx, A, 1e-3)
+    monkeypatch.setenv("EACHAM_BA_CHOL32", "1")
+    narrow = ba.debug_step(hip_ctx, A, 1e-3)
+    assert rel(narrow[2], wide[2]) < 1e-10 and rel(narrow[3], wide[3]) < 1e-10
+    assert rel(wide[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
 
 
 @pytest.mark.parametrize("lam", [-1e-3, -0.05, -0.5, -1.5])  # the first two: landmark blocks fine, reduced system indefinite
