@@ -329,7 +329,7 @@ def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=Tru
                          "solve": {"bound": "fp64", "achieved": solve_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": solve_tf / FP64_PEAK_TFLOPS,
                                    "note": f"n^3/3 flops of the Cholesky factorisation / solve time; the chain of {(n + 31) // 32} "
-                                           "dependent block steps is latency-bound"}}}
+                                           f"dependent diagonal-block factors ({(n + 63) // 64} launches) is latency-bound"}}}
 
 
 def ba_measured_traffic():

@@ -44,7 +44,8 @@ for k, v in sorted(ba.items()):
     b = (2.0 * v.get("FETCH_SIZE_KB_mean_per_dispatch", 0.0) + v.get("WRITE_SIZE_KB_mean_per_dispatch", 0.0)) * 1024.0 * n
     per_kernel[k] = {"dispatches": n, "hbm_bytes_total": b, "hbm_bytes_per_inner_iteration": b / max(tries, 1)}
     total += b
-# the memset of the reduced system (hipMemsetAsync -> fillBufferAligned) belongs to every try as well
+# a memset of the reduced system (hipMemsetAsync -> fillBufferAligned), if a build still issues one, belongs to every try
+# as well (since r02 ba_eliminate_landmarks clears S itself)
 for k, v in out.items():
     if "fillBufferAligned" in k and v.get("WRITE_SIZE_KB_mean_per_dispatch", 0.0) > 1024.0:
         n = v.get("dispatches_WRITE_SIZE", 0)
@@ -55,7 +56,7 @@ dst = os.path.join(root, "profiles", f"{rnd}_pmc_ba_traffic.json")
 with open(dst, "w") as f:
     json.dump({"__meta__": meta, "tries": tries,
                "per_inner_iteration": {"hbm_bytes": total / max(tries, 1),
-                                       "note": "sum over the BA kernels (ba_*, chol_*, the memset of S) of (2 FETCH + WRITE) x dispatches / "
+                                       "note": "sum over the BA kernels (ba_*, chol_*) of (2 FETCH + WRITE) x dispatches / "
                                                "tryLambda calls; the linearisation kernels run once per OUTER iteration and are included "
                                                "(outer = inner on this window)"},
                "kernels": per_kernel}, f, indent=1)
