@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Builds profiles/r01_pmc_sq_match_tile.json from the three SQ counter passes of tools/pmc.sh
-(gpurun_out/sq_a, sq_b, sq_c): mean per dispatch of the LARGEST-grid match_tile_kernel launch + the
+"""usage: tools/pmc_sq_json.py [tiles] [round] [prefix]
+Builds profiles/<round>_pmc_sq_match_tile.json from the three SQ counter passes of tools/pmc.sh
+(gpurun_out/<prefix>_a, _b, _c; defaults r01, sq): mean per dispatch of the LARGEST-grid match_tile_kernel launch + the
 derived fractions quoted in DESIGN.md (formulas in the `derived_from` field)."""
 import collections, csv, glob, json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("sq_a", "sq_b", "sq_c"):
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+prefix = sys.argv[3] if len(sys.argv) > 3 else "sq"
+for d in (prefix + "_a", prefix + "_b", prefix + "_c"):
     for fn in glob.glob(os.path.join(root, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
         with open(fn) as f:
             for row in csv.DictReader(f):
@@ -35,7 +38,7 @@ out = {
     "derived_from": "cycles = GRBM_GUI_ACTIVE/8 (sum over 8 XCDs); SQ_ACTIVE_*/SQ_WAVE_CYCLES/SQ_WAIT_* count quad-cycles; "
                     "busy fractions are per SIMD (1024 SIMDs); per-wave-tile counts divide by SQ_WAVES and the tiles of a sweep",
 }
-dst = os.path.join(root, "profiles", "r01_pmc_sq_match_tile.json")
+dst = os.path.join(root, "profiles", f"{rnd}_pmc_sq_match_tile.json")
 with open(dst, "w") as f:
     json.dump(out, f, indent=1)
 print(dst, json.dumps(out["derived"]))
