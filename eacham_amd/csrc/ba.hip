@@ -1067,6 +1067,7 @@ __global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, 
 //     inverts the factor right behind it -> Winv[k+1], for the next launch and for the back-substitution.
 #ifdef EXP_BA_STAMPS
 __device__ unsigned long long g_ba_dbg[16];
+__device__ unsigned long long g_wg_times[3 * 1200];  // per workgroup of the 1128-tile launch: start, end (s_memrealtime), HW_ID
 #define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_ba_dbg[i], now_ - st_prev); st_prev = now_; } } while (0)
 #else
 #define BSTAMP(i) do {} while (0)
@@ -1474,6 +1475,14 @@ __device__ __forceinline__ void store_panel64(double (*Li)[LS2], double* __restr
     }
 }
 
+// MODE 0: the whole step in one launch (every tile forms the panel strips of its row and column itself: the chain pays one
+//         launch per 64 columns, the right trade while a launch is bound by tile (0,0)'s chain).
+// MODE 1 + MODE 2: for launches bound by their tile grid (config 4: 1128 tiles, four rounds of 256 CUs). A tile of
+//         MODE 0 is 144 MFMAs per wave, 80 of which re-form strips that every tile of the row / column forms again — and
+//         the f64 MFMA of this chip runs at the vector rate (64 cycles per instruction). MODE 1 (grid = tile rows) forms
+//         every strip ONCE and stores it to Lm; MODE 2 (grid = tiles) reads the finished strips from Lm and only makes
+//         the rank-64 update (+ tile (0,0)'s factorisations).
+template <int MODE>
 __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr, int k0,
                                                       double* __restrict__ Winv, double* __restrict__ Wops, int* __restrict__ flags) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 64 * LS2];
@@ -1481,29 +1490,36 @@ __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, do
     double (*Lj)[LS2] = reinterpret_cast<double (*)[LS2]>(lds + 64 * LS2);
 #ifdef EXP_BA_STAMPS
     unsigned long long st_prev = __builtin_readcyclecounter();
+    if (gridDim.x == 1128 && threadIdx.x == 0) {
+        g_wg_times[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        g_wg_times[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    }
 #else
     const unsigned long long st_prev = 0;
 #endif
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mc = tid & 15, mg = (tid >> 4) & 3;
     const int k1 = k0 + PB;
     int t = blockIdx.x, ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
+    if (MODE == 1) ti = t;  // one workgroup per tile row
+    else while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = MODE == 1 ? ti : t - ti * (ti + 1) / 2;
     const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
     const bool same = ti == tj;
-    const bool first = t == 0 && k1 < n;  // the tile that holds the next two diagonal blocks
+    const bool first = MODE != 1 && t == 0 && k1 < n;  // the tile that holds the next two diagonal blocks
     // Every global read is issued up front, none is predicated (see chol_step: S has 64 rows and columns of padding).
     // A wave fetches ITS 16 rows of each raw strip, two whole rows (2 x 512 bytes) per instruction, and is the only
     // reader of their LDS image: no workgroup barrier before the panel product.
+    const double* __restrict__ Src = MODE == 2 ? Lm : A;  // MODE 2: the strips are the finished panel (rows / columns past n: zeros)
     double2 pi[8], pj[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) pi[m] = *reinterpret_cast<const double2*>(&A[(size_t)(i0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
+    for (int m = 0; m < 8; ++m) pi[m] = *reinterpret_cast<const double2*>(&Src[(size_t)(i0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
 #pragma unroll
     for (int m = 0; m < 8; ++m)  // (a diagonal tile fetches the same rows twice: the second strip is then never used)
-        pj[m] = *reinterpret_cast<const double2*>(&A[(size_t)(j0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
+        pj[m] = *reinterpret_cast<const double2*>(&Src[(size_t)(j0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
     // the B operands of the panel product, stored in operand order by the producer: one coalesced load per k-step
     const double* __restrict__ ops = Wops + (size_t)(k0 / PB) * TILE_OPS;
     double wa[12], wb[12], xp[16];
+    if (MODE != 2) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (q < 6) {
@@ -1513,8 +1529,9 @@ __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, do
         const double2 u = *reinterpret_cast<const double2*>(&ops[2 * WOP + op_index(2 * q, lane)]);
         xp[2 * q] = u.x, xp[2 * q + 1] = u.y;
     }
+    }
     const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;  // first quadrant of tile 0: blocks (0,0), (1,0), (1,1)
-    const bool block_thread = !first || wv >= 2;             // a wave owns 16 rows of the tile and its four 16-column blocks
+    const bool block_thread = MODE != 1 && (!first || wv >= 2);  // a wave owns 16 rows of the tile and its four 16-column blocks
     mfma_d4 old[4];
     if (block_thread) {
 #pragma unroll
@@ -1533,14 +1550,20 @@ __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, do
         *reinterpret_cast<double2*>(&Li[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pi[m];
         *reinterpret_cast<double2*>(&Lj[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pj[m];
     }
-    wave_lds_sync();
-    panel64(Li, wv, mc, mg, wa, wb, xp);
-    if (!same) panel64(Lj, wv, mc, mg, wa, wb, xp);
+    if (MODE != 2) {
+        wave_lds_sync();
+        panel64(Li, wv, mc, mg, wa, wb, xp);
+        if (!same) panel64(Lj, wv, mc, mg, wa, wb, xp);
+    }
     __syncthreads();
     BSTAMP(0);
     double (*LjE)[LS2] = same ? Li : Lj;
     // the tiles of the first tile column keep the panel for the back-substitution (coalesced, from LDS)
-    if (tj == 0 && !first) store_panel64<TPB>(Li, Lm, ld, n, nr, i0, k0, tid);
+    if (MODE == 1) {
+        store_panel64<TPB>(Li, Lm, ld, n, nr, i0, k0, tid);
+        return;
+    }
+    if (MODE == 0 && tj == 0 && !first) store_panel64<TPB>(Li, Lm, ld, n, nr, i0, k0, tid);
     if (first) {
         // images of the factorisation: second strip's region (a diagonal tile never writes it)
         double* base = lds + 64 * LS2;
@@ -1592,7 +1615,7 @@ __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, do
 #ifdef EXP_BA_STAMPS
             if (lane == 0) atomicAdd(&g_ba_dbg[wv == 2 ? 13 : 11], __builtin_readcyclecounter() - st_q);
 #endif
-            store_panel64<128>(Li, Lm, ld, n, nr, i0, k0, tid - 128);
+            if (MODE == 0) store_panel64<128>(Li, Lm, ld, n, nr, i0, k0, tid - 128);
 #ifdef EXP_BA_STAMPS
             if (lane == 0 && wv == 3) atomicAdd(&g_ba_dbg[14], __builtin_readcyclecounter() - st_q);
 #endif
@@ -1638,6 +1661,10 @@ __global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, do
             const bool inside = (i < n || i == nr) && j < n && j <= i;
             if (inside && !(same && cb > wv)) A[(size_t)i * ld + j] = old[cb][reg];
         }
+#ifdef EXP_BA_STAMPS
+    __syncthreads();
+    if (gridDim.x == 1128 && threadIdx.x == 0) g_wg_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // back substitution L^T x = y (y = row nr of Lm) in super-blocks of SB = 4 x NB columns, one launch per
@@ -2782,7 +2809,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
     TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
     TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
-    TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 1) * D.ld));
+    TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 64) * D.ld));  // padded like S: the split steps read whole 64-row strips of it
+    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.Lm, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));  // rows / columns past n stay zero
     TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
     TRY(dev_alloc(ctx, h, &D.Wops, (size_t)(D.nr / PB) * TILE_OPS));  // W_a, W_b, X = -W_b L_ba W_a of every 64x64 diagonal tile in operand order
     TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
@@ -2901,11 +2929,18 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
                 chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
             }
         } else {
+            const char* se = getenv("EACHAM_BA_SPLIT_TILES");  // (diagnostic: tile count above which a step is two launches)
+            const int split_tiles = se ? atoi(se) : 256;
             chol_diag64<<<1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.Winv, D.Wops, D.flags);
             for (int k0 = 0; k0 < D.nr; k0 += PB) {
                 const int k1 = k0 + PB;
                 const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-                chol_step64<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
+                if (nt * (nt + 1) / 2 > split_tiles) {  // bound by the tile grid: every strip formed once (see chol_step64)
+                    chol_step64<1><<<nt, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
+                    chol_step64<2><<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
+                } else {
+                    chol_step64<0><<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
+                }
             }
         }
         const int nsb = (n + SB - 1) / SB;
@@ -3212,6 +3247,9 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
 }  // namespace eacham
 
 #ifdef EXP_BA_STAMPS
+extern "C" int eacham_ba_debug_wg_times(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eacham::g_wg_times), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
 extern "C" int eacham_ba_debug_read(unsigned long long* out, int n) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(eacham::g_ba_dbg), sizeof(unsigned long long) * n) != hipSuccess) return -1;
     unsigned long long z[16] = {0};

@@ -91,6 +91,18 @@ def test_32_column_steps_agree_with_the_64_column_steps(hip_ctx, monkeypatch):
     assert rel(wide[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
 
 
+@pytest.mark.parametrize("n_cams", [10, 31, 60])
+def test_split_steps_agree_with_the_fused_steps(hip_ctx, monkeypatch, n_cams):
+    """A step whose tile grid is larger than the chip forms every panel strip once (chol_step64<1>) and updates from the
+    stored strips (chol_step64<2>); EACHAM_BA_SPLIT_TILES=0 forces that path for every step of a small system."""
+    sc, A = scene_arrays(seed=9, n_cams=n_cams, n_lm=300, k=6)
+    fused = ba.debug_step(hip_ctx, A, 1e-3)
+    monkeypatch.setenv("EACHAM_BA_SPLIT_TILES", "0")
+    split = ba.debug_step(hip_ctx, A, 1e-3)
+    assert rel(split[2], fused[2]) < 1e-10 and rel(split[3], fused[3]) < 1e-10
+    assert rel(fused[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
+
+
 @pytest.mark.parametrize("lam", [-1e-3, -0.05, -0.5, -1.5])  # the first two: landmark blocks fine, reduced system indefinite
 def test_indefinite_system_is_reported_like_the_oracle(hip_ctx, lam):
     """A negative damping makes the damped blocks indefinite at some stage. The diagonal-block factor tests one
