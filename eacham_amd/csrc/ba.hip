@@ -18,7 +18,8 @@
 //   landmarks are eliminated first (3x3 blocks, one thread each), the reduced camera system
 //   S (n = 6 nc + 5, the 5 shared-calibration columns are a dense border) is assembled WITHOUT
 //   atomics — every block is a deterministic sequential sum over its pair list — factorised by a
-//   blocked right-looking Cholesky on v_mfma_f64_16x16x4_f64 with the right-hand side carried as an
+//   blocked right-looking Cholesky on v_mfma_f64_16x16x4_f64 (64 columns per launch, the two 32x32 diagonal
+//   blocks of a step factorised by one wave each inside tile (0,0)) with the right-hand side carried as an
 //   extra row, and the landmark steps follow by back-substitution.
 // Roofline: every kernel except the dense factorisation streams observation-sized arrays once
 // (HBM-bound); see DESIGN.md for the per-kernel byte counts.
@@ -766,7 +767,10 @@ __global__ __launch_bounds__(TPB) void ba_assemble(BaDev D, double lambda, unsig
 }
 
 // ---- K-E: blocked right-looking Cholesky of S (lower triangle), rhs carried as row n ------------------
-// One launch per block column k (NB = 32 wide), every launch is a grid of 64x64 tiles of the
+// The product path retires 64 columns per launch (chol_diag64 / chol_step64 further down, built from the factor_32 and
+// invert_behind_factor of this section). chol_diag0 / chol_step are the chain it grew out of — one launch per block
+// column k (NB = 32 wide) — kept behind EACHAM_BA_CHOL32 for A/B measurements and as a second implementation the
+// tests hold the product path against. In that chain every launch is a grid of 64x64 tiles of the
 // trailing matrix. A workgroup
 //   * loads W_k = L_kk^-1 (computed by the previous launch) and the RAW panel strips A[i.., k] of its
 //     tile, and forms the factor strips L_ik = A_ik W_k^T itself (a 32-wide MFMA product instead of a
@@ -1262,14 +1266,17 @@ __global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double*
 // the tile itself, so one workgroup can factorise both without a launch in between. chol_step64 therefore retires
 // 64 columns per launch:
 //   * the panel of a tile row is ONE product with the inverse of the 64x64 factor, [L_ia L_ib] = [A_ia A_ib] W64^T,
-//     W64 = [[W_a, 0], [X, W_b]], X = -W_b L_ba W_a (stored by the producer next to W_a, W_b). Both operands come
-//     straight from global memory in MFMA operand layout (lane (i, kk) holds element [i][4t + kk]): 40 MFMAs per 16
-//     rows, no LDS staging, no barrier before the product;
+//     W64 = [[W_a, 0], [X, W_b]], X = -W_b L_ba W_a: 40 MFMAs per 16 rows. The producer stores W_a, W_b, X in MFMA
+//     operand order (wop_index), so the B operands are coalesced 16-byte loads; a wave fetches its own 16 rows of each
+//     raw strip as whole rows and is their only reader in LDS: no workgroup barrier before the product. (Operands
+//     fetched from the row-major images — 64 lanes x 8 bytes out of 16 rows per instruction, 92 such loads per wave —
+//     cost 19k cycles in this stage);
 //   * the trailing update is rank 64 (half the reads and writes of the trailing matrix per retired column: the first
 //     steps of a 3005-column system are bound by that traffic);
 //   * tile (0,0) updates its first quadrant first (waves 0-2), then wave 0 factorises it, wave 1 inverts behind it and
-//     waves 2-3 update the other quadrants (kept in registers); after a barrier waves 0-1 form L_ba, waves 0-2 D_b,
-//     then wave 0 factorises D_b, wave 1 inverts, waves 2-3 form L_ba W_a, and all four waves finish X.
+//     waves 2-3 update the other quadrants (kept in registers) and store the panel; after a barrier waves 2-3 form
+//     L_ba from the rows they hold (waves 0-1 publish W_a meanwhile), waves 0-2 D_b, then wave 0 factorises D_b, wave 1
+//     inverts, waves 2-3 form L_ba W_a, and all four waves finish X and publish W_b.
 // LDS: two 64 x 66 strips (67.6 KB, two workgroups per CU). Tile (0,0) is a diagonal tile — it never uses the second
 // strip — and its first strip is dead once the quadrants are updated: the factor images live in the second strip's
 // region, the four 32 x 33 images of the second half in the first's.
