@@ -65,11 +65,17 @@ def parse():
 
 
 def kernel_source_sha() -> str:
-    """Identity of the kernels a profile was taken with: sha256 over the HIP sources of the library."""
+    """Identity of the kernels a profile was taken with: sha256 over the CODE of the library's HIP sources — comments
+    and white space are dropped first, so rewording a comment does not disown a profile, changing a token does."""
+    import re
     h = hashlib.sha256()
     for fn in sorted(glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hpp"))):
-        with open(fn, "rb") as f:
-            h.update(f.read())
+        with open(fn, "r", encoding="utf-8", errors="replace") as f:
+            src = f.read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)        # block comments
+        src = re.sub(r"(?m)(?<![:\"'])//.*$", " ", src)          # line comments (not the // of a URL inside a string)
+        h.update(os.path.basename(fn).encode())
+        h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
