@@ -20,6 +20,7 @@ descriptor shapes as sub-objects, each with its own roofline against the peak of
   c3_tum         configs[2] stand-in: 500 frames x 600 x 128-D all pairs + a sequence of local-window RefineBA
   c4_ba          configs[3]: 500 cams / 100k landmarks / 1M observations, LM inner loop
   c5_kitti       configs[4] stand-in: 100 frames x 1500 x 128-D through the shard path (+ RCCL all-gather, N > 1)
+  c5_kitti_long  the 1000-frame variant of the same: 499 500 pairs, ~12 s including the synthesis
 With N > 1 only the headline and c5_kitti run (the lines that shard); `--lines` selects explicitly.
 
 The CPU oracle (oracle/) is used here only for the `cpu_baseline` leg (rank 0, N=1, bounded sample).
@@ -43,7 +44,7 @@ I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the ~2.5 PF bf16 dense rate (M
 F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = the fp32 vector rate (same guide)
 HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6
-ALL_LINES = ["s200_d128_i8", "s200_d256_f32", "c2", "c3_tum", "c4_ba", "c5_kitti"]
+ALL_LINES = ["s200_d128_i8", "s200_d256_f32", "c2", "c3_tum", "c4_ba", "c5_kitti", "c5_kitti_long"]
 
 
 def parse():
@@ -503,6 +504,17 @@ def main():
         out["scaling"] = "strong"
         return out
     leg("c5_kitti", kitti_line)
+
+    def kitti_long_line():
+        # the longer KITTI-like sequence of SURVEY.md §8(d): 1000 frames x 1500 x 128-D, 499 500 pairs through the shard path
+        kit = synth.make_scene(1000, 150_000, 10, seed=6)
+        kd, _ = synth.make_frame_descriptors(kit, 1500, 128, seed=6)
+        out, _r = matching_line(D, kd, "i8", 128, 1, 1,
+                                f"KITTI-like long sequence: 1000 frames x 1500 kpts x 128-D, 499500 pairs sharded over {D.world} GPU(s)"
+                                + (" + RCCL all-gather of the match graph" if D.world > 1 else ""), "match_tile_kernel<4, 2>")
+        out["scaling"] = "strong"
+        return out
+    leg("c5_kitti_long", kitti_long_line)
 
     if D.rank == 0:
         out = {
