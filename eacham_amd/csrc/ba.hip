@@ -2609,7 +2609,12 @@ using namespace eacham;
 
 struct eacham_ba_handle {
     BaDev D;
-    std::vector<void*> allocs;
+    int block = -1;            // index into ctx->ba_pool: the arena all device arrays of this problem live in
+    char* arena = nullptr;
+    size_t arena_off = 0;      // bump pointer (planning pass: the total)
+    bool planning = false;     // first pass over the allocation sequence: sizes only
+    size_t upload_end = 0;     // end of the last uploaded array in the arena (the uploads come first in the sequence)
+    std::vector<char> stage;   // small problems: host image of the uploaded arrays, sent with ONE copy
     std::vector<int> lm_order;  // landmark-sorted observation index -> caller's observation index
     double *kpart = nullptr, *err_cam = nullptr, *lin_cam = nullptr;
     double* scal_host = nullptr;  // pinned: the per-try scalar read-back sits on the LM loop's critical path
@@ -2623,10 +2628,10 @@ namespace eacham {
 
 template <class T>
 static int dev_alloc(eacham_ctx* ctx, eacham_ba_handle* h, T** p, size_t count) {
-    void* q = nullptr;
-    EACHAM_HIP_TRY(ctx, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
-    h->allocs.push_back(q);
-    *p = (T*)q;
+    (void)ctx;
+    const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+    *p = h->planning ? nullptr : (T*)(h->arena + h->arena_off);
+    h->arena_off += bytes;
     return EACHAM_OK;
 }
 template <class T>
@@ -2634,7 +2639,12 @@ static int dev_upload(eacham_ctx* ctx, eacham_ba_handle* h, const T** p, const s
     T* q = nullptr;
     int rc = dev_alloc(ctx, h, &q, v.size());
     if (rc) return rc;
-    if (!v.empty()) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (h->planning) {
+        h->upload_end = h->arena_off;
+    } else if (!v.empty()) {
+        if (!h->stage.empty()) memcpy(h->stage.data() + ((char*)q - h->arena), v.data(), v.size() * sizeof(T));
+        else EACHAM_HIP_TRY(ctx, hipMemcpyAsync(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    }
     *p = q;
     return EACHAM_OK;
 }
@@ -2651,6 +2661,50 @@ static void pose_to_Twc(const double* x, double* T) {
     }
     T[12] = T[13] = T[14] = 0.0;
     T[15] = 1.0;
+}
+
+// An arena of at least `bytes` from the context's pool: the smallest free one that fits, else a new one (free arenas
+// are dropped first once the pool holds eight: a long sequence of growing windows must not keep every size).
+static int ba_block_acquire(eacham_ctx* ctx, size_t bytes, int* index) {
+    int best = -1, n_free = 0;
+    for (int i = 0; i < (int)ctx->ba_pool.size(); ++i) {
+        const BaBlock& b = ctx->ba_pool[i];
+        if (b.busy || !b.dev) continue;
+        ++n_free;
+        if (b.bytes >= bytes && (best < 0 || b.bytes < ctx->ba_pool[best].bytes)) best = i;
+    }
+    if (best < 0) {
+        if ((int)ctx->ba_pool.size() >= 8 && n_free > 0) {
+            for (BaBlock& b : ctx->ba_pool)
+                if (!b.busy && b.dev) {
+                    (void)hipFree(b.dev);
+                    b.dev = nullptr;
+                    b.bytes = 0;
+                }
+        }
+        for (int i = 0; i < (int)ctx->ba_pool.size() && best < 0; ++i)
+            if (!ctx->ba_pool[i].busy && !ctx->ba_pool[i].dev) best = i;  // an emptied slot (its pinned block is kept)
+        if (best < 0) {
+            ctx->ba_pool.emplace_back();
+            best = (int)ctx->ba_pool.size() - 1;
+        }
+        BaBlock& b = ctx->ba_pool[best];
+        const size_t want = bytes + bytes / 8;  // some headroom: the next window is rarely the same size
+        EACHAM_HIP_TRY(ctx, hipMalloc(&b.dev, want));
+        b.bytes = want;
+        if (!b.pinned) {
+            hipError_t e = hipHostMalloc((void**)&b.pinned, SCAL * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+            if (e != hipSuccess) {
+                (void)hipFree(b.dev);
+                b.dev = nullptr;
+                b.bytes = 0;
+                return ctx->fail(EACHAM_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    ctx->ba_pool[best].busy = true;
+    *index = best;
+    return EACHAM_OK;
 }
 
 static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
@@ -2777,82 +2831,113 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     std::vector<double> pts(P->points, P->points + 3 * (size_t)nl);
     std::vector<int> fixed(P->cam_fixed, P->cam_fixed + nc);
 
+    // Every device array of the problem is carved out of one arena: the allocation sequence below runs twice, first
+    // to add up the sizes, then — with an arena of that size taken from the context's pool — to hand out the
+    // pointers and issue the uploads. An arena that served another problem holds its bytes: nothing here may rely on
+    // fresh memory being zero (S is cleared by every tryLambda, Lm and the flags below).
     int rc = EACHAM_OK;
-#define TRY(x) do { rc = (x); if (rc) { for (void* q : h->allocs) (void)hipFree(q); delete h; return rc; } } while (0)
-    const double *c_pose0, *c_pt0, *c_K0, *c_lmprior, *c_uv;
-    TRY(dev_upload(ctx, h, &c_pose0, pose));
-    TRY(dev_upload(ctx, h, &c_pt0, pts));
-    TRY(dev_upload(ctx, h, &c_K0, K5));
-    TRY(dev_upload(ctx, h, &c_lmprior, lmprior));
-    TRY(dev_upload(ctx, h, &c_uv, obs_uv));
-    D.pose0 = (double*)c_pose0; D.pt0 = (double*)c_pt0; D.K0 = (double*)c_K0; D.lmprior = c_lmprior; D.obs_uv = c_uv;
-    h->pose_init = D.pose0; h->pt_init = D.pt0; h->K_init = D.K0;
-    TRY(dev_upload(ctx, h, &D.fixed, fixed));
-    TRY(dev_upload(ctx, h, &D.lm_ptr, lm_ptr));
-    TRY(dev_upload(ctx, h, &D.cam_ptr, cam_ptr));
-    TRY(dev_upload(ctx, h, &D.cam_obs, cam_obs));
-    TRY(dev_upload(ctx, h, &D.cam_lm, cam_lm));
-    TRY(dev_upload(ctx, h, &D.cam_chunks, cam_chunks));
-    TRY(dev_upload(ctx, h, &D.cam_chunk_ptr, cam_chunk_ptr));
-    TRY(dev_upload(ctx, h, &D.obs_pos, obs_pos));
-    TRY(dev_upload(ctx, h, &D.pos_cam, pos_cam));
-    TRY(dev_upload(ctx, h, &D.cam_uv, cam_uv));
-    TRY(dev_upload(ctx, h, &D.obs_cam, obs_cam));
-    TRY(dev_upload(ctx, h, &D.obs_lm, obs_lm));
-    TRY(dev_upload(ctx, h, &D.pair_entries, entries));
-    TRY(dev_upload(ctx, h, &D.pair_chunks, chunks));
-    TRY(dev_upload(ctx, h, &D.blocks, blocks));
-    TRY(dev_alloc(ctx, h, &D.pose, 12 * (size_t)nc));
-    TRY(dev_alloc(ctx, h, &D.pose_new, 12 * (size_t)nc));
-    TRY(dev_alloc(ctx, h, &D.pt, 3 * (size_t)nl));
-    TRY(dev_alloc(ctx, h, &D.pt_new, 3 * (size_t)nl));
-    TRY(dev_alloc(ctx, h, &D.Kc, 8));
-    TRY(dev_alloc(ctx, h, &D.K_new, 8));
-    TRY(dev_alloc(ctx, h, &D.E, 18 * (size_t)no));
-    TRY(dev_alloc(ctx, h, &D.Et, 18 * (size_t)no));
-    TRY(dev_alloc(ctx, h, &D.lmlin, (size_t)LMLIN * nl));
-    TRY(dev_alloc(ctx, h, &D.lmtry, (size_t)LMLIN * nl));
-    TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
-    TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
-    TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
-    TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
-    TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 64) * D.ld));  // padded like S: the split steps read whole 64-row strips of it
-    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.Lm, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));  // rows / columns past n stay zero
-    TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
-    TRY(dev_alloc(ctx, h, &D.Wops, (size_t)(D.nr / PB) * TILE_OPS));  // W_a, W_b, X = -W_b L_ba W_a of every 64x64 diagonal tile in operand order
-    TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
-    TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
-    TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
-    TRY(dev_alloc(ctx, h, &D.delta_l, 3 * (size_t)nl));
-    TRY(dev_alloc(ctx, h, &D.err_part, (size_t)D.n_lm_blocks));
-    TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)D.n_lm_blocks));
-    TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
-    TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
-    TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
-    TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * std::max(D.n_cam_chunks, 1)));
-    TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
-    TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
-    TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
-    {
-        const size_t nn = (size_t)D.n + 8, n3 = 3 * (size_t)std::max(nl, 1);
-        TRY(dev_alloc(ctx, h, &D.pcg_rc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_zc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_pc, nn));
-        TRY(dev_alloc(ctx, h, &D.pcg_qc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_Dc, nn));
-        TRY(dev_alloc(ctx, h, &D.pcg_rl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_zl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_pl, n3));
-        TRY(dev_alloc(ctx, h, &D.pcg_ql, n3)); TRY(dev_alloc(ctx, h, &D.pcg_Dl, n3));
-        TRY(dev_alloc(ctx, h, &D.pcg_Mc, (size_t)36 * std::max(nc, 1))); TRY(dev_alloc(ctx, h, &D.pcg_MK, 32));
-        TRY(dev_alloc(ctx, h, &D.pcg_Ml, 3 * n3));
-        TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks)); TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
-        TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
-    }
-    TRY(dev_alloc(ctx, h, &D.flags, N_FLAGS));  // [0..3] status, [4..] hand-off flags of the back-substitution
-    EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, N_FLAGS * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
-    EACHAM_HIP_TRY(ctx, hipHostMalloc((void**)&h->scal_host, SCAL * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-    EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
-    for (int k = 0; k < SCAL; ++k) h->scal_host[k] = 0.0;  // (tickets start at 1)
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    auto layout = [&]() -> int {
+        const double *c_pose0, *c_pt0, *c_K0, *c_lmprior, *c_uv;
+        TRY(dev_upload(ctx, h, &c_pose0, pose));
+        TRY(dev_upload(ctx, h, &c_pt0, pts));
+        TRY(dev_upload(ctx, h, &c_K0, K5));
+        TRY(dev_upload(ctx, h, &c_lmprior, lmprior));
+        TRY(dev_upload(ctx, h, &c_uv, obs_uv));
+        D.pose0 = (double*)c_pose0; D.pt0 = (double*)c_pt0; D.K0 = (double*)c_K0; D.lmprior = c_lmprior; D.obs_uv = c_uv;
+        h->pose_init = D.pose0; h->pt_init = D.pt0; h->K_init = D.K0;
+        TRY(dev_upload(ctx, h, &D.fixed, fixed));
+        TRY(dev_upload(ctx, h, &D.lm_ptr, lm_ptr));
+        TRY(dev_upload(ctx, h, &D.cam_ptr, cam_ptr));
+        TRY(dev_upload(ctx, h, &D.cam_obs, cam_obs));
+        TRY(dev_upload(ctx, h, &D.cam_lm, cam_lm));
+        TRY(dev_upload(ctx, h, &D.cam_chunks, cam_chunks));
+        TRY(dev_upload(ctx, h, &D.cam_chunk_ptr, cam_chunk_ptr));
+        TRY(dev_upload(ctx, h, &D.obs_pos, obs_pos));
+        TRY(dev_upload(ctx, h, &D.pos_cam, pos_cam));
+        TRY(dev_upload(ctx, h, &D.cam_uv, cam_uv));
+        TRY(dev_upload(ctx, h, &D.obs_cam, obs_cam));
+        TRY(dev_upload(ctx, h, &D.obs_lm, obs_lm));
+        TRY(dev_upload(ctx, h, &D.pair_entries, entries));
+        TRY(dev_upload(ctx, h, &D.pair_chunks, chunks));
+        TRY(dev_upload(ctx, h, &D.blocks, blocks));
+        TRY(dev_alloc(ctx, h, &D.pose, 12 * (size_t)nc));
+        TRY(dev_alloc(ctx, h, &D.pose_new, 12 * (size_t)nc));
+        TRY(dev_alloc(ctx, h, &D.pt, 3 * (size_t)nl));
+        TRY(dev_alloc(ctx, h, &D.pt_new, 3 * (size_t)nl));
+        TRY(dev_alloc(ctx, h, &D.Kc, 8));
+        TRY(dev_alloc(ctx, h, &D.K_new, 8));
+        TRY(dev_alloc(ctx, h, &D.E, 18 * (size_t)no));
+        TRY(dev_alloc(ctx, h, &D.Et, 18 * (size_t)no));
+        TRY(dev_alloc(ctx, h, &D.lmlin, (size_t)LMLIN * nl));
+        TRY(dev_alloc(ctx, h, &D.lmtry, (size_t)LMLIN * nl));
+        TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
+        TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
+        TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
+        TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
+        TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 64) * D.ld));  // padded like S: the split steps read whole 64-row strips of it
+        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.Lm, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));  // rows / columns past n stay zero
+        TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
+        TRY(dev_alloc(ctx, h, &D.Wops, (size_t)(D.nr / PB) * TILE_OPS));  // W_a, W_b, X = -W_b L_ba W_a of every 64x64 diagonal tile in operand order
+        TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
+        TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
+        TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
+        TRY(dev_alloc(ctx, h, &D.delta_l, 3 * (size_t)nl));
+        TRY(dev_alloc(ctx, h, &D.err_part, (size_t)D.n_lm_blocks));
+        TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)D.n_lm_blocks));
+        TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
+        TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
+        TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
+        TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * std::max(D.n_cam_chunks, 1)));
+        TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
+        TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
+        TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
+        {
+            const size_t nn = (size_t)D.n + 8, n3 = 3 * (size_t)std::max(nl, 1);
+            TRY(dev_alloc(ctx, h, &D.pcg_rc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_zc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_pc, nn));
+            TRY(dev_alloc(ctx, h, &D.pcg_qc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_Dc, nn));
+            TRY(dev_alloc(ctx, h, &D.pcg_rl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_zl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_pl, n3));
+            TRY(dev_alloc(ctx, h, &D.pcg_ql, n3)); TRY(dev_alloc(ctx, h, &D.pcg_Dl, n3));
+            TRY(dev_alloc(ctx, h, &D.pcg_Mc, (size_t)36 * std::max(nc, 1))); TRY(dev_alloc(ctx, h, &D.pcg_MK, 32));
+            TRY(dev_alloc(ctx, h, &D.pcg_Ml, 3 * n3));
+            TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks)); TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
+            TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
+        }
+        TRY(dev_alloc(ctx, h, &D.flags, N_FLAGS));  // [0..3] status, [4..] hand-off flags of the back-substitution
+        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, N_FLAGS * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
+        if (!h->planning) {
+            h->scal_host = ctx->ba_pool[h->block].pinned;
+            EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
+            for (int k = 0; k < SCAL; ++k) h->scal_host[k] = 0.0;  // (tickets start at 1; the block may have served another problem)
+        }
+        return EACHAM_OK;
+    };
 #undef TRY
+    h->planning = true;
+    h->arena_off = 0;
+    rc = layout();
+    if (!rc) rc = ba_block_acquire(ctx, h->arena_off, &h->block);
+    if (!rc) {
+        h->arena = (char*)ctx->ba_pool[h->block].dev;
+        h->planning = false;
+        h->arena_off = 0;
+        // a local window uploads ~20 arrays of a few KB: one copy of their image instead of 20 (each is a staged,
+        // synchronous-looking call from pageable memory); large problems keep the per-array copies (no second host copy)
+        if (h->upload_end <= ((size_t)4 << 20)) h->stage.assign(h->upload_end, 0);
+        rc = layout();
+        if (!rc && !h->stage.empty())
+            rc = hipMemcpyAsync(h->arena, h->stage.data(), h->stage.size(), hipMemcpyHostToDevice, ctx->stream) == hipSuccess
+                     ? EACHAM_OK : ctx->fail(EACHAM_ERR_HIP, "BA upload failed");
+    }
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);  // (uploads from the host vectors may be in flight)
+        if (h->block >= 0) ctx->ba_pool[h->block].busy = false;
+        delete h;
+        return rc;
+    }
     hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
     if (e != hipSuccess) {
-        for (void* q : h->allocs) (void)hipFree(q);
+        ctx->ba_pool[h->block].busy = false;
         delete h;
         return ctx->fail(EACHAM_ERR_HIP, "BA upload failed: %s", hipGetErrorString(e));
     }
@@ -2867,8 +2952,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
 static void ba_release(eacham_ctx* ctx, eacham_ba_handle* h) {
     if (!h) return;
     (void)hipStreamSynchronize(ctx->stream);
-    for (void* q : h->allocs) (void)hipFree(q);
-    if (h->scal_host) (void)hipHostFree(h->scal_host);
+    if (h->block >= 0) ctx->ba_pool[h->block].busy = false;  // the arena and its pinned scalars stay with the context
     delete h;
 }
 

@@ -270,6 +270,10 @@ void eacham_ctx_destroy(eacham_ctx* ctx) {
     if (ctx->pairs_safe) (void)hipFree(ctx->pairs_safe);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->io) (void)hipFree(ctx->io);
+    for (auto& b : ctx->ba_pool) {
+        if (b.dev) (void)hipFree(b.dev);
+        if (b.pinned) (void)hipHostFree(b.pinned);
+    }
     for (auto& s : ctx->prof)
         for (auto& ev : s.events) {
             (void)hipEventDestroy(ev.first);

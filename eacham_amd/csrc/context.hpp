@@ -48,6 +48,17 @@ struct FrameHost {
     int tiles_used = 0;  // tiles in use (<= ntiles), known after sync_frame_table
 };
 
+// One arena of the bundle adjuster: every device array of a prepared problem is carved out of ONE allocation, and the
+// arena (with its block of pinned host scalars) goes back to the context's pool when the problem is released. The
+// reference calls RefineBA for a new local window after every frame (apps/sfm/main.cpp:207): ~60 hipMalloc + hipFree +
+// a pinned allocation per call were 0.8 ms of a 1.9 ms window.
+struct BaBlock {
+    void* dev = nullptr;
+    size_t bytes = 0;
+    double* pinned = nullptr;
+    bool busy = false;
+};
+
 struct ProfileSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t used = 0;
@@ -83,6 +94,8 @@ struct eacham_ctx {
     int pairs_safe_cap = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
+
+    std::vector<eacham::BaBlock> ba_pool;  // arenas of released BA problems, reused by the next eacham_ba_prepare
 
     // profiling
     bool profile = false;
