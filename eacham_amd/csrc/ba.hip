@@ -1783,7 +1783,8 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
 // The two fences cost ~3 us per hand-off, on a chain of nsb - 1 hand-offs.
 __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nsb,
                                                                 const double* __restrict__ Winv, const double* __restrict__ y0,
-                                                                double* __restrict__ xv, int* __restrict__ flags) {
+                                                                double* __restrict__ xv, int* __restrict__ flags,
+                                                                const double* __restrict__ rhs_raw, int fold_col) {
     __shared__ double xK[SB];
     __shared__ double ys[SB];
     __shared__ double part[BSTEP_THREADS / SB][SB];
@@ -1809,6 +1810,31 @@ __global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __
         Lin[r][c] = (c < (r / NB) * NB && c0 + r < n) ? Lm[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
     }
     if (tid < SB) ys[tid] = (c0 + tid < n) ? y0[c0 + tid] : 0.0;  // xv only ever holds solutions
+    if (fold_col >= 0 && s == nsb - 1) {
+        // The forward substitution of the LAST 64 columns is made here instead of by one more launch of the
+        // factorisation (whose only tile would be the right-hand-side row: 11-13 us of launch for three small
+        // products): y_a = W_a a_a, y_b = W_b (a_b - L_ba y_a), a = row nr of S as the last step left it. This
+        // workgroup waits for nobody and has W_a, W_b and L_ba in LDS for its own solve anyway.
+        const int t0 = fold_col - c0, bA = t0 / NB;  // 0 or 64: the last tile inside this super-block
+        __syncthreads();
+        if (tid < PB) ys[t0 + tid] = (fold_col + tid < n) ? rhs_raw[fold_col + tid] : 0.0;
+        __syncthreads();
+        const int i = (tid >> 4) & (NB - 1), p = tid & 15;
+        for (int stage = 0; stage < 3; ++stage) {
+            double v;
+            if (stage == 0) v = Ws[bA][i][p] * ys[t0 + p] + Ws[bA][i][p + 16] * ys[t0 + p + 16];
+            else if (stage == 1) v = Lin[t0 + NB + i][t0 + p] * ys[t0 + p] + Lin[t0 + NB + i][t0 + p + 16] * ys[t0 + p + 16];
+            else v = Ws[bA + 1][i][p] * ys[t0 + NB + p] + Ws[bA + 1][i][p + 16] * ys[t0 + NB + p + 16];
+            v = dpp_row_sum<16>(v);
+            __syncthreads();  // every read of the vector this stage overwrites is done
+            if (tid < 16 * NB && p == 15) {
+                if (stage == 0) ys[t0 + i] = v;
+                else if (stage == 1) ys[t0 + NB + i] -= v;
+                else ys[t0 + NB + i] = v;
+            }
+            __syncthreads();
+        }
+    }
     // 8 threads per column, 16 rows each (rows are contiguous along columns: coalesced)
     const int cl = tid & (SB - 1), pr = tid / SB, col = c0 + cl;
     constexpr int RP = SB / (BSTEP_THREADS / SB);
@@ -3012,7 +3038,11 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
 #endif
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
-        if (getenv("EACHAM_BA_CHOL32")) {  // diagnostic switch: one launch per 32 columns
+        const int nsb = (n + SB - 1) / SB;
+        const bool single_backsolve = nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES");
+        const bool chol32 = getenv("EACHAM_BA_CHOL32") != nullptr;
+        const bool fold_last = single_backsolve && !chol32;
+        if (chol32) {  // diagnostic switch: one launch per 32 columns
             chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
             for (int k0 = 0; k0 < n; k0 += NB) {
                 const int k1 = k0 + NB;
@@ -3023,7 +3053,8 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
             const char* se = getenv("EACHAM_BA_SPLIT_TILES");  // (diagnostic: tile count above which a step is two launches)
             const int split_tiles = se ? atoi(se) : 256;
             chol_diag64<<<1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.Winv, D.Wops, D.flags);
-            for (int k0 = 0; k0 < D.nr; k0 += PB) {
+            // the last step (its only tile is the right-hand-side row) is folded into the back-substitution
+            for (int k0 = 0; k0 < (fold_last ? D.nr - PB : D.nr); k0 += PB) {
                 const int k1 = k0 + PB;
                 const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
                 if (nt * (nt + 1) / 2 > split_tiles) {  // bound by the tile grid: every strip formed once (see chol_step64)
@@ -3034,9 +3065,9 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
                 }
             }
         }
-        const int nsb = (n + SB - 1) / SB;
-        if (nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES")) {  // (y = row nr of Lm is read in place)
-            chol_backsolve<<<nsb, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, D.Winv, D.Lm + (size_t)D.nr * D.ld, D.delta_c, D.flags);
+        if (single_backsolve) {  // (y = row nr of Lm is read in place)
+            chol_backsolve<<<nsb, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, D.Winv, D.Lm + (size_t)D.nr * D.ld, D.delta_c, D.flags,
+                                                                   D.S + (size_t)D.nr * D.ld, fold_last ? D.nr - PB : -1);
         } else {  // more super-blocks than hand-off flags (n > 8192), or the diagnostic switch: one launch per super-block
             EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
                                                hipMemcpyDeviceToDevice, ctx->stream));
