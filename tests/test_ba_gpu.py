@@ -301,6 +301,34 @@ def test_dogleg_hard_start_shrinks_the_region(hip_ctx):
     assert rel(out.points, ref.points) < POSE_POINT_RTOL and rel(out.cam_T_wc, ref.cam_T_wc) < POSE_POINT_RTOL
 
 
+def test_problems_share_the_arena_pool_without_seeing_each_other(hip_ctx):
+    """Every prepared problem lives in one arena taken from the context's pool and gives it back on release: problems
+    of different sizes alive at the same time, released out of order and followed by new ones that reuse their arenas
+    (dirty memory) must solve exactly as they do alone."""
+    cfg = ba.OptimizerConfig.refine_ba()
+    scenes = [scene_arrays(seed=21 + k, n_cams=nc, n_lm=nl, k=6)[1] for k, (nc, nl) in enumerate([(6, 120), (25, 500), (12, 260), (40, 300)])]
+    alone = []
+    for A in scenes:
+        P = ba.PreparedBA(hip_ctx, A)
+        alone.append(P.run(cfg, trace_cap=0))
+        P.close()
+    live = [ba.PreparedBA(hip_ctx, A) for A in scenes[:3]]      # three arenas busy at once
+    outs = [None] * 4
+    outs[1] = live[1].run(cfg, trace_cap=0)
+    outs[0] = live[0].run(cfg, trace_cap=0)
+    live[1].close()                                             # the big one goes back first ...
+    late = ba.PreparedBA(hip_ctx, scenes[3])                    # ... and is taken by a problem of another shape
+    outs[2] = live[2].run(cfg, trace_cap=0)
+    outs[3] = late.run(cfg, trace_cap=0)
+    again = live[0].run(cfg, trace_cap=0)                       # a handle solves from its uploaded start every time
+    for P in (live[0], live[2], late):
+        P.close()
+    for got, ref in zip(outs + [again], alone + [alone[0]]):
+        assert got.outer_iterations == ref.outer_iterations and got.inner_iterations == ref.inner_iterations
+        assert got.final_error == ref.final_error
+        assert np.array_equal(got.cam_T_wc, ref.cam_T_wc) and np.array_equal(got.points, ref.points)
+
+
 def test_fewer_than_50_landmarks_is_a_silent_no_op(hip_ctx):
     sc, A = scene_arrays(n_cams=4, n_lm=49, k=3, outliers=False)
     out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
