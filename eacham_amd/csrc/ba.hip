@@ -231,14 +231,29 @@ struct BaDev {
     int* flags;
     double* scal_pinned;  // device view of the pinned host copy of scal[0..2] (ba_final_sums)
     int n_lm_blocks;  // grid of the per-landmark kernels
+    // Small problems (a local window: 1.5 k landmarks = six workgroups) are bound by the LENGTH of a thread's instruction
+    // stream, not by bandwidth: a landmark's ~8 observations cost ~3 k fp64 instructions in one lane, ~10 us per kernel
+    // whatever the landmark count. There the three kernels that loop over a landmark's observations spread it over
+    // lpl = 8 adjacent lanes (observation o0 + sub, o0 + sub + 8, ...; xor-shuffle sums in a fixed order), on a grid of
+    // n_ll_blocks workgroups; large problems keep lpl = 1 (n_ll_blocks = n_lm_blocks): their time is traffic.
+    int lpl, n_ll_blocks;
     Noise nz;
 };
 
+// sum over the LPL adjacent lanes that share a landmark, the same value in all of them (fixed butterfly order)
+template <int LPL>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int m = 1; m < LPL; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
 // ---- K-A: per-landmark linearisation (thread = landmark) --------------------------------------------
 // Hll, gl, ElK of the landmark (+ its prior) and E_o = Ap^T Al (6x3) of each of its observations.
+template <int LPL>
 __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
-    const int j = blockIdx.x * TPB + threadIdx.x;
-    if (j >= D.nl) return;
+    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
+    if (j >= D.nl) return;  // (the LPL lanes of a landmark leave together)
     const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
     double* out = D.lmlin + (size_t)LMLIN * j;
     double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, EK[15];
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
     double K[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
-    for (int o = o0; o < o1; ++o) {
+    for (int o = o0 + sub; o < o1; o += LPL) {
         const double* x = D.pose + 12 * (size_t)D.obs_cam[o];
         double xr[12];
 #pragma unroll
@@ -274,6 +289,15 @@ __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) E[3 * a + c] = Ap[a] * Al[c] + Ap[6 + a] * Al[3 + c];
         }
+    }
+    if (LPL > 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H[k] = group_sum<LPL>(H[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = group_sum<LPL>(g[k]);
+#pragma unroll
+        for (int k = 0; k < 15; ++k) EK[k] = group_sum<LPL>(EK[k]);
+        if (sub != 0) return;
     }
     if (o1 > o0) {  // PriorFactor<Point3>, Robust(Huber(3/obs), Isotropic(1/obs))
         const double sg = D.lmprior[2 * j], kh = D.lmprior[2 * j + 1];
@@ -1921,13 +1945,14 @@ __device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lam
                                                double* lin_cam);
 // The workgroups behind the landmarks' (blockIdx.x >= n_lm_blocks) retract the cameras and K (K-G1, thread = camera):
 // both read delta_c and nothing of each other, and a launch of one workgroup costs the chain as much as this one.
+template <int LPL>
 __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lambda, double* err_cam, double* lin_cam) {
     __shared__ double sm[(TPB / 64) * 1];
-    if ((int)blockIdx.x >= D.n_lm_blocks) {
-        retract_camera(D, ((int)blockIdx.x - D.n_lm_blocks) * TPB + threadIdx.x, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, err_cam, lin_cam);
+    if ((int)blockIdx.x >= D.n_ll_blocks) {
+        retract_camera(D, ((int)blockIdx.x - D.n_ll_blocks) * TPB + threadIdx.x, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, err_cam, lin_cam);
         return;
     }
-    const int j = blockIdx.x * TPB + threadIdx.x;
+    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
     double lin[1] = {0.0};
     if (j < D.nl) {
         const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
@@ -1951,7 +1976,7 @@ __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lamb
 #pragma unroll
             for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
             double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-            for (int o = o0; o < o1; ++o) {
+            for (int o = o0 + sub; o < o1; o += LPL) {
                 const int cam = (int)D.obs_cam[o];
                 const double* x = D.pose + 12 * (size_t)cam;
                 const double* dc = D.delta_c + 6 * (size_t)cam;
@@ -1970,6 +1995,7 @@ __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lamb
                 w1 += Al[1] * u0 + Al[4] * u1;
                 w2 += Al[2] * u0 + Al[5] * u1;
             }
+            if (LPL > 1) w0 = group_sum<LPL>(w0), w1 = group_sum<LPL>(w1), w2 = group_sum<LPL>(w2);  // (a landmark's lanes take this branch together)
             const double m00 = lt[0], m10 = lt[1], m11 = lt[2], m20 = lt[3], m21 = lt[4], m22 = lt[5];
             t0 -= m00 * w0;
             t1 -= m10 * w0 + m11 * w1;
@@ -1978,16 +2004,19 @@ __global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lamb
             d1 = m11 * t1 + m21 * t2;
             d2 = m22 * t2;
             const double* in = D.lmlin + (size_t)LMLIN * j;
-            lin[0] = 0.5 * (d0 * in[6] + d1 * in[7] + d2 * in[8]) +
-                     0.5 * lambda * (clampd(in[0], 1e-6, 1e32) * d0 * d0 + clampd(in[3], 1e-6, 1e32) * d1 * d1 +
-                                     clampd(in[5], 1e-6, 1e32) * d2 * d2);
+            if (sub == 0)
+                lin[0] = 0.5 * (d0 * in[6] + d1 * in[7] + d2 * in[8]) +
+                         0.5 * lambda * (clampd(in[0], 1e-6, 1e32) * d0 * d0 + clampd(in[3], 1e-6, 1e32) * d1 * d1 +
+                                         clampd(in[5], 1e-6, 1e32) * d2 * d2);
         }
+        if (sub == 0) {
         D.delta_l[3 * (size_t)j] = d0;
         D.delta_l[3 * (size_t)j + 1] = d1;
         D.delta_l[3 * (size_t)j + 2] = d2;
         D.pt_new[3 * (size_t)j] = D.pt[3 * (size_t)j] + d0;
         D.pt_new[3 * (size_t)j + 1] = D.pt[3 * (size_t)j + 1] + d1;
         D.pt_new[3 * (size_t)j + 2] = D.pt[3 * (size_t)j + 2] + d2;
+        }
     }
     block_sum<1>(lin, sm);
     if (threadIdx.x == 0) D.lin_part[blockIdx.x] = lin[0];
@@ -2043,10 +2072,11 @@ __global__ void ba_retract_cameras(BaDev D, double lambda, const double* pose_in
 }
 
 // ---- K-G2: nonlinear error of the reprojection + landmark-prior factors (thread = landmark) -----------
+template <int LPL>
 __global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double* __restrict__ pose,
                                                           const double* __restrict__ pt, const double* __restrict__ Kc) {
     __shared__ double sm[(TPB / 64) * 1];
-    const int j = blockIdx.x * TPB + threadIdx.x;
+    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
     double e[1] = {0.0};
     if (j < D.nl) {
         const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
@@ -2055,7 +2085,7 @@ __global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double*
             double K[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) K[k] = Kc[k];
-            for (int o = o0; o < o1; ++o) {
+            for (int o = o0 + sub; o < o1; o += LPL) {
                 const double* x = pose + 12 * (size_t)D.obs_cam[o];
                 double xr[12], r[2];
 #pragma unroll
@@ -2063,14 +2093,16 @@ __global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double*
                 reproj<false>(xr, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], r, nullptr, nullptr, nullptr);
                 e[0] += huber_loss(sqrt(r[0] * r[0] + r[1] * r[1]) / D.nz.pix_sigma, D.nz.pix_huber);
             }
-            const double sg = D.lmprior[2 * j], kh = D.lmprior[2 * j + 1];
-            double n2 = 0.0;
+            if (sub == 0) {  // the landmark's prior, once
+                const double sg = D.lmprior[2 * j], kh = D.lmprior[2 * j + 1];
+                double n2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double w = (l[a] - D.pt0[3 * (size_t)j + a]) / sg;
-                n2 += w * w;
+                for (int a = 0; a < 3; ++a) {
+                    const double w = (l[a] - D.pt0[3 * (size_t)j + a]) / sg;
+                    n2 += w * w;
+                }
+                e[0] += huber_loss(sqrt(n2), kh);
             }
-            e[0] += huber_loss(sqrt(n2), kh);
         }
     }
     block_sum<1>(e, sm);
@@ -2078,16 +2110,15 @@ __global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double*
 }
 
 // ---- K-G3: fixed-order final sums -> scal[0] = error, scal[1] = linearised cost change -----------------
-__global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_cam, const double* lin_cam, int with_lin, double ticket) {
+// n_lin = workgroups that left a partial of the linearised cost change in lin_part (0: no such term in this pass)
+__global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_cam, const double* lin_cam, int n_lin, double ticket) {
     __shared__ double sm[(TPB / 64) * 2];
     double v[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < D.n_lm_blocks; i += TPB) {
-        v[0] += D.err_part[i];
-        if (with_lin) v[1] += D.lin_part[i];
-    }
+    for (int i = threadIdx.x; i < D.n_ll_blocks; i += TPB) v[0] += D.err_part[i];  // (ba_error_landmarks' grid)
+    for (int i = threadIdx.x; i < n_lin; i += TPB) v[1] += D.lin_part[i];
     for (int i = threadIdx.x; i <= D.nc; i += TPB) {
         v[0] += err_cam[i];
-        if (with_lin) v[1] += lin_cam[i];
+        if (n_lin) v[1] += lin_cam[i];
     }
     block_sum<2>(v, sm);
     // The status word and the hand-off flags of the back-substitution are consumed here, so this kernel also clears
@@ -2754,6 +2785,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     if ((D.ld / 32) % 2 == 0) D.ld += 32;
     D.nz = make_noise();
     D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
+    D.lpl = nl <= 8192 ? 8 : 1;
+    D.n_ll_blocks = std::max(1, (int)(((long long)nl * D.lpl + TPB - 1) / TPB));
 
     // ---- structure: observations grouped by landmark (stable), then by camera ----
     std::vector<int> lm_ptr(nl + 1, 0);
@@ -2909,8 +2942,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
         TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
         TRY(dev_alloc(ctx, h, &D.delta_l, 3 * (size_t)nl));
-        TRY(dev_alloc(ctx, h, &D.err_part, (size_t)D.n_lm_blocks));
-        TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)D.n_lm_blocks));
+        TRY(dev_alloc(ctx, h, &D.err_part, (size_t)D.n_ll_blocks));
+        TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)D.n_ll_blocks));
         TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
         TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
         TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
@@ -2992,18 +3025,33 @@ static int ba_reset(eacham_ctx* ctx, eacham_ba_handle* h) {
 }
 
 // graph.error at (pose, pt, K) -> scal[0]
+// the three kernels that walk a landmark's observations, in the lanes-per-landmark variant of the problem (BaDev::lpl)
+static void launch_error_landmarks(eacham_ctx* ctx, const BaDev& D, const double* pose, const double* pt, const double* Kc) {
+    if (D.lpl == 8) ba_error_landmarks<8><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
+    else ba_error_landmarks<1><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
+}
+static void launch_linearize_landmarks(eacham_ctx* ctx, const BaDev& D) {
+    if (D.lpl == 8) ba_linearize_landmarks<8><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D);
+    else ba_linearize_landmarks<1><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D);
+}
+static void launch_backsub_landmarks(eacham_ctx* ctx, const BaDev& D, double lambda, double* err_cam, double* lin_cam) {
+    const int grid = D.n_ll_blocks + (D.nc + 1 + TPB - 1) / TPB;  // + the camera retraction
+    if (D.lpl == 8) ba_backsub_landmarks<8><<<grid, TPB, 0, ctx->stream>>>(D, lambda, err_cam, lin_cam);
+    else ba_backsub_landmarks<1><<<grid, TPB, 0, ctx->stream>>>(D, lambda, err_cam, lin_cam);
+}
+
 static void launch_error(eacham_ctx* ctx, eacham_ba_handle* h, const double* pose, const double* pt, const double* Kc) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
     ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, pose, D.pose_new, Kc, D.K_new, 0, h->err_cam, h->lin_cam);
-    ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
+    launch_error_landmarks(ctx, D, pose, pt, Kc);
     ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0, (double)++h->ticket);
 }
 
 static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
-    ba_linearize_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D);
+    launch_linearize_landmarks(ctx, D);
     if (D.nc > 0) ba_linearize_cameras<<<D.nc * LSEG, TPB, 0, ctx->stream>>>(D, h->kpart);
     ba_finish_linearize<<<KLIN + D.nc, 64, 0, ctx->stream>>>(D, h->kpart);
 }
@@ -3077,9 +3125,9 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
-        ba_backsub_landmarks<<<D.n_lm_blocks + (D.nc + 1 + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam);
-        ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
-        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1, (double)++h->ticket);
+        launch_backsub_landmarks(ctx, D, lambda, h->err_cam, h->lin_cam);
+        launch_error_landmarks(ctx, D, D.pose_new, D.pt_new, D.K_new);
+        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, D.n_ll_blocks, (double)++h->ticket);
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     return EACHAM_OK;
@@ -3113,8 +3161,8 @@ static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, l
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
         pcg_landmark_step<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
-        ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
-        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 1, (double)++h->ticket);
+        launch_error_landmarks(ctx, D, D.pose_new, D.pt_new, D.K_new);
+        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, D.n_lm_blocks /* pcg_landmark_step's grid */, (double)++h->ticket);
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     return EACHAM_OK;
@@ -3245,7 +3293,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
                         const int na = std::max(3 * D.nl, D.n);
                         ba_dl_apply<<<(na + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, cu * alpha, cn);
                         ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
-                        ba_error_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, D.pose_new, D.pt_new, D.K_new);
+                        launch_error_landmarks(ctx, D, D.pose_new, D.pt_new, D.K_new);
                         ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0, (double)++h->ticket);
                     }
                     rc = read_scal(ctx, h, sc);
