@@ -1,3 +1,6 @@
+"""S-sized-down RefineBA solves for kernel-floor measurements under rocprofv3: python3 tools/ba_tiny.py <cams> <landmarks>
+(with 8 cameras / 64 landmarks every per-landmark kernel is ONE wave: what it still costs is launch + the length of a thread's
+instruction stream, the reading behind BaDev::lpl)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from eacham_amd import HipContext, synth, ba
