@@ -251,8 +251,8 @@ __device__ __forceinline__ double group_sum(double v) {
 // ---- K-A: per-landmark linearisation (thread = landmark) --------------------------------------------
 // Hll, gl, ElK of the landmark (+ its prior) and E_o = Ap^T Al (6x3) of each of its observations.
 template <int LPL>
-__global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
-    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
+__device__ __forceinline__ void linearize_landmark(const BaDev& D, int gid) {
+    const int j = gid / LPL, sub = gid % LPL;
     if (j >= D.nl) return;  // (the LPL lanes of a landmark leave together)
     const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
     double* out = D.lmlin + (size_t)LMLIN * j;
@@ -332,10 +332,10 @@ __global__ __launch_bounds__(TPB) void ba_linearize_landmarks(BaDev D) {
 // -> clpart[(c * LSEG + seg)][256] = the block's 16 x 16 accumulator (waves added in order).
 constexpr int LSEG = 4;     // segments per camera
 constexpr int CLP = 256;    // 16 x 16 accumulator image per (camera, segment)
-__global__ __launch_bounds__(TPB) void ba_linearize_cameras(BaDev D, double* __restrict__ clpart) {
+__device__ __forceinline__ void linearize_camera_segment(const BaDev& D, double* __restrict__ clpart, int block) {
     __shared__ __attribute__((aligned(16))) double stage[TPB / 64][64 * 16];  // 8 KB per wave
     __shared__ double wsum[TPB / 64][4][64];
-    const int c = blockIdx.x / LSEG, seg = blockIdx.x % LSEG;
+    const int c = block / LSEG, seg = block % LSEG;
     const int q0c = D.cam_ptr[c], q1c = D.cam_ptr[c + 1];
     const int len = (q1c - q0c + LSEG - 1) / LSEG;
     const int p0 = q0c + seg * len, p1 = min(p0 + len, q1c);
@@ -402,8 +402,17 @@ __global__ __launch_bounds__(TPB) void ba_linearize_cameras(BaDev D, double* __r
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < TPB / 64; ++w) v += wsum[w][r][l];
-        clpart[(size_t)CLP * blockIdx.x + 16 * ((l >> 4) + 4 * r) + (l & 15)] = v;
+        clpart[(size_t)CLP * block + 16 * ((l >> 4) + 4 * r) + (l & 15)] = v;
     }
+}
+
+// K-A and K-B in ONE launch: the landmark side and the camera side of the linearisation read the same values and
+// write disjoint outputs; as two launches the second waited for the first (18 + 23 us on S200). The camera segments
+// (the longer role) take the low workgroup ids.
+template <int LPL>
+__global__ __launch_bounds__(TPB) void ba_linearize(BaDev D, double* __restrict__ clpart, int n_cam_blocks) {
+    if ((int)blockIdx.x < n_cam_blocks) linearize_camera_segment(D, clpart, (int)blockIdx.x);
+    else linearize_landmark<LPL>(D, ((int)blockIdx.x - n_cam_blocks) * TPB + threadIdx.x);
 }
 
 // Second stage, one launch: blocks [0, KLIN) sum the calibration parts over every (camera, segment) in fixed order
@@ -3030,9 +3039,10 @@ static void launch_error_landmarks(eacham_ctx* ctx, const BaDev& D, const double
     if (D.lpl == 8) ba_error_landmarks<8><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
     else ba_error_landmarks<1><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
 }
-static void launch_linearize_landmarks(eacham_ctx* ctx, const BaDev& D) {
-    if (D.lpl == 8) ba_linearize_landmarks<8><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D);
-    else ba_linearize_landmarks<1><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D);
+static void launch_linearize_both(eacham_ctx* ctx, const BaDev& D, double* clpart) {
+    const int ncb = D.nc * LSEG;
+    if (D.lpl == 8) ba_linearize<8><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
+    else ba_linearize<1><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
 }
 static void launch_backsub_landmarks(eacham_ctx* ctx, const BaDev& D, double lambda, double* err_cam, double* lin_cam) {
     const int grid = D.n_ll_blocks + (D.nc + 1 + TPB - 1) / TPB;  // + the camera retraction
@@ -3051,8 +3061,7 @@ static void launch_error(eacham_ctx* ctx, eacham_ba_handle* h, const double* pos
 static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
-    launch_linearize_landmarks(ctx, D);
-    if (D.nc > 0) ba_linearize_cameras<<<D.nc * LSEG, TPB, 0, ctx->stream>>>(D, h->kpart);
+    launch_linearize_both(ctx, D, h->kpart);
     ba_finish_linearize<<<KLIN + D.nc, 64, 0, ctx->stream>>>(D, h->kpart);
 }
 
