@@ -35,6 +35,9 @@ class OptimizerConfig:
         return OptimizerConfig("LM", 50, 1e-4, 10.0, False)
 
 
+ORDERINGS = {"auto": capi.BA_ORDER_AUTO, "natural": capi.BA_ORDER_NATURAL, "rcm": capi.BA_ORDER_RCM, "nd": capi.BA_ORDER_ND}
+
+
 @dataclass
 class BaArrays:
     """The BA window as plain arrays (see eacham_ba_problem in include/eacham_hip.h)."""
@@ -46,6 +49,7 @@ class BaArrays:
     obs_point: np.ndarray         # n_obs uint32
     obs_uv: np.ndarray            # n_obs x 2
     K: np.ndarray                 # fx, fy, cx, cy
+    ordering: str = "auto"        # elimination order of the reduced camera system (EACHAM_BA_ORDER_*): auto | natural | rcm | nd
     _keep: list = field(default_factory=list, repr=False)
 
     @staticmethod
@@ -73,6 +77,7 @@ class BaArrays:
         self._keep = arrs
         p = capi.BaProblem()
         p.n_cams, p.n_points, p.n_obs = arrs[0].shape[0], arrs[2].shape[0], arrs[4].shape[0]
+        p.ordering = ORDERINGS[self.ordering]
         (p.cam_T_wc, p.cam_fixed, p.points, p.point_observers, p.obs_cam, p.obs_point, p.obs_uv) = [a.ctypes.data for a in arrs]
         for i in range(4):
             p.K[i] = float(self.K[i])
@@ -166,6 +171,14 @@ class PreparedBA:
                              config, min_landmarks, trace_cap, lm_factor=lm_factor)
         self.ctx._check(rc)
         return out
+
+    def plan_info(self) -> dict:
+        """eacham_ba_get_plan_info: what the analysis of the reduced camera system decided (panels, tiles, tree height, ordering)."""
+        info = capi.BaPlanInfo()
+        self.ctx._check(self._L.eacham_ba_get_plan_info(self.ctx.handle, self._h, C.byref(info)))
+        return {"panels": info.n_panels, "tiles": info.n_tiles, "levels": info.n_levels,
+                "ordering": {v: k for k, v in ORDERINGS.items()}[info.ordering], "nd_leaf": info.nd_leaf,
+                "tile_updates": int(info.tile_updates), "est_us": round(info.est_us, 1)}
 
     def close(self):
         if self._h:

@@ -70,6 +70,7 @@ def lib() -> C.CDLL:
     L.eacham_ba_release.argtypes = [vp, vp]
     L.eacham_ba_release.restype = None
     L.eacham_ba_debug_step.argtypes = [vp, vp, dbl, vp, vp, vp, vp, vp, vp]
+    L.eacham_ba_get_plan_info.argtypes = [vp, vp, vp]
     L.eacham_triangulate_tracks.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     L.eacham_two_view_points.argtypes = [vp, i32, vp, vp, vp, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp]
     L.eacham_score_hypotheses.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp]
@@ -89,13 +90,19 @@ def lib() -> C.CDLL:
 BA_LM, BA_DOGLEG = 0, 1
 BA_DONE, BA_SKIPPED, BA_INDETERMINATE = 0, 1, 2
 BA_LM_FACTOR_RESET, BA_LM_FACTOR_DOUBLE = 0, 1
+BA_ORDER_AUTO, BA_ORDER_NATURAL, BA_ORDER_RCM, BA_ORDER_ND = 0, 1, 2, 3
 
 
 class BaProblem(C.Structure):
-    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32), ("ordering", C.c_int32),
                 ("cam_T_wc", C.c_void_p), ("cam_fixed", C.c_void_p), ("points", C.c_void_p),
                 ("point_observers", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_point", C.c_void_p),
                 ("obs_uv", C.c_void_p), ("K", C.c_double * 4)]
+
+
+class BaPlanInfo(C.Structure):
+    _fields_ = [("n_panels", C.c_int32), ("n_tiles", C.c_int32), ("n_levels", C.c_int32), ("ordering", C.c_int32),
+                ("nd_leaf", C.c_int32), ("reserved", C.c_int32), ("tile_updates", C.c_int64), ("est_us", C.c_double)]
 
 
 class BaOptions(C.Structure):

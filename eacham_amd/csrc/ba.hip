@@ -17,13 +17,15 @@
 // Linear algebra of one damped step (H + lambda diag(clamp(diag H))) delta = g:
 //   landmarks are eliminated first (3x3 blocks, one thread each), the reduced camera system
 //   S (n = 6 nc + 5, the 5 shared-calibration columns are a dense border) is assembled WITHOUT
-//   atomics — every block is a deterministic sequential sum over its pair list — factorised by a
-//   blocked right-looking Cholesky on v_mfma_f64_16x16x4_f64 (64 columns per launch, the two 32x32 diagonal
-//   blocks of a step factorised by one wave each inside tile (0,0)) with the right-hand side carried as an
-//   extra row, and the landmark steps follow by back-substitution.
+//   atomics — every block is a deterministic sequential sum over its pair list — into 64x64 TILES of the symbolic
+//   pattern of its Cholesky factor under a fill-reducing camera ordering (ba_plan.hpp: what GTSAM's multifrontal solver
+//   with COLAMD does for the reference, BundleAdjuster.cpp:182-190), factorised level by level of the elimination tree
+//   on v_mfma_f64_16x16x4_f64 (64 columns per panel, the two 32x32 diagonal blocks of a panel factorised by one wave
+//   each) with the right-hand side carried as a row of the root panel, and the landmark steps follow by back-substitution.
 // Roofline: every kernel except the dense factorisation streams observation-sized arrays once
 // (HBM-bound); see DESIGN.md for the per-kernel byte counts.
 #include "context.hpp"
+#include "ba_plan.hpp"
 
 #include <cstdlib>
 
@@ -62,12 +64,12 @@ static Noise make_noise() {
 constexpr int TPB = 256;           // threads per block of the streaming kernels
 constexpr int PAIR_CHUNK = 256;    // pair-list entries summed by one wave (lane e takes entries e, e+64, ...)
 constexpr int NB = 32;             // Cholesky block size
-constexpr int PB = 2 * NB;         // columns retired per launch of the factorisation (chol_step64)
+constexpr int PB = 2 * NB;         // columns of a panel: what one workgroup factorises per launch (sp_level)
 constexpr int LMLIN = 24;          // per-landmark linearisation: Hll(6) gl(3) ElK(15)
 constexpr int CAMLIN = 72;         // per-camera: Hcc(36) HcK(30) gc(6)
 constexpr int KLIN = 30;           // HKK(25) gK(5)
 constexpr int SCAL = 16;           // scalar block read back per try
-constexpr int N_FLAGS = 4 + 64;    // flags[0..3] status, [4..] hand-off flags of the back-substitution
+constexpr int N_STATUS = 4;        // flags[0..3] status, flags[4 + P] = hand-off flag of panel P (back-substitution)
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64: D[(lane >> 4) + 4 reg][lane & 15]
 
@@ -193,8 +195,12 @@ __device__ __forceinline__ void pose_local(const double* x, const double* p, dou
 
 // ---- device-side view of a prepared problem --------------------------------------------------------
 struct BaDev {
-    int nc, nl, no, n, ld, nr;  // n = 6 nc + 5; S is (nr+64) x ld, nr = n rounded up to the Cholesky
-                                // block size; rows n..nr-1 are padding, row nr is the right-hand side
+    int nc, nl, no, n;          // n = 6 nc + 5
+    // the reduced system in tiles (ba_plan.hpp): camera c starts at padded column sp_pos[c], K at sp_posK, the
+    // right-hand side is row sp_rhs_row (row 63 of the root panel); sp_tile_map[I (I + 1) / 2 + J] = tile of (I >= J)
+    int sp_npan, sp_ntiles, sp_posK, sp_rhs_row, sp_n_pad;
+    const int *sp_pos, *sp_tile_map, *sp_pad_cols, *sp_diag_tile;
+    double *T, *Xrow, *zsol;    // tiles [sp_ntiles][64][64]; X of every panel row-major; z of the back-substitution
     // values
     double *pose, *pose0, *pose_new, *pt, *pt0, *pt_new, *Kc, *K0, *K_new;  // Kc: fx fy s u0 v0
     const int* fixed;
@@ -218,7 +224,7 @@ struct BaDev {
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
-    double *Et, *lmtry, *S, *Lm, *Winv, *Wops, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
+    double *Et, *lmtry, *Winv, *Wops, *partial, *kk_part, *delta_c, *delta_l, *err_part, *lin_part, *scal;
     // DogLeg: Gauss-Newton step (cameras+K | landmarks) and per-block partial sums of the six forms
     double *dl_nc, *dl_nl, *dl_part;
     double* bpart;  // [n_cam_chunks][36] partial border sums
@@ -478,14 +484,14 @@ __global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double*
 // ---- K-C: per-landmark elimination for one lambda (thread = landmark) -------------------------------
 // Hd = Hll + lambda clamp(diag), Hd = L L^T, Linv; EKt = ElK Linv^T, gt = Linv gl (Et_o = E_o Linv^T: K-C2).
 // Also this block's share of the (K,K) Schur term: sum EKt EKt^T (25) and EKt gt (5) -> kk_part.
-// The launch also clears S for the assembly kernels behind it (the factorisation works in place, so S is rebuilt for
-// every lambda): the stores are issued first and drain under the arithmetic — a 12 MB fill node less per try on S200.
+// The launch also clears the tiles of S for the assembly kernels behind it (the factorisation works in place, so S is
+// rebuilt for every lambda): the stores are issued first and drain under the arithmetic — no fill node per try.
 __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double lambda) {
     __shared__ double sm[(TPB / 64) * 30];
     const int j = blockIdx.x * TPB + threadIdx.x;
     {
-        double2* S2 = reinterpret_cast<double2*>(D.S);  // ld is a multiple of 32: whole double2s
-        const size_t total = (size_t)(D.nr + 64) * D.ld / 2;
+        double2* S2 = reinterpret_cast<double2*>(D.T);
+        const size_t total = (size_t)D.sp_ntiles * (PB * PB / 2);
         for (size_t e = (size_t)j; e < total; e += (size_t)gridDim.x * TPB) S2[e] = make_double2(0.0, 0.0);
     }
     double kk[30];
@@ -734,6 +740,14 @@ __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
 }
 
 // ---- K-D2: assemble the camera blocks of S (thread = block element) ---------------------------------
+// Element (r, q) of the permuted, padded matrix (ba_plan.hpp) goes to its tile; only the lower triangle of tiles is
+// stored (a call that names an upper tile is dropped: the caller stores both (r, q) and (q, r)), a diagonal tile holds
+// both of its triangles.
+__device__ __forceinline__ void sp_store(const BaDev& D, int r, int q, double v) {
+    const int I = r >> 6, J = q >> 6;
+    if (I < J) return;
+    D.T[(size_t)D.sp_tile_map[I * (I + 1) / 2 + J] * (PB * PB) + (r & (PB - 1)) * PB + (q & (PB - 1))] = v;
+}
 __device__ __forceinline__ void assemble_blocks(const BaDev& D, double lambda, unsigned block) {
     const long long idx = (long long)block * TPB + threadIdx.x;
     const int blk = (int)(idx / 36), el = (int)(idx % 36);
@@ -748,8 +762,9 @@ __device__ __forceinline__ void assemble_blocks(const BaDev& D, double lambda, u
         v += h;
         if (a == b) v += lambda * clampd(h, 1e-6, 1e32);
     }
-    D.S[(size_t)(6 * B.x + a) * D.ld + 6 * B.y + b] = v;
-    if (B.x != B.y) D.S[(size_t)(6 * B.y + b) * D.ld + 6 * B.x + a] = v;
+    const int r = D.sp_pos[B.x] + a, q = D.sp_pos[B.y] + b;
+    sp_store(D, r, q, v);
+    if (B.x != B.y) sp_store(D, q, r, v);
 }
 
 // ---- K-D3: the calibration border and the right-hand side -------------------------------------------
@@ -765,12 +780,20 @@ __device__ __forceinline__ void assemble_border(const BaDev& D, double lambda, i
             if (k < 30) {
                 const int a = k / 5, bb = k % 5;
                 const double v = cl[36 + k] - s;
-                D.S[(size_t)(6 * c + a) * D.ld + 6 * D.nc + bb] = v;
-                D.S[(size_t)(6 * D.nc + bb) * D.ld + 6 * c + a] = v;
+                sp_store(D, D.sp_pos[c] + a, D.sp_posK + bb, v);
+                sp_store(D, D.sp_posK + bb, D.sp_pos[c] + a, v);
             } else {
-                D.S[(size_t)D.nr * D.ld + 6 * c + (k - 30)] = cl[66 + (k - 30)] - s;  // rhs row
+                sp_store(D, D.sp_rhs_row, D.sp_pos[c] + (k - 30), cl[66 + (k - 30)] - s);  // rhs row
             }
         }
+    } else if (c > D.nc) {
+        // identity on the padding columns of the panels; the pivot of the right-hand-side row: far above anything
+        // y^T y can reach, so the last pivot of the root only ever fails through a NaN from before
+        for (int k = threadIdx.x; k < D.sp_n_pad; k += TPB) {
+            const int q = D.sp_pad_cols[k];
+            D.T[(size_t)D.sp_diag_tile[q >> 6] * (PB * PB) + (q & (PB - 1)) * (PB + 1)] = 1.0;
+        }
+        if (threadIdx.x == 0) sp_store(D, D.sp_rhs_row, D.sp_rhs_row, 1e100);
     } else if (threadIdx.x < 240) {
         // K corner: 8 lanes per entry take every 8th partial (independent loads), then a fixed 3-step
         // shuffle tree
@@ -785,9 +808,9 @@ __device__ __forceinline__ void assemble_border(const BaDev& D, double lambda, i
             const int a = i / 5, bb = i % 5;
             double v = D.klin[i] - s;
             if (a == bb) v += lambda * clampd(D.klin[i], 1e-6, 1e32);
-            D.S[(size_t)(6 * D.nc + a) * D.ld + 6 * D.nc + bb] = v;
+            sp_store(D, D.sp_posK + a, D.sp_posK + bb, v);
         } else {
-            D.S[(size_t)D.nr * D.ld + 6 * D.nc + (i - 25)] = D.klin[i] - s;
+            sp_store(D, D.sp_rhs_row, D.sp_posK + (i - 25), D.klin[i] - s);
         }
     }
 }
@@ -799,22 +822,12 @@ __global__ __launch_bounds__(TPB) void ba_assemble(BaDev D, double lambda, unsig
     else assemble_border(D, lambda, (int)(blockIdx.x - n_block_groups));
 }
 
-// ---- K-E: blocked right-looking Cholesky of S (lower triangle), rhs carried as row n ------------------
-// The product path retires 64 columns per launch (chol_diag64 / chol_step64 further down, built from the factor_32 and
-// invert_behind_factor of this section). chol_diag0 / chol_step are the chain it grew out of — one launch per block
-// column k (NB = 32 wide) — kept behind EACHAM_BA_CHOL32 for A/B measurements and as a second implementation the
-// tests hold the product path against. In that chain every launch is a grid of 64x64 tiles of the
-// trailing matrix. A workgroup
-//   * loads W_k = L_kk^-1 (computed by the previous launch) and the RAW panel strips A[i.., k] of its
-//     tile, and forms the factor strips L_ik = A_ik W_k^T itself (a 32-wide MFMA product instead of a
-//     triangular solve; the tiles of the first tile column also store L_ik into Lm for the
-//     back-substitution) — so panel solve and trailing update share one launch;
-//   * updates its tile A_ij -= L_ik L_jk^T;
-//   * tile (0,0), which holds the next diagonal block, factorises it and stores W_{k+1}.
-// The raw matrix A is never overwritten inside the columns a concurrent workgroup may still read.
-// The serial chain of the whole factorisation is, per launch: tile (0,0)'s loads, its panel product, the
-// 32x32 look-ahead update, the diagonal-block factor (ONE wave, the block in MFMA accumulators) and the few
-// hundred cycles the inverting wave trails the factor by. Everything else runs beside that chain.
+// ---- K-E: the building blocks of the factorisation of a 64x64 diagonal tile -------------------------------------------
+// (factor_32: one wave factorises a 32x32 block in MFMA accumulators; invert_behind_factor: a second wave inverts the
+// factor right behind it.) The sparse, level-scheduled factorisation that uses them follows further down (sp_diag /
+// sp_level / sp_backsolve); its serial chain is, per level of the elimination tree: the factorising workgroup's loads,
+// its panel product, the look-ahead update of the first quadrant, the two diagonal-block factors (ONE wave each, the
+// block in MFMA accumulators) and the few hundred cycles the inverting wave trails each factor by.
 
 // first wave only; Dn complete. Publishes L (strictly lower part) and 1/diag through the FactorImage.
 // The 32x32 block lives in the accumulators of v_mfma_f64_16x16x4_f64 (three 16x16 blocks of the lower
@@ -975,7 +988,7 @@ __device__ __forceinline__ void factor_32(double (*Dn)[NB + 1], double (&P)[NB *
 // A lower-triangular 32x32 inverse W as the B operand of the panel product L = A W^T: lane (j = lane & 15, kk = lane >> 4)
 // of k-step t holds W[j][4t + kk] (rows 0..15, t < 4: slots 0..3) or W[16 + j][4t + kk] (t < 8: slots 4..11). Stored in
 // that order — two slots per 16-byte lane element, op_index — a consumer wave fetches a slot pair with ONE coalesced 1 KB load; read from the
-// row-major image, 64 lanes x 8 bytes out of 16 different rows, the operand fetches of chol_step64 (40 per wave) took
+// row-major image, 64 lanes x 8 bytes out of 16 different rows, the operand fetches of a 64-column panel product (40 per wave) took
 // most of 19k cycles per launch. X (a full 32x32 block) uses slots 0..7 for its rows 0..15 and 8..15 for rows 16..31.
 constexpr int WOP = 12 * 64, XOP = 16 * 64, TILE_OPS = 2 * WOP + XOP;  // per 64x64 diagonal tile: W_a | W_b | X
 __device__ __forceinline__ int op_index(int slot, int lane) { return (slot >> 1) * 128 + 2 * lane + (slot & 1); }  // slot pairs: 16-byte loads
@@ -1071,251 +1084,26 @@ __device__ __forceinline__ void invert_behind_factor(const FactorImage& F, doubl
     }
 }
 
-// W_0 = L_0^-1 of the first diagonal block
-__global__ __launch_bounds__(TPB) void chol_diag0(const double* __restrict__ A, int ld, int n, double* __restrict__ Winv,
-                                                  int* __restrict__ flags) {
-    __shared__ double Dn[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
-    __shared__ __attribute__((aligned(16))) FactorImage Fimg;
-    double raw[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {  // all four loads in flight together (S is zero-padded: no bounds tests)
-        const int idx = threadIdx.x + TPB * m;
-        raw[m] = A[(size_t)(idx / NB) * ld + idx % NB];
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int idx = threadIdx.x + TPB * m, i = idx / NB, j = idx % NB;
-        Dn[i][j] = (i < n && j < n) ? raw[m] : (i == j ? 1.0 : 0.0);
-    }
-    if (threadIdx.x == 0) Fimg.progress = 0;
-    __syncthreads();
-    if (threadIdx.x < 64) factor_32(Dn, Pslab, Fimg, flags, true);
-    else if (threadIdx.x < 128) invert_behind_factor(Fimg, Winv, flags);
-}
-
-// K-E step k. Grid = lower-triangular 64x64 tiles of the trailing matrix.
-//   * every tile workgroup loads W_k = L_kk^-1 and the RAW strips A[i.., k] of its tile and forms the factor
-//     strips L_ik = A_ik W_k^T itself with v_mfma_f64_16x16x4_f64 (the first tile column also stores L_ik into
-//     Lm) — panel solve and trailing update share one launch; the raw matrix A is never overwritten inside
-//     the columns a concurrent workgroup may still read;
-//   * updates its tile A_ij -= L_ik L_jk^T;
-//   * tile (0,0), which holds the next diagonal block, factorises it on its first wave while its fourth wave
-//     inverts the factor right behind it -> Winv[k+1], for the next launch and for the back-substitution.
-#ifdef EXP_BA_STAMPS
-__device__ unsigned long long g_ba_dbg[16];
-__device__ unsigned long long g_wg_times[3 * 1200];  // per workgroup of the 1128-tile launch: start, end (s_memrealtime), HW_ID
-#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_ba_dbg[i], now_ - st_prev); st_prev = now_; } } while (0)
-#else
-#define BSTAMP(i) do {} while (0)
-#endif
-__global__ __launch_bounds__(TPB) void chol_step(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr,
-                                                 int k0, double* __restrict__ Winv, int* __restrict__ flags) {
-#ifdef EXP_BA_STAMPS
-    unsigned long long st_prev = __builtin_readcyclecounter();
-    const unsigned long long st_start = st_prev;
-#endif
-    constexpr int LS = NB + 2;   // even row stride: 16-byte aligned pairs for ds_read_b128, still conflict-free
-    constexpr int WLD = NB + 4;  // row stride of W_k in LDS: the MFMA operand reads (16 rows x 4 columns) stay 2-way
-    // 44 KB of LDS per workgroup: three workgroups per CU (the structures only tile 0 needs for the next diagonal block
-    // live in regions that are dead by then: Dn / Pslab over Lj — a diagonal tile never reads its second strip —, the
-    // factor image over W_k, which nobody reads after the panel product). With 66 KB the steps of a large system ran
-    // their tile grids (1128 tiles at n = 3005) in two and a half rounds of 512 resident workgroups.
-    struct NextDiag { double Dn[NB][NB + 1]; double Pslab[NB * PLD]; };
-    static_assert(sizeof(double) * NB * (NB + 1) % 16 == 0, "Pslab stays 16-byte aligned");
-    __shared__ __attribute__((aligned(16))) union { double Wk[NB][WLD]; FactorImage F; } uW;
-    __shared__ __attribute__((aligned(16))) double Li[64][LS];
-    __shared__ __attribute__((aligned(16))) union { double Lj[64][LS]; NextDiag nd; } uJ;
-    static_assert(sizeof(FactorImage) <= sizeof(double) * NB * WLD && sizeof(NextDiag) <= sizeof(double) * 64 * LS, "aliases fit");
-    double (&Wk)[NB][WLD] = uW.Wk;
-    FactorImage& Fimg = uW.F;
-    double (&Lj)[64][LS] = uJ.Lj;
-    double (&Dn)[NB][NB + 1] = uJ.nd.Dn;
-    double (&Pslab)[NB * PLD] = uJ.nd.Pslab;
-    const int tid = threadIdx.x;
-    const double* __restrict__ Wsrc = Winv + (size_t)(k0 / NB) * NB * NB;
-    // W_k goes through registers so that its loads are in flight together with the panel and tile loads
-    // below: a load -> LDS-store loop costs one full memory round trip per trip, on the critical path
-    static_assert(NB * NB == 4 * TPB, "W_k is four values per thread");
-    double wraw[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) wraw[m] = Wsrc[tid + TPB * m];
-    const int k1 = k0 + NB;  // columns >= n inside the block are zero padding
-    int t = blockIdx.x, ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
-    const bool same = ti == tj;  // a diagonal tile: both strips are the same rows, one is computed
-    double (*LjE)[LS] = same ? Li : Lj;
-    // Every global read of this workgroup is issued up front so that the latencies overlap each other.
-    // The two 64 x 32 panel strips arrive coalesced (a row is 256 contiguous bytes, fetched as 16-byte pairs).
-    // No load of this kernel is predicated: S is allocated with 64 rows and columns of zero padding beyond the
-    // rhs row / the last block (ba_prepare), rows n..nr-1 and columns >= n stay zero, and values read
-    // outside the lower triangle only feed outputs that are never stored. That keeps the ~750 instructions
-    // of address arithmetic and branches off the front of the critical path.
-    double2 praw[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;  // m < 4: strip i, else strip j
-        praw[m] = *reinterpret_cast<const double2*>(&A[(size_t)((m < 4 ? i0 : j0) + rr) * ld + k0 + lp]);
-    }
-    // Tile 0 holds the next diagonal block. Its workgroup is the critical path of the whole chain, so it
-    // first updates only that 32x32 block — waves 0-2 take one 16x16 block of its lower triangle each, eight
-    // v_mfma_f64_16x16x4_f64 over the 32 panel columns — then wave 0 factorises it while waves 1-2 update the
-    // other three quarters of the tile beside it. The block itself is not written back to A: nothing reads
-    // rows k1..k1+31 of A after this step.
-    const bool first = t == 0;
-    const int wv = tid >> 6, mc = tid & 15, mg = (tid >> 4) & 3;                  // MFMA column / row group
-    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;                     // mini: block (0,0), (1,0), (1,1)
-    // trailing update: a wave owns 16 rows of the tile (row block urb) and its four 16-column blocks, in the
-    // MFMA accumulator layout. In tile 0 only waves 1-2 update (rows 32..63): wave 0 factors, wave 3 inverts.
-    const int rest_idx = tid - 64;
-    const bool rest_thread = first && rest_idx >= 0 && rest_idx < 128;
-    const bool block_thread = first ? rest_thread : true;
-    const int urb = first ? (wv == 1 ? 2 : 3) : wv;
-    mfma_d4 old[4];
-    if (block_thread) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                old[cb][reg] = (same && cb > urb) ? 0.0 : A[(size_t)(i0 + 16 * urb + mg + 4 * reg) * ld + j0 + 16 * cb + mc];
-    }
-    mfma_d4 mold = {0.0, 0.0, 0.0, 0.0};
-    if (first && wv < 3) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(size_t)(i0 + mbi + mg + 4 * reg) * ld + j0 + mbj + mc];
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) Wk[(tid + TPB * m) / NB][(tid + TPB * m) % NB] = wraw[m];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int rr = tid / 16 + 16 * (m & 3), lp = (tid % 16) * 2;
-        *reinterpret_cast<double2*>(&(m < 4 ? Li : Lj)[rr][lp]) = praw[m];  // (a diagonal tile loads the same rows twice)
-    }
-    __syncthreads();
-    BSTAMP(0);
-    {   // L_ik = A_ik W_k^T: wave w takes rows 16w..16w+15 of each strip. A operand: lane (i, kk) holds
-        // A[i][4t + kk]; B operand: lane (j, kk) holds W[j][4t + kk]; W is lower triangular, so the first 16
-        // columns only need the first four k-steps: 12 MFMAs per 16 rows instead of a 32-step substitution
-        // (6.4k cycles per step of the chain as a substitution shared by the two halves of a wave).
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            if (st == 1 && same) break;
-            double (*strip)[LS] = st == 0 ? Li : Lj;
-            double av[NB / 4];
-#pragma unroll
-            for (int ks = 0; ks < NB / 4; ++ks) av[ks] = strip[16 * wv + mc][4 * ks + mg];
-            mfma_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {  // three independent accumulation chains
-                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], Wk[mc][4 * ks + mg], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], Wk[16 + mc][4 * ks + mg], x1, 0, 0, 0);
-                x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks + 4], Wk[16 + mc][4 * ks + 16 + mg], x2, 0, 0, 0);
-            }
-            // the wave's own 16 rows: every read above precedes these writes in the wave's LDS order
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                strip[16 * wv + mg + 4 * reg][mc] = x0[reg];
-                strip[16 * wv + mg + 4 * reg][16 + mc] = x1[reg] + x2[reg];
-            }
-        }
-    }
-    __syncthreads();
-    BSTAMP(1);
-    // the tiles of the first tile column keep L_ik for the back-substitution. The store is made from LDS,
-    // coalesced, after the barrier — by everybody, except in tile 0 where waves 1-2 do it after their update.
-    auto store_panel = [&](int lane, int nlanes) {
-        for (int e = lane; e < 64 * (NB / 2); e += nlanes) {
-            const int rr = e / (NB / 2), lp = (e % (NB / 2)) * 2, grow = i0 + rr;
-            if ((grow < n || grow == nr) && k0 + lp < n)
-                *reinterpret_cast<double2*>(&Lm[(size_t)grow * ld + k0 + lp]) = *reinterpret_cast<const double2*>(&Li[rr][lp]);
-        }
-    };
-    if (tj == 0 && t != 0) store_panel(tid, TPB);
-    const bool next_diag = first && (k1 < n);
-    if (first) {
-        if (tid == 0) Fimg.progress = 0;  // (W_k's region: free since the barrier behind the panel product)
-        if (wv < 3 && next_diag) {
-            mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};  // two accumulators: two independent MFMA chains
-#pragma unroll
-            for (int ks = 0; ks < NB / 4; ks += 2) {
-                const double a0 = Li[mbi + mc][4 * ks + mg], b0 = Li[mbj + mc][4 * ks + mg];
-                const double a1 = Li[mbi + mc][4 * ks + 4 + mg], b1 = Li[mbj + mc][4 * ks + 4 + mg];
-                m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
-                m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int rr = mbi + mg + 4 * reg, cc = mbj + mc;  // rows / columns past n: identity padding
-                Dn[rr][cc] = (k1 + rr < n && k1 + cc < n) ? m0[reg] + m1[reg] : (rr == cc ? 1.0 : 0.0);
-            }
-        }
-        __syncthreads();
-        BSTAMP(2);
-        if (tid < 64) {
-            if (next_diag) factor_32(Dn, Pslab, Fimg, flags);
-            BSTAMP(4);
-#ifdef EXP_BA_STAMPS
-            if (tid == 0 && next_diag) atomicAdd(&g_ba_dbg[8], 1ull);
-            if (tid == 0 && next_diag) atomicAdd(&g_ba_dbg[6], __builtin_readcyclecounter() - st_start);
-#endif
-            return;
-        }
-        if (!rest_thread) {  // the inverting wave starts with the factor; L_ik is stored by waves 1-2, which idle early
-            if (next_diag) invert_behind_factor(Fimg, Winv + (size_t)(k1 / NB) * NB * NB, flags);
-#ifdef EXP_BA_STAMPS
-            if (tid == 192 && next_diag) atomicAdd(&g_ba_dbg[5], __builtin_readcyclecounter() - st_start);
-#endif
-            return;
-        }
-    }
-    {   // A_ij -= L_ik L_jk^T on v_mfma_f64_16x16x4_f64: eight k-steps per 16x16 block, the four blocks of the
-        // wave's rows as four independent accumulation chains (a diagonal tile skips the blocks above it)
-        double av[NB / 4];
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) av[ks] = -Li[16 * urb + mc][4 * ks + mg];
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-                if (!(same && cb > urb)) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], LjE[16 * cb + mc][4 * ks + mg], old[cb], 0, 0, 0);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int i = i0 + 16 * urb + mg + 4 * reg, j = j0 + 16 * cb + mc;
-                const bool inside = (i < n || i == nr) && j < n && j <= i;
-                if (inside && !(same && cb > urb)) A[(size_t)i * ld + j] = old[cb][reg];
-            }
-    }
-    if (first) store_panel(rest_idx, 128);
-}
-
-// ---- K-E in steps of 64 columns ---------------------------------------------------------------------------------
-// The chain of a 32-column step is launch + loads (6k cycles) + panel product + look-ahead update (3.6k) + the
-// one-wave factor (10k): a third of it is paid per LAUNCH, not per column. A 64x64 diagonal tile holds two diagonal
-// blocks a, b, and everything the second one needs — L_ba = A'_ba W_a^T and D_b = A'_bb - L_ba L_ba^T — comes from
-// the tile itself, so one workgroup can factorise both without a launch in between. chol_step64 therefore retires
-// 64 columns per launch:
+// ---- K-E in panels of 64 columns ----------------------------------------------------------------------------------
+// A 64x64 diagonal tile holds two 32x32 diagonal blocks a, b, and everything the second one needs — L_ba = A'_ba W_a^T
+// and D_b = A'_bb - L_ba L_ba^T — comes from the tile itself, so ONE workgroup factorises both without a launch in
+// between (a third of a 32-column step was paid per LAUNCH: kernel start + dependent global loads):
 //   * the panel of a tile row is ONE product with the inverse of the 64x64 factor, [L_ia L_ib] = [A_ia A_ib] W64^T,
 //     W64 = [[W_a, 0], [X, W_b]], X = -W_b L_ba W_a: 40 MFMAs per 16 rows. The producer stores W_a, W_b, X in MFMA
 //     operand order (wop_index), so the B operands are coalesced 16-byte loads; a wave fetches its own 16 rows of each
-//     raw strip as whole rows and is their only reader in LDS: no workgroup barrier before the product. (Operands
-//     fetched from the row-major images — 64 lanes x 8 bytes out of 16 rows per instruction, 92 such loads per wave —
-//     cost 19k cycles in this stage);
-//   * the trailing update is rank 64 (half the reads and writes of the trailing matrix per retired column: the first
-//     steps of a 3005-column system are bound by that traffic);
-//   * tile (0,0) updates its first quadrant first (waves 0-2), then wave 0 factorises it, wave 1 inverts behind it and
-//     waves 2-3 update the other quadrants (kept in registers) and store the panel; after a barrier waves 2-3 form
+//     raw strip as whole rows and is their only reader in LDS: no workgroup barrier before the product;
+//   * the update of a target tile is rank 64 per source panel;
+//   * a factorising workgroup updates the first quadrant of its tile first (waves 0-2), then wave 0 factorises it, wave 1
+//     inverts behind it and waves 2-3 update the other quadrants (kept in registers); after a barrier waves 2-3 form
 //     L_ba from the rows they hold (waves 0-1 publish W_a meanwhile), waves 0-2 D_b, then wave 0 factorises D_b, wave 1
 //     inverts, waves 2-3 form L_ba W_a, and all four waves finish X and publish W_b.
-// LDS: two 64 x 66 strips (67.6 KB, two workgroups per CU). Tile (0,0) is a diagonal tile — it never uses the second
-// strip — and its first strip is dead once the quadrants are updated: the factor images live in the second strip's
-// region, the four 32 x 33 images of the second half in the first's.
+// LDS: two 64 x 66 strips (67.6 KB, two workgroups per CU). A diagonal target never uses the second strip, and its
+// first strip is dead once the quadrants are updated: the factor images live in the second strip's region, the four
+// 32 x 33 images of the second half in the first's.
 constexpr int LS2 = PB + 2;  // row stride of the strips
 constexpr int TS = NB + 1;   // row stride of the 32x32 images of the second half (8-byte accesses only)
 constexpr int WLS = NB + 2;  // row stride of the LDS copy of W_a
+constexpr int TILE = PB * PB;  // doubles per tile of the sparse storage (row-major, row stride PB)
 
 // L = A W^T for 16 rows whose A operand a[0..7] (columns 0..31) sits in registers, W (lower triangular, row stride ws)
 // in LDS or global memory: columns 0..15 -> x0, 16..31 -> x1 + x2
@@ -1345,13 +1133,12 @@ struct DiagImages {  // LDS views of a 64x64 diagonal tile being factorised
 };
 
 // Second half of a diagonal tile: every thread of the workgroup, after a barrier behind which W_a (LDS copy), T10 and
-// T11 are complete. kb = global index of block b's first row. Stores L_ba -> Lm, W_b -> Wout_b (row-major, for the
-// back-substitution) and Wop_b, X -> Xop (operand order, for the next launch's panel products).
-__device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, int n, int ld, double* __restrict__ Lm,
-                                                 double* __restrict__ Wout_b, double* __restrict__ Wop_b, double* __restrict__ Xop,
-                                                 int* __restrict__ flags, int w0 = 0, unsigned long long st_prev = 0) {
+// T11 are complete. Stores W_b -> Wout_b (row-major) and Wop_b, X -> Xop (operand order, for the panel products of the
+// launches that use this panel as a source) and Xrow (row-major, for the back-substitution).
+__device__ __forceinline__ void diag_second_half(const DiagImages& I, double* __restrict__ Wout_b, double* __restrict__ Wop_b,
+                                                 double* __restrict__ Xop, double* __restrict__ Xrow, int* __restrict__ flags, int w0 = 0) {
     const int tid = threadIdx.x, mc = tid & 15, mg = (tid >> 4) & 3;
-    int wv = (tid >> 6) - w0;  // waves w0, w0 + 1 form L_ba (in chol_step64 the two that just wrote those rows of T10)
+    int wv = (tid >> 6) - w0;  // waves w0, w0 + 1 form L_ba (in sp_level the two that just wrote those rows of T10)
     if (wv >= 0 && wv < 2) {  // L_ba = A'_ba W_a^T, 16 rows per wave, in place (the wave's own rows: reads before writes, in LDS order)
         double a[8];
 #pragma unroll
@@ -1363,16 +1150,11 @@ __device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, in
             const int row = 16 * wv + mg + 4 * reg;
             I.T10[row * TS + mc] = lo[reg];
             I.T10[row * TS + 16 + mc] = hi[reg];
-            if (kb + row < n) {  // (columns kb - 32 .. kb - 1 are inside the matrix whenever block b has a real row)
-                Lm[(size_t)(kb + row) * ld + kb - NB + mc] = lo[reg];
-                Lm[(size_t)(kb + row) * ld + kb - NB + 16 + mc] = hi[reg];
-            }
         }
     }
     if (tid == 0) I.F->progress = 0;
     wv = tid >> 6;
     __syncthreads();
-    if (st_prev) BSTAMP(5);
     if (wv < 3) {  // D_b = A'_bb - L_ba L_ba^T, one 16x16 block of the lower triangle per wave
         const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;
         mfma_d4 m0, m1 = {0.0, 0.0, 0.0, 0.0};
@@ -1386,16 +1168,11 @@ __device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, in
             m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int rr = mbi + mg + 4 * reg, cc = mbj + mc;  // rows / columns past n: identity padding
-            I.Dn[rr][cc] = (kb + rr < n && kb + cc < n) ? m0[reg] + m1[reg] : (rr == cc ? 1.0 : 0.0);
-        }
+        for (int reg = 0; reg < 4; ++reg) I.Dn[mbi + mg + 4 * reg][mbj + mc] = m0[reg] + m1[reg];
     }
     __syncthreads();
-    if (st_prev) BSTAMP(6);
     if (wv == 0) {
         factor_32(I.Dn, *reinterpret_cast<double (*)[NB * PLD]>(I.Pslab), *I.F, flags);
-        if (st_prev) BSTAMP(7);
     } else if (wv == 1) {
         invert_behind_factor(*I.F, nullptr, flags, I.Wb, TS);
     } else {  // P1 = L_ba W_a beside the factor: rows 16 (wv - 2) .., W_a[k][j] = 0 for k < j
@@ -1414,7 +1191,6 @@ __device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, in
         }
     }
     __syncthreads();
-    if (st_prev) BSTAMP(9);
     {   // X = -W_b P1: one 16x16 block per wave, W_b[i][k] = 0 for k > i; W_b is published in the shadow of the chain
         const int bi = wv >> 1, bj = wv & 1;
         mfma_d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = x;  // two chains: a dependent f64 MFMA waits out the full 64-cycle pass
@@ -1426,42 +1202,56 @@ __device__ __forceinline__ void diag_second_half(const DiagImages& I, int kb, in
             }
         publish_w<TPB>(I.Wb, TS, Wout_b, Wop_b, tid);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Xop[xop_index(16 * bi + mg + 4 * reg, 16 * bj + mc)] = x[reg] + x2[reg];
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * bi + mg + 4 * reg, col = 16 * bj + mc;
+            const double v = x[reg] + x2[reg];
+            Xop[xop_index(row, col)] = v;
+            Xrow[row * NB + col] = v;
+        }
     }
-    if (st_prev) BSTAMP(10);
 }
 
-// the first diagonal tile: W_0, W_1, L_10 and X_0
-__global__ __launch_bounds__(TPB) void chol_diag64(const double* __restrict__ A, double* __restrict__ Lm, int ld, int n,
-                                                   double* __restrict__ Winv, double* __restrict__ Wops, int* __restrict__ flags) {
+// ---- the sparse, level-scheduled factorisation (plan: ba_plan.hpp) ------------------------------------------------
+// S lives as 64x64 tiles of the symbolic pattern of its Cholesky factor (cameras permuted and laid out in panels by the
+// plan; padding columns carry an identity diagonal, the right-hand side is row 63 of the root panel). Per panel P the
+// factorisation leaves W64_P = [[W_a, 0], [X, W_b]] = (factor of the fully updated diagonal tile)^-1 in Winv (W_a, W_b
+// row-major), Xrow and Wops (operand order); the off-diagonal tiles end as the RAW updated strips A'[I][P] — the factor
+// strips L[I][P] = A'[I][P] W64_P^T are formed on the fly by every consumer and never stored: the back-substitution
+// works on the raw tiles too (sp_backsolve).
+
+// Launch 0: the diagonal tiles of the leaves of the elimination tree (nothing updates them), one workgroup each.
+__global__ __launch_bounds__(TPB) void sp_diag(const double* __restrict__ T, const int* __restrict__ leaves, const int* __restrict__ diag_tile,
+                                               double* __restrict__ Winv, double* __restrict__ Wops, double* __restrict__ Xrow,
+                                               int* __restrict__ flags) {
     __shared__ double Dn[NB][NB + 1];
     __shared__ __attribute__((aligned(16))) double Pslab[NB * PLD];
     __shared__ __attribute__((aligned(16))) FactorImage Fimg;
     __shared__ double Wa[NB * WLS], T10[NB * TS], T11[NB * TS], P1[NB * TS], Wb[NB * TS];
     const int tid = threadIdx.x;
+    const int P = leaves[blockIdx.x];
+    const double* __restrict__ A = T + (size_t)diag_tile[P] * TILE;
     double raw[12];
 #pragma unroll
-    for (int m = 0; m < 12; ++m) {  // the three quadrants of the lower triangle, all loads in flight together (S is zero-padded)
+    for (int m = 0; m < 12; ++m) {  // the three quadrants of the lower triangle, all loads in flight together
         const int q = m >> 2, idx = tid + TPB * (m & 3), i = idx / NB + (q > 0 ? NB : 0), j = idx % NB + (q == 2 ? NB : 0);
-        raw[m] = A[(size_t)i * ld + j];
+        raw[m] = A[i * PB + j];
     }
 #pragma unroll
     for (int m = 0; m < 12; ++m) {
         const int q = m >> 2, idx = tid + TPB * (m & 3), i = idx / NB, j = idx % NB;
-        const int gi = i + (q > 0 ? NB : 0), gj = j + (q == 2 ? NB : 0);
-        const bool in = gi < n && gj < n;
-        if (q == 0) Dn[i][j] = in ? raw[m] : (i == j ? 1.0 : 0.0);
-        else if (q == 1) T10[i * TS + j] = in ? raw[m] : 0.0;
-        else T11[i * TS + j] = in ? raw[m] : (i == j ? 1.0 : 0.0);
+        if (q == 0) Dn[i][j] = raw[m];
+        else if (q == 1) T10[i * TS + j] = raw[m];
+        else T11[i * TS + j] = raw[m];
     }
     if (tid == 0) Fimg.progress = 0;
     __syncthreads();
-    if (tid < 64) factor_32(Dn, Pslab, Fimg, flags, true);
+    if (tid < 64) factor_32(Dn, Pslab, Fimg, flags, blockIdx.x == 0);
     else if (tid < 128) invert_behind_factor(Fimg, nullptr, flags, Wa, WLS);
     __syncthreads();
-    if (tid >= 128) publish_w<128>(Wa, WLS, Winv, Wops, tid - 128);  // (waves 0-1 form L_ba next)
+    if (tid >= 128) publish_w<128>(Wa, WLS, Winv + (size_t)(2 * P) * NB * NB, Wops + (size_t)P * TILE_OPS, tid - 128);  // (waves 0-1 form L_ba next)
     DiagImages I{Dn, Pslab, &Fimg, Wa, T10, T11, P1, Wb};
-    diag_second_half(I, NB, n, ld, Lm, Winv + NB * NB, Wops + WOP, Wops + 2 * WOP, flags);
+    diag_second_half(I, Winv + (size_t)(2 * P + 1) * NB * NB, Wops + (size_t)P * TILE_OPS + WOP, Wops + (size_t)P * TILE_OPS + 2 * WOP,
+                     Xrow + (size_t)P * NB * NB, flags);
 }
 
 // [L_a L_b] = [A_a A_b] W64^T for the wave's 16 rows of a strip, in place: every operand read of the strip precedes the
@@ -1495,294 +1285,187 @@ __device__ __forceinline__ void panel64(double (*strip)[LS2], int wv, int mc, in
     }
 }
 
-// the 64 x 64 panel of a tile row: LDS -> Lm, coalesced, every LDS read in flight before the first store
-template <int NT>
-__device__ __forceinline__ void store_panel64(double (*Li)[LS2], double* __restrict__ Lm, int ld, int n, int nr, int i0, int k0, int thread) {
-    constexpr int PER = 64 * (PB / 2) / NT;
-#pragma unroll
-    for (int h = 0; h < PER; h += 8) {  // eight 16-byte pieces at a time (sixteen registers)
-        double2 v[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int e = thread + NT * (h + m);
-            v[m] = *reinterpret_cast<const double2*>(&Li[e / (PB / 2)][(e % (PB / 2)) * 2]);
-        }
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int e = thread + NT * (h + m), rr = e / (PB / 2), lp = (e % (PB / 2)) * 2, grow = i0 + rr;
-            if ((grow < n || grow == nr) && k0 + lp < n) *reinterpret_cast<double2*>(&Lm[(size_t)grow * ld + k0 + lp]) = v[m];
-        }
-    }
-}
-
-// MODE 0: the whole step in one launch (every tile forms the panel strips of its row and column itself: the chain pays one
-//         launch per 64 columns, the right trade while a launch is bound by tile (0,0)'s chain).
-// MODE 1 + MODE 2: for launches bound by their tile grid (config 4: 1128 tiles, four rounds of 256 CUs). A tile of
-//         MODE 0 is 144 MFMAs per wave, 80 of which re-form strips that every tile of the row / column forms again — and
-//         the f64 MFMA of this chip runs at the vector rate (64 cycles per instruction). MODE 1 (grid = tile rows) forms
-//         every strip ONCE and stores it to Lm; MODE 2 (grid = tiles) reads the finished strips from Lm and only makes
-//         the rank-64 update (+ tile (0,0)'s factorisations).
-template <int MODE>
-__global__ __launch_bounds__(TPB, 2) void chol_step64(double* __restrict__ A, double* __restrict__ Lm, int ld, int n, int nr, int k0,
-                                                      double* __restrict__ Winv, double* __restrict__ Wops, int* __restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 64 * LS2];
+// Launch l + 1: the updates of every source panel J of level l, one workgroup per TARGET tile (I1, I2):
+//   A[I1][I2] -= sum_J L[I1][J] L[I2][J]^T,   L[I][J] = A'[I][J] W64_J^T formed from the raw strip and J's operands,
+// the sources in the plan's order (ascending J: a fixed summation order, no atomics; a tile is written by exactly one
+// workgroup of a launch and read as a strip only in the launch of its own column's level). A diagonal target (P, P)
+// whose panel P has level l + 1 is complete after its last source: that workgroup goes on and factorises it ->
+// W_a, W_b, X of P (the chain of the launch: these items are dispatched first). Its tile is not written back: nothing
+// reads a diagonal tile after its factorisation.
+template <bool FIRST>
+__device__ __forceinline__ void sp_level_item(double* lds, double* __restrict__ T, const BaPlanItem* __restrict__ items,
+                                              const BaPlanSrc* __restrict__ srcs, double* __restrict__ Winv, double* __restrict__ Wops,
+                                              double* __restrict__ Xrow, int* __restrict__ flags) {
     double (*Li)[LS2] = reinterpret_cast<double (*)[LS2]>(lds);
     double (*Lj)[LS2] = reinterpret_cast<double (*)[LS2]>(lds + 64 * LS2);
-#ifdef EXP_BA_STAMPS
-    unsigned long long st_prev = __builtin_readcyclecounter();
-    if (gridDim.x == 1128 && threadIdx.x == 0) {
-        g_wg_times[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-        g_wg_times[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
-    }
-#else
-    const unsigned long long st_prev = 0;
-#endif
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mc = tid & 15, mg = (tid >> 4) & 3;
-    const int k1 = k0 + PB;
-    int t = blockIdx.x, ti = 0;
-    if (MODE == 1) ti = t;  // one workgroup per tile row
-    else while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = MODE == 1 ? ti : t - ti * (ti + 1) / 2;
-    const int i0 = k1 + 64 * ti, j0 = k1 + 64 * tj;
-    const bool same = ti == tj;
-    const bool first = MODE != 1 && t == 0 && k1 < n;  // the tile that holds the next two diagonal blocks
-    // Every global read is issued up front, none is predicated (see chol_step: S has 64 rows and columns of padding).
-    // A wave fetches ITS 16 rows of each raw strip, two whole rows (2 x 512 bytes) per instruction, and is the only
-    // reader of their LDS image: no workgroup barrier before the panel product.
-    const double* __restrict__ Src = MODE == 2 ? Lm : A;  // MODE 2: the strips are the finished panel (rows / columns past n: zeros)
-    double2 pi[8], pj[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) pi[m] = *reinterpret_cast<const double2*>(&Src[(size_t)(i0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
-#pragma unroll
-    for (int m = 0; m < 8; ++m)  // (a diagonal tile fetches the same rows twice: the second strip is then never used)
-        pj[m] = *reinterpret_cast<const double2*>(&Src[(size_t)(j0 + 16 * wv + 2 * m + (lane >> 5)) * ld + k0 + 2 * (lane & 31)]);
-    // the B operands of the panel product, stored in operand order by the producer: one coalesced load per k-step
-    const double* __restrict__ ops = Wops + (size_t)(k0 / PB) * TILE_OPS;
-    double wa[12], wb[12], xp[16];
-    if (MODE != 2) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if (q < 6) {
-            const double2 u = *reinterpret_cast<const double2*>(&ops[op_index(2 * q, lane)]), v = *reinterpret_cast<const double2*>(&ops[WOP + op_index(2 * q, lane)]);
-            wa[2 * q] = u.x, wa[2 * q + 1] = u.y, wb[2 * q] = v.x, wb[2 * q + 1] = v.y;
-        }
-        const double2 u = *reinterpret_cast<const double2*>(&ops[2 * WOP + op_index(2 * q, lane)]);
-        xp[2 * q] = u.x, xp[2 * q + 1] = u.y;
-    }
-    }
-    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;  // first quadrant of tile 0: blocks (0,0), (1,0), (1,1)
-    const bool block_thread = MODE != 1 && (!first || wv >= 2);  // a wave owns 16 rows of the tile and its four 16-column blocks
+    const BaPlanItem it = items[blockIdx.x];
+    const bool first = FIRST;                          // a diagonal target that this workgroup factorises after its last source
+    const bool same = FIRST || (it.flags & 1) != 0;    // a diagonal target: both strips are the same rows, one is formed
+    double* __restrict__ A = T + (size_t)it.tgt * TILE;
+    const int mbi = wv == 0 ? 0 : 16, mbj = wv == 2 ? 16 : 0;  // first quadrant of a factorising item: blocks (0,0), (1,0), (1,1)
+    const bool block_thread = !first || wv >= 2;  // a wave owns 16 rows of the tile and its four 16-column blocks
     mfma_d4 old[4];
     if (block_thread) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-                old[cb][reg] = (same && cb > wv) ? 0.0 : A[(size_t)(i0 + 16 * wv + mg + 4 * reg) * ld + j0 + 16 * cb + mc];
+                old[cb][reg] = (same && cb > wv) ? 0.0 : A[(16 * wv + mg + 4 * reg) * PB + 16 * cb + mc];
     }
     mfma_d4 mold = {0.0, 0.0, 0.0, 0.0};
     if (first && wv < 3) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(size_t)(i0 + mbi + mg + 4 * reg) * ld + j0 + mbj + mc];
+        for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(mbi + mg + 4 * reg) * PB + mbj + mc];
     }
+#pragma unroll 1
+    for (int s = 0; s < it.nsrc; ++s) {
+        const BaPlanSrc sr = srcs[it.src0 + s];
+        // Every global read of a source is issued up front, none is predicated. A wave fetches ITS 16 rows of each raw
+        // strip, two whole rows (2 x 512 bytes) per instruction, and is the only reader of their LDS image: no
+        // workgroup barrier before the panel product.
+        const double* __restrict__ Si = T + (size_t)sr.tile_i * TILE;
+        const double* __restrict__ Sj = T + (size_t)sr.tile_j * TILE;
+        double2 pi[8], pj[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        *reinterpret_cast<double2*>(&Li[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pi[m];
-        *reinterpret_cast<double2*>(&Lj[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pj[m];
-    }
-    if (MODE != 2) {
+        for (int m = 0; m < 8; ++m) pi[m] = *reinterpret_cast<const double2*>(&Si[(16 * wv + 2 * m + (lane >> 5)) * PB + 2 * (lane & 31)]);
+        if (!FIRST) {  // (a diagonal target fetches the same rows twice: a conditionally initialised array would live in scratch)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) pj[m] = *reinterpret_cast<const double2*>(&Sj[(16 * wv + 2 * m + (lane >> 5)) * PB + 2 * (lane & 31)]);
+        }
+        // the B operands of the panel product, stored in operand order by the producer: one coalesced load per k-step
+        const double* __restrict__ ops = Wops + (size_t)sr.J * TILE_OPS;
+        double wa[12], wb[12], xp[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < 6) {
+                const double2 u = *reinterpret_cast<const double2*>(&ops[op_index(2 * q, lane)]), v = *reinterpret_cast<const double2*>(&ops[WOP + op_index(2 * q, lane)]);
+                wa[2 * q] = u.x, wa[2 * q + 1] = u.y, wb[2 * q] = v.x, wb[2 * q + 1] = v.y;
+            }
+            const double2 u = *reinterpret_cast<const double2*>(&ops[2 * WOP + op_index(2 * q, lane)]);
+            xp[2 * q] = u.x, xp[2 * q + 1] = u.y;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) *reinterpret_cast<double2*>(&Li[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pi[m];
+        if (!FIRST) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) *reinterpret_cast<double2*>(&Lj[16 * wv + 2 * m + (lane >> 5)][2 * (lane & 31)]) = pj[m];
+        }
         wave_lds_sync();
         panel64(Li, wv, mc, mg, wa, wb, xp);
         if (!same) panel64(Lj, wv, mc, mg, wa, wb, xp);
-    }
-    __syncthreads();
-    BSTAMP(0);
-    double (*LjE)[LS2] = same ? Li : Lj;
-    // the tiles of the first tile column keep the panel for the back-substitution (coalesced, from LDS)
-    if (MODE == 1) {
-        store_panel64<TPB>(Li, Lm, ld, n, nr, i0, k0, tid);
-        return;
-    }
-    if (MODE == 0 && tj == 0 && !first) store_panel64<TPB>(Li, Lm, ld, n, nr, i0, k0, tid);
-    if (first) {
-        // images of the factorisation: second strip's region (a diagonal tile never writes it)
-        double* base = lds + 64 * LS2;
-        double (*Dn)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(base);
-        double* Pslab = base + NB * (NB + 1);  // 1056 doubles in: 16-byte aligned
-        FactorImage* F = reinterpret_cast<FactorImage*>(Pslab + NB * PLD);
-        double* Wal = reinterpret_cast<double*>(F) + (sizeof(FactorImage) + 7) / 8 + 1;
-        static_assert(NB * (NB + 1) % 2 == 0 && (NB * PLD) % 2 == 0, "Pslab and the factor image stay 16-byte aligned");
-        static_assert(NB * (NB + 1) + NB * PLD + (sizeof(FactorImage) + 7) / 8 + 1 + NB * WLS <= 64 * LS2, "the images fit the second strip");
-        static_assert(4 * NB * TS <= 64 * LS2, "the images of the second half fit the first strip");
-        DiagImages I{Dn, Pslab, F, Wal, lds, lds + NB * TS, lds + 2 * NB * TS, lds + 3 * NB * TS};
-        if (tid == 0) F->progress = 0;
-        if (wv < 3) {  // first quadrant: A_00 - L_0 L_0^T over the 64 panel columns
-            mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < PB / 4; q += 2) {
-                const double a0 = Li[mbi + mc][4 * q + mg], b0 = Li[mbj + mc][4 * q + mg];
-                const double a1 = Li[mbi + mc][4 * q + 4 + mg], b1 = Li[mbj + mc][4 * q + 4 + mg];
-                m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
-                m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int rr = mbi + mg + 4 * reg, cc = mbj + mc;
-                Dn[rr][cc] = (k1 + rr < n && k1 + cc < n) ? m0[reg] + m1[reg] : (rr == cc ? 1.0 : 0.0);
-            }
-        }
         __syncthreads();
-        BSTAMP(1);
-#ifdef EXP_BA_STAMPS
-        const unsigned long long st_q = __builtin_readcyclecounter();
-#endif
-        if (wv == 0) {
-            factor_32(Dn, *reinterpret_cast<double (*)[NB * PLD]>(Pslab), *F, flags);
-            BSTAMP(2);
-        } else if (wv == 1) {
-            invert_behind_factor(*F, nullptr, flags, Wal, WLS);
-#ifdef EXP_BA_STAMPS
-            if (lane == 0) atomicAdd(&g_ba_dbg[12], __builtin_readcyclecounter() - st_q);
-#endif
-        } else {  // rows 32..63 of the tile beside the factor; the results stay in registers until the strip is dead
+        if (first) {
+            if (s + 1 == it.nsrc) break;  // the last source: its updates are interleaved with the factorisation below
+            if (wv < 3) {  // first quadrant, kept in registers
+                mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < PB / 4; ++q) {
-                const double av = -Li[16 * wv + mc][4 * q + mg];
+                for (int q = 0; q < PB / 4; q += 2) {
+                    const double a0 = Li[mbi + mc][4 * q + mg], b0 = Li[mbj + mc][4 * q + mg];
+                    const double a1 = Li[mbi + mc][4 * q + 4 + mg], b1 = Li[mbj + mc][4 * q + 4 + mg];
+                    m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
+                    m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
+                }
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-                    if (cb <= wv) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
+                for (int reg = 0; reg < 4; ++reg) mold[reg] = m0[reg] + m1[reg];
             }
-#ifdef EXP_BA_STAMPS
-            if (lane == 0) atomicAdd(&g_ba_dbg[wv == 2 ? 13 : 11], __builtin_readcyclecounter() - st_q);
-#endif
-            if (MODE == 0) store_panel64<128>(Li, Lm, ld, n, nr, i0, k0, tid - 128);
-#ifdef EXP_BA_STAMPS
-            if (lane == 0 && wv == 3) atomicAdd(&g_ba_dbg[14], __builtin_readcyclecounter() - st_q);
-#endif
+            if (wv >= 2) {  // rows 32..63
+#pragma unroll
+                for (int q = 0; q < PB / 4; ++q) {
+                    const double av = -Li[16 * wv + mc][4 * q + mg];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        if (cb <= wv) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // every read of this source's strips is complete (no array of loads is live across this barrier)
+            continue;
         }
-        __syncthreads();  // the strip is dead: W_a's copy, the factor of block a and every read of Li are complete
-        BSTAMP(3);
-        if (wv >= 2) {  // the wave's 16 rows of A'_ba (own rows of T10: wave-local) and of A'_bb
-            const int r0 = 16 * (wv - 2);
-            const bool interior = k1 + PB <= n;
+        // A_ij -= L_i L_j^T over the 64 panel columns: the four 16-column blocks of the wave's rows as four chains
+        double (*LjE)[LS2] = same ? Li : Lj;
+#pragma unroll
+        for (int q = 0; q < PB / 4; ++q) {
+            const double av = -Li[16 * wv + mc][4 * q + mg];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = r0 + mg + 4 * reg, col = 16 * (cb & 1) + mc;
-                    const bool rin = interior || k1 + NB + row < n;  // (a tile inside the matrix takes no padding)
-                    if (cb < 2) I.T10[row * TS + col] = (rin && (interior || k1 + col < n)) ? old[cb][reg] : 0.0;
-                    else I.T11[row * TS + col] = (rin && (interior || k1 + NB + col < n)) ? old[cb][reg] : (row == col ? 1.0 : 0.0);
-                }
-            wave_lds_sync();
-        } else {  // waves 0-1 are idle until D_b: they publish W_a
-            publish_w<128>(Wal, WLS, Winv + (size_t)(k1 / NB) * NB * NB, Wops + (size_t)(k1 / PB) * TILE_OPS, tid);
+                if (!(same && cb > wv)) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LjE[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
         }
-#ifdef EXP_BA_STAMPS
-        if (tid == 0) atomicAdd(&g_ba_dbg[15], 1ull);
-#endif
-        diag_second_half(I, k1 + NB, n, ld, Lm, Winv + (size_t)(k1 / NB + 1) * NB * NB, Wops + (size_t)(k1 / PB) * TILE_OPS + WOP,
-                         Wops + (size_t)(k1 / PB) * TILE_OPS + 2 * WOP, flags, 2, st_prev);
-        return;
+        if (s + 1 < it.nsrc) __syncthreads();  // every read of this source's strips is complete before the next one's land
     }
-    // A_ij -= L_i L_j^T over the 64 panel columns: the four 16-column blocks of the wave's rows as four chains
-#pragma unroll
-    for (int q = 0; q < PB / 4; ++q) {
-        const double av = -Li[16 * wv + mc][4 * q + mg];
+    if (!first) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-            if (!(same && cb > wv)) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LjE[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (!(same && cb > wv)) A[(16 * wv + mg + 4 * reg) * PB + 16 * cb + mc] = old[cb][reg];
+        return;
     }
+    // ---- the factorising item, behind the barrier of its last source's panel product ----
+    // images of the factorisation: second strip's region (a diagonal target never writes it)
+    double* base = lds + 64 * LS2;
+    double (*Dn)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(base);
+    double* Pslab = base + NB * (NB + 1);  // 1056 doubles in: 16-byte aligned
+    FactorImage* F = reinterpret_cast<FactorImage*>(Pslab + NB * PLD);
+    double* Wal = reinterpret_cast<double*>(F) + (sizeof(FactorImage) + 7) / 8 + 1;
+    static_assert(NB * (NB + 1) % 2 == 0 && (NB * PLD) % 2 == 0, "Pslab and the factor image stay 16-byte aligned");
+    static_assert(NB * (NB + 1) + NB * PLD + (sizeof(FactorImage) + 7) / 8 + 1 + NB * WLS <= 64 * LS2, "the images fit the second strip");
+    static_assert(4 * NB * TS <= 64 * LS2, "the images of the second half fit the first strip");
+    DiagImages I{Dn, Pslab, F, Wal, lds, lds + NB * TS, lds + 2 * NB * TS, lds + 3 * NB * TS};
+    const int P = it.panel;
+    if (tid == 0) F->progress = 0;
+    if (wv < 3) {  // first quadrant: A_00 - L_0 L_0^T over the 64 panel columns
+        mfma_d4 m0 = mold, m1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int i = i0 + 16 * wv + mg + 4 * reg, j = j0 + 16 * cb + mc;
-            const bool inside = (i < n || i == nr) && j < n && j <= i;
-            if (inside && !(same && cb > wv)) A[(size_t)i * ld + j] = old[cb][reg];
+        for (int q = 0; q < PB / 4; q += 2) {
+            const double a0 = Li[mbi + mc][4 * q + mg], b0 = Li[mbj + mc][4 * q + mg];
+            const double a1 = Li[mbi + mc][4 * q + 4 + mg], b1 = Li[mbj + mc][4 * q + 4 + mg];
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, m1, 0, 0, 0);
         }
-#ifdef EXP_BA_STAMPS
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Dn[mbi + mg + 4 * reg][mbj + mc] = m0[reg] + m1[reg];
+    }
     __syncthreads();
-    if (gridDim.x == 1128 && threadIdx.x == 0) g_wg_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
+    if (wv == 0) {
+        factor_32(Dn, *reinterpret_cast<double (*)[NB * PLD]>(Pslab), *F, flags);
+    } else if (wv == 1) {
+        invert_behind_factor(*F, nullptr, flags, Wal, WLS);
+    } else {  // rows 32..63 of the tile beside the factor; the results stay in registers until the strip is dead
+#pragma unroll
+        for (int q = 0; q < PB / 4; ++q) {
+            const double av = -Li[16 * wv + mc][4 * q + mg];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                if (cb <= wv) old[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[16 * cb + mc][4 * q + mg], old[cb], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // the strip is dead: W_a's copy, the factor of block a and every read of Li are complete
+    if (wv >= 2) {  // the wave's 16 rows of A'_ba (own rows of T10: wave-local) and of A'_bb
+        const int r0 = 16 * (wv - 2);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = r0 + mg + 4 * reg, col = 16 * (cb & 1) + mc;
+                if (cb < 2) I.T10[row * TS + col] = old[cb][reg];
+                else I.T11[row * TS + col] = old[cb][reg];  // (block (2, 3) of wave 2 is the zero it was loaded as: never read)
+            }
+        wave_lds_sync();
+    } else {  // waves 0-1 are idle until D_b: they publish W_a
+        publish_w<128>(Wal, WLS, Winv + (size_t)(2 * P) * NB * NB, Wops + (size_t)P * TILE_OPS, tid);
+    }
+    diag_second_half(I, Winv + (size_t)(2 * P + 1) * NB * NB, Wops + (size_t)P * TILE_OPS + WOP, Wops + (size_t)P * TILE_OPS + 2 * WOP,
+                     Xrow + (size_t)P * NB * NB, flags, 2);
 }
 
-// back substitution L^T x = y (y = row nr of Lm) in super-blocks of SB = 4 x NB columns, one launch per
-// super-block so that the n^2/2 doubles of L are streamed by many CUs instead of one (a single
-// workgroup reads ~14 GB/s). Launch for super-block K (descending):
-//   * workgroup s < K updates its own 128 columns  y_s -= L[K-rows, s-cols]^T x_K
-//   * workgroup K-1 then solves its own super-block (4 inner steps with the explicit inverses W_b)
-//     and publishes x_{K-1} for the next launch. The first launch only solves the last super-block.
-// xv holds y on entry (copied from row nr of Lm) and x on exit.
-constexpr int SB = 4 * NB;
-constexpr int BSTEP_THREADS = 1024;
-__global__ __launch_bounds__(BSTEP_THREADS) void chol_backstep(const double* __restrict__ Lm, int ld, int n, int K, int s_base,
-                                                               int solve_only, const double* __restrict__ Winv,
-                                                               double* __restrict__ xv) {
-    __shared__ double xK[SB];                     // x of super-block K (update) / running y of the solved block
-    __shared__ double part[BSTEP_THREADS / SB][SB];
-    __shared__ double Ws[SB / NB][NB][NB + 1];    // inverses of the 4 inner diagonal blocks (solver only)
-    __shared__ double Lin[SB][SB - NB + 1];       // rows of the super-block, columns left of their inner block
-    const int tid = threadIdx.x;
-    const int s = blockIdx.x + s_base;            // column slice = super-block index of this workgroup
-    const int c0 = s * SB;
-    const bool solver = solve_only || s == K - 1;
-    if (solver) {  // issue the solver's loads first: their latency overlaps the update below
-        for (int idx = tid; idx < (SB / NB) * NB * NB; idx += BSTEP_THREADS) {
-            const int b = idx / (NB * NB), e = idx % (NB * NB);
-            const int kb = c0 / NB + b;
-            Ws[b][e / NB][e % NB] = (kb * NB < n) ? Winv[(size_t)kb * NB * NB + e] : 0.0;
-        }
-        for (int idx = tid; idx < SB * (SB - NB); idx += BSTEP_THREADS) {
-            const int r = idx / (SB - NB), c = idx % (SB - NB);
-            Lin[r][c] = (c < (r / NB) * NB && c0 + r < n) ? Lm[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
-        }
-    }
-    if (!solve_only) {
-        const int K0 = K * SB;
-        if (tid < SB) xK[tid] = (K0 + tid < n) ? xv[K0 + tid] : 0.0;
-        __syncthreads();
-        // 8 threads per column, 16 rows each (rows are contiguous along columns: coalesced)
-        const int cl = tid & (SB - 1), pr = tid / SB, col = c0 + cl;
-        constexpr int RP = SB / (BSTEP_THREADS / SB);
-        double sacc = 0.0;
-        if (col < n) {
-#pragma unroll
-            for (int r = pr * RP; r < (pr + 1) * RP; ++r)
-                if (K0 + r < n) sacc += Lm[(size_t)(K0 + r) * ld + col] * xK[r];
-        }
-        part[pr][cl] = sacc;
-        __syncthreads();
-        if (tid < SB && c0 + tid < n) {
-            double tot = 0.0;
-#pragma unroll
-            for (int q = 0; q < BSTEP_THREADS / SB; ++q) tot += part[q][tid];
-            xv[c0 + tid] -= tot;
-        }
-        if (!solver) return;
-    }
-    // solve super-block s: inner blocks b = 3..0, everything from LDS
-    __syncthreads();
-    double* ys = xK;
-    if (tid < SB) ys[tid] = (c0 + tid < n) ? xv[c0 + tid] : 0.0;
-    __syncthreads();
-    for (int b = SB / NB - 1; b >= 0; --b) {
-        double xb = 0.0;
-        if (tid < NB) {              // x_b = W^T y_b
-            for (int m = tid; m < NB; ++m) xb += Ws[b][m][tid] * ys[b * NB + m];
-        }
-        __syncthreads();
-        if (tid < NB) ys[b * NB + tid] = xb;
-        __syncthreads();
-        if (tid < b * NB) {          // y[inner cols < b] -= L[block-b rows, col]^T x_b
-            double sacc = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < NB; ++j) sacc += Lin[b * NB + j][tid] * ys[b * NB + j];
-            ys[tid] -= sacc;
-        }
-        __syncthreads();
-    }
-    if (tid < SB && c0 + tid < n) xv[c0 + tid] = ys[tid];
+// The factorising items of a launch come first in its item list (n_first of them): the two roles are separate code paths
+// of one kernel (as two kernels the second would wait for the first: a launch more on the chain of every level).
+__global__ __launch_bounds__(TPB, 2) void sp_level(double* __restrict__ T, const BaPlanItem* __restrict__ items, const BaPlanSrc* __restrict__ srcs,
+                                                   int n_first, double* __restrict__ Winv, double* __restrict__ Wops,
+                                                   double* __restrict__ Xrow, int* __restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 64 * LS2];
+    if ((int)blockIdx.x < n_first) sp_level_item<true>(lds, T, items, srcs, Winv, Wops, Xrow, flags);
+    else sp_level_item<false>(lds, T, items, srcs, Winv, Wops, Xrow, flags);
 }
 
 // sum of v over aligned groups of W lanes inside a 16-lane DPP row; valid in each group's last lane
@@ -1803,147 +1486,123 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
     return v;
 }
 
-// Back substitution in ONE launch: workgroup s owns super-block s, the super-blocks hand their solutions
-// down through global memory with release/acquire flags instead of kernel boundaries (the chain of
-// launches cost ~18 us per super-block: launch + dependent global round trips; the hand-off ~7 us).
-// Every workgroup is resident at once (<= 64 workgroups on 256 CUs) and every wait is bounded: a
-// workgroup that times out raises flags[0] bit 2 (the solve counts as failed) and publishes anyway, so
-// no wave can spin forever. Protocol (cdna_hip_programming.md section 6, Guideline 16, write-through form): the
-// solution x_s is stored with agent-scope atomic stores (sc1: write-through, no release fence), the storing
-// waves drain (vmcnt(0)), barrier, one lane sets the flag with an agent-scope atomic; the consumer polls it with
-// an agent-scope atomic, barrier, and reads x_s with agent-scope atomic loads (sc1: they bypass this CU's L1),
-// so no acquire fence either — every other load of the kernel reads bytes no workgroup writes in this launch.
-// The two fences cost ~3 us per hand-off, on a chain of nsb - 1 hand-offs.
-__global__ __launch_bounds__(BSTEP_THREADS) void chol_backsolve(const double* __restrict__ Lm, int ld, int n, int nsb,
-                                                                const double* __restrict__ Winv, const double* __restrict__ y0,
-                                                                double* __restrict__ xv, int* __restrict__ flags,
-                                                                const double* __restrict__ rhs_raw, int fold_col) {
-    __shared__ double xK[SB];
-    __shared__ double ys[SB];
-    __shared__ double part[BSTEP_THREADS / SB][SB];
-    __shared__ double Ws[SB / NB][NB][NB + 1];
-    __shared__ double Lin[SB][SB - NB + 1];
-    __shared__ int timed_out;
-    const int tid = threadIdx.x;
-    // Workgroup s waits for the super-blocks K > s. The hardware hands out workgroup ids in ascending order, so
-    // the producers take the low ids: the only workgroup that waits for nobody (s = nsb - 1) is dispatched first
-    // and a consumer never occupies a CU its producer still needs (with the chip shared by another context or
-    // stream the grid need not be co-resident). Every wait stays bounded all the same.
-    const int s = nsb - 1 - (int)blockIdx.x;
-    const int c0 = s * SB;
-    int* handoff = flags + 4;
-    if (tid == 0) timed_out = 0;
-    for (int idx = tid; idx < (SB / NB) * NB * NB; idx += BSTEP_THREADS) {
-        const int b = idx / (NB * NB), e = idx % (NB * NB);
-        const int kb = c0 / NB + b;
-        Ws[b][e / NB][e % NB] = (kb * NB < n) ? Winv[(size_t)kb * NB * NB + e] : 0.0;
-    }
-    for (int idx = tid; idx < SB * (SB - NB); idx += BSTEP_THREADS) {
-        const int r = idx / (SB - NB), c = idx % (SB - NB);
-        Lin[r][c] = (c < (r / NB) * NB && c0 + r < n) ? Lm[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
-    }
-    if (tid < SB) ys[tid] = (c0 + tid < n) ? y0[c0 + tid] : 0.0;  // xv only ever holds solutions
-    if (fold_col >= 0 && s == nsb - 1) {
-        // The forward substitution of the LAST 64 columns is made here instead of by one more launch of the
-        // factorisation (whose only tile would be the right-hand-side row: 11-13 us of launch for three small
-        // products): y_a = W_a a_a, y_b = W_b (a_b - L_ba y_a), a = row nr of S as the last step left it. This
-        // workgroup waits for nobody and has W_a, W_b and L_ba in LDS for its own solve anyway.
-        const int t0 = fold_col - c0, bA = t0 / NB;  // 0 or 64: the last tile inside this super-block
-        __syncthreads();
-        if (tid < PB) ys[t0 + tid] = (fold_col + tid < n) ? rhs_raw[fold_col + tid] : 0.0;
-        __syncthreads();
-        const int i = (tid >> 4) & (NB - 1), p = tid & 15;
-        for (int stage = 0; stage < 3; ++stage) {
-            double v;
-            if (stage == 0) v = Ws[bA][i][p] * ys[t0 + p] + Ws[bA][i][p + 16] * ys[t0 + p + 16];
-            else if (stage == 1) v = Lin[t0 + NB + i][t0 + p] * ys[t0 + p] + Lin[t0 + NB + i][t0 + p + 16] * ys[t0 + p + 16];
-            else v = Ws[bA + 1][i][p] * ys[t0 + NB + p] + Ws[bA + 1][i][p + 16] * ys[t0 + NB + p + 16];
-            v = dpp_row_sum<16>(v);
-            __syncthreads();  // every read of the vector this stage overwrites is done
-            if (tid < 16 * NB && p == 15) {
-                if (stage == 0) ys[t0 + i] = v;
-                else if (stage == 1) ys[t0 + NB + i] -= v;
-                else ys[t0 + NB + i] = v;
-            }
-            __syncthreads();
+// Back-substitution on the elimination tree, ONE launch: workgroup b solves panel J = order[b] (root first, a panel
+// after its parent) and the panels hand their solutions down through global memory with a flag per panel instead of
+// kernel boundaries. With the right-hand side carried as row 63 of the root, z = [x; -1] solves L_aug^T z = -delta e_63:
+//   root:   z = -W[63][:] / W[63][63]                    (W = W64 of the root, delta = its last pivot)
+//   J:      t = -sum_{I in struct(J)} A'[I][J]^T z_I     (the RAW strips: L[I][J] = A'[I][J] W_J^T is never stored; the
+//                                                          root's row 63 times z_root[63] = -1 brings in the rhs)
+//           z_J = W_J^T (W_J t)                          (= D_J^-1 t, D_J the fully updated diagonal tile)
+// The chain is one hand-off per level of the tree, and only the PARENT's strip sits on it: a workgroup consumes its
+// strips from the far end (root side) as their z appear, so what is left when the parent publishes is one poll, eight
+// loads, one strip of multiply-adds (its values prefetched), a cross-wave sum, two 64x64 triangular products and the
+// publication. Protocol as in cdna_hip_programming.md section 6 (write-through form): z_J is stored by ONE wave with
+// agent-scope atomic stores (sc1), that wave drains (vmcnt(0)) and its lane 0 sets the flag; every consuming wave polls
+// the flag itself with an agent-scope atomic and reads z with agent-scope atomic loads (they bypass its CU's L1) — no
+// fences, no workgroup barrier per strip. A wave whose wait expires raises flags[0] bit 2 (the solve counts as failed,
+// EACHAM_ERR_HIP) and goes on: no wave can spin forever. The low workgroup ids go to the producers (the hardware
+// dispatches in ascending order), so a consumer never occupies a CU its producer still needs.
+constexpr int BS_THREADS = 512;  // eight waves: wave g owns rows 8 g .. 8 g + 7 of every strip
+constexpr int BS_PF = 4;         // strips whose values are in flight ahead of the one being consumed
+__global__ __launch_bounds__(BS_THREADS) void sp_backsolve(const double* __restrict__ T, const int* __restrict__ order, const int* __restrict__ ptr,
+                                                           const int2* __restrict__ ent, const double* __restrict__ Winv,
+                                                           const double* __restrict__ Xrow, double* __restrict__ z,
+                                                           const int* __restrict__ col_dest, double* __restrict__ delta_c,
+                                                           int* __restrict__ flags) {
+    __shared__ double Wl[PB][PB + 1];
+    __shared__ double part[BS_THREADS / PB][PB];
+    __shared__ double tl[PB], ul[PB], zl[PB];
+    const int tid = threadIdx.x, j = tid & (PB - 1), g = tid >> 6;
+    constexpr int RPT = PB / (BS_THREADS / PB);  // rows of a strip per thread: 8
+    const int b = blockIdx.x, J = order[b], e0 = ptr[b], e1 = ptr[b + 1];
+    int* handoff = flags + N_STATUS;
+    {   // W64_J = [[W_a, 0], [X, W_b]]
+        const double* __restrict__ Wa = Winv + (size_t)(2 * J) * NB * NB;
+        const double* __restrict__ Wb = Wa + NB * NB;
+        const double* __restrict__ X = Xrow + (size_t)J * NB * NB;
+        for (int idx = tid; idx < PB * PB; idx += BS_THREADS) {
+            const int r = idx >> 6, c = idx & 63;
+            Wl[r][c] = r < NB ? (c < NB ? Wa[r * NB + c] : 0.0) : (c < NB ? X[(r - NB) * NB + c] : Wb[(r - NB) * NB + c - NB]);
         }
     }
-    // 8 threads per column, 16 rows each (rows are contiguous along columns: coalesced)
-    const int cl = tid & (SB - 1), pr = tid / SB, col = c0 + cl;
-    constexpr int RP = SB / (BSTEP_THREADS / SB);
-    double lnext[RP];
-    auto fetch = [&](int K) {  // the L block of super-block K over my columns: independent of any x
-        const int K0 = K * SB;
+    if (e0 == e1) {  // the root: it waits for nobody
+        __syncthreads();
+        if (tid < PB) zl[tid] = -Wl[PB - 1][tid] / Wl[PB - 1][PB - 1];
+    } else {
+        // The strips of column J are listed nearest ancestor first; they are consumed from the FAR end: those ancestors
+        // published long ago, so everything but the parent's strip is summed in the shadow of the chain. A wave polls
+        // the hand-off flags itself (no workgroup barrier per strip) and reads the eight z it needs straight from
+        // global memory; the strip values (independent of any z) run BS_PF strips ahead.
+        double pre[BS_PF][RPT];
+        auto fetch = [&](int e, double (&v)[RPT]) {
+            const double* __restrict__ A = T + (size_t)ent[e].x * TILE;
 #pragma unroll
-        for (int r = 0; r < RP; ++r) {
-            const int row = K0 + pr * RP + r;
-            lnext[r] = (col < n && row < n) ? Lm[(size_t)row * ld + col] : 0.0;
-        }
-    };
-    if (s < nsb - 1) fetch(nsb - 1);
-    __syncthreads();
-    for (int K = nsb - 1; K > s; --K) {
-        double lcur[RP];
+            for (int r = 0; r < RPT; ++r) v[r] = A[(RPT * g + r) * PB + j];
+        };
 #pragma unroll
-        for (int r = 0; r < RP; ++r) lcur[r] = lnext[r];
-        if (K - 1 > s) fetch(K - 1);  // in flight while this workgroup waits for x_K
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&handoff[K], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                if (++spins > (1 << 22)) {
-                    timed_out = 1;
-                    break;
+        for (int p = 0; p < BS_PF; ++p)
+            if (e1 - 1 - p >= e0) fetch(e1 - 1 - p, pre[p]);
+        double acc = 0.0;
+        bool late = false;
+        for (int base = e1 - 1; base >= e0; base -= BS_PF) {
+#pragma unroll
+            for (int p = 0; p < BS_PF; ++p) {
+                const int e = base - p;
+                if (e < e0) break;
+                const int I = ent[e].y;
+                int spins = 0;
+                while (__hip_atomic_load(&handoff[I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    if (++spins > (1 << 22)) {
+                        late = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
+                double zr[RPT];
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) zr[r] = __hip_atomic_load(&z[(size_t)I * PB + RPT * g + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) acc += pre[p][r] * zr[r];
+                if (e - BS_PF >= e0) fetch(e - BS_PF, pre[p]);
             }
         }
+        if (late && (tid & 63) == 0) atomicOr(flags, 4);
+        part[g][j] = acc;
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
-        if (tid < SB) xK[tid] = (K * SB + tid < n) ? __hip_atomic_load(&xv[K * SB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        __syncthreads();
-        double sacc = 0.0;
-#pragma unroll
-        for (int r = 0; r < RP; ++r) sacc += lcur[r] * xK[pr * RP + r];
-        part[pr][cl] = sacc;
-        __syncthreads();
-        if (tid < SB) {
+        if (tid < PB) {
             double tot = 0.0;
 #pragma unroll
-            for (int q = 0; q < BSTEP_THREADS / SB; ++q) tot += part[q][tid];
-            ys[tid] -= tot;
+            for (int q = 0; q < BS_THREADS / PB; ++q) tot += part[q][tid];
+            tl[tid] = -tot;
         }
         __syncthreads();
-    }
-    // solve super-block s: inner blocks b = 3..0, everything from LDS. Both products of an inner step are spread
-    // over the whole workgroup and summed inside DPP rows (a 32-term dot product on one thread is a chain of
-    // 32 dependent v_fma_f64, ~0.2 us, eight times per super-block on the hand-off chain).
-    for (int b = SB / NB - 1; b >= 0; --b) {
-        {   // x_b = W^T y_b: output i on the 16 lanes of row tid / 16 (tid < 512), two terms per lane
-            const int i = (tid >> 4) & (NB - 1), p = tid & 15;
-            double v = Ws[b][p][i] * ys[b * NB + p] + Ws[b][p + 16][i] * ys[b * NB + p + 16];
-            v = dpp_row_sum<16>(v);
-            __syncthreads();  // every read of y_b is done
-            if (tid < 16 * NB && p == 15) ys[b * NB + i] = v;
-        }
-        __syncthreads();
-        if (b > 0) {  // y[inner cols < b NB] -= L[block-b rows, col]^T x_b: column on 8 lanes, four terms per lane
-            const int cidx = tid >> 3, q = tid & 7;
+        {   // u = W t: output i on 8 lanes, eight terms per lane (W is lower triangular: the rest are stored zeros)
+            const int i = tid >> 3, q = tid & 7;
             double v = 0.0;
-            if (cidx < b * NB) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) v += Lin[b * NB + 4 * q + jj][cidx] * ys[b * NB + 4 * q + jj];
-            }
+            for (int k = 0; k < 8; ++k) v += Wl[i][8 * q + k] * tl[8 * q + k];
             v = dpp_row_sum<8>(v);
-            if (cidx < b * NB && q == 7) ys[cidx] -= v;
-            __syncthreads();
+            if (q == 7) ul[i] = v;
+        }
+        __syncthreads();
+        {   // z = W^T u
+            const int c = tid >> 3, q = tid & 7;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += Wl[8 * q + k][c] * ul[8 * q + k];
+            v = dpp_row_sum<8>(v);
+            if (q == 7) zl[c] = v;
         }
     }
-    if (tid < SB && c0 + tid < n) __hip_atomic_store(&xv[c0 + tid], ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        if (timed_out) atomicOr(flags, 4);
-        if (!(BA_FAULT(1) && s == nsb - 1)) __hip_atomic_store(&handoff[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // publication by ONE wave: its stores drain (vmcnt(0)) before its lane 0 raises the flag — no workgroup barrier
+    if (tid < PB) {
+        __hip_atomic_store(&z[(size_t)J * PB + tid], zl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int dst = col_dest[J * PB + tid];
+        if (dst >= 0) delta_c[dst] = zl[tid];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && !(BA_FAULT(1) && e0 == e1)) __hip_atomic_store(&handoff[J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2146,7 +1805,7 @@ __global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_
             *(volatile double*)&D.scal_pinned[3] = ticket;
         }
     }
-    if (threadIdx.x < N_FLAGS) D.flags[threadIdx.x] = 0;  // (thread 0 read flags[0] above, in program order)
+    for (int k = threadIdx.x; k < N_STATUS + D.sp_npan; k += TPB) D.flags[k] = 0;  // (thread 0 read flags[0] above, in program order)
 }
 
 // ---- the iterative solve the reference can select: PCG + block-Jacobi (BundleAdjuster.cpp:192-200) -----------------
@@ -2688,6 +2347,13 @@ struct eacham_ba_handle {
     double *pose_init = nullptr, *pt_init = nullptr, *K_init = nullptr;
     int n_landmarks_used = 0;
     size_t bytes_linearize = 0, bytes_try = 0;
+    // the sparse solve (ba_plan.hpp): the plan stays on the host for the launch sequence and the diagnostic read-back
+    eacham::BaPlan plan;
+    const int* sp_leaves = nullptr;
+    const eacham::BaPlanItem* sp_items = nullptr;
+    const eacham::BaPlanSrc* sp_srcs = nullptr;
+    const int *bs_order = nullptr, *bs_ptr = nullptr, *sp_col_dest = nullptr;
+    const int2* bs_ent = nullptr;
 };
 
 namespace eacham {
@@ -2786,12 +2452,6 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     BaDev& D = h->D;
     memset(&D, 0, sizeof(D));
     D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
-    D.nr = ((D.n + PB - 1) / PB) * PB;  // whole 64-column steps (chol_step64); rows / columns n..nr-1 are identity padding
-    // 64 columns (and, for S, 64 rows) of zero padding beyond the last 64x64 tile a Cholesky step can touch:
-    // chol_step reads its tiles without bounds tests. An odd multiple of 256 bytes as the row stride keeps
-    // a column of S from landing on one memory channel.
-    D.ld = D.nr + 64;
-    if ((D.ld / 32) % 2 == 0) D.ld += 32;
     D.nz = make_noise();
     D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
     D.lpl = nl <= 8192 ? 8 : 1;
@@ -2886,6 +2546,25 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         }
     D.n_chunks = (int)chunks.size();
     D.n_blocks = (int)blocks.size();
+    // ---- the sparse solve: ordering, panels, symbolic factor, level schedule (ba_plan.hpp) ----
+    {
+        std::vector<std::pair<int, int>> cam_edges;
+        cam_edges.reserve(blocks.size());
+        for (const int4& b : blocks)
+            if (b.x != b.y) cam_edges.emplace_back(b.x, b.y);
+        int hint = P->ordering;
+        if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
+        if (hint < EACHAM_BA_ORDER_AUTO || hint > EACHAM_BA_ORDER_ND) {
+            delete h;
+            return ctx->fail(EACHAM_ERR_INVALID, "unknown BA ordering %d", hint);
+        }
+        build_ba_plan(nc, cam_edges, hint, h->plan);
+    }
+    const BaPlan& plan = h->plan;
+    D.sp_npan = plan.npan; D.sp_ntiles = plan.ntiles; D.sp_posK = plan.posK; D.sp_rhs_row = plan.rhs_row;
+    D.sp_n_pad = (int)plan.pad_cols.size();
+    std::vector<int2> bs_ent(plan.bs_ent.size());
+    for (size_t e = 0; e < bs_ent.size(); ++e) bs_ent[e] = make_int2(plan.bs_ent[e].first, plan.bs_ent[e].second);
 
     // ---- values ----
     std::vector<double> pose(12 * (size_t)nc), lmprior(2 * (size_t)nl), K5(5);
@@ -2929,6 +2608,17 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         TRY(dev_upload(ctx, h, &D.pair_entries, entries));
         TRY(dev_upload(ctx, h, &D.pair_chunks, chunks));
         TRY(dev_upload(ctx, h, &D.blocks, blocks));
+        TRY(dev_upload(ctx, h, &D.sp_pos, plan.pos));
+        TRY(dev_upload(ctx, h, &D.sp_tile_map, plan.tile_map));
+        TRY(dev_upload(ctx, h, &D.sp_pad_cols, plan.pad_cols));
+        TRY(dev_upload(ctx, h, &D.sp_diag_tile, plan.diag_tile));
+        TRY(dev_upload(ctx, h, &h->sp_leaves, plan.leaves));
+        TRY(dev_upload(ctx, h, &h->sp_items, plan.items));
+        TRY(dev_upload(ctx, h, &h->sp_srcs, plan.srcs));
+        TRY(dev_upload(ctx, h, &h->bs_order, plan.bs_order));
+        TRY(dev_upload(ctx, h, &h->bs_ptr, plan.bs_ptr));
+        TRY(dev_upload(ctx, h, &h->bs_ent, bs_ent));
+        TRY(dev_upload(ctx, h, &h->sp_col_dest, plan.col_dest));
         TRY(dev_alloc(ctx, h, &D.pose, 12 * (size_t)nc));
         TRY(dev_alloc(ctx, h, &D.pose_new, 12 * (size_t)nc));
         TRY(dev_alloc(ctx, h, &D.pt, 3 * (size_t)nl));
@@ -2942,11 +2632,11 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
         TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
         TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
-        TRY(dev_alloc(ctx, h, &D.S, (size_t)(D.nr + 64) * D.ld));
-        TRY(dev_alloc(ctx, h, &D.Lm, (size_t)(D.nr + 64) * D.ld));  // padded like S: the split steps read whole 64-row strips of it
-        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.Lm, 0, sizeof(double) * (size_t)(D.nr + 64) * D.ld, ctx->stream));  // rows / columns past n stay zero
-        TRY(dev_alloc(ctx, h, &D.Winv, (size_t)((D.n + NB - 1) / NB + 1) * NB * NB));
-        TRY(dev_alloc(ctx, h, &D.Wops, (size_t)(D.nr / PB) * TILE_OPS));  // W_a, W_b, X = -W_b L_ba W_a of every 64x64 diagonal tile in operand order
+        TRY(dev_alloc(ctx, h, &D.T, (size_t)plan.ntiles * TILE));
+        TRY(dev_alloc(ctx, h, &D.Winv, (size_t)2 * plan.npan * NB * NB));   // W_a, W_b of every panel, row-major
+        TRY(dev_alloc(ctx, h, &D.Xrow, (size_t)plan.npan * NB * NB));       // X = -W_b L_ba W_a, row-major
+        TRY(dev_alloc(ctx, h, &D.Wops, (size_t)plan.npan * TILE_OPS));      // W_a, W_b, X of every panel in MFMA operand order
+        TRY(dev_alloc(ctx, h, &D.zsol, (size_t)plan.npan * PB));
         TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
         TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
         TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
@@ -2971,8 +2661,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
             TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks)); TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
             TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
         }
-        TRY(dev_alloc(ctx, h, &D.flags, N_FLAGS));  // [0..3] status, [4..] hand-off flags of the back-substitution
-        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, N_FLAGS * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
+        TRY(dev_alloc(ctx, h, &D.flags, (size_t)N_STATUS + plan.npan));  // [0..3] status, [4 + P] hand-off flag of panel P
+        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (N_STATUS + plan.npan) * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
         if (!h->planning) {
             h->scal_host = ctx->ba_pool[h->block].pinned;
             EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
@@ -3076,14 +2766,25 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
         const unsigned nbg = (unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB);
-        ba_assemble<<<nbg + D.nc + 1, TPB, 0, ctx->stream>>>(D, lambda, nbg);
+        ba_assemble<<<nbg + D.nc + 2, TPB, 0, ctx->stream>>>(D, lambda, nbg);  // camera blocks | border per camera | K corner | padding
     }
-    if (S_copy) {
+    if (S_copy) {  // diagnostic read-back: S and its right-hand side in the caller's order, from the tiles
+        const BaPlan& pl = h->plan;
+        std::vector<double> tiles((size_t)pl.ntiles * TILE);
         EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        EACHAM_HIP_TRY(ctx, hipMemcpy2D(S_copy, sizeof(double) * (size_t)n, D.S, sizeof(double) * (size_t)D.ld,
-                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToHost));
-        EACHAM_HIP_TRY(ctx, hipMemcpy(S_copy + (size_t)n * n, D.S + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
-                                      hipMemcpyDeviceToHost));
+        EACHAM_HIP_TRY(ctx, hipMemcpy(tiles.data(), D.T, sizeof(double) * tiles.size(), hipMemcpyDeviceToHost));
+        std::vector<int> colpos((size_t)n);
+        for (int c = 0; c < D.nc; ++c)
+            for (int a = 0; a < 6; ++a) colpos[6 * (size_t)c + a] = pl.pos[c] + a;
+        for (int k = 0; k < 5; ++k) colpos[6 * (size_t)D.nc + k] = pl.posK + k;
+        auto at = [&](int r, int q) -> double {
+            if (r < q) std::swap(r, q);
+            const int t = pl.tile(r >> 6, q >> 6);
+            return t < 0 ? 0.0 : tiles[(size_t)t * TILE + (r & 63) * PB + (q & 63)];
+        };
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) S_copy[(size_t)i * n + j] = at(colpos[i], colpos[j]);
+        for (int j = 0; j < n; ++j) S_copy[(size_t)n * n + j] = at(pl.rhs_row, colpos[j]);
     }
 #ifdef EXP_BA_FAULT
     {
@@ -3094,43 +2795,14 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     }
 #endif
     {
+        // the factorisation, level by level of the elimination tree, and the back-substitution (one launch)
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
-        const int nsb = (n + SB - 1) / SB;
-        const bool single_backsolve = nsb <= 64 && !getenv("EACHAM_BA_BACKSTEP_LAUNCHES");
-        const bool chol32 = getenv("EACHAM_BA_CHOL32") != nullptr;
-        const bool fold_last = single_backsolve && !chol32;
-        if (chol32) {  // diagnostic switch: one launch per 32 columns
-            chol_diag0<<<1, TPB, 0, ctx->stream>>>(D.S, D.ld, n, D.Winv, D.flags);
-            for (int k0 = 0; k0 < n; k0 += NB) {
-                const int k1 = k0 + NB;
-                const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-                chol_step<<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.flags);
-            }
-        } else {
-            const char* se = getenv("EACHAM_BA_SPLIT_TILES");  // (diagnostic: tile count above which a step is two launches)
-            const int split_tiles = se ? atoi(se) : 256;
-            chol_diag64<<<1, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.Winv, D.Wops, D.flags);
-            // the last step (its only tile is the right-hand-side row) is folded into the back-substitution
-            for (int k0 = 0; k0 < (fold_last ? D.nr - PB : D.nr); k0 += PB) {
-                const int k1 = k0 + PB;
-                const int nt = (D.nr + 1 - k1 + 63) / 64;  // rows k1 .. nr (the rhs row) in 64-row tiles
-                if (nt * (nt + 1) / 2 > split_tiles) {  // bound by the tile grid: every strip formed once (see chol_step64)
-                    chol_step64<1><<<nt, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
-                    chol_step64<2><<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
-                } else {
-                    chol_step64<0><<<nt * (nt + 1) / 2, TPB, 0, ctx->stream>>>(D.S, D.Lm, D.ld, n, D.nr, k0, D.Winv, D.Wops, D.flags);
-                }
-            }
-        }
-        if (single_backsolve) {  // (y = row nr of Lm is read in place)
-            chol_backsolve<<<nsb, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, D.Winv, D.Lm + (size_t)D.nr * D.ld, D.delta_c, D.flags,
-                                                                   D.S + (size_t)D.nr * D.ld, fold_last ? D.nr - PB : -1);
-        } else {  // more super-blocks than hand-off flags (n > 8192), or the diagnostic switch: one launch per super-block
-            EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.delta_c, D.Lm + (size_t)D.nr * D.ld, sizeof(double) * (size_t)n,
-                                               hipMemcpyDeviceToDevice, ctx->stream));
-            chol_backstep<<<1, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, nsb, nsb - 1, 1, D.Winv, D.delta_c);
-            for (int K = nsb - 1; K >= 1; --K) chol_backstep<<<K, BSTEP_THREADS, 0, ctx->stream>>>(D.Lm, D.ld, n, K, 0, 0, D.Winv, D.delta_c);
-        }
+        const BaPlan& pl = h->plan;
+        sp_diag<<<(unsigned)pl.leaves.size(), TPB, 0, ctx->stream>>>(D.T, h->sp_leaves, D.sp_diag_tile, D.Winv, D.Wops, D.Xrow, D.flags);
+        for (const auto& la : pl.launches)
+            sp_level<<<(unsigned)la.count, TPB, 0, ctx->stream>>>(D.T, h->sp_items + la.first, h->sp_srcs, la.n_first, D.Winv, D.Wops, D.Xrow, D.flags);
+        sp_backsolve<<<(unsigned)pl.npan, BS_THREADS, 0, ctx->stream>>>(D.T, h->bs_order, h->bs_ptr, h->bs_ent, D.Winv, D.Xrow, D.zsol,
+                                                                        h->sp_col_dest, D.delta_c, D.flags);
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
@@ -3425,18 +3097,6 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
 
 }  // namespace eacham
 
-#ifdef EXP_BA_STAMPS
-extern "C" int eacham_ba_debug_wg_times(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eacham::g_wg_times), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
-}
-extern "C" int eacham_ba_debug_read(unsigned long long* out, int n) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(eacham::g_ba_dbg), sizeof(unsigned long long) * n) != hipSuccess) return -1;
-    unsigned long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(eacham::g_ba_dbg), z, sizeof(z));
-    return 0;
-}
-#endif
-
 extern "C" {
 
 int eacham_ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* problem, eacham_ba_handle** out_handle) {
@@ -3459,6 +3119,16 @@ void eacham_ba_release(eacham_ctx* ctx, eacham_ba_handle* handle) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
     ba_release(ctx, handle);
+}
+
+int eacham_ba_get_plan_info(eacham_ctx* ctx, const eacham_ba_handle* handle, eacham_ba_plan_info* out) {
+    if (!ctx || !handle || !out) return EACHAM_ERR_INVALID;
+    const BaPlan& pl = handle->plan;
+    out->n_panels = pl.npan; out->n_tiles = pl.ntiles; out->n_levels = pl.n_levels;
+    out->ordering = pl.ordering; out->nd_leaf = pl.nd_leaf; out->reserved = 0;
+    out->tile_updates = pl.tile_updates;
+    out->est_us = pl.est_us;
+    return EACHAM_OK;
 }
 
 int eacham_ba_solve(eacham_ctx* ctx, const eacham_ba_problem* problem, const eacham_ba_options* options, eacham_ba_result* result) {

@@ -1,0 +1,454 @@
+// ba_plan.hpp — host-side analysis of the reduced camera system: fill-reducing ordering, panel layout, symbolic
+// factorisation, elimination tree and the level schedule the device executes (ba.hip: sp_diag / sp_level /
+// sp_backsolve). Pure C++ (no HIP): the CPU suite compiles and tests it on its own (tests/cpp/plan_driver.cpp).
+//
+// What it replaces: GTSAM's MULTIFRONTAL_CHOLESKY with COLAMD ordering, which the reference selects through
+// LevenbergMarquardtParams::SetCeresDefaults (modules/sfm/reconstruction/BundleAdjuster.cpp:182-190). GTSAM orders and
+// eliminates ALL variables; here the landmarks are eliminated first in closed form (3x3 blocks, ba.hip) and what is
+// analysed is the camera graph of the Schur complement S (n = 6 nc + 5): cameras c, c' are adjacent iff they share a
+// landmark; the five calibration columns K and the right-hand side are dense and go last.
+//
+// Layout. The permuted cameras are laid out in 64-column PANELS (the unit the device factorises per launch: two
+// 32x32 diagonal blocks in one workgroup). An ordering is a list of NODES (sets of cameras: the leaves and separators of
+// a nested dissection, or one node for a band ordering); every node starts on a panel boundary and its cameras are
+// packed without gaps (a camera's six columns may straddle two panels of its node), the columns left over in a
+// node's last panel are identity padding. K follows the last node; the right-hand side is carried as ROW 63 of the
+// last panel (the root of the elimination tree, a neighbour of every panel because K is dense), with 1e100 on its
+// diagonal: the factorisation then performs the forward substitution by itself and the back-substitution starts from
+// z_root = -W[63][:] / W[63][63] (W = inverse of the root's 64x64 factor).
+// Storage is TILES of 64 x 64 doubles, only those of the symbolic pattern of L (lower triangle incl. fill).
+//
+// Schedule. level(J) = 1 + max level(children of J) in the panel elimination tree (leaves 0). Launch 0 factorises the
+// diagonal tiles of all leaves; launch l + 1 applies the updates A[I1][I2] -= L[I1][J] L[I2][J]^T of every panel J of
+// level l — one workgroup per TARGET tile, its sources in ascending J: a fixed summation order, no atomics — and the
+// workgroup of a diagonal target (P, P) with level(P) = l + 1 then factorises it. The dependent chain of the solve is
+// the HEIGHT of the tree, not n / 64, and a launch touches only tiles of the pattern.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <numeric>
+#include <utility>
+#include <vector>
+
+namespace eacham {
+
+constexpr int PLAN_PANEL = 64;   // columns per panel
+constexpr int PLAN_CAM = 6;      // columns per camera
+constexpr int PLAN_K = 5;        // calibration columns
+
+enum BaOrdering { BA_ORDER_AUTO = 0, BA_ORDER_NATURAL = 1, BA_ORDER_RCM = 2, BA_ORDER_ND = 3 };
+
+struct BaPlanItem {   // one workgroup of a level launch
+    int tgt;          // tile index of the target A[I1][I2]
+    int nsrc, src0;   // its sources of this level: srcs[src0 .. src0 + nsrc)
+    int flags;        // bit 0: diagonal target (I1 == I2); bit 1: the target's panel is complete after this launch: factorise it
+    int panel;        // I1 (the panel whose W the factorising item writes)
+    int col;          // I2
+    int pad[2];
+};
+struct BaPlanSrc {
+    int tile_i, tile_j;  // raw strips A'[I1][J], A'[I2][J]
+    int J;               // source panel (its W operands)
+    int pad;
+};
+
+struct BaPlan {
+    int nc = 0, npan = 0, ntiles = 0, n_levels = 0;
+    int posK = 0, rhs_row = 0;
+    int ordering = BA_ORDER_NATURAL;   // the candidate chosen
+    int nd_leaf = 0;                   // its leaf size (ND)
+    double est_us = 0.0;               // cost model of the factorisation + back-substitution
+    long long tile_updates = 0;        // rank-64 tile updates of the factorisation (dense: sum over steps of nt (nt + 1) / 2)
+    std::vector<int> pos;              // [nc] first padded column of camera c
+    std::vector<int> tile_map;         // [npan (npan + 1) / 2] (I >= J) -> tile index or -1
+    std::vector<int> diag_tile;        // [npan]
+    std::vector<int> parent, level;    // [npan]
+    std::vector<std::vector<int>> strct;  // [npan] row panels I > J of column J in L, ascending
+    std::vector<int> leaves;           // panels of level 0 (launch 0)
+    std::vector<BaPlanItem> items;
+    std::vector<BaPlanSrc> srcs;
+    struct Launch { int first, count, n_first; };  // items [first, first + count), the first n_first of them factorise
+    std::vector<Launch> launches;      // one per level l = 0 .. n_levels - 2
+    std::vector<int> bs_order;         // back-substitution: workgroup b solves panel bs_order[b] (root first)
+    std::vector<int> bs_ptr;           // [npan + 1] into bs_ent, indexed by workgroup
+    std::vector<std::pair<int, int>> bs_ent;  // (tile of A'[I][J], I)
+    std::vector<int> col_dest;         // [64 npan] index into delta_c (6 c + a, 6 nc + k) or -1
+    std::vector<int> pad_cols;         // padded columns that carry an identity diagonal (the rhs row excluded)
+
+    int tile(int I, int J) const { return tile_map[(size_t)I * (I + 1) / 2 + J]; }
+};
+
+namespace plan_detail {
+
+typedef std::vector<std::vector<int>> Adj;
+
+// breadth-first levels of the subgraph induced by the nodes with mark[v] == tag, from `start`; returns the visit order
+inline std::vector<int> bfs(const Adj& adj, const std::vector<int>& mark, int tag, int start, std::vector<int>& lev) {
+    std::vector<int> order;
+    order.push_back(start);
+    lev[start] = 0;
+    for (size_t h = 0; h < order.size(); ++h) {
+        const int u = order[h];
+        for (int v : adj[u])
+            if (mark[v] == tag && lev[v] < 0) {
+                lev[v] = lev[u] + 1;
+                order.push_back(v);
+            }
+    }
+    return order;
+}
+
+// George-Liu pseudo-peripheral node of the component of `seed`
+inline int pseudo_peripheral(const Adj& adj, const std::vector<int>& mark, int tag, int seed, std::vector<int>& lev) {
+    int s = seed, best = -1;
+    for (int it = 0; it < 6; ++it) {
+        std::vector<int> order = bfs(adj, mark, tag, s, lev);
+        const int ecc = lev[order.back()];
+        int cand = -1;
+        size_t cdeg = 0;
+        for (int u : order)
+            if (lev[u] == ecc && (cand < 0 || adj[u].size() < cdeg)) cand = u, cdeg = adj[u].size();
+        for (int u : order) lev[u] = -1;
+        if (ecc <= best) break;
+        best = ecc;
+        s = cand;
+    }
+    return s;
+}
+
+// Nested dissection by level-structure separators: nodes are appended children first, separator last.
+inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const std::vector<int>& nodes, int leaf,
+                    std::vector<std::vector<int>>& out, std::vector<int>& lev) {
+    if ((int)nodes.size() <= leaf) {
+        out.push_back(nodes);
+        return;
+    }
+    const int tag = next_tag++;
+    for (int u : nodes) mark[u] = tag;
+    // connected components first
+    {
+        std::vector<int> first = bfs(adj, mark, tag, nodes[0], lev);
+        for (int u : first) lev[u] = -1;
+        if (first.size() < nodes.size()) {
+            std::vector<std::vector<int>> comps;
+            std::vector<char> seen(adj.size(), 0);
+            for (int s : nodes) {
+                if (seen[s]) continue;
+                std::vector<int> comp = bfs(adj, mark, tag, s, lev);
+                for (int u : comp) lev[u] = -1, seen[u] = 1;
+                comps.push_back(std::move(comp));
+            }
+            for (auto& c : comps) dissect(adj, mark, next_tag, c, leaf, out, lev);
+            return;
+        }
+    }
+    // candidate roots of the level structure: the pseudo-peripheral node of the lowest-degree node and of a node far from it
+    int s0 = nodes[0];
+    for (int u : nodes)
+        if (adj[u].size() < adj[s0].size()) s0 = u;
+    const int root = pseudo_peripheral(adj, mark, tag, s0, lev);
+    std::vector<int> order = bfs(adj, mark, tag, root, lev);
+    const int depth = lev[order.back()];
+    if (depth < 2) {  // (nearly) complete graph: no separator
+        for (int u : order) lev[u] = -1;
+        out.push_back(order);
+        return;
+    }
+    std::vector<int> cnt(depth + 1, 0);
+    for (int u : order) cnt[lev[u]]++;
+    long long before = 0, total = (long long)order.size();
+    int best_l = 1;
+    long long best_score = -1;
+    for (int l = 0; l <= depth; ++l) {
+        if (l >= 1 && l < depth) {
+            const long long a = before, b = total - before - cnt[l];
+            const long long score = std::max(a, b) + cnt[l];
+            if (best_score < 0 || score < best_score) best_score = score, best_l = l;
+        }
+        before += cnt[l];
+    }
+    // trim: a node of the separator level without a neighbour beyond it joins the near side; one without a
+    // neighbour before it joins the far side unless a level-mate that just left for the near side touches it
+    std::vector<int> left, right, sep;
+    std::vector<int> moved_left;
+    for (int u : order) {
+        if (lev[u] != best_l) continue;
+        bool ar = false;
+        for (int v : adj[u])
+            if (mark[v] == tag && lev[v] > best_l) ar = true;
+        if (!ar) moved_left.push_back(u);
+    }
+    for (int u : moved_left) lev[u] = best_l - 1;  // (only the comparison with best_l matters from here on)
+    for (int u : order) {
+        if (lev[u] < best_l) left.push_back(u);
+        else if (lev[u] > best_l) right.push_back(u);
+        else {
+            bool al = false;
+            for (int v : adj[u])
+                if (mark[v] == tag && lev[v] < best_l) al = true;
+            if (al) sep.push_back(u);
+            else right.push_back(u);
+        }
+    }
+    for (int u : order) lev[u] = -1;
+    if (left.empty() || right.empty()) {
+        out.push_back(order);
+        return;
+    }
+    dissect(adj, mark, next_tag, left, leaf, out, lev);
+    dissect(adj, mark, next_tag, right, leaf, out, lev);
+    if (!sep.empty()) out.push_back(sep);
+}
+
+// reverse Cuthill-McKee over all components
+inline std::vector<int> rcm(const Adj& adj) {
+    const int n = (int)adj.size();
+    std::vector<int> mark(n, 0), lev(n, -1), perm;
+    std::vector<char> done(n, 0);
+    for (int s = 0; s < n; ++s) {
+        if (done[s]) continue;
+        std::vector<int> comp = bfs(adj, mark, 0, s, lev);
+        for (int u : comp) lev[u] = -1;
+        std::vector<int> cm(n, 1);  // restrict to this component
+        for (int u : comp) cm[u] = 2;
+        const int root = pseudo_peripheral(adj, cm, 2, comp[0], lev);
+        // Cuthill-McKee: neighbours in ascending degree
+        std::vector<int> order;
+        order.push_back(root);
+        lev[root] = 0;
+        for (size_t h = 0; h < order.size(); ++h) {
+            const int u = order[h];
+            std::vector<int> nb;
+            for (int v : adj[u])
+                if (cm[v] == 2 && lev[v] < 0) lev[v] = 1, nb.push_back(v);
+            std::sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b; });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+        for (int u : order) lev[u] = -1, done[u] = 1;
+        perm.insert(perm.end(), order.rbegin(), order.rend());
+    }
+    return perm;
+}
+
+}  // namespace plan_detail
+
+// Cost model of one candidate (microseconds on MI355X, calibrated on the S200 / config-4 scenes): a level
+// launch is bound either by the chain of a factorising workgroup (panel product + two one-wave 32x32 factors, plus a panel
+// product per extra source of that target) or by its tile grid (two workgroups per CU).
+struct BaPlanCost {
+    double diag_us = 13.0, chain_us = 14.0, extra_src_us = 2.6, launch_us = 4.0, src_us = 2.6, backsolve_level_us = 3.0, backsolve_base_us = 6.0;
+    int slots = 512;      // resident workgroups of a level launch (two per CU)
+    int defer_cap = 3;    // sources a target takes per launch ahead of its deadline
+};
+
+// Lays out the nodes, derives the symbolic factor and the schedule. `nodes` = the ordering (cameras of each node in
+// order); every camera exactly once.
+inline void plan_from_nodes(int nc, const plan_detail::Adj& adj, const std::vector<std::vector<int>>& nodes, BaPlan& P,
+                            const BaPlanCost& cm = BaPlanCost()) {
+    P.nc = nc;
+    P.pos.assign(nc, 0);
+    int col = 0, end = 0;
+    for (const auto& nd : nodes) {
+        if (nd.empty()) continue;
+        for (int c : nd) P.pos[c] = col, col += PLAN_CAM;
+        end = col;
+        col = (col + PLAN_PANEL - 1) / PLAN_PANEL * PLAN_PANEL;
+    }
+    // K behind the last camera if it fits the panel together with the rhs row (row 63), else on a fresh panel
+    P.posK = end;
+    if (end % PLAN_PANEL == 0 || end % PLAN_PANEL + PLAN_K > PLAN_PANEL - 1) P.posK = (end + PLAN_PANEL - 1) / PLAN_PANEL * PLAN_PANEL;
+    P.npan = P.posK / PLAN_PANEL + 1;
+    P.rhs_row = P.npan * PLAN_PANEL - 1;
+    const int np = P.npan, root = np - 1;
+    // panel adjacency
+    std::vector<std::vector<char>> PA(np, std::vector<char>(np, 0));
+    auto touch = [&](int c, int out[2]) { out[0] = P.pos[c] / PLAN_PANEL, out[1] = (P.pos[c] + PLAN_CAM - 1) / PLAN_PANEL; };
+    for (int c = 0; c < nc; ++c) {
+        int a[2], b[2];
+        touch(c, a);
+        PA[a[1]][a[0]] = 1;  // a straddling camera couples its two panels
+        for (int c2 : adj[c]) {
+            touch(c2, b);
+            for (int x : a)
+                for (int y : b) PA[std::max(x, y)][std::min(x, y)] = 1;
+        }
+    }
+    for (int J = 0; J < root; ++J) PA[root][J] = 1;  // K and the right-hand side are dense
+    P.strct.assign(np, {});
+    P.parent.assign(np, -1);
+    P.level.assign(np, 0);
+    {
+        std::vector<std::vector<char>> L = PA;  // symbolic factor, column by column
+        for (int J = 0; J < np; ++J) {
+            for (int I = J + 1; I < np; ++I)
+                if (L[I][J]) P.strct[J].push_back(I);
+            if (P.strct[J].empty()) continue;
+            const int par = P.strct[J][0];
+            P.parent[J] = par;
+            for (int I : P.strct[J])
+                if (I > par) L[I][par] = 1;
+        }
+    }
+    for (int J = 0; J < np; ++J)
+        if (P.parent[J] >= 0) P.level[P.parent[J]] = std::max(P.level[P.parent[J]], P.level[J] + 1);
+    P.n_levels = 1 + *std::max_element(P.level.begin(), P.level.end());
+    // tiles
+    P.tile_map.assign((size_t)np * (np + 1) / 2, -1);
+    P.diag_tile.assign(np, -1);
+    P.ntiles = 0;
+    for (int J = 0; J < np; ++J) {
+        P.diag_tile[J] = P.tile_map[(size_t)J * (J + 1) / 2 + J] = P.ntiles++;
+        for (int I : P.strct[J]) P.tile_map[(size_t)I * (I + 1) / 2 + J] = P.ntiles++;
+    }
+    // level launches
+    P.leaves.clear();
+    P.items.clear();
+    P.srcs.clear();
+    P.launches.clear();
+    P.tile_updates = 0;
+    for (int J = 0; J < np; ++J)
+        if (P.level[J] == 0) P.leaves.push_back(J);
+    double est = cm.diag_us;
+    // Every update (J; I1 >= I2) of the structure may run in any launch from level(J) (its source exists) to
+    // level(I2) - 1 (the launch before its target is read as a strip, or the launch that factorises it): a target whose
+    // sources all sit on one level — (root, root) receives one from every leaf — would otherwise make ONE workgroup walk
+    // a dozen sources while the launch waits. The sources of a target are dealt over its window, at most `defer_cap` per
+    // launch ahead of the deadline; their order stays fixed (by level, then by panel): the sums are deterministic.
+    struct Tgt { int I1, I2; std::vector<int> src; size_t next = 0; };  // src: panels J, sorted by (level, J)
+    std::vector<Tgt> tgts;
+    {
+        std::vector<int> tgt_of((size_t)np * (np + 1) / 2, -1);
+        std::vector<int> by_level(np);
+        std::iota(by_level.begin(), by_level.end(), 0);
+        std::stable_sort(by_level.begin(), by_level.end(), [&](int a, int b) { return P.level[a] < P.level[b]; });
+        for (int J : by_level) {
+            const auto& st = P.strct[J];
+            for (size_t a = 0; a < st.size(); ++a)
+                for (size_t b = a; b < st.size(); ++b) {
+                    const int I2 = st[a], I1 = st[b];
+                    const size_t key = (size_t)I1 * (I1 + 1) / 2 + I2;
+                    if (tgt_of[key] < 0) {
+                        tgt_of[key] = (int)tgts.size();
+                        tgts.push_back(Tgt{I1, I2, {}});
+                    }
+                    tgts[tgt_of[key]].src.push_back(J);
+                    ++P.tile_updates;
+                }
+        }
+    }
+    for (int l = 0; l + 1 < P.n_levels; ++l) {
+        struct Tmp { int t, first, count; bool fin; };
+        std::vector<Tmp> tmp;
+        for (int t = 0; t < (int)tgts.size(); ++t) {
+            Tgt& g = tgts[t];
+            if (g.next == g.src.size()) continue;
+            const int deadline = P.level[g.I2] - 1;
+            size_t avail = g.next;
+            while (avail < g.src.size() && P.level[g.src[avail]] <= l) ++avail;
+            int take = (int)(avail - g.next);
+            if (take == 0) continue;
+            if (l < deadline) take = std::min(take, std::max(cm.defer_cap, (take + deadline - l) / (deadline - l + 1)));
+            tmp.push_back(Tmp{t, (int)g.next, take, g.I1 == g.I2 && deadline == l});
+            g.next += take;
+        }
+        // factorising items first (they are the launch's chain), then the longest lists
+        std::stable_sort(tmp.begin(), tmp.end(), [&](const Tmp& x, const Tmp& y) {
+            if (x.fin != y.fin) return x.fin;
+            return x.count > y.count;
+        });
+        const int first = (int)P.items.size();
+        int max_final_src = 0, max_src = 0, n_first = 0;
+        long long work = 0;
+        for (const Tmp& m : tmp) {
+            const Tgt& g = tgts[m.t];
+            BaPlanItem it{};
+            it.tgt = P.tile(g.I1, g.I2);
+            it.nsrc = m.count;
+            it.src0 = (int)P.srcs.size();
+            it.flags = (g.I1 == g.I2 ? 1 : 0) | (m.fin ? 2 : 0);
+            it.panel = g.I1;
+            it.col = g.I2;
+            P.items.push_back(it);
+            for (int k = m.first; k < m.first + m.count; ++k) {
+                const int J = g.src[k];
+                P.srcs.push_back(BaPlanSrc{P.tile(g.I1, J), P.tile(g.I2, J), J, 0});
+            }
+            if (m.fin) max_final_src = std::max(max_final_src, m.count), ++n_first;
+            max_src = std::max(max_src, m.count);
+            work += m.count;
+        }
+        P.launches.push_back(BaPlan::Launch{first, (int)P.items.size() - first, n_first});
+        const double chain = cm.chain_us + cm.extra_src_us * std::max(0, max_final_src - 1);
+        const double longest = cm.launch_us + cm.src_us * max_src;
+        const double grid = cm.launch_us + cm.src_us * (double)((work + cm.slots - 1) / cm.slots);
+        est += std::max(chain, std::max(longest, grid));
+    }
+    est += cm.backsolve_base_us + cm.backsolve_level_us * P.n_levels;
+    P.est_us = est;
+    // back-substitution: root first, a panel after its parent
+    P.bs_order.resize(np);
+    std::iota(P.bs_order.begin(), P.bs_order.end(), 0);
+    std::stable_sort(P.bs_order.begin(), P.bs_order.end(), [&](int a, int b) { return P.level[a] != P.level[b] ? P.level[a] > P.level[b] : a > b; });
+    P.bs_ptr.assign(np + 1, 0);
+    P.bs_ent.clear();
+    for (int b = 0; b < np; ++b) {
+        const int J = P.bs_order[b];
+        for (int I : P.strct[J]) P.bs_ent.emplace_back(P.tile(I, J), I);
+        P.bs_ptr[b + 1] = (int)P.bs_ent.size();
+    }
+    // columns
+    P.col_dest.assign((size_t)np * PLAN_PANEL, -1);
+    for (int c = 0; c < nc; ++c)
+        for (int a = 0; a < PLAN_CAM; ++a) P.col_dest[P.pos[c] + a] = PLAN_CAM * c + a;
+    for (int k = 0; k < PLAN_K; ++k) P.col_dest[P.posK + k] = PLAN_CAM * nc + k;
+    P.pad_cols.clear();
+    for (int q = 0; q < np * PLAN_PANEL; ++q)
+        if (P.col_dest[q] < 0 && q != P.rhs_row) P.pad_cols.push_back(q);
+}
+
+// edges: camera pairs (c < c') that share a landmark. hint: BaOrdering.
+inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges, int hint, BaPlan& P,
+                          const BaPlanCost& cm = BaPlanCost()) {
+    plan_detail::Adj adj(nc);
+    for (const auto& e : edges)
+        if (e.first != e.second) {
+            adj[e.first].push_back(e.second);
+            adj[e.second].push_back(e.first);
+        }
+    for (auto& a : adj) {
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    std::vector<int> all(nc);
+    std::iota(all.begin(), all.end(), 0);
+    const int cams_per_panel = PLAN_PANEL / PLAN_CAM;  // 10
+    // the natural order is always a candidate: (it is what a window of a sequence already is)
+    BaPlan best;
+    plan_from_nodes(nc, adj, {all}, best, cm);
+    best.ordering = BA_ORDER_NATURAL;
+    auto consider = [&](const std::vector<std::vector<int>>& nodes, int ordering, int leaf, bool force) {
+        BaPlan cand;
+        plan_from_nodes(nc, adj, nodes, cand, cm);
+        cand.ordering = ordering;
+        cand.nd_leaf = leaf;
+        if (force || cand.est_us < best.est_us - 1e-9) best = std::move(cand);
+    };
+    const bool small = nc <= 2 * cams_per_panel;  // two panels: nothing to reorder
+    if (hint == BA_ORDER_RCM || (hint == BA_ORDER_AUTO && !small)) consider({plan_detail::rcm(adj)}, BA_ORDER_RCM, 0, hint == BA_ORDER_RCM);
+    if (hint == BA_ORDER_ND || (hint == BA_ORDER_AUTO && !small)) {
+        bool first = true;
+        for (int leaf : {cams_per_panel, 2 * cams_per_panel + 1, 3 * cams_per_panel + 2, 4 * cams_per_panel + 2}) {
+            std::vector<std::vector<int>> nodes;
+            std::vector<int> mark(nc, 0), lev(nc, -1);
+            int tag = 1;
+            plan_detail::dissect(adj, mark, tag, all, leaf, nodes, lev);
+            consider(nodes, BA_ORDER_ND, leaf, hint == BA_ORDER_ND && first);
+            first = false;
+        }
+    }
+    P = std::move(best);
+}
+
+}  // namespace eacham

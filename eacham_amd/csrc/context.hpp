@@ -96,6 +96,8 @@ struct eacham_ctx {
     size_t io_bytes = 0;
 
     std::vector<eacham::BaBlock> ba_pool;  // arenas of released BA problems, reused by the next eacham_ba_prepare
+    int ba_ordering = 0;  // EACHAM_BA_ORDERING=natural|rcm|nd read ONCE at eacham_ctx_create (diagnostic override of
+                          // eacham_ba_problem.ordering == AUTO); nothing on the solve path reads the environment
 
     // profiling
     bool profile = false;

@@ -144,7 +144,8 @@ typedef struct eacham_ba_problem {
     int32_t n_cams;
     int32_t n_points;
     int32_t n_obs;
-    int32_t reserved;
+    int32_t ordering;                /* EACHAM_BA_ORDER_* below: elimination order of the reduced camera system;  */
+                                     /* 0 (a zero-initialised problem) = chosen by the library's cost model       */
     const double* cam_T_wc;          /* n_cams x 16, row-major world->camera (Node::GetTransform())   */
     const int32_t* cam_fixed;        /* n_cams, Graph::IsFixed(id) (:69)                              */
     const double* points;            /* n_points x 3 (Map::Get(id3d), :102)                          */
@@ -155,6 +156,15 @@ typedef struct eacham_ba_problem {
     const double* obs_uv;            /* n_obs x 2, keypoint in pixels (cv::Point2f widened, :93)     */
     double K[4];                     /* fx, fy, cx, cy = K(0,0), K(1,1), K(0,2), K(1,2) (:47-49)     */
 } eacham_ba_problem;
+
+/* Elimination order of the reduced camera system (the counterpart of GTSAM's COLAMD ordering, which the reference
+ * gets through LevenbergMarquardtParams::SetCeresDefaults, BundleAdjuster.cpp:182-190). Every choice solves the same
+ * system; they differ in the height of the elimination tree (the number of dependent launches) and in fill.
+ * AUTO evaluates the candidates with a cost model and keeps the cheapest (eacham_amd/csrc/ba_plan.hpp). */
+#define EACHAM_BA_ORDER_AUTO 0
+#define EACHAM_BA_ORDER_NATURAL 1  /* the caller's camera order: a band for a sequence                                */
+#define EACHAM_BA_ORDER_RCM 2      /* reverse Cuthill-McKee: minimal band, the tree is a path                        */
+#define EACHAM_BA_ORDER_ND 3       /* nested dissection: independent subtrees are factorised in the same launch      */
 
 #define EACHAM_BA_LM 0
 #define EACHAM_BA_DOGLEG 1
@@ -232,6 +242,17 @@ int eacham_ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* problem, eacham_
 int eacham_ba_run(eacham_ctx* ctx, eacham_ba_handle* handle, const eacham_ba_options* options,
                   eacham_ba_result* result);
 void eacham_ba_release(eacham_ctx* ctx, eacham_ba_handle* handle);
+
+/* What the analysis of the reduced camera system decided for a prepared problem (reporting: the benchmark's BA line
+ * carries it): panels of 64 columns, tiles of the symbolic factor, height of the elimination tree = number of
+ * dependent factorisation launches, the ordering used (EACHAM_BA_ORDER_NATURAL / _RCM / _ND), rank-64 tile updates of
+ * one factorisation and the cost model's estimate for factorisation + back-substitution in microseconds. */
+typedef struct eacham_ba_plan_info {
+    int32_t n_panels, n_tiles, n_levels, ordering, nd_leaf, reserved;
+    int64_t tile_updates;
+    double est_us;
+} eacham_ba_plan_info;
+int eacham_ba_get_plan_info(eacham_ctx* ctx, const eacham_ba_handle* handle, eacham_ba_plan_info* out);
 
 /* Test/diagnostic entry point: linearises at the problem's initial values and returns the reduced
  * camera system of one damped Gauss-Newton step: S (n x n, row-major, n = 6*n_cams + 5, cameras

@@ -56,11 +56,11 @@ def test_step_with_repeated_camera_and_cheirality(hip_ctx):
     assert np.isclose(err, erro, rtol=1e-12) and not dl[-1].any()
 
 
-@pytest.mark.parametrize("n_cams", [2, 3, 5, 10, 11, 15, 16, 21, 22, 26, 31, 43])  # n = 6 cams + 5 around the 32- and 64-column edges
+@pytest.mark.parametrize("n_cams", [2, 3, 5, 9, 10, 11, 15, 16, 20, 21, 22, 26, 31, 32, 43])  # n = 6 cams + 5 around the 32- and 64-column edges
 def test_block_boundaries_of_the_reduced_system(hip_ctx, n_cams):
-    """n = 6 n_cams + 5 against the 32-column Cholesky blocks, the 64-row tiles and the 128-column
-    back-substitution super-blocks: a single partial block (17, 23), one real column in the last block (65),
-    exact multiples nearby (131 = 4 x 32 + 3, 137, 263 = two super-blocks + 7)."""
+    """n = 6 n_cams + 5 against the 32-column diagonal blocks and the 64-column panels: a single partial block (17, 23),
+    one real column in the last panel (65), the calibration columns and the right-hand-side row sharing the last panel
+    with cameras or getting a panel of their own (n mod 64 > 58: 10, 21, 31 cameras), cameras straddling two panels."""
     sc, A = scene_arrays(seed=20 + n_cams, n_cams=n_cams, n_lm=60 + 12 * n_cams, k=min(n_cams, 5))
     S, g, dc, dl, err, lin = ba.debug_step(hip_ctx, A, 1e-3)
     So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
@@ -69,38 +69,49 @@ def test_block_boundaries_of_the_reduced_system(hip_ctx, n_cams):
     assert np.isclose(err, erro, rtol=1e-12) and np.isclose(lin, lino, rtol=1e-9)
 
 
-def test_launch_chain_back_substitution_agrees_with_the_single_launch(hip_ctx, monkeypatch):
-    """The back-substitution normally runs as one launch with in-kernel hand-offs; systems with more than 64
-    super-blocks (n > 8192) and the EACHAM_BA_BACKSTEP_LAUNCHES switch take one launch per super-block."""
-    sc, A = scene_arrays(seed=5, n_cams=60, n_lm=400, k=8)  # n = 365: three super-blocks
-    one = ba.debug_step(hip_ctx, A, 1e-3)
-    monkeypatch.setenv("EACHAM_BA_BACKSTEP_LAUNCHES", "1")
-    chain = ba.debug_step(hip_ctx, A, 1e-3)
-    assert rel(chain[2], one[2]) < 1e-10 and rel(chain[3], one[3]) < 1e-10
-    assert rel(one[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
+@pytest.mark.parametrize("n_cams,n_lm,k", [(12, 200, 6), (31, 400, 6), (60, 600, 8), (130, 2600, 6)])
+def test_every_elimination_order_solves_the_same_system(hip_ctx, n_cams, n_lm, k):
+    """The reduced camera system is factorised in tiles of the symbolic pattern, level by level of the elimination
+    tree of the chosen camera ordering (ba_plan.hpp; the reference gets COLAMD + multifrontal Cholesky through
+    SetCeresDefaults, BundleAdjuster.cpp:182-190). The caller's order (one path: the dense chain), reverse
+    Cuthill-McKee, nested dissection (independent subtrees in one launch, several sources per target) and the cost
+    model's choice must all return the step of the oracle; S itself comes back in the caller's order whatever the layout."""
+    sc, A = scene_arrays(seed=30 + n_cams, n_cams=n_cams, n_lm=n_lm, k=k)
+    ref = O.ba_step(A, 1e-3, 0)
+    assert ref[-1]
+    steps = {}
+    for name in ("natural", "rcm", "nd", "auto"):
+        A.ordering = name
+        S, g, dc, dl, err, lin = ba.debug_step(hip_ctx, A, 1e-3)
+        assert rel(S, ref[0]) < 1e-11 and rel(g, ref[1]) < 1e-11, name
+        assert rel(dc, ref[2]) < 1e-8 and rel(dl, ref[3]) < 1e-8, name
+        assert np.isclose(err, ref[4], rtol=1e-12) and np.isclose(lin, ref[5], rtol=1e-9), name
+        steps[name] = dc
+    for name in ("rcm", "nd", "auto"):
+        assert rel(steps[name], steps["natural"]) < 1e-9
 
 
-def test_32_column_steps_agree_with_the_64_column_steps(hip_ctx, monkeypatch):
-    """The factorisation retires 64 columns per launch (chol_step64); EACHAM_BA_CHOL32 selects the older chain of
-    one launch per 32 columns (kept for A/B measurements): same factor, same step."""
-    sc, A = scene_arrays(seed=6, n_cams=60, n_lm=400, k=8)  # n = 365
-    wide = ba.debug_step(hip_ctx, A, 1e-3)
-    monkeypatch.setenv("EACHAM_BA_CHOL32", "1")
-    narrow = ba.debug_step(hip_ctx, A, 1e-3)
-    assert rel(narrow[2], wide[2]) < 1e-10 and rel(narrow[3], wide[3]) < 1e-10
-    assert rel(wide[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
+def test_unknown_ordering_is_rejected(hip_ctx):
+    sc, A = scene_arrays(n_cams=4, n_lm=60, k=3)
+    import ctypes as C
+    prob, opt = A.c_problem(), ba.c_options(ba.OptimizerConfig.refine_ba())
+    prob.ordering = 9
+    res = capi.BaResult()
+    T = np.zeros((prob.n_cams, 16)); P = np.zeros((prob.n_points, 3))
+    res.cam_T_wc, res.points = T.ctypes.data, P.ctypes.data
+    assert capi.lib().eacham_ba_solve(hip_ctx.handle, C.byref(prob), C.byref(opt), C.byref(res)) == capi.ERR_INVALID
 
 
-@pytest.mark.parametrize("n_cams", [10, 31, 60])
-def test_split_steps_agree_with_the_fused_steps(hip_ctx, monkeypatch, n_cams):
-    """A step whose tile grid is larger than the chip forms every panel strip once (chol_step64<1>) and updates from the
-    stored strips (chol_step64<2>); EACHAM_BA_SPLIT_TILES=0 forces that path for every step of a small system."""
-    sc, A = scene_arrays(seed=9, n_cams=n_cams, n_lm=300, k=6)
-    fused = ba.debug_step(hip_ctx, A, 1e-3)
-    monkeypatch.setenv("EACHAM_BA_SPLIT_TILES", "0")
-    split = ba.debug_step(hip_ctx, A, 1e-3)
-    assert rel(split[2], fused[2]) < 1e-10 and rel(split[3], fused[3]) < 1e-10
-    assert rel(fused[2], O.ba_step(A, 1e-3, 0)[2]) < 1e-8
+@pytest.mark.parametrize("ordering", ["natural", "nd"])
+def test_lm_run_is_the_same_under_every_ordering(hip_ctx, ordering):
+    """A whole LM solve (golden-sized window with outliers): same decisions, same optimum as the oracle."""
+    sc, A = scene_arrays(seed=21, n_cams=45, n_lm=1500, k=6)
+    A.ordering = ordering
+    out = ba.RefineBA(hip_ctx, A, ba.OptimizerConfig.refine_ba())
+    ref = O.ba_solve(A, ba.OptimizerConfig.refine_ba())
+    assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+    assert np.allclose(out.trace, ref.trace, rtol=1e-6)
+    assert rel(out.cam_T_wc, ref.cam_T_wc) < 1e-7 and rel(out.points, ref.points) < 1e-7
 
 
 @pytest.mark.parametrize("lam", [-1e-3, -0.05, -0.5, -1.5])  # the first two: landmark blocks fine, reduced system indefinite
@@ -147,7 +158,7 @@ FAULT_LIB = os.path.join(os.path.dirname(capi.LIB_PATH), "exp", "libeacham_hip_f
 FAULT_SCRIPT = """
 import sys, numpy as np
 from eacham_amd import ba, synth, capi, HipContext, EachamError
-A = ba.BaArrays.from_scene(synth.make_scene(60, 400, 8, seed=5))      # n = 365: three super-blocks
+A = ba.BaArrays.from_scene(synth.make_scene(60, 400, 8, seed=5))      # n = 365: six panels
 with HipContext(0) as ctx:
     try:
         ba.RefineBA(ctx, A, ba.OptimizerConfig(sys.argv[1], 100, 1e-5, 10.0, False))
@@ -161,8 +172,8 @@ sys.exit(4)
 @pytest.mark.parametrize("fault", ["handoff", "progress"])
 @pytest.mark.parametrize("method", ["LM", "DogLeg"])
 def test_an_expired_in_kernel_wait_is_an_error_not_a_rejected_step(fault, method):
-    """The two in-kernel hand-offs of the dense solve (super-block to super-block in chol_backsolve, factorising
-    wave to inverting wave in the diagonal-block factor) have bounded waits. The diagnostic build
+    """The two in-kernel hand-offs of the solve (panel to panel in sp_backsolve, factorising wave to inverting wave
+    in the diagonal-block factor) have bounded waits. The diagnostic build
     (-DEXP_BA_FAULT, `make fault`) withholds one signal: the wait must expire, the launch must end, and the solve
     must come back as EACHAM_ERR_HIP — not as 'not positive definite', which LM would answer by silently raising
     lambda. Runs in a child process because the library to load is chosen at import time."""
@@ -365,8 +376,8 @@ def test_metric_scene_s200(hip_ctx):
 
 
 def test_config4_size_properties(hip_ctx):
-    """BASELINE configs[3]: 500 cams / 100k landmarks / 1M observations (n = 3005, 94 Cholesky block steps, 24
-    super-blocks in the single-launch back-substitution). Too large for the oracle to finish in seconds, so
+    """BASELINE configs[3]: 500 cams / 100k landmarks / 1M observations (n = 3005: 47 panels in the caller's order,
+    ~59 under nested dissection with an elimination tree 16 levels high). Too large for the oracle to finish in seconds, so
     the check is by size-independent properties: determinism, a large error drop, recovery of the truth, and
     agreement of LM and DogLeg on the optimum."""
     sc = synth.make_scene(500, 100_000, 10, seed=4)
