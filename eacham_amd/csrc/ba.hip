@@ -1318,6 +1318,22 @@ __device__ __forceinline__ void sp_level_item(double* lds, double* __restrict__ 
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) mold[reg] = A[(mbi + mg + 4 * reg) * PB + mbj + mc];
     }
+    // a target that takes more sources than its window allows has shadow accumulators (ba_plan.hpp): other workgroups summed
+    // part of its updates into them in earlier launches; they join the target here, in the launch of its deadline
+    for (int k = 0; k < it.nshadow; ++k) {
+        const double* __restrict__ Sh = T + (size_t)(it.shadow0 + k) * TILE;
+        if (block_thread) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (!(same && cb > wv)) old[cb][reg] += Sh[(16 * wv + mg + 4 * reg) * PB + 16 * cb + mc];
+        }
+        if (first && wv < 3) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) mold[reg] += Sh[(mbi + mg + 4 * reg) * PB + mbj + mc];
+        }
+    }
 #pragma unroll 1
     for (int s = 0; s < it.nsrc; ++s) {
         const BaPlanSrc sr = srcs[it.src0 + s];

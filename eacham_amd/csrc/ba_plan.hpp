@@ -46,7 +46,7 @@ struct BaPlanItem {   // one workgroup of a level launch
     int flags;        // bit 0: diagonal target (I1 == I2); bit 1: the target's panel is complete after this launch: factorise it
     int panel;        // I1 (the panel whose W the factorising item writes)
     int col;          // I2
-    int pad[2];
+    int shadow0, nshadow;  // tiles [shadow0, shadow0 + nshadow) are added to the target first (see plan_from_nodes)
 };
 struct BaPlanSrc {
     int tile_i, tile_j;  // raw strips A'[I1][J], A'[I2][J]
@@ -55,7 +55,8 @@ struct BaPlanSrc {
 };
 
 struct BaPlan {
-    int nc = 0, npan = 0, ntiles = 0, n_levels = 0;
+    int nc = 0, npan = 0, ntiles = 0, n_levels = 0;   // ntiles: tiles of the pattern + shadow accumulators
+    int n_shadow = 0;
     int posK = 0, rhs_row = 0;
     int ordering = BA_ORDER_NATURAL;   // the candidate chosen
     int nd_leaf = 0;                   // its leaf size (ND)
@@ -238,9 +239,10 @@ inline std::vector<int> rcm(const Adj& adj) {
 // launch is bound either by the chain of a factorising workgroup (panel product + two one-wave 32x32 factors, plus a panel
 // product per extra source of that target) or by its tile grid (two workgroups per CU).
 struct BaPlanCost {
-    double diag_us = 13.0, chain_us = 14.0, extra_src_us = 2.6, launch_us = 4.0, src_us = 2.6, backsolve_level_us = 3.0, backsolve_base_us = 6.0;
+    double diag_us = 13.0, chain_us = 14.0, extra_src_us = 5.0, launch_us = 3.0, src_us = 5.0, backsolve_level_us = 3.0, backsolve_base_us = 6.0;
     int slots = 512;      // resident workgroups of a level launch (two per CU)
-    int defer_cap = 3;    // sources a target takes per launch ahead of its deadline
+    int src_cap = 2;      // sources an accumulator takes per launch ahead of its target's deadline (two fit under the chain)
+    int max_shadows = 7;  // shadow accumulators per target
 };
 
 // Lays out the nodes, derives the symbolic factor and the schedule. `nodes` = the ordering (cameras of each node in
@@ -314,9 +316,18 @@ inline void plan_from_nodes(int nc, const plan_detail::Adj& adj, const std::vect
     // Every update (J; I1 >= I2) of the structure may run in any launch from level(J) (its source exists) to
     // level(I2) - 1 (the launch before its target is read as a strip, or the launch that factorises it): a target whose
     // sources all sit on one level — (root, root) receives one from every leaf — would otherwise make ONE workgroup walk
-    // a dozen sources while the launch waits. The sources of a target are dealt over its window, at most `defer_cap` per
-    // launch ahead of the deadline; their order stays fixed (by level, then by panel): the sums are deterministic.
-    struct Tgt { int I1, I2; std::vector<int> src; size_t next = 0; };  // src: panels J, sorted by (level, J)
+    // a dozen sources while the launch waits. So (1) the sources of a target are dealt over its window, `src_cap` per
+    // launch, and (2) a target that receives more than its window can take at that rate — the tiles of the root's row
+    // receive a rank-64 update from EVERY panel, because K is dense — gets SHADOW tiles: zero-initialised accumulators
+    // of their own workgroups that take the overflow in the launches before the deadline and are added to the target by
+    // its workgroup in the deadline launch. Which source goes to which accumulator in which launch is fixed by the plan,
+    // every accumulator sums in a fixed order: the result is deterministic (and no atomics).
+    struct Tgt {
+        int I1, I2;
+        std::vector<int> src;  // source panels J, sorted by (level, J)
+        size_t next = 0;
+        int shadow0 = -1, nshadow = 0;
+    };
     std::vector<Tgt> tgts;
     {
         std::vector<int> tgt_of((size_t)np * (np + 1) / 2, -1);
@@ -331,27 +342,55 @@ inline void plan_from_nodes(int nc, const plan_detail::Adj& adj, const std::vect
                     const size_t key = (size_t)I1 * (I1 + 1) / 2 + I2;
                     if (tgt_of[key] < 0) {
                         tgt_of[key] = (int)tgts.size();
-                        tgts.push_back(Tgt{I1, I2, {}});
+                        Tgt t;
+                        t.I1 = I1, t.I2 = I2;
+                        tgts.push_back(std::move(t));
                     }
                     tgts[tgt_of[key]].src.push_back(J);
                     ++P.tile_updates;
                 }
         }
     }
+    P.n_shadow = 0;
+    for (Tgt& g : tgts) {
+        const int deadline = P.level[g.I2] - 1, early_launches = deadline - P.level[g.src[0]];
+        int early = 0;  // sources that exist before the deadline launch
+        for (int J : g.src) early += P.level[J] < deadline ? 1 : 0;
+        if (early_launches > 0) {
+            const int rate = (early + early_launches - 1) / early_launches;  // sources per launch the target must absorb
+            g.nshadow = std::min(cm.max_shadows, std::max(0, (rate + cm.src_cap - 1) / cm.src_cap - 1));
+        }
+        if (g.nshadow) {
+            g.shadow0 = P.ntiles;
+            P.ntiles += g.nshadow;
+            P.n_shadow += g.nshadow;
+        }
+    }
     for (int l = 0; l + 1 < P.n_levels; ++l) {
-        struct Tmp { int t, first, count; bool fin; };
+        struct Tmp { int t, acc, first, count; bool fin; };  // acc: 0 = the target itself, k > 0 = its shadow k - 1
         std::vector<Tmp> tmp;
         for (int t = 0; t < (int)tgts.size(); ++t) {
             Tgt& g = tgts[t];
-            if (g.next == g.src.size()) continue;
             const int deadline = P.level[g.I2] - 1;
+            if (l > deadline) continue;
             size_t avail = g.next;
             while (avail < g.src.size() && P.level[g.src[avail]] <= l) ++avail;
-            int take = (int)(avail - g.next);
-            if (take == 0) continue;
-            if (l < deadline) take = std::min(take, std::max(cm.defer_cap, (take + deadline - l) / (deadline - l + 1)));
-            tmp.push_back(Tmp{t, (int)g.next, take, g.I1 == g.I2 && deadline == l});
-            g.next += take;
+            int have = (int)(avail - g.next);
+            if (l == deadline) {  // everything that is left, and the shadows
+                if (have || g.nshadow) tmp.push_back(Tmp{t, 0, (int)g.next, have, g.I1 == g.I2});
+                g.next += have;
+                continue;
+            }
+            if (!have) continue;
+            // the launches before the deadline: src_cap per accumulator, more only if the rest of the window could not take it
+            const int nacc = 1 + g.nshadow, left = deadline - l;  // launches of the window after this one (the deadline's among them)
+            const int per = std::max(cm.src_cap, (have + nacc * (left + 1) - 1) / (nacc * (left + 1)));
+            for (int k = 0; k < nacc && have > 0; ++k) {
+                const int take = std::min(have, per);
+                tmp.push_back(Tmp{t, k, (int)g.next, take, false});
+                g.next += take;
+                have -= take;
+            }
         }
         // factorising items first (they are the launch's chain), then the longest lists
         std::stable_sort(tmp.begin(), tmp.end(), [&](const Tmp& x, const Tmp& y) {
@@ -364,12 +403,15 @@ inline void plan_from_nodes(int nc, const plan_detail::Adj& adj, const std::vect
         for (const Tmp& m : tmp) {
             const Tgt& g = tgts[m.t];
             BaPlanItem it{};
-            it.tgt = P.tile(g.I1, g.I2);
+            it.tgt = m.acc == 0 ? P.tile(g.I1, g.I2) : g.shadow0 + m.acc - 1;
             it.nsrc = m.count;
             it.src0 = (int)P.srcs.size();
             it.flags = (g.I1 == g.I2 ? 1 : 0) | (m.fin ? 2 : 0);
             it.panel = g.I1;
             it.col = g.I2;
+            const bool fold = m.acc == 0 && l == P.level[g.I2] - 1 && g.nshadow > 0;
+            it.shadow0 = fold ? g.shadow0 : 0;
+            it.nshadow = fold ? g.nshadow : 0;
             P.items.push_back(it);
             for (int k = m.first; k < m.first + m.count; ++k) {
                 const int J = g.src[k];
@@ -377,7 +419,7 @@ inline void plan_from_nodes(int nc, const plan_detail::Adj& adj, const std::vect
             }
             if (m.fin) max_final_src = std::max(max_final_src, m.count), ++n_first;
             max_src = std::max(max_src, m.count);
-            work += m.count;
+            work += std::max(1, m.count);
         }
         P.launches.push_back(BaPlan::Launch{first, (int)P.items.size() - first, n_first});
         const double chain = cm.chain_us + cm.extra_src_us * std::max(0, max_final_src - 1);

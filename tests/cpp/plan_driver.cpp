@@ -75,14 +75,21 @@ int main() {
         // exists (level(J)), not after the launch before its target's column is read or factorised (level(I2) - 1), and a
         // target's sources in ascending (level, panel) order over the launches
         std::set<std::vector<int>> done;
+        int nnz_off = 0;
+        for (int J = 0; J < np; ++J) nnz_off += (int)P.strct[J].size();
+        if (P.ntiles != np + nnz_off + P.n_shadow) ++bad;
         for (size_t l = 0; l < P.launches.size(); ++l)
             for (int i = P.launches[l].first; i < P.launches[l].first + P.launches[l].count; ++i) {
                 const BaPlanItem& it = P.items[i];
                 if (((it.flags & 2) != 0) != (i - P.launches[l].first < P.launches[l].n_first)) ++bad;  // factorising items first
+                const bool main_acc = it.tgt == P.tile(it.panel, it.col);
+                if (((it.flags & 2) != 0) != (main_acc && it.panel == it.col && (int)l == P.level[it.col] - 1)) ++bad;
+                if (!main_acc && (it.tgt < np + nnz_off || (int)l >= P.level[it.col] - 1)) ++bad;  // a shadow works before the deadline only
+                if (it.nshadow && (!main_acc || (int)l != P.level[it.col] - 1)) ++bad;               // and is folded in at the deadline
                 for (int s = it.src0; s < it.src0 + it.nsrc; ++s) {
                     if (P.level[P.srcs[s].J] > (int)l || (int)l > P.level[it.col] - 1) ++bad;
-                    if (((it.flags & 2) != 0) != (it.panel == it.col && (int)l == P.level[it.col] - 1)) ++bad;
-                    if (!done.insert({P.srcs[s].J, it.tgt}).second) ++bad;
+                    if (P.srcs[s].tile_i != P.tile(it.panel, P.srcs[s].J) || P.srcs[s].tile_j != P.tile(it.col, P.srcs[s].J)) ++bad;
+                    if (!done.insert({P.srcs[s].J, P.tile(it.panel, it.col)}).second) ++bad;
                 }
             }
         if ((long long)done.size() != P.tile_updates) ++bad;
@@ -171,6 +178,8 @@ int main() {
         for (int i = la.first; i < la.first + la.count; ++i) {
             const BaPlanItem& it = P.items[i];
             Mat& tgt = T[it.tgt];
+            for (int k = 0; k < it.nshadow; ++k)
+                for (int e = 0; e < 64 * 64; ++e) tgt[e] += T[it.shadow0 + k][e];
             for (int s = it.src0; s < it.src0 + it.nsrc; ++s) {
                 const BaPlanSrc& sr = P.srcs[s];
                 if (W[sr.J].empty()) { ++bad; continue; }  // a source whose factor does not exist yet
@@ -226,13 +235,15 @@ int main() {
             err = std::max(err, std::fabs(z[q] - x[P.col_dest[q]]));
             ref = std::max(ref, std::fabs(x[P.col_dest[q]]));
         }
-    int max_final_src = 0;
-    for (const auto& it : P.items)
+    int max_final_src = 0, max_src = 0;
+    for (const auto& it : P.items) {
         if (it.flags & 2) max_final_src = std::max(max_final_src, it.nsrc);
+        max_src = std::max(max_src, it.nsrc);
+    }
     printf("{\"nc\": %d, \"npan\": %d, \"ntiles\": %d, \"levels\": %d, \"ordering\": %d, \"nd_leaf\": %d, \"est_us\": %.1f, "
-           "\"tile_updates\": %lld, \"launch_items\": [",
-           nc, np, P.ntiles, P.n_levels, P.ordering, P.nd_leaf, P.est_us, P.tile_updates);
+           "\"tile_updates\": %lld, \"shadows\": %d, \"launch_items\": [",
+           nc, np, P.ntiles, P.n_levels, P.ordering, P.nd_leaf, P.est_us, P.tile_updates, P.n_shadow);
     for (size_t l = 0; l < P.launches.size(); ++l) printf("%s%d", l ? ", " : "", P.launches[l].count);
-    printf("], \"max_final_src\": %d, \"bad\": %d, \"spd\": %d, \"rel_err\": %.3e}\n", max_final_src, bad, ok ? 1 : 0, ref > 0 ? err / ref : err);
+    printf("], \"max_final_src\": %d, \"max_src\": %d, \"bad\": %d, \"spd\": %d, \"rel_err\": %.3e}\n", max_final_src, max_src, bad, ok ? 1 : 0, ref > 0 ? err / ref : err);
     return bad ? 1 : 0;
 }
