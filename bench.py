@@ -11,9 +11,11 @@ all-gather of the match graph. Inputs are resident in HBM before the timed regio
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Besides the headline line the JSON carries `lines`: the other BASELINE.json configurations and the real
-descriptor shapes as sub-objects, each with its own roofline against the peak of the arithmetic it runs on
-(SURVEY.md §8(d) "Other configs as inputs"):
+Output: rank 0 prints one JSON line per sub-line as it finishes ({"line": "<name>", ...}: the other BASELINE.json
+configurations and the real descriptor shapes, each with its own roofline against the peak of the arithmetic it runs
+on, SURVEY.md §8(d) "Other configs as inputs"; {"line": "ba", ...} is the full bundle-adjustment record) and, LAST,
+the headline line of the contract — kept short (headline + roofline + cpu_baseline + a compact `ba` + one
+value / roofline fraction per sub-line) so that a tail of the log holds it whole. The sub-lines:
   s200_d128_i8   S200 with 128-D integer descriptors (what eacham's SIFT extractor produces)
   s200_d256_f32  S200 with 256-D unit-norm float descriptors (SuperPoint / LightGlue style), fp32 MFMA
   c2             configs[1]: 100 frames x 2000 x 256-D
@@ -65,12 +67,22 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_source_sha() -> str:
+SOURCE_GROUPS = {"match": ("matcher.hip", "matcher_f32.hip", "context.hip", "context.hpp"),
+                 "ba": ("ba.hip", "ba_plan.hpp", "context.hpp")}
+PROFILE_ROUND = "r03"  # profiles/<round>_pmc_*.json read for roofline.traffic
+
+
+def kernel_source_sha(group: str | None = None) -> str:
     """Identity of the kernels a profile was taken with: sha256 over the CODE of the library's HIP sources — comments
-    and white space are dropped first, so rewording a comment does not disown a profile, changing a token does."""
+    and white space are dropped first, so rewording a comment does not disown a profile, changing a token does.
+    `group` ("match" / "ba") restricts it to the sources of one path: a change to the bundle adjuster does not disown
+    the matcher's counters."""
     import re
     h = hashlib.sha256()
-    for fn in sorted(glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hpp"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eacham_amd", "csrc", "*.hpp")))
+    if group is not None:
+        files = [f for f in files if os.path.basename(f) in SOURCE_GROUPS[group]]
+    for fn in files:
         with open(fn, "r", encoding="utf-8", errors="replace") as f:
             src = f.read()
         src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)        # block comments
@@ -85,15 +97,17 @@ def measured_traffic(kernel_prefix: str, grid: int | None = None):
     (profiles/r02_pmc_hbm_traffic.json, written by tools/pmc_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate
     passes, KB units, FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md). The file records the sha of
     the kernel sources it was taken with; a figure from other sources is NOT reported (None + the reason)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm_traffic.json")
     try:
         with open(path) as f:
             tab = json.load(f)
     except (OSError, ValueError):
         return None, "no PMC profile committed"
     meta = tab.get("__meta__", {})
-    if meta.get("kernel_source_sha") != kernel_source_sha():
-        return None, f"stale: profile taken with kernel sources {meta.get('kernel_source_sha')}, running {kernel_source_sha()}"
+    want = kernel_source_sha("match") if "kernel_source_sha_match" in meta else kernel_source_sha()
+    have = meta.get("kernel_source_sha_match", meta.get("kernel_source_sha"))
+    if have != want:
+        return None, f"stale: profile taken with kernel sources {have}, running {want}"
     keys = [k for k in tab if k.startswith(kernel_prefix) and " grid=" in k]
     if grid is not None:
         keys = [k for k in keys if int(k.rsplit("=", 1)[1]) == grid] or keys
@@ -102,7 +116,7 @@ def measured_traffic(kernel_prefix: str, grid: int | None = None):
     try:
         d = tab[max(keys, key=lambda k: int(k.rsplit("=", 1)[1]))]
         return (2.0 * d["FETCH_SIZE_KB_mean_per_dispatch"] + d["WRITE_SIZE_KB_mean_per_dispatch"]) * 1024.0, \
-            f"profiles/r02_pmc_hbm_traffic.json ({meta.get('command', 'tools/prof.sh')})"
+            f"profiles/{PROFILE_ROUND}_pmc_hbm_traffic.json ({meta.get('command', 'tools/prof.sh')})"
     except (KeyError, TypeError, ValueError):
         return None, "malformed PMC profile entry"
 
@@ -139,11 +153,32 @@ class Dist:
         self.local = local
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
+        self.backend = args.backend
+        self.group_note = None
         if self.world > 1:
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:
                 dist.init_process_group(args.backend)
+        elif args.backend == "nccl":
+            # N = 1: a one-rank RCCL group, so that the device-tensor all-gather of the shard path and its stream
+            # join execute on every single-GPU run too (the c5_kitti line gathers through it)
+            try:
+                import socket
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    port = so.getsockname()[1]
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=self.dev)
+            except Exception as e:  # noqa: BLE001 - reported in the line, never fatal for the single-GPU numbers
+                self.group_note = f"one-rank nccl group not available: {type(e).__name__}: {e}"
+
+    @property
+    def has_group(self) -> bool:
+        return self.dist.is_available() and self.dist.is_initialized()
+
+    @property
+    def collective_name(self) -> str:
+        return "RCCL (torch.distributed backend nccl)" if self.backend == "nccl" else f"torch.distributed backend {self.backend}"
 
     def barrier(self):
         if self.world > 1:
@@ -162,15 +197,17 @@ class Dist:
         return float(t.item())
 
 
-def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
+def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int, gather_at_one: bool = False):
     """The matching hot path over all unordered pairs of `descs` (list of N x dim fp32 matrices), sharded over
     the ranks: pairs ordered by train frame, contiguous shard per rank, one eacham_match_all_pairs_dev per step
     and (N > 1) the asynchronous RCCL all-gather of the match graph, double-buffered against the next step.
     kind: "i8" (integer descriptors, exact int8 MFMA path) or "f32" (float descriptors, fp32 MFMA path).
+    gather_at_one: at N = 1 run the all-gather all the same, through the one-rank group (and check what it returns).
     Returns the timing of exactly `steps` steps bracketed by barrier + synchronize, max over ranks."""
     torch, dist = D.torch, D.dist
     from eacham_amd import HipContext, synth, capi, shard
     world, rank, dev = D.world, D.rank, D.dev
+    gather = world > 1 or (gather_at_one and D.has_group)
     pairs_all = shard.order_pairs(synth.all_pairs(len(descs)))
     npairs_total = len(pairs_all)
     pairs = shard.shard_pairs(pairs_all, world, rank)
@@ -203,10 +240,10 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
         del edges0, counts0
         # two output sets: the all-gather of step i (its own RCCL stream) overlaps the matching of step i+1
         sets = []
-        for _ in range(2 if world > 1 else 1):
+        for _ in range(2 if gather else 1):
             st = {"counts": torch.zeros(shard_max, dtype=torch.int32, device=dev),
                   "edges": torch.zeros(edge_cap * 2, dtype=torch.int32, device=dev), "pending": []}
-            if world > 1:
+            if gather:
                 st["g_counts"] = torch.zeros(world * shard_max, dtype=torch.int32, device=dev)
                 st["g_edges"] = torch.zeros(world * edge_cap * 2, dtype=torch.int32, device=dev)
             sets.append(st)
@@ -221,7 +258,7 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
             st["pending"] = []
             ctx.match_all_pairs_dev(pairs_dev.data_ptr(), npairs, st["counts"].data_ptr(), offsets.data_ptr(),
                                     st["edges"].data_ptr(), edge_cap, total.data_ptr())
-            if world > 1:  # RCCL all-gather of the match graph (counts + padded edge lists) over xGMI
+            if gather:  # all-gather of the match graph (counts + padded edge lists): RCCL over xGMI with the nccl backend
                 _, _, st["pending"] = shard.all_gather_match_graph(st["counts"], st["edges"], shard_max, edge_cap, world,
                                                                    st["g_counts"], st["g_edges"], async_op=True)
 
@@ -247,16 +284,23 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int):
     ctx.profile_enable(False)
     launches, tile_ms = ctx.profile_get(capi.KERNEL_MATCH_TILE)
     _, fin_ms = ctx.profile_get(capi.KERNEL_MATCH_FINALIZE)
+    gathered_ok = None
+    if gather:  # the last step's gathered graph against this rank's own shard
+        st = sets[(step_no[0] - 1) % len(sets)]
+        mine_c = st["g_counts"][rank * shard_max:(rank + 1) * shard_max]
+        mine_e = st["g_edges"][rank * edge_cap * 2:(rank + 1) * edge_cap * 2]
+        gathered_ok = bool(torch.equal(mine_c, st["counts"]) and torch.equal(mine_e, st["edges"]))
     out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms,
+           "gathered": gather, "gathered_ok": gathered_ok,
            "fin_ms": fin_ms, "matches": int(total.item()), "pairs_all": pairs_all, "edge_cap": edge_cap, "upload_s": t_up,
            "upload_bytes": int(sum(d.nbytes for d in descs))}
     ctx.close()
     return out
 
 
-def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str):
+def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str, gather_at_one: bool = False):
     """One matching sub-line: value + roofline against the MFMA peak of the arithmetic used."""
-    r = run_matching(D, descs, kind, steps, warmup)
+    r = run_matching(D, descs, kind, steps, warmup, gather_at_one)
     n = np.array([d.shape[0] for d in descs], dtype=np.float64)
     # algorithmic work of this rank's launches: 2 * N1 * N2 * D per unordered pair (SURVEY.md §8(d))
     ops = 2.0 * dim * float(np.mean(n)) ** 2 * r["npairs"] * steps
@@ -265,6 +309,7 @@ def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, 
     return {"workload": workload, "value": r["npairs_total"] * steps / r["elapsed"], "unit": "image-pairs/s",
             "dtype": kind, "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3, "pairs": r["npairs_total"],
             "pairs_per_rank": r["npairs"], "mutual_matches_rank0": r["matches"],
+            **({"all_gather": {"collective": D.collective_name, "world": D.world, "gathered_equals_local_shard": r["gathered_ok"]}} if r["gathered"] else {}),
             # the descriptor hand-over happens once per job, before the timed steps (host fp32 -> HBM int8 / fp32 fragments)
             "upload_once": {"seconds": r["upload_s"], "host_bytes": r["upload_bytes"],
                             "pairs_per_s_if_paid_every_step": r["npairs_total"] / (r["elapsed"] / steps + r["upload_s"])},
@@ -288,6 +333,7 @@ def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=Tru
 
     arrays = ba.BaArrays.from_scene(scene)
     solver = ba.PreparedBA(ctx, arrays)
+    plan = solver.plan_info()
     first = solver.run(cfg)  # warm-up (allocations, code objects)
     D.barrier()
     torch.cuda.synchronize()
@@ -328,6 +374,9 @@ def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=Tru
             "ms_per_inner_iter": dt / max(inner, 1) * 1e3, "dtype": "f64",
             "workload": f"{label}: {nc} cams / {nl} landmarks / {no} obs, {cfg.method} ({cfg.maxIter}, {cfg.maxTolerance:g})",
             "final_error": first.final_error, "initial_error": first.initial_error, **stage,
+            # the analysis of the reduced camera system (ba_plan.hpp): ordering, 64-column panels, tiles of the symbolic
+            # factor, height of the elimination tree = dependent factorisation launches per solve
+            "plan": plan,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                          "algorithmic_bytes_per_inner_iter": bytes_iter,
@@ -335,23 +384,27 @@ def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=Tru
                          # the dense reduced solve against the fp64 vector peak (SURVEY.md §8(d) asks for both)
                          "solve": {"bound": "fp64", "achieved": solve_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": solve_tf / FP64_PEAK_TFLOPS,
-                                   "note": f"n^3/3 flops of the Cholesky factorisation / solve time; the chain of {(n + 31) // 32} "
-                                           f"dependent diagonal-block factors ({(n + 63) // 64} launches) is latency-bound"}}}
+                                   "note": f"n^3/3 flops of the DENSE Cholesky factorisation / solve time (the sparse factorisation does "
+                                           f"{plan['tile_updates']} rank-64 tile updates in {plan['levels']} dependent launches: "
+                                           "latency-bound by the chain of diagonal-tile factors)"}}}
 
 
 def ba_measured_traffic():
     """HBM bytes of ONE LM inner iteration of the S200 window: sum over the BA kernels of (2 FETCH + WRITE) per
-    dispatch x dispatches per inner iteration, from profiles/r02_pmc_ba_traffic.json (tools/pmc_ba_traffic_json.py)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_ba_traffic.json")
+    dispatch x dispatches per inner iteration, from profiles/<round>_pmc_ba_traffic.json (tools/pmc_traffic_json.py)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_ba_traffic.json")
     try:
         with open(path) as f:
             tab = json.load(f)
     except (OSError, ValueError):
         return None, "no PMC profile committed"
-    if tab.get("__meta__", {}).get("kernel_source_sha") != kernel_source_sha():
-        return None, f"stale: profile taken with kernel sources {tab.get('__meta__', {}).get('kernel_source_sha')}, running {kernel_source_sha()}"
+    meta = tab.get("__meta__", {})
+    want = kernel_source_sha("ba") if "kernel_source_sha_ba" in meta else kernel_source_sha()
+    have = meta.get("kernel_source_sha_ba", meta.get("kernel_source_sha"))
+    if have != want:
+        return None, f"stale: profile taken with kernel sources {have}, running {want}"
     try:
-        return float(tab["per_inner_iteration"]["hbm_bytes"]), "profiles/r02_pmc_ba_traffic.json"
+        return float(tab["per_inner_iteration"]["hbm_bytes"]), f"profiles/{PROFILE_ROUND}_pmc_ba_traffic.json"
     except (KeyError, TypeError, ValueError):
         return None, "malformed PMC profile"
 
@@ -455,11 +508,19 @@ def main():
         ba_out["global_ba"] = bench_ba(D, ctx, scene, args.ba_solves, ba.OptimizerConfig.global_ba(), "S200 RefineBA(-1)",
                                        with_traffic=False)
 
+    def emit(name, obj):  # one JSON line per sub-record, as soon as it exists; the contract's line comes last
+        if D.rank == 0:
+            print(json.dumps({"line": name, **obj}), flush=True)
+
+    if ba_out is not None:
+        emit("ba", ba_out)
+
     def leg(name, fn):
         if name in lines:
             t0 = time.time()
             sub[name] = fn()
             sub[name]["wall_s_incl_setup"] = round(time.time() - t0, 2)
+            emit(name, sub[name])
 
     sub_steps = max(1, min(args.steps, 3))
     leg("s200_d128_i8", lambda: matching_line(
@@ -499,8 +560,10 @@ def main():
         kd, _ = synth.make_frame_descriptors(kit, 1500, 128, seed=5)
         out, _r = matching_line(D, kd, "i8", 128, sub_steps, 1,
                                 f"BASELINE configs[4] stand-in (KITTI seq-00 sizes): 100 frames x 1500 kpts x 128-D, 4950 pairs sharded "
-                                f"over {D.world} GPU(s)" + (" + RCCL all-gather of the match graph" if D.world > 1 else ""),
-                                "match_tile_kernel<4, 2>")
+                                f"over {D.world} GPU(s) + all-gather of the match graph ({D.collective_name})",
+                                "match_tile_kernel<4, 2>", gather_at_one=True)
+        if D.group_note:
+            out["all_gather_note"] = D.group_note
         out["scaling"] = "strong"
         return out
     leg("c5_kitti", kitti_line)
@@ -511,12 +574,15 @@ def main():
         kd, _ = synth.make_frame_descriptors(kit, 1500, 128, seed=6)
         out, _r = matching_line(D, kd, "i8", 128, 1, 1,
                                 f"KITTI-like long sequence: 1000 frames x 1500 kpts x 128-D, 499500 pairs sharded over {D.world} GPU(s)"
-                                + (" + RCCL all-gather of the match graph" if D.world > 1 else ""), "match_tile_kernel<4, 2>")
+                                + (f" + all-gather of the match graph ({D.collective_name})" if D.world > 1 else ""), "match_tile_kernel<4, 2>")
         out["scaling"] = "strong"
         return out
     leg("c5_kitti_long", kitti_long_line)
 
     if D.rank == 0:
+        def compact_roofline(rf, keys=("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")):
+            return {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rf.items() if k in keys}
+
         out = {
             "metric": "image-pairs matched/s + BA iters/s, 200-frame/50k-landmark synthetic",
             "value": head["value"],
@@ -531,23 +597,37 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": head["workload"], "pairs_per_rank": head["pairs_per_rank"],
-                       "mutual_matches_rank0": head["mutual_matches_rank0"], "upload_once": head["upload_once"],
-                       "parallelism": f"pairs sharded over {D.world} GPU(s)" + (" + RCCL all-gather" if D.world > 1 else "")},
-            "roofline": head["roofline"],
+                       "parallelism": f"pairs sharded over {D.world} GPU(s)" + (f" + all-gather ({D.collective_name})" if D.world > 1 else "")},
+            "roofline": compact_roofline(head["roofline"]),
             "kernel_source_sha": kernel_source_sha(),
         }
-        if ba_out is not None:
-            out["ba"] = ba_out
-        if sub:
-            out["lines"] = sub
         if D.world == 1 and args.cpu_pairs != 0:
             out["cpu_baseline"] = cpu_baseline(descs, r["pairs_all"], args)
-            if ba_out is not None:
+        if ba_out is not None:  # compact: the full record is the {"line": "ba"} line above
+            g = ba_out["global_ba"]
+            out["ba"] = {"value": ba_out["value"], "unit": ba_out["unit"], "ms_per_inner_iter": round(ba_out["ms_per_inner_iter"], 5),
+                         "inner_iters_per_s": ba_out["inner_iters_per_s"], "workload": ba_out["workload"], "dtype": "f64",
+                         "replicas": ba_out["replicas"], "solve_ms_per_inner_iter": round(ba_out["solve_ms_per_inner_iter"], 5),
+                         "roofline": compact_roofline(ba_out["roofline"]), "plan": ba_out["plan"],
+                         "global_ba": {"value": g["value"], "ms_per_inner_iter": round(g["ms_per_inner_iter"], 5), "workload": g["workload"]}}
+            if D.world == 1 and args.cpu_pairs != 0:
                 out["ba"]["cpu_baseline"] = cpu_baseline_ba(scene)
+        if sub:  # one value and one roofline fraction per sub-line; the full records are the lines above
+            out["lines"] = {}
+            for name, v in sub.items():
+                c = {"value": v["value"], "unit": v["unit"], "frac": round(v["roofline"]["frac"], 5)}
+                if "ms_per_inner_iter" in v:
+                    c["ms_per_inner_iter"] = round(v["ms_per_inner_iter"], 5)
+                if "ba" in v:
+                    c["ba_windows_per_s"] = v["ba"]["windows_per_s"]
+                if "all_gather" in v:
+                    c["all_gather_ok"] = v["all_gather"]["gathered_equals_local_shard"]
+                out["lines"][name] = c
         print(json.dumps(out), flush=True)
     ctx.close()
     if D.world > 1:
         D.dist.barrier()
+    if D.has_group:
         D.dist.destroy_process_group()
 
 

@@ -82,6 +82,18 @@ def lib() -> C.CDLL:
     if hasattr(L, "eacham_order_pairs"):  # (absent from older diagnostic builds selected with EACHAM_HIP_LIB)
         L.eacham_order_pairs.argtypes = [vp, i32]
         L.eacham_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    if hasattr(L, "eacham_comm_init"):
+        L.eacham_comm_init.argtypes = [i32, vp, C.POINTER(vp)]
+        L.eacham_comm_destroy.argtypes = [vp]
+        L.eacham_comm_destroy.restype = None
+        L.eacham_comm_last_error.argtypes = [vp]
+        L.eacham_comm_last_error.restype = C.c_char_p
+        L.eacham_comm_size.argtypes = [vp]
+        L.eacham_comm_ctx.argtypes = [vp, i32]
+        L.eacham_comm_ctx.restype = vp
+        L.eacham_comm_upload_descriptors.argtypes = [vp, i32, vp, i32, i32]
+        L.eacham_match_all_pairs_sharded.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64)]
+        L.eacham_assemble_match_graph.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
     _lib = L
     return L
 

@@ -121,7 +121,7 @@ inline int pseudo_peripheral(const Adj& adj, const std::vector<int>& mark, int t
 
 // Nested dissection by level-structure separators: nodes are appended children first, separator last.
 inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const std::vector<int>& nodes, int leaf,
-                    std::vector<std::vector<int>>& out, std::vector<int>& lev) {
+                    std::vector<std::vector<int>>& out, std::vector<int>& lev, int variants = 0) {
     if ((int)nodes.size() <= leaf) {
         out.push_back(nodes);
         return;
@@ -141,34 +141,58 @@ inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const
                 for (int u : comp) lev[u] = -1, seen[u] = 1;
                 comps.push_back(std::move(comp));
             }
-            for (auto& c : comps) dissect(adj, mark, next_tag, c, leaf, out, lev);
+            for (auto& c : comps) dissect(adj, mark, next_tag, c, leaf, out, lev, variants);
             return;
         }
     }
-    // candidate roots of the level structure: the pseudo-peripheral node of the lowest-degree node and of a node far from it
-    int s0 = nodes[0];
-    for (int u : nodes)
-        if (adj[u].size() < adj[s0].size()) s0 = u;
-    const int root = pseudo_peripheral(adj, mark, tag, s0, lev);
-    std::vector<int> order = bfs(adj, mark, tag, root, lev);
-    const int depth = lev[order.back()];
-    if (depth < 2) {  // (nearly) complete graph: no separator
-        for (int u : order) lev[u] = -1;
+    // candidate roots of the level structure: pseudo-peripheral nodes reached from a few spread-out seeds; the level whose
+    // removal leaves the smallest larger side + separator wins
+    std::vector<int> seeds;
+    {
+        int s0 = nodes[0];
+        for (int u : nodes)
+            if (adj[u].size() < adj[s0].size()) s0 = u;
+        seeds.push_back(s0);
+        for (int k = 1; k <= variants; ++k) seeds.push_back(nodes[(size_t)k * nodes.size() / (variants + 1)]);
+    }
+    std::vector<int> order;
+    int best_l = -1, depth = 0;
+    long long best_score = -1;
+    {
+        std::vector<int> tried;
+        for (int seed : seeds) {
+            const int root = pseudo_peripheral(adj, mark, tag, seed, lev);
+            if (std::find(tried.begin(), tried.end(), root) != tried.end()) continue;
+            tried.push_back(root);
+            std::vector<int> ord = bfs(adj, mark, tag, root, lev);
+            const int dep = lev[ord.back()];
+            if (dep >= 2) {
+                std::vector<int> cnt(dep + 1, 0);
+                for (int u : ord) cnt[lev[u]]++;
+                long long before = 0, total = (long long)ord.size();
+                for (int l = 0; l <= dep; ++l) {
+                    if (l >= 1 && l < dep) {
+                        const long long a = before, b = total - before - cnt[l];
+                        auto pan = [](long long cams) { return (cams * PLAN_CAM + PLAN_PANEL - 1) / PLAN_PANEL; };
+                        const long long score = 1000 * (pan(std::max(a, b)) + pan(cnt[l])) + std::max(a, b) + cnt[l];  // height in panels first
+                        if (best_score < 0 || score < best_score) best_score = score, best_l = l, order = ord, depth = dep;
+                    }
+                    before += cnt[l];
+                }
+            } else if (order.empty()) {
+                order = ord;
+            }
+            for (int u : ord) lev[u] = -1;
+        }
+    }
+    if (best_l < 0) {  // (nearly) complete graph: no separator
         out.push_back(order);
         return;
     }
-    std::vector<int> cnt(depth + 1, 0);
-    for (int u : order) cnt[lev[u]]++;
-    long long before = 0, total = (long long)order.size();
-    int best_l = 1;
-    long long best_score = -1;
-    for (int l = 0; l <= depth; ++l) {
-        if (l >= 1 && l < depth) {
-            const long long a = before, b = total - before - cnt[l];
-            const long long score = std::max(a, b) + cnt[l];
-            if (best_score < 0 || score < best_score) best_score = score, best_l = l;
-        }
-        before += cnt[l];
+    {   // the levels of the winning structure again
+        std::vector<int> again = bfs(adj, mark, tag, order[0], lev);
+        (void)again;
+        (void)depth;
     }
     // trim: a node of the separator level without a neighbour beyond it joins the near side; one without a
     // neighbour before it joins the far side unless a level-mate that just left for the near side touches it
@@ -198,8 +222,8 @@ inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const
         out.push_back(order);
         return;
     }
-    dissect(adj, mark, next_tag, left, leaf, out, lev);
-    dissect(adj, mark, next_tag, right, leaf, out, lev);
+    dissect(adj, mark, next_tag, left, leaf, out, lev, variants);
+    dissect(adj, mark, next_tag, right, leaf, out, lev, variants);
     if (!sep.empty()) out.push_back(sep);
 }
 
@@ -481,14 +505,15 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     if (hint == BA_ORDER_RCM || (hint == BA_ORDER_AUTO && !small)) consider({plan_detail::rcm(adj)}, BA_ORDER_RCM, 0, hint == BA_ORDER_RCM);
     if (hint == BA_ORDER_ND || (hint == BA_ORDER_AUTO && !small)) {
         bool first = true;
-        for (int leaf : {cams_per_panel, 2 * cams_per_panel + 1, 3 * cams_per_panel + 2, 4 * cams_per_panel + 2}) {
-            std::vector<std::vector<int>> nodes;
-            std::vector<int> mark(nc, 0), lev(nc, -1);
-            int tag = 1;
-            plan_detail::dissect(adj, mark, tag, all, leaf, nodes, lev);
-            consider(nodes, BA_ORDER_ND, leaf, hint == BA_ORDER_ND && first);
-            first = false;
-        }
+        for (int variants : {0, 3})
+            for (int leaf : {cams_per_panel, 2 * cams_per_panel + 1, 3 * cams_per_panel + 2, 4 * cams_per_panel + 2}) {
+                std::vector<std::vector<int>> nodes;
+                std::vector<int> mark(nc, 0), lev(nc, -1);
+                int tag = 1;
+                plan_detail::dissect(adj, mark, tag, all, leaf, nodes, lev, variants);
+                consider(nodes, BA_ORDER_ND, leaf, hint == BA_ORDER_ND && first);
+                first = false;
+            }
     }
     P = std::move(best);
 }

@@ -71,3 +71,54 @@ def assemble_match_graph(g_counts: np.ndarray, g_edges: np.ndarray, npairs: int,
     offsets = np.zeros(npairs + 1, dtype=np.int64)
     np.cumsum(counts, out=offsets[1:])
     return counts, offsets, np.concatenate(qs).astype(np.uint32), np.concatenate(ts).astype(np.uint32)
+
+
+class Comm:
+    """Single-process multi-GPU communicator of the C-ABI (eacham_comm_init / eacham_match_all_pairs_sharded): one
+    context + one host thread per device, descriptors replicated, RCCL all-gather of the match graph. Used by the
+    tests and by callers that run the reference's one-process layout (apps/sfm/main.cpp:31)."""
+
+    def __init__(self, ndev: int = 1, devices=None):
+        import ctypes as C
+        from . import capi
+        self._C, self._capi, self._L = C, capi, capi.lib()
+        h = C.c_void_p()
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self._L.eacham_comm_init(int(ndev), None if dev is None else dev.ctypes.data, C.byref(h))
+        if rc:
+            raise capi.EachamError(rc, "eacham_comm_init failed (no device, RCCL not loadable, or ncclCommInitAll refused the devices)")
+        self.handle, self.size = h, int(self._L.eacham_comm_size(h))
+        self.rows = {}
+
+    def _check(self, rc):
+        if rc:
+            raise self._capi.EachamError(rc, (self._L.eacham_comm_last_error(self.handle) or b"").decode())
+
+    def upload_descriptors(self, frame_id: int, desc: np.ndarray):
+        d = np.ascontiguousarray(desc, dtype=np.float32)
+        self._check(self._L.eacham_comm_upload_descriptors(self.handle, int(frame_id), d.ctypes.data, d.shape[0], d.shape[1] if d.ndim == 2 else 0))
+        self.rows[int(frame_id)] = d.shape[0]
+
+    def match_all_pairs(self, pairs: np.ndarray, ratio: float = 0.8, min_dir: int = 30, min_mutual: int = 30):
+        """(counts, offsets, q, t) in the caller's pair order, as HipContext.match_all_pairs returns them."""
+        C = self._C
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        n = len(pairs)
+        cap = int(sum(self.rows.get(int(f), 0) for f in pairs[:, 0])) + 1
+        counts = np.zeros(n, np.int32); offsets = np.zeros(n + 1, np.int64)
+        q = np.zeros(cap, np.uint32); t = np.zeros(cap, np.uint32)
+        total = C.c_int64(0)
+        self._check(self._L.eacham_match_all_pairs_sharded(self.handle, pairs.ctypes.data, n, float(ratio), int(min_dir), int(min_mutual),
+                                                           counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total)))
+        return counts, offsets, q[: total.value].copy(), t[: total.value].copy()
+
+    def close(self):
+        if self.handle:
+            self._L.eacham_comm_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -364,13 +364,43 @@ int eacham_profile_get(eacham_ctx* ctx, int kernel_id, int64_t* launches, double
 /* ---- multi-GPU sharding of the pair loop (host-side helpers, no device needed) ---------------------
  * One process per GPU, one context each: every rank orders the pair list the same
  * way, takes its contiguous shard, runs eacham_match_all_pairs(_dev) on it and all-gathers counts + edges with
- * RCCL (the collective stays with the host: bench.py / eacham_amd/shard.py show the torch.distributed form).
+ * RCCL (bench.py / eacham_amd/shard.py show the torch.distributed form; the single-process form is
+ * eacham_match_all_pairs_sharded below).
  * Replaces the std::for_each(par_unseq) over pairs of apps/sfm/main.cpp:98-109 across devices. */
 /* Sorts [npairs][2] in place by train frame (second column), then query frame: consecutive workgroups stream
  * the same train frame, which keeps it in the XCD's L2. */
 int eacham_order_pairs(int32_t* pairs, int npairs);
 /* Contiguous shard of rank `rank` of `world`: [*begin, *end), sizes differ by at most one. */
 int eacham_shard_bounds(int npairs, int world, int rank, int* begin, int* end);
+
+/* ---- single-process multi-GPU form of the pair loop -----------------------
+ * The reference app is ONE C++ process (apps/sfm/main.cpp:31) whose pair loop (:84-147) fans out over host threads
+ * (:98-109). A communicator owns one context and one host thread per device and an RCCL communicator over them
+ * (ncclCommInitAll; RCCL is loaded at run time, EACHAM_ERR_UNSUPPORTED if it cannot be): descriptors are replicated on
+ * every device, the pair list is ordered by train frame and cut into contiguous shards (eacham_order_pairs /
+ * eacham_shard_bounds), every device matches its shard, and the match graph is assembled on every device by
+ * ncclAllGather of the per-pair counts and of the edge lists (padded to the largest shard) over xGMI, enqueued on each
+ * context's stream behind its matching. devices = NULL means devices 0 .. ndev-1. */
+typedef struct eacham_comm eacham_comm;
+int eacham_comm_init(int ndev, const int* devices, eacham_comm** out_comm);
+void eacham_comm_destroy(eacham_comm* comm);
+const char* eacham_comm_last_error(const eacham_comm* comm);
+int eacham_comm_size(const eacham_comm* comm);
+/* The context of rank `rank` (owned by the communicator): for uploads of other kinds, profiling, BA replicas. */
+eacham_ctx* eacham_comm_ctx(eacham_comm* comm, int rank);
+/* eacham_upload_descriptors on every device of the communicator. */
+int eacham_comm_upload_descriptors(eacham_comm* comm, int frame_id, const float* rowmajor, int n, int dim);
+/* eacham_match_all_pairs over all devices: same arguments, same result (CSR over the caller's pair order, sorted by q). */
+int eacham_match_all_pairs_sharded(eacham_comm* comm, const int32_t* pairs, int npairs, double ratio,
+                                   int min_dir, int min_mutual, int32_t* counts, int64_t* offsets,
+                                   uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total);
+/* Host-side assembly of gathered shards (what eacham_match_all_pairs_sharded does after its all-gather; also for callers
+ * that run one process per GPU and gather with their own collective): g_counts = world x shard_cap per-pair counts,
+ * g_edges = world x edge_cap x {q, t}; shard r holds pairs [eacham_shard_bounds(npairs, world, r)) of the ORDERED list,
+ * sorted_index[k] = position of ordered pair k in the caller's list (NULL = identity). */
+int eacham_assemble_match_graph(const int32_t* g_counts, const uint32_t* g_edges, int npairs, int world, int shard_cap,
+                                int64_t edge_cap, const int32_t* sorted_index, int32_t* counts, int64_t* offsets,
+                                uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total);
 
 #ifdef __cplusplus
 }

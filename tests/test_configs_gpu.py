@@ -107,6 +107,33 @@ def test_config3_tum_standin_window_sequence(hip_ctx, tum):
     assert max(errs) < 0.1
 
 
+def test_single_process_communicator_runs_the_rccl_gather(hip_ctx):
+    """eacham_comm_init / eacham_match_all_pairs_sharded with the one device this box has:
+    RCCL is loaded, ncclCommInitAll builds a 1-rank communicator, the two ncclAllGather calls run on the context's stream
+    behind the matching, and the assembled graph — returned in the CALLER's pair order, not the train-frame order the
+    shards use — equals eacham_match_all_pairs on the same frames."""
+    sc = synth.make_scene(24, 4000, 8, seed=12)
+    descs, _ = synth.make_frame_descriptors(sc, 700, 128, seed=12)
+    descs[5] = descs[5][:333]
+    pairs = synth.all_pairs(24)
+    rng = np.random.default_rng(3)
+    pairs = pairs[rng.permutation(len(pairs))]              # the caller's order is arbitrary
+    _upload(hip_ctx, descs)
+    want = hip_ctx.match_all_pairs(pairs)
+    with shard.Comm(1) as comm:
+        assert comm.size == 1
+        for f, d in enumerate(descs):
+            comm.upload_descriptors(f, d)
+        got = comm.match_all_pairs(pairs)
+        again = comm.match_all_pairs(pairs[:7])             # buffers are reused; a shorter list afterwards
+    for g, w in zip(got, want[:4]):
+        assert np.array_equal(g, w)
+    assert want[0].sum() > 1000
+    assert np.array_equal(again[0], want[0][:7]) and np.array_equal(again[2], want[2][:want[1][7]])
+    with pytest.raises(Exception):
+        shard.Comm(2)                                       # a second device does not exist on this box
+
+
 def test_config5_kitti_standin_through_the_shard_path(hip_ctx):
     sc = synth.make_scene(100, 15_000, 10, seed=5)          # 1500 observed landmarks per frame
     descs, ids = synth.make_frame_descriptors(sc, 1500, 128, seed=5)

@@ -81,6 +81,53 @@ def test_c_abi_sharding_helpers_agree_with_the_python_mirror():
     assert L.eacham_order_pairs(None, 0) == 0
 
 
+def test_c_abi_assembly_of_gathered_shards_agrees_with_the_python_mirror():
+    """eacham_assemble_match_graph — the host half of eacham_match_all_pairs_sharded (what follows its RCCL all-gather;
+    no device needed) — against eacham_amd/shard.py on synthetic gathered buffers, for worlds of 1 .. 8 ranks, with
+    the caller's pair order restored from the train-frame order."""
+    import ctypes as C
+    from eacham_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(11)
+    for npairs, world in [(1, 1), (5, 8), (37, 2), (300, 3), (300, 8)]:
+        pairs = rng.integers(0, 25, size=(npairs, 2)).astype(np.int32)
+        order = np.lexsort((pairs[:, 0], pairs[:, 1])).astype(np.int32)  # sorted pair k sits at order[k] in the caller's list
+        counts_sorted = rng.integers(0, 6, size=npairs).astype(np.int32)
+        cap = shard.shard_capacity(npairs, world)
+        b = shard.shard_bounds(npairs, world)
+        edge_cap = max(1, max(int(counts_sorted[b[r]:b[r + 1]].sum()) for r in range(world)))
+        g_counts = np.zeros((world, cap), np.int32)
+        g_edges = rng.integers(0, 1 << 20, size=(world, edge_cap, 2)).astype(np.uint32)
+        for r in range(world):
+            g_counts[r, : b[r + 1] - b[r]] = counts_sorted[b[r]:b[r + 1]]
+        want = shard.assemble_match_graph(g_counts, g_edges.astype(np.int64), npairs, world, cap, edge_cap)  # CSR over the SORTED list
+        counts = np.zeros(npairs, np.int32); offsets = np.zeros(npairs + 1, np.int64)
+        tot_cap = int(counts_sorted.sum())
+        q = np.zeros(max(tot_cap, 1), np.uint32); t = np.zeros(max(tot_cap, 1), np.uint32)
+        total = C.c_int64(-1)
+        rc = L.eacham_assemble_match_graph(g_counts.ctypes.data, g_edges.ctypes.data, npairs, world, cap, edge_cap, order.ctypes.data,
+                                           counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data, tot_cap, C.byref(total))
+        assert rc == 0 and total.value == tot_cap
+        for k in range(npairs):   # sorted pair k -> caller's position order[k]
+            p = int(order[k])
+            assert counts[p] == want[0][k]
+            assert np.array_equal(q[offsets[p]:offsets[p + 1]], want[2][want[1][k]:want[1][k + 1]])
+            assert np.array_equal(t[offsets[p]:offsets[p + 1]], want[3][want[1][k]:want[1][k + 1]])
+        if tot_cap > 0:  # a short output buffer is an error, the total is still reported
+            rc = L.eacham_assemble_match_graph(g_counts.ctypes.data, g_edges.ctypes.data, npairs, world, cap, edge_cap, order.ctypes.data,
+                                               counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data, tot_cap - 1, C.byref(total))
+            assert rc == capi.ERR_CAPACITY and total.value == tot_cap
+
+
+def test_communicator_needs_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from eacham_amd import capi
+    with pytest.raises(capi.EachamError):
+        shard.Comm(1)
+
+
 def test_two_rank_all_gather_reproduces_the_single_process_graph(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as O
