@@ -22,7 +22,6 @@ namespace eacham {
 namespace {
 
 constexpr int TRI_SWEEPS = 12;
-constexpr int TRI_MAX_OBS = 64;
 constexpr int TRI_BLOCK = 256;
 
 __device__ __forceinline__ void null_vector_4x4(double (&A)[4][4], double (&x)[4]) {
@@ -102,28 +101,10 @@ __device__ __forceinline__ bool is_inlier(const double* __restrict__ T, double u
     return err < max_err && pz >= 2.220446049250313e-16;
 }
 
-// K1: one thread per (track, pair).
-__global__ __launch_bounds__(TRI_BLOCK) void tri_pairs_kernel(
-    const double* __restrict__ transforms, int n_tracks, const int* __restrict__ track_ptr,
-    const long long* __restrict__ pair_ptr, const unsigned* __restrict__ obs_frame, const double2* __restrict__ obs_uv,
-    const double* __restrict__ Kdev, float max_err, float min_angle, double* __restrict__ points,
-    int* __restrict__ pair_inl, unsigned long long* __restrict__ pair_mask) {
-    const long long pid = (long long)blockIdx.x * TRI_BLOCK + threadIdx.x;
-    const long long total = pair_ptr[n_tracks];
-    if (pid >= total) return;
-    int lo = 0, hi = n_tracks;  // largest t with pair_ptr[t] <= pid
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (pair_ptr[mid] <= pid) lo = mid; else hi = mid;
-    }
-    const int t = lo;
-    const int o0 = track_ptr[t], m = track_ptr[t + 1] - o0;
-    int idx = (int)(pid - pair_ptr[t]), r1 = 0;
-    while (idx >= m - 1 - r1) { idx -= m - 1 - r1; ++r1; }
-    const int r2 = r1 + 1 + idx;
-    const bool last = pid + 1 == pair_ptr[t + 1];
-
-    const double K[4] = {Kdev[0], Kdev[1], Kdev[2], Kdev[3]};
+// the triangulation of observations r1 < r2 of a track (TriangulatePoint, Triangulator.cpp:49-63) and its angle gate
+__device__ __forceinline__ bool tri_pair_point(const double* __restrict__ transforms, const unsigned* __restrict__ obs_frame,
+                                               const double2* __restrict__ obs_uv, int o0, int r1, int r2, const double (&K)[4],
+                                               float min_angle, double (&X)[3]) {
     const double* T1 = transforms + 16 * (size_t)obs_frame[o0 + r1];
     const double* T2 = transforms + 16 * (size_t)obs_frame[o0 + r2];
     const double2 p1 = obs_uv[o0 + r1], p2 = obs_uv[o0 + r2];
@@ -138,59 +119,103 @@ __global__ __launch_bounds__(TRI_BLOCK) void tri_pairs_kernel(
         A[2][j] = y2 * T2[8 + j] - T2[4 + j];
     }
     null_vector_4x4(A, x);
-    const double X[3] = {x[0] / x[3], x[1] / x[3], x[2] / x[3]};
+    X[0] = x[0] / x[3], X[1] = x[1] / x[3], X[2] = x[2] / x[3];
+    return tri_angle(T1, T2, X) >= (double)min_angle;
+}
+
+// pair index of a track with m observations -> (r1 < r2), pairs in the reference's loop order
+__device__ __forceinline__ void tri_pair_rows(int m, long long idx, int& r1, int& r2) {
+    r1 = 0;
+    while (idx >= m - 1 - r1) { idx -= m - 1 - r1; ++r1; }
+    r2 = r1 + 1 + (int)idx;
+}
+
+// K1: one thread per (track, pair): the pair's triangulation, its inlier count over ALL observations of the track
+// (-1: the angle gate failed). No per-pair mask is kept — a 64-bit word per pair used to cap a track at 64
+// observations; the reference has no such limit (a 500-frame sequence can exceed it) — the selection kernel
+// re-derives the mask of the ONE winning pair.
+__global__ __launch_bounds__(TRI_BLOCK) void tri_pairs_kernel(
+    const double* __restrict__ transforms, int n_tracks, const int* __restrict__ track_ptr,
+    const long long* __restrict__ pair_ptr, const unsigned* __restrict__ obs_frame, const double2* __restrict__ obs_uv,
+    const double* __restrict__ Kdev, float max_err, float min_angle, double* __restrict__ points,
+    int* __restrict__ pair_inl) {
+    const long long pid = (long long)blockIdx.x * TRI_BLOCK + threadIdx.x;
+    const long long total = pair_ptr[n_tracks];
+    if (pid >= total) return;
+    int lo = 0, hi = n_tracks;  // largest t with pair_ptr[t] <= pid
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pair_ptr[mid] <= pid) lo = mid; else hi = mid;
+    }
+    const int t = lo;
+    const int o0 = track_ptr[t], m = track_ptr[t + 1] - o0;
+    int r1, r2;
+    tri_pair_rows(m, pid - pair_ptr[t], r1, r2);
+    const bool last = pid + 1 == pair_ptr[t + 1];
+    const double K[4] = {Kdev[0], Kdev[1], Kdev[2], Kdev[3]};
+    double X[3];
+    const bool wide = tri_pair_point(transforms, obs_frame, obs_uv, o0, r1, r2, K, min_angle, X);
     if (last) {
         points[3 * (size_t)t + 0] = X[0];
         points[3 * (size_t)t + 1] = X[1];
         points[3 * (size_t)t + 2] = X[2];
     }
     int inl = -1;
-    unsigned long long mask = 0;
-    if (tri_angle(T1, T2, X) >= (double)min_angle) {
+    if (wide) {
         inl = 0;
         for (int i = 0; i < m; ++i) {
             const double2 p = obs_uv[o0 + i];
-            if (is_inlier(transforms + 16 * (size_t)obs_frame[o0 + i], p.x, p.y, K, X, max_err)) {
-                ++inl;
-                mask |= 1ull << i;
-            }
+            if (is_inlier(transforms + 16 * (size_t)obs_frame[o0 + i], p.x, p.y, K, X, max_err)) ++inl;
         }
     }
     pair_inl[pid] = inl;
-    pair_mask[pid] = mask;
 }
 
-// K2: one thread per track: sequential selection exactly as the reference's loop leaves it.
+// K2: one thread per track: sequential selection exactly as the reference's loop leaves it; the inlier mask of the
+// winning pair is evaluated again from that pair's triangulation (the same instructions on the same inputs as K1).
 __global__ __launch_bounds__(TRI_BLOCK) void tri_select_kernel(
-    int n_tracks, const int* __restrict__ track_ptr, const long long* __restrict__ pair_ptr,
-    const int* __restrict__ pair_inl, const unsigned long long* __restrict__ pair_mask, double* __restrict__ points,
-    int* __restrict__ accept, unsigned char* __restrict__ masks) {
+    const double* __restrict__ transforms, int n_tracks, const int* __restrict__ track_ptr, const long long* __restrict__ pair_ptr,
+    const unsigned* __restrict__ obs_frame, const double2* __restrict__ obs_uv, const double* __restrict__ Kdev, float max_err,
+    float min_angle, const int* __restrict__ pair_inl, double* __restrict__ points, int* __restrict__ accept,
+    unsigned char* __restrict__ masks) {
     const int t = blockIdx.x * TRI_BLOCK + threadIdx.x;
     if (t >= n_tracks) return;
     const int o0 = track_ptr[t], m = track_ptr[t + 1] - o0;
     const long long p0 = pair_ptr[t], p1 = pair_ptr[t + 1];
-    unsigned long long mask = 0;
+    long long winner = -1;          // the pair whose mask the reference keeps
+    int best = 0;
     bool ok = false, full = false;  // ok = TriangulatePointRansac's return value
     if (m < 2) {
         points[3 * (size_t)t] = points[3 * (size_t)t + 1] = points[3 * (size_t)t + 2] = 0.0;
     } else if (m == 2) {
-        const int inl = pair_inl[p0];
-        if (inl >= 0) {
-            mask = pair_mask[p0];
+        best = pair_inl[p0];
+        if (best >= 0) {
+            winner = p0;
             ok = points[3 * (size_t)t + 2] > 0.0;
-            full = mask == 3ull;
+            full = best == 2;
         }
     } else {
-        int best = 0;
         for (long long p = p0; p < p1; ++p) {
             const int inl = pair_inl[p];
-            if (inl > best) { best = inl; mask = pair_mask[p]; }
+            if (inl > best) { best = inl; winner = p; }
         }
         ok = points[3 * (size_t)t + 2] > 0.0 && best > 2;
         full = best == m;
     }
     accept[t] = (ok ? 1 : 0) | (full ? 2 : 0);
-    for (int i = 0; i < m; ++i) masks[o0 + i] = (unsigned char)((mask >> i) & 1ull);
+    if (winner < 0) {
+        for (int i = 0; i < m; ++i) masks[o0 + i] = 0;
+        return;
+    }
+    const double K[4] = {Kdev[0], Kdev[1], Kdev[2], Kdev[3]};
+    int r1, r2;
+    tri_pair_rows(m, winner - p0, r1, r2);
+    double X[3];
+    (void)tri_pair_point(transforms, obs_frame, obs_uv, o0, r1, r2, K, min_angle, X);
+    for (int i = 0; i < m; ++i) {
+        const double2 p = obs_uv[o0 + i];
+        masks[o0 + i] = is_inlier(transforms + 16 * (size_t)obs_frame[o0 + i], p.x, p.y, K, X, max_err) ? 1 : 0;
+    }
 }
 
 // CalcReprojectionError for existing map points seen again (Triangulator.cpp:222-236).
@@ -274,8 +299,6 @@ extern "C" int eacham_triangulate_tracks(eacham_ctx* ctx, const double* transfor
     for (int t = 0; t < n_tracks; ++t) {
         const long long m = (long long)track_ptr[t + 1] - track_ptr[t];
         if (m < 0) return ctx->fail(EACHAM_ERR_INVALID, "triangulate: track_ptr not monotone at track %d", t);
-        if (m > TRI_MAX_OBS)
-            return ctx->fail(EACHAM_ERR_CAPACITY, "triangulate: track %d has %lld observations (max %d)", t, m, TRI_MAX_OBS);
         pair_ptr[t + 1] = pair_ptr[t] + (m < 2 ? 0 : m == 2 ? 1 : m * (m - 1) / 2);
     }
     const long long n_obs = track_ptr[n_tracks], n_pairs = pair_ptr[n_tracks];
@@ -294,7 +317,6 @@ extern "C" int eacham_triangulate_tracks(eacham_ctx* ctx, const double* transfor
     const size_t o_of = take(sizeof(unsigned) * (size_t)n_obs), o_uv = take(sizeof(double) * 2 * (size_t)n_obs);
     const size_t o_pt = take(sizeof(double) * 3 * (size_t)n_tracks), o_ac = take(sizeof(int) * (size_t)n_tracks);
     const size_t o_mk = take((size_t)n_obs), o_pi = take(sizeof(int) * (size_t)n_pairs);
-    const size_t o_pm = take(sizeof(unsigned long long) * (size_t)n_pairs);
     if (int rc = ensure_io(ctx, off)) return rc;
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
@@ -312,11 +334,11 @@ extern "C" int eacham_triangulate_tracks(eacham_ctx* ctx, const double* transfor
             tri_pairs_kernel<<<(unsigned)((n_pairs + TRI_BLOCK - 1) / TRI_BLOCK), TRI_BLOCK, 0, st>>>(
                 (const double*)(base + o_T), n_tracks, (const int*)(base + o_tp), (const long long*)(base + o_pp),
                 (const unsigned*)(base + o_of), (const double2*)(base + o_uv), (const double*)(base + o_K), max_repr_error,
-                min_tri_angle, (double*)(base + o_pt), (int*)(base + o_pi), (unsigned long long*)(base + o_pm));
+                min_tri_angle, (double*)(base + o_pt), (int*)(base + o_pi));
         tri_select_kernel<<<(unsigned)((n_tracks + TRI_BLOCK - 1) / TRI_BLOCK), TRI_BLOCK, 0, st>>>(
-            n_tracks, (const int*)(base + o_tp), (const long long*)(base + o_pp), (const int*)(base + o_pi),
-            (const unsigned long long*)(base + o_pm), (double*)(base + o_pt), (int*)(base + o_ac),
-            (unsigned char*)(base + o_mk));
+            (const double*)(base + o_T), n_tracks, (const int*)(base + o_tp), (const long long*)(base + o_pp),
+            (const unsigned*)(base + o_of), (const double2*)(base + o_uv), (const double*)(base + o_K), max_repr_error,
+            min_tri_angle, (const int*)(base + o_pi), (double*)(base + o_pt), (int*)(base + o_ac), (unsigned char*)(base + o_mk));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(points, base + o_pt, sizeof(double) * 3 * (size_t)n_tracks, hipMemcpyDeviceToHost, st));

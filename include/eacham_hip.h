@@ -267,8 +267,8 @@ int eacham_ba_debug_step(eacham_ctx* ctx, const eacham_ba_problem* problem, doub
  * (/root/reference/modules/sfm/reconstruction/Triangulator.cpp:96-186 and :248-275; call sites
  * apps/sfm/main.cpp:203-210 with config.maxReprError / config.minTriAngle in radians).
  *   transforms   n_frames x 16 row-major world->camera matrices (Node::GetTransform)
- *   track_ptr    n_tracks+1 CSR offsets into the observation arrays (track = one candidate point;
- *                at most 64 observations per track, else EACHAM_ERR_CAPACITY)
+ *   track_ptr    n_tracks+1 CSR offsets into the observation arrays (track = one candidate point, any number
+ *                of observations: the reference has no limit and a long sequence can see a point a hundred times)
  *   obs_frame    row of `transforms` per observation;  obs_uv  pixel (x, y) per observation
  *   K            fx, fy, cx, cy
  * Outputs (host): points n_tracks x 3 = the `point3d` the reference leaves behind (the LAST pair's

@@ -18,6 +18,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define TRI_SWEEPS 12
@@ -123,6 +124,7 @@ int oracle_triangulate_track(const double* transforms, const uint32_t* frame, co
         mask_len = m;
     } else {
         int best = 0;
+        uint8_t* loc = (uint8_t*)malloc((size_t)m);
         mask_len = 0;
         for (int r1 = 0; r1 < m - 1; ++r1)
             for (int r2 = r1 + 1; r2 < m; ++r2) {
@@ -130,7 +132,6 @@ int oracle_triangulate_track(const double* transforms, const uint32_t* frame, co
                 oracle_triangulate_point(T1, T2, uv + 2 * r1, uv + 2 * r2, K, point);
                 if (oracle_triangulation_angle(T1, T2, point) >= (double)min_angle) {
                     int inl = 0;
-                    uint8_t loc[64];
                     for (int i = 0; i < m; ++i) {
                         loc[i] = (uint8_t)is_inlier(transforms + 16 * (size_t)frame[i], uv + 2 * i, K, point, max_err);
                         inl += loc[i];
@@ -142,6 +143,7 @@ int oracle_triangulate_track(const double* transforms, const uint32_t* frame, co
                     }
                 }
             }
+        free(loc);
         ransac_ok = point[2] > 0.0 && best > 2;
     }
     int cnt = 0;
@@ -149,12 +151,12 @@ int oracle_triangulate_track(const double* transforms, const uint32_t* frame, co
     return (ransac_ok ? 1 : 0) | ((mask_len > 0 && cnt == m) ? 2 : 0);
 }
 
-/* batch: tracks in CSR form. status[t] (bits above), points[t][3], masks per observation. m <= 64 per track. */
+/* batch: tracks in CSR form. status[t] (bits above), points[t][3], masks per observation (any track length). */
 int oracle_triangulate_tracks(const double* transforms, int n_tracks, const int32_t* track_ptr, const uint32_t* obs_frame,
                               const double* obs_uv, const double* K, float max_err, float min_angle, double* points,
                               int32_t* accept, uint8_t* masks) {
     for (int t = 0; t < n_tracks; ++t)
-        if (track_ptr[t + 1] - track_ptr[t] > 64) return -1;
+        if (track_ptr[t + 1] < track_ptr[t]) return -1;
 #pragma omp parallel for schedule(dynamic, 64)
     for (int t = 0; t < n_tracks; ++t) {
         const int o0 = track_ptr[t], m = track_ptr[t + 1] - o0;

@@ -144,7 +144,6 @@ int eacham_triangulate_tracks(eacham_ctx* c, const double* T, int n_frames, int 
     for (int i = 0; i < 16 * n_frames; ++i) acc += T[i];
     for (int t = 0; t < n_tracks; ++t) {
         const int m = ptr[t + 1] - ptr[t];
-        if (m > 64) return fail(c, EACHAM_ERR_CAPACITY, "more than 64 observations");
         for (int k = ptr[t]; k < ptr[t + 1]; ++k) {
             if (of[k] >= (uint32_t)n_frames) return fail(c, EACHAM_ERR_INVALID, "frame out of range");
             acc += uv[2 * k] + uv[2 * k + 1];

@@ -179,7 +179,7 @@ def tri_tracks(transforms, track_ptr, obs_frame, obs_uv, K4, max_err, min_angle)
                                      vp(K4.ctypes.data), C.c_float(max_err), C.c_float(min_angle), vp(pts.ctypes.data),
                                      vp(status.ctypes.data), vp(masks.ctypes.data))
     if rc != 0:
-        raise ValueError("oracle_triangulate_tracks: a track has more than 64 observations")
+        raise ValueError("oracle_triangulate_tracks: track_ptr is not monotone")
     return pts, status, masks
 
 

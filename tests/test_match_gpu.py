@@ -132,6 +132,29 @@ def test_frames_beyond_one_column_chunk(hip_ctx):
     hip_ctx.clear_descriptors()
 
 
+def test_sift_feature_cap_of_config1(hip_ctx):
+    """configs[0]: config/SfmConfigNerf.json:10 caps SIFT at 15 000 features per frame. Two frames at the cap, 128-D
+    integers: four column chunks of 4096, 59 row blocks of 256 per direction, through eacham_match_pair both ways and
+    eacham_match_all_pairs, bit-exact against the oracle (planted correspondences, duplicates across chunk borders)."""
+    n, m = 15000, 6000
+    A = synth.random_u8_descriptors(n, 128, 71, 0)
+    B = synth.random_u8_descriptors(n, 128, 71, 1)
+    perm = synth.rng_permutation(71, 5, n)[:m]
+    B[perm] = np.clip(A[:m] + np.rint(6 * synth.rng_normal(71, 3, (m, 128))), 0, 255)
+    B[12300:12310] = B[4090:4100]        # duplicates in chunks 0/1 and 3: the lower index wins the tie
+    A[14999] = A[8191]
+    _upload(hip_ctx, [A, B])
+    for a, b, X, Y in [(0, 1, A, B), (1, 0, B, A)]:
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(X, Y)
+        assert np.array_equal(q, qo) and np.array_equal(t, to) and len(q) > 4000
+    got = hip_ctx.match_all_pairs(np.array([[0, 1]]))
+    want = O.match_all_pairs([A, B], np.array([[0, 1]]))
+    _assert_csr_equal(got, want)
+    assert got[0][0] > 4000
+    hip_ctx.clear_descriptors()
+
+
 def _with_norm_parity(D, parity):
     """Forces the parity of every row's centred squared norm (= the parity of its count of odd
     values, 128 being even): parity 0/1 per row, or None to leave the row alone."""
@@ -324,6 +347,22 @@ def test_f32_path_is_bit_exact_against_the_dot_form_oracle(hip_ctx, ns, dim):
     want = O.match_all_pairs(descs, pairs, min_dir=3, min_mutual=2, force_f32=2)
     _assert_csr_equal(got, want)
     assert got[0].sum() > 0 or min(ns) < 8
+    hip_ctx.clear_descriptors()
+
+
+def test_f32_pair_beyond_8192_rows(hip_ctx):
+    """The float path at the upper end of its range (limit 16 384 rows): an 8 200-row frame against a 3 000-row one,
+    both directions and the mutual form, bit-exact against the dot-form oracle."""
+    descs = _float_frames((8200, 3000), 256, seed=17)
+    _upload_f32(hip_ctx, descs)
+    for a, b in ((0, 1), (1, 0)):
+        q, t = hip_ctx.match_pair(a, b)
+        qo, to = O.match_directed(descs[a], descs[b], force_f32=2)
+        assert np.array_equal(q, qo) and np.array_equal(t, to), (a, b)
+        assert len(q) > 500
+    got = hip_ctx.match_all_pairs(np.array([[0, 1]]))
+    want = O.match_all_pairs(descs, np.array([[0, 1]]), force_f32=2)
+    _assert_csr_equal(got, want)
     hip_ctx.clear_descriptors()
 
 
