@@ -222,6 +222,7 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     eacham_ctx* ctx = new (std::nothrow) eacham_ctx();
     if (!ctx) return EACHAM_ERR_INVALID;
     ctx->device = device_id;
+    ctx->match_no_overlap = getenv("EACHAM_NO_OVERLAP") != nullptr;
     if (const char* o = getenv("EACHAM_BA_ORDERING"))
         ctx->ba_ordering = !strcmp(o, "natural") ? EACHAM_BA_ORDER_NATURAL : !strcmp(o, "rcm") ? EACHAM_BA_ORDER_RCM : !strcmp(o, "nd") ? EACHAM_BA_ORDER_ND : EACHAM_BA_ORDER_AUTO;
     if (hipSetDevice(device_id) != hipSuccess ||

@@ -194,9 +194,6 @@ __device__ __forceinline__ unsigned vmed3(unsigned a, unsigned b, unsigned c) {
 __device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
 
-#if defined(EXP_STAMPS) || defined(EXP_CLOCK)
-__device__ unsigned long long g_dbg[16];
-#endif
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
@@ -222,10 +219,6 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     struct ColBuf { uint2 e[2][BURST][2][WAVES][32]; };  // [buffer][tile % BURST][row-parity group][wave][column]
     struct RowSlab { uint2 e[WAVES][32 * 33]; };
     __shared__ union { ColBuf c; RowSlab r; } sU;
-#ifdef EXP_ONE_WG
-    __shared__ int exp_pad[24 * 1024];  // diagnostic build: 96 KB more LDS -> one workgroup per CU (one wave per SIMD)
-    if (blockIdx.x == 0x7fffffff) exp_pad[threadIdx.x] = 1;
-#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -341,23 +334,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             }
         }
     };
-#ifdef EXP_STAMPS
-    // diagnostic build: where does a wave's time go? (sums of s_memtime deltas per segment)
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
-#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0);} while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-#ifdef EXP_CLOCK
-    // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the main loop
-    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     constexpr int EPK = 16 / KS;         // epilogue elements interleaved per MFMA (KS = 8 -> 2)
-#ifdef EXP_NO_EPI
-    constexpr bool EPK_ON = false;       // diagnostic build: MFMA + LDS + DMA only
-#else
-    constexpr bool EPK_ON = true;
-#endif
     constexpr int NSTEP = NSUB * KS;     // (phase, ks) steps per tile
     // One tile of the sweep. The LDS slot ring (tile t lives in slot t % 3) and the fragment register ring (step i of the
     // (phase, ks) sequence lives in bq[(i + PH) % 3]; a tile advances it by NSTEP % 3) both have period 3 in t: the body
@@ -372,11 +349,8 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
         hb_cur = Bhb[32 * t1 + cl];
         if (t > 0 && t % BURST == 0) merge_burst(t - BURST);  // tiles t-8 .. t-1 are published; their buffer is rewritten from tile t+8 on
-#ifndef EXP_NO_DMA
         stage_tile(t2, slot_new);  // lands during this iteration; the barrier below publishes it
-#endif
         unsigned cm1[NSUB], cm2[NSUB], pend[3] = {0, 0, 0};  // column top-2 per sub-tile (a sub-tile has one parity)
-        STAMP(0);
         if (active) {
             // LDS byte addresses of this lane's 16 bytes in the two live slots. The fragment reads
             // are inline asm with hand-placed s_waitcnt lgkmcnt(1): hipcc waits with lgkmcnt(0)
@@ -395,26 +369,12 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                 // tile t+1.
                 const int j = i + 2;
                 asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[(i + PH) % 3]));  // step i landed (i+1 may be in flight)
-#ifndef EXP_NO_LDSREAD
                 lds_read_frag(bq[(j + PH) % 3], (j / KS < NSUB - 1) ? curB : nxtB, (j % KS) * 1024);
-#endif
                 const int q = (ph + 1) % NSUB;       // accumulator of the chain being issued
                 // (the last iteration recomputes tile T-1 into acc[0]; it is never read)
-#if defined(EXP_SHAPE16)
-                {   // diagnostic build (wrong results): same MACs issued as two 16x16x64 MFMAs per 32x32x32
-                    v4i lo = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]}, hi = {acc[q][4], acc[q][5], acc[q][6], acc[q][7]};
-                    lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[(i + PH) % 3], lo, 0, 0, 0);
-                    hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[q][ks], bq[(i + PH) % 3], hi, 0, 0, 0);
-                    acc[q][0] = lo[0]; acc[q][1] = lo[1]; acc[q][2] = lo[2]; acc[q][3] = lo[3];
-                    acc[q][4] = hi[0]; acc[q][5] = hi[1]; acc[q][6] = hi[2]; acc[q][7] = hi[3];
-                }
-#elif !defined(EXP_NO_MFMA)
                 acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q][ks], bq[(i + PH) % 3], ks ? acc[q] : cinit[q], 0, 0, 0);
-#else
-                acc[q][ks] += bq[(i + PH) % 3][0] + a[q][ks][0];
-#endif
 #pragma unroll
-                for (int e = 0; e < (EPK_ON ? EPK : 0); ++e) {
+                for (int e = 0; e < EPK; ++e) {
                     const int r = ks * EPK + e;
                     const unsigned key = ((unsigned)acc[ph][r] << (KEY_SHIFT + 1)) + lowc;  // one v_lshl_add_u32
                     rm2[ph][r] = vmed3(rm1[ph][r], rm2[ph][r], key);
@@ -440,9 +400,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == KS - 1) STAMP(1);
             }
-            STAMP(2);
             // steps NSTEP and NSTEP + 1 (= steps 0, 1 of the next tile, whose ring phase is PH + NSTEP) are in flight:
             // they have landed before the barrier below lets anybody overwrite their slot
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));
@@ -480,12 +438,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][0][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
             if (split && h == 0) sU.c.e[(t / BURST) & 1][t % BURST][1][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
         }
-        STAMP(3);
-        STAMP(4);
-#ifndef EXP_NO_BARRIER
         __syncthreads();
-#endif
-        STAMP(5);
     };
     {
         constexpr int ADV = NSTEP % 3;  // ring advance per tile
@@ -505,23 +458,6 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             if (t + 1 < T) tile(P1{}, S1{}, t + 1);
         }
     }
-#ifdef EXP_CLOCK
-    if (lane == 0 && active && blockIdx.x % 61 == 0) {
-        const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
-        atomicAdd(&g_dbg[8], ck_t1 - ck_t0);
-        atomicAdd(&g_dbg[9], ck_r1 - ck_r0);
-        atomicAdd(&g_dbg[10], 1ull);
-        atomicAdd(&g_dbg[11], (unsigned long long)T);
-    }
-#endif
-#ifdef EXP_STAMPS
-    if (lane == 0 && blockIdx.x % 97 == 0) {
-        unsigned long long* dbg = g_dbg;
-        for (int i = 0; i < 6; ++i) atomicAdd(&dbg[i], st_acc[i]);
-        atomicAdd(&dbg[6], 1ull);
-        atomicAdd(&dbg[7], (unsigned long long)T);
-    }
-#endif
     if (T > 0) merge_burst((T - 1) / BURST * BURST);  // the last 1..8 tiles, published by the loop's last barrier
     __syncthreads();                                  // the region becomes the row slab
     if (!active) return;
@@ -838,7 +774,7 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
     // of its first half runs beside the tile kernel of the second
     if (batch >= npairs && npairs >= 8 * round_pairs) batch = ((npairs + 1) / 2 + round_pairs - 1) / round_pairs * round_pairs;
     pl.batch = std::max(batch, 1);
-    pl.slots = (pl.batch < npairs && !getenv("EACHAM_NO_OVERLAP")) ? 2 : 1;  // env: diagnostic switch
+    pl.slots = (pl.batch < npairs && !ctx->match_no_overlap) ? 2 : 1;  // (diagnostic switch, read once at eacham_ctx_create)
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     pl.off_rowres = 0;
     pl.off_colpart = align(pl.off_rowres + (size_t)pl.batch * pl.col_chunks * pl.row_stride * sizeof(int4));
@@ -945,16 +881,6 @@ using namespace eacham;
 
 extern "C" {
 
-#if defined(EXP_STAMPS) || defined(EXP_CLOCK)
-int eacham_debug_read(unsigned long long* out, int n, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
-    }
-    return 0;
-}
-#endif
 
 int eacham_upload_descriptors_dev(eacham_ctx* ctx, int frame_id, const float* rowmajor_dev, int n, int dim) {
     if (!ctx) return EACHAM_ERR_INVALID;
