@@ -134,12 +134,38 @@ public:
     }
 #endif
 
-    // Forgets every cached upload (call it when descriptor buffers have been freed and their addresses may be
-    // reused with other values of the same shape; the sampled fingerprint catches most such reuse, not all).
+    // Forgets every cached upload.
     void ClearCache() {
         std::unique_lock<std::mutex> lk(mu_);
         while (leader_active_) cv_.wait(lk);
         drop_cache(true);
+    }
+    // A cached upload is recognised by (data pointer, rows, dim) + a fingerprint of the values. By default the
+    // fingerprint SAMPLES the matrix (1024 words + the last): a buffer that is freed and reused with other values
+    // of the same shape that happen to agree on every sample would be matched as the OLD frame — silently, on a path
+    // whose claim is bit-exactness. Two ways to close that hole:
+    //   * SetFullContentCheck(true): the fingerprint covers EVERY word of the matrix on every call (about 0.1 ms per
+    //     2000 x 128 frame per call on the host): no reuse can go unnoticed, at the price of reading the descriptors
+    //     once per Match();
+    //   * Invalidate(data): the caller states that the buffer at `data` was rewritten or freed (what eacham's
+    //     Node::SetDescriptors amounts to): the next Match() with that address uploads it again.
+    void SetFullContentCheck(bool on) {
+        std::unique_lock<std::mutex> lk(mu_);
+        while (leader_active_) cv_.wait(lk);
+        if (on != full_check_) drop_cache(false);  // fingerprints of the two kinds do not compare
+        full_check_ = on;
+    }
+    void Invalidate(const float* data) {
+        std::unique_lock<std::mutex> lk(mu_);
+        while (leader_active_) cv_.wait(lk);
+        for (auto it = cache_.begin(); it != cache_.end();) {
+            if (it->first.data == data) {
+                free_slots_.push_back(it->second.slot);
+                it = cache_.erase(it);
+            } else {
+                ++it;
+            }
+        }
     }
     struct Stats {
         uint64_t calls = 0, batches = 0, uploads = 0, cache_hits = 0;
@@ -190,6 +216,29 @@ private:
         return h;
     }
 
+    // every word of the matrix: four interleaved multiply-xorshift lanes over 8-byte words (runs at memory speed)
+    static uint64_t full_fingerprint(const DescriptorView& v) {
+        const size_t total = (size_t)(v.rows > 0 ? v.rows : 0) * (size_t)(v.dim > 0 ? v.dim : 0);
+        uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ total, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+        const size_t words = total / 2;  // 8-byte words
+        const char* p = reinterpret_cast<const char*>(v.data);
+        for (size_t i = 0; i < words; ++i) {
+            uint64_t w;
+            std::memcpy(&w, p + 8 * i, 8);
+            uint64_t& x = h[i & 3];
+            x = (x ^ w) * 0xFF51AFD7ED558CCDull;
+            x ^= x >> 29;
+        }
+        if (total & 1) {
+            uint32_t w;
+            std::memcpy(&w, v.data + total - 1, 4);
+            h[0] = (h[0] ^ w) * 0xC4CEB9FE1A85EC53ull;
+        }
+        uint64_t r = h[0];
+        for (int k = 1; k < 4; ++k) r = (r ^ (h[k] + 0x9E3779B97F4A7C15ull + (r << 6) + (r >> 2))) * 0xFF51AFD7ED558CCDull;
+        return r ^ (r >> 32);
+    }
+
     void drop_cache(bool clear_device) {
         cache_.clear();
         free_slots_.clear();
@@ -201,7 +250,7 @@ private:
     // device slot holding `v`, uploading it when it is not resident. Returns -1 with *rc set when the upload fails.
     int slot_for(const DescriptorView& v, uint64_t tick, int* rc) {
         const Key key{v.data, v.rows, v.dim};
-        const uint64_t fp = fingerprint(v);
+        const uint64_t fp = full_check_ ? full_fingerprint(v) : fingerprint(v);
         auto it = cache_.find(key);
         if (it != cache_.end() && it->second.fingerprint == fp) {
             it->second.last_use = tick;
@@ -307,6 +356,7 @@ private:
     std::vector<int> free_slots_;
     int next_slot_ = 0;
     bool f32_ = false;
+    bool full_check_ = false;  // SetFullContentCheck
     uint64_t tick_ = 0, hits_ = 0, uploads_ = 0;
     unsigned generation_seen_ = 0;
 };

@@ -8,6 +8,13 @@
 #include <iostream>
 #include <thread>
 
+#ifdef EACHAM_TEST_GLUE  // the RefineBA leg goes through the reference-typed glue on stand-ins of Graph / Node / Map / cv::Mat
+#include "ref_standins.hpp"
+#include "eacham/ReferenceGlue.hpp"
+// the drop-in definition has exactly the reference's signature (BundleAdjuster.h:13-17)
+static void (*const kRefineBA)(const int, std::shared_ptr<eacham::graph_t>, std::shared_ptr<eacham::Map>, cv::Mat&,
+                               const eacham::OptimizerConfig&) = &eacham::RefineBA;
+#endif
 #include "eacham/BundleAdjusterHip.hpp"
 #include "eacham/FeatureMatcherHip.hpp"
 
@@ -100,8 +107,50 @@ int main(int argc, char** argv) {
     }
     auto K = rd<double>(in, 9);
     const int current = rd1<int32_t>(in);
+#ifdef EACHAM_TEST_GLUE
+    // the same fixture as reference-shaped objects; RefineBA(currentFrameId, graph, map, K, config) as the app calls it
+    (void)kRefineBA;
+    auto rgraph = std::make_shared<eacham::graph_t>();
+    auto rmap = std::make_shared<eacham::Map>();
+    for (auto& kv : graph.nodes) {
+        auto* node = rgraph->TestCreate(kv.first);
+        node->TestSetValid(kv.second.valid);
+        if (kv.second.fixed) rgraph->FixNode(kv.first);
+        Eigen::Matrix4d M;
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) M(r, c) = kv.second.transform[4 * r + c];
+        node->SetTransform(M);
+        std::vector<cv::Point2f> kps(kv.second.keypoints.size() / 2);
+        for (size_t k = 0; k < kps.size(); ++k) kps[k].x = kv.second.keypoints[2 * k], kps[k].y = kv.second.keypoints[2 * k + 1];
+        node->TestSetFeatures(kps);
+        for (auto& p : kv.second.points3d) node->SetPoint3d(p.first, p.second, false);
+        for (unsigned nb : kv.second.neighbours) node->TestFactor(nb);
+    }
+    for (auto& kv : map.points) {
+        auto& mp = rmap->TestInsert(kv.first);
+        mp.point3d = Eigen::Vector3d(kv.second.point3d[0], kv.second.point3d[1], kv.second.point3d[2]);
+        mp.isValid = kv.second.status;
+        for (unsigned k = 0; k < kv.second.observers; ++k) mp.observers[1000 + k] = 0;   // only the COUNT is read (:109)
+    }
+    cv::Mat Kmat;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Kmat.at<double>(r, c) = K[3 * r + c];
+    eacham::OptimizerConfig rcfg{"LM", 100, 1e-5f, 10.0f, false};
+    RefineBAReport rep = glue::RefineBA(current, rgraph, rmap, Kmat, rcfg);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) K[3 * r + c] = Kmat.at<double>(r, c);
+    for (auto& kv : graph.nodes)      // read the objects back into the views the common tail writes out
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) kv.second.transform[4 * r + c] = rgraph->Get(kv.first)->GetTransform()(r, c);
+    for (auto& kv : map.points) {
+        const Eigen::Vector3d X = rmap->Get(kv.first);
+        kv.second.point3d[0] = X(0), kv.second.point3d[1] = X(1), kv.second.point3d[2] = X(2);
+        kv.second.status = rmap->GetStatus(kv.first);
+    }
+#else
     OptimizerConfig cfg; cfg.method = "LM"; cfg.maxIter = 100; cfg.maxTolerance = 1e-5f;
     RefineBAReport rep = RefineBA(matcher.context().get(), current, graph, map, K.data(), cfg);
+#endif
     std::vector<double> meta = {(double)rep.skipped, rep.initial_error, rep.final_error, (double)rep.outer_iterations,
                                 (double)rep.inner_iterations, (double)rep.frames, (double)rep.landmarks, (double)rep.observations};
     wr(out, meta); wr(out, K);

@@ -68,6 +68,38 @@ int main(int argc, char** argv) {
     const auto st = matcher.stats();
     const double tail[5] = {seconds, (double)st.calls, (double)st.batches, (double)st.uploads, (double)st.cache_hits};
     out.write((const char*)tail, sizeof(tail));
+    {   // A descriptor buffer rewritten IN PLACE, only at words the sampled fingerprint does not look at (2048 words: the
+        // samples are the even ones + the last): the default cache cannot see it; SetFullContentCheck(true) and
+        // Invalidate(data) must both make the next Match() use the new values.
+        const int rows = 64;
+        std::vector<float> X((size_t)rows * dim);
+        for (size_t i = 0; i < X.size(); ++i) X[i] = (float)((i * 37 + 11) % 251);
+        const DescriptorView xv{X.data(), rows, dim}, other = frames[0];
+        auto rewrite = [&](int salt) {
+            for (size_t i = 1; i + 1 < X.size(); i += 2) X[i] = (float)((i * 53 + 7 * salt) % 241);  // odd words, not the last
+        };
+        auto fresh = [&] { FeatureMatcherHip m(0.8f); return m.Match(xv, other); };
+        int bad = 0;
+        if ((size_t)rows * dim == 2048 && other.rows >= 2) {
+            FeatureMatcherHip sampled(0.8f), full(0.8f), told(0.8f);
+            full.SetFullContentCheck(true);
+            const auto before = sampled.Match(xv, other);
+            (void)full.Match(xv, other);
+            (void)told.Match(xv, other);
+            rewrite(1);
+            const auto want = fresh();
+            const bool changed = want != before;                 // the rewrite does change the answer
+            const bool stale = sampled.Match(xv, other) == before && changed;
+            told.Invalidate(X.data());
+            if (full.Match(xv, other) != want) ++bad;
+            if (told.Match(xv, other) != want) ++bad;
+            if (full.stats().uploads < 3) ++bad;                 // X, other, X again
+            std::printf("stale-buffer check: answer changed %d, sampled fingerprint served the old frame %d, full check / Invalidate wrong %d\n",
+                        (int)changed, (int)stale, bad);
+            if (!changed) bad += 100;
+        }
+        if (bad) return 3;
+    }
     std::printf("match_async_driver: %zu ordered pairs, %d threads, %.4f s (last of %d) = %.0f Match()/s; calls %llu batches %llu uploads %llu hits %llu\n",
                 pairs.size(), threads, seconds, repeat, pairs.size() / seconds, (unsigned long long)st.calls,
                 (unsigned long long)st.batches, (unsigned long long)st.uploads, (unsigned long long)st.cache_hits);

@@ -5,6 +5,12 @@
 #include <fstream>
 #include <vector>
 
+#ifdef EACHAM_TEST_GLUE  // TriangulateFrame goes through the reference-typed glue on stand-ins of Graph / Node / Map / cv::Mat
+#include "ref_standins.hpp"
+#include "eacham/ReferenceGlue.hpp"
+static void (*const kTriangulateFrame)(const unsigned, std::shared_ptr<eacham::graph_t>, std::shared_ptr<eacham::Map>, const cv::Mat&,
+                                       const unsigned, const float, const float) = &eacham::TriangulateFrame;  // Triangulator.h:41-43
+#endif
 #include "eacham/TriangulatorHip.hpp"
 
 using namespace eacham::hip;
@@ -81,7 +87,54 @@ int main(int argc, char** argv) {
     for (bool b : inl) single.push_back(b ? 1 : 0);
     wr(out, single); wr(out, X);
 
+#ifdef EACHAM_TEST_GLUE
+    (void)kTriangulateFrame;
+    auto rgraph = std::make_shared<eacham::graph_t>();
+    auto rmap = std::make_shared<eacham::Map>();
+    for (auto& kv : graph.nodes) {
+        auto* node = rgraph->TestCreate(kv.first);
+        node->TestSetValid(kv.second.valid);
+        Eigen::Matrix4d M;
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) M(r, c) = kv.second.transform[4 * r + c];
+        node->SetTransform(M);
+        std::vector<cv::Point2f> kps(kv.second.keypoints.size() / 2);
+        for (size_t k = 0; k < kps.size(); ++k) kps[k].x = kv.second.keypoints[2 * k], kps[k].y = kv.second.keypoints[2 * k + 1];
+        node->TestSetFeatures(kps);
+        for (auto& p : kv.second.points3d) node->SetPoint3d(p.first, p.second, false);
+        for (auto& f : kv.second.factors) {
+            auto& fac = node->TestFactor(f.first);
+            for (auto& mm : f.second) fac.matches[mm.first] = mm.second;
+        }
+    }
+    for (auto& kv : map.points) {
+        auto& mp = rmap->TestInsert(kv.first);
+        mp.point3d = Eigen::Vector3d(kv.second.point3d[0], kv.second.point3d[1], kv.second.point3d[2]);
+        mp.isValid = kv.second.isValid;
+        for (auto& o : kv.second.observers) mp.observers[o.first] = o.second;
+    }
+    cv::Mat Kmat;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Kmat.at<double>(r, c) = K[3 * r + c];
+    TriangulateFrameReport rep = glue::TriangulateFrame(frameId, rgraph, rmap, Kmat, minObservers, maxErr, minAngle);
+    // the objects back into the views the common tail writes out
+    for (auto& kv : graph.nodes) {
+        kv.second.points3d.clear();
+        for (auto& p : rgraph->Get(kv.first)->GetPoints3d()) kv.second.points3d[p.first] = p.second;
+    }
+    map.points.clear();
+    map.mapPointId = 0;
+    for (auto& kv : rmap->GetAll()) {
+        TriMapPoint mp;
+        mp.point3d[0] = kv.second.point3d(0), mp.point3d[1] = kv.second.point3d(1), mp.point3d[2] = kv.second.point3d(2);
+        mp.isValid = kv.second.isValid;
+        for (auto& o : kv.second.observers) mp.observers[o.first] = o.second;
+        map.points[kv.first] = mp;
+        if (kv.first > map.mapPointId) map.mapPointId = kv.first;
+    }
+#else
     TriangulateFrameReport rep = TriangulateFrame(ctx, frameId, graph, map, K.data(), minObservers, maxErr, minAngle);
+#endif
     std::vector<uint32_t> meta{rep.total, rep.added, rep.reobserved, map.mapPointId};
     wr(out, meta);
     for (auto& kv : graph.nodes) {   // per node (ascending id): points3d as flat pairs

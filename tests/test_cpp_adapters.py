@@ -14,10 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _build(tmp, name="adapter_driver"):
-    exe = os.path.join(tmp, name)
+def _build(tmp, name="adapter_driver", glue=False):
+    """glue: the RefineBA / TriangulateFrame leg goes through include/eacham/ReferenceGlue.hpp — the reference-typed entry
+    points — on stand-ins of Graph / Node / Map / cv::Mat (tests/cpp/ref_standins.hpp) instead of hand-filled views."""
+    exe = os.path.join(tmp, name + ("_glue" if glue else ""))
     lib = os.path.join(ROOT, "eacham_amd", "lib")
-    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "cpp"),
+           *(["-DEACHAM_TEST_GLUE"] if glue else []), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
            "-o", exe, "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
@@ -75,9 +78,10 @@ def write_adapter_fixture(tmp):
     return types.SimpleNamespace(**locals())
 
 
-def test_cpp_adapters_against_oracle(tmp_path):
+@pytest.mark.parametrize("glue", [False, True])
+def test_cpp_adapters_against_oracle(tmp_path, glue):
     tmp = str(tmp_path)
-    exe = _build(tmp)
+    exe = _build(tmp, glue=glue)
     fx = write_adapter_fixture(tmp)
     (fin, fout, descs, bsc, ids, valid, fixed, neighbours, n_lm, status, observers, kp, p3) = (
         fx.fin, fx.fout, fx.descs, fx.bsc, fx.ids, fx.valid, fx.fixed, fx.neighbours, fx.n_lm, fx.status, fx.observers, fx.kp, fx.p3)
@@ -202,10 +206,11 @@ def write_tri_fixture(tmp):
     return types.SimpleNamespace(**locals())
 
 
-def test_cpp_triangulate_frame_against_oracle_walk(tmp_path):
+@pytest.mark.parametrize("glue", [False, True])
+def test_cpp_triangulate_frame_against_oracle_walk(tmp_path, glue):
     """TriangulatorHip.hpp: TriangulatePointRansac + TriangulateFrame (Triangulator.cpp:96-300)."""
     tmp = str(tmp_path)
-    exe = _build(tmp, "tri_driver")
+    exe = _build(tmp, "tri_driver", glue=glue)
     fx = write_tri_fixture(tmp)
     (fin, fout, sc, ids, valid, frame_id, K, T, max_err, min_angle, min_obs, kp, p3, mpts, factors, single) = (
         fx.fin, fx.fout, fx.sc, fx.ids, fx.valid, fx.frame_id, fx.K, fx.T, fx.max_err, fx.min_angle, fx.min_obs, fx.kp, fx.p3, fx.mpts,

@@ -29,7 +29,8 @@ def _gcc_file(name):
 
 def _build(tmp, driver, flags, tag):
     exe = os.path.join(tmp, f"{driver}_{tag}")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", *flags, "-I" + os.path.join(ROOT, "include"), os.path.join(CPP, driver + ".cpp"),
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", *flags, "-I" + os.path.join(ROOT, "include"), "-I" + CPP,
+           os.path.join(CPP, driver + ".cpp"),
            os.path.join(CPP, "stub_abi.cpp"), "-o", exe, "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -114,6 +115,15 @@ def test_adapters_under_asan_ubsan(tmp_path):
     assert "adapter driver ok" in r.stdout
     tx = T.write_tri_fixture(tmp)
     _run([_build(tmp, "tri_driver", ASAN, "asan"), tx.fin, tx.fout])
+    # The reference-typed entry points (include/eacham/ReferenceGlue.hpp: RefineBA(int, shared_ptr<graph_t>, shared_ptr<Map>,
+    # cv::Mat&, const OptimizerConfig&) and TriangulateFrame(...), BundleAdjuster.h:13-17 / Triangulator.h:41-43) compiled
+    # against stand-ins that carry the accessor names of modules/sfm/data/{Graph,Node,Map}.h (tests/cpp/ref_standins.hpp):
+    # filling the views from the objects, the call and the write-back into the objects must give, byte for byte, what the
+    # drivers get with hand-filled views.
+    for driver, fixture in (("adapter_driver", fx), ("tri_driver", tx)):
+        plain = open(fixture.fout, "rb").read()
+        _run([_build(tmp, driver, ASAN + ["-DEACHAM_TEST_GLUE"], "glue_asan"), fixture.fin, fixture.fout])
+        assert open(fixture.fout, "rb").read() == plain and len(plain) > 1000, driver
     # SfmIO.hpp needs no ABI at all
     exe = os.path.join(tmp, "io_driver_asan")
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", *ASAN, "-I" + os.path.join(ROOT, "include"), os.path.join(CPP, "io_driver.cpp"), "-o", exe],
