@@ -235,7 +235,8 @@ struct BaDev {
     double *pcg_rc, *pcg_rl, *pcg_zc, *pcg_zl, *pcg_pc, *pcg_pl, *pcg_qc, *pcg_ql, *pcg_Mc, *pcg_MK, *pcg_Ml, *pcg_Dc, *pcg_Dl,
         *pcg_p1, *pcg_p2, *pcg_p3, *pcg_s;
     int* flags;
-    double* scal_pinned;  // device view of the pinned host copy of scal[0..2] (ba_final_sums)
+    double* scal_pinned;  // device view of the pinned host copy of scal[0..2] (final_sums)
+    int* sync_counter;    // ticket counter of the "last workgroup makes the final sums" hand-over (self-resetting)
     int n_lm_blocks;  // grid of the per-landmark kernels
     // Small problems (a local window: 1.5 k landmarks = six workgroups) are bound by the LENGTH of a thread's instruction
     // stream, not by bandwidth: a landmark's ~8 observations cost ~3 k fp64 instructions in one lane, ~10 us per kernel
@@ -243,6 +244,10 @@ struct BaDev {
     // lpl = 8 adjacent lanes (observation o0 + sub, o0 + sub + 8, ...; xor-shuffle sums in a fixed order), on a grid of
     // n_ll_blocks workgroups; large problems keep lpl = 1 (n_ll_blocks = n_lm_blocks): their time is traffic.
     int lpl, n_ll_blocks;
+    // the same idea for the kernels of the step's tail (back-substitution + error: two passes of dependent gathers per
+    // observation): their own lanes-per-landmark count and grid (measured on S200 / config 4: 2 lanes 35.6 / 72 us,
+    // 1 lane 41.7 / 75, 4 lanes 41.8 / 71, 8 lanes 55 / 92)
+    int lpl_step, n_step_blocks;
     Noise nz;
 };
 
@@ -1622,88 +1627,43 @@ __global__ __launch_bounds__(BS_THREADS) void sp_backsolve(const double* __restr
     }
 }
 
-// ---- K-F: landmark back-substitution + tentative points + linearised-cost terms (thread = landmark) ----
-// delta_l = Linv^T (gt - sum_o Et_o^T dc[c_o] - EKt^T dK);  lin += 1/2 (dl.gl + lambda dl.D dl)
-__device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lambda, const double* pose_in, double* pose_out,
-                                               const double* K_in, double* K_out, int apply_delta, double* err_cam,
-                                               double* lin_cam);
-// The workgroups behind the landmarks' (blockIdx.x >= n_lm_blocks) retract the cameras and K (K-G1, thread = camera):
-// both read delta_c and nothing of each other, and a launch of one workgroup costs the chain as much as this one.
-template <int LPL>
-__global__ __launch_bounds__(TPB) void ba_backsub_landmarks(BaDev D, double lambda, double* err_cam, double* lin_cam) {
-    __shared__ double sm[(TPB / 64) * 1];
-    if ((int)blockIdx.x >= D.n_ll_blocks) {
-        retract_camera(D, ((int)blockIdx.x - D.n_ll_blocks) * TPB + threadIdx.x, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, err_cam, lin_cam);
-        return;
+// ---- K-F / K-G: the tail of a tryLambda() in ONE launch ----------------------------------------------------------
+// landmark back-substitution + tentative points + linearised-cost terms, the retraction of the cameras and K with their
+// prior errors, the nonlinear error at the tentative values, and the final sums:
+//   delta_l = Linv^T (gt - sum_o Et_o^T dc[c_o] - EKt^T dK);  lin += 1/2 (dl.gl + lambda dl.D dl)
+//   error   = sum_o rho(|r_o(x (+) dc, l + dl, K + dK)|) + priors
+// Until round 3 these were three dependent launches (back-substitution + retraction, error pass over the retracted poses,
+// one-block final sums): 34 us of 0.48 ms on S200, 16 of 118 us on a local window. The error pass only waited for
+// pose_new — so a landmark's thread retracts the pose of each of its observations' cameras itself (the same instructions on
+// the same inputs as the retraction workgroups, which still write pose_new / K_new for the next linearisation) — and the
+// final sums are made by whichever workgroup of the launch finishes LAST. The hand-over is fence-free like the
+// back-substitution's: partial sums are stored write-through (agent-scope atomic stores), the storing wave drains,
+// one lane takes a ticket from an agent-scope counter; the workgroup that draws the last ticket reads every partial with
+// agent-scope atomic loads and adds them in index order — the same order whichever workgroup that is: the sums stay
+// deterministic. The counter resets itself.
+__device__ __forceinline__ void retract_pose(const double* x, const double* d, double* y) {  // x (+) [omega, v], first-order chart (Cayley)
+    double C[9];
+    cayley(d, C);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) y[3 * i + j] = x[3 * i] * C[j] + x[3 * i + 1] * C[3 + j] + x[3 * i + 2] * C[6 + j];
+    for (int i = 0; i < 3; ++i) y[9 + i] = x[9 + i] + x[3 * i] * d[3] + x[3 * i + 1] * d[4] + x[3 * i + 2] * d[5];
+}
+
+__device__ __forceinline__ void store_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double load_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Every thread of the workgroup calls it after the workgroup's write-through stores; true in the workgroup that arrives last.
+__device__ __forceinline__ bool last_workgroup(int* counter) {
+    __shared__ int last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partials have left for memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = t == (int)gridDim.x - 1;
+        if (last_flag) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
-    double lin[1] = {0.0};
-    if (j < D.nl) {
-        const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-        if (o1 > o0) {
-            const double* lt = D.lmtry + (size_t)LMLIN * j;
-            double t0 = lt[6], t1 = lt[7], t2 = lt[8];
-            const double* dK = D.delta_c + 6 * D.nc;
-#pragma unroll
-            for (int a = 0; a < 5; ++a) {
-                t0 -= lt[9 + 3 * a] * dK[a];
-                t1 -= lt[10 + 3 * a] * dK[a];
-                t2 -= lt[11 + 3 * a] * dK[a];
-            }
-            // sum_o Et_o^T dc = Linv sum_o E_o^T dc and E_o^T dc = Al^T (Ap dc): the Jacobians are recomputed at the
-            // linearisation point (pose / pt / Kc do not change inside the lambda loop) from this landmark's own
-            // observation records instead of gathering its ten 144-byte Et rows out of the camera-ordered array
-            // (137 MB of HBM traffic per try, profiles/r02_pmc_ba_traffic.json of the first round-2 build)
-            const double l[3] = {D.pt[3 * (size_t)j], D.pt[3 * (size_t)j + 1], D.pt[3 * (size_t)j + 2]};
-            double K[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
-            double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-            for (int o = o0 + sub; o < o1; o += LPL) {
-                const int cam = (int)D.obs_cam[o];
-                const double* x = D.pose + 12 * (size_t)cam;
-                const double* dc = D.delta_c + 6 * (size_t)cam;
-                double xr[12];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) xr[k] = x[k];
-                double Ap[12], Al[6], Ak[10], b[2];
-                obs_factor(xr, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
-                double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    u0 += Ap[a] * dc[a];
-                    u1 += Ap[6 + a] * dc[a];
-                }
-                w0 += Al[0] * u0 + Al[3] * u1;
-                w1 += Al[1] * u0 + Al[4] * u1;
-                w2 += Al[2] * u0 + Al[5] * u1;
-            }
-            if (LPL > 1) w0 = group_sum<LPL>(w0), w1 = group_sum<LPL>(w1), w2 = group_sum<LPL>(w2);  // (a landmark's lanes take this branch together)
-            const double m00 = lt[0], m10 = lt[1], m11 = lt[2], m20 = lt[3], m21 = lt[4], m22 = lt[5];
-            t0 -= m00 * w0;
-            t1 -= m10 * w0 + m11 * w1;
-            t2 -= m20 * w0 + m21 * w1 + m22 * w2;
-            d0 = m00 * t0 + m10 * t1 + m20 * t2;
-            d1 = m11 * t1 + m21 * t2;
-            d2 = m22 * t2;
-            const double* in = D.lmlin + (size_t)LMLIN * j;
-            if (sub == 0)
-                lin[0] = 0.5 * (d0 * in[6] + d1 * in[7] + d2 * in[8]) +
-                         0.5 * lambda * (clampd(in[0], 1e-6, 1e32) * d0 * d0 + clampd(in[3], 1e-6, 1e32) * d1 * d1 +
-                                         clampd(in[5], 1e-6, 1e32) * d2 * d2);
-        }
-        if (sub == 0) {
-        D.delta_l[3 * (size_t)j] = d0;
-        D.delta_l[3 * (size_t)j + 1] = d1;
-        D.delta_l[3 * (size_t)j + 2] = d2;
-        D.pt_new[3 * (size_t)j] = D.pt[3 * (size_t)j] + d0;
-        D.pt_new[3 * (size_t)j + 1] = D.pt[3 * (size_t)j + 1] + d1;
-        D.pt_new[3 * (size_t)j + 2] = D.pt[3 * (size_t)j + 2] + d2;
-        }
-    }
-    block_sum<1>(lin, sm);
-    if (threadIdx.x == 0) D.lin_part[blockIdx.x] = lin[0];
+    __syncthreads();
+    return last_flag != 0;
 }
 
 // ---- K-G1: retract cameras + K, pose/K prior errors and their linearised-cost terms (thread = camera) --
@@ -1717,11 +1677,7 @@ __device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lam
         double lin = 0.0;
         if (apply_delta) {
             const double* d = D.delta_c + 6 * (size_t)c;
-            double C[9];
-            cayley(d, C);
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) y[3 * i + j] = x[3 * i] * C[j] + x[3 * i + 1] * C[3 + j] + x[3 * i + 2] * C[6 + j];
-            for (int i = 0; i < 3; ++i) y[9 + i] = x[9 + i] + x[3 * i] * d[3] + x[3 * i + 1] * d[4] + x[3 * i + 2] * d[5];
+            retract_pose(x, d, y);
             const double* cl = D.camlin + (size_t)CAMLIN * c;
             for (int a = 0; a < 6; ++a) lin += 0.5 * d[a] * cl[66 + a] + 0.5 * lambda * clampd(cl[7 * a], 1e-6, 1e32) * d[a] * d[a];
         } else {
@@ -1733,8 +1689,8 @@ __device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lam
         const bool fx = D.fixed[c] != 0;
         const double* sg = fx ? D.nz.fixed_sigma : D.nz.pose_sigma;
         for (int k = 0; k < 6; ++k) n2 += (xi[k] / sg[k]) * (xi[k] / sg[k]);
-        err_cam[c] = fx ? 0.5 * n2 : huber_loss(sqrt(n2), D.nz.pose_huber);
-        lin_cam[c] = lin;
+        store_wt(&err_cam[c], fx ? 0.5 * n2 : huber_loss(sqrt(n2), D.nz.pose_huber));
+        store_wt(&lin_cam[c], lin);
     } else if (c == D.nc) {
         double e = 0.0, lin = 0.0;
         for (int a = 0; a < 5; ++a) {
@@ -1745,8 +1701,8 @@ __device__ __forceinline__ void retract_camera(const BaDev& D, int c, double lam
             e += 0.5 * w * w;
             if (apply_delta) lin += 0.5 * d * D.klin[25 + a] + 0.5 * lambda * clampd(D.klin[6 * a], 1e-6, 1e32) * d * d;
         }
-        err_cam[D.nc] = e;
-        lin_cam[D.nc] = lin;
+        store_wt(&err_cam[D.nc], e);
+        store_wt(&lin_cam[D.nc], lin);
     }
 }
 __global__ void ba_retract_cameras(BaDev D, double lambda, const double* pose_in, double* pose_out,
@@ -1755,59 +1711,21 @@ __global__ void ba_retract_cameras(BaDev D, double lambda, const double* pose_in
     retract_camera(D, blockIdx.x * blockDim.x + threadIdx.x, lambda, pose_in, pose_out, K_in, K_out, apply_delta, err_cam, lin_cam);
 }
 
-// ---- K-G2: nonlinear error of the reprojection + landmark-prior factors (thread = landmark) -----------
-template <int LPL>
-__global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double* __restrict__ pose,
-                                                          const double* __restrict__ pt, const double* __restrict__ Kc) {
-    __shared__ double sm[(TPB / 64) * 1];
-    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
-    double e[1] = {0.0};
-    if (j < D.nl) {
-        const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
-        if (o1 > o0) {
-            const double l[3] = {pt[3 * (size_t)j], pt[3 * (size_t)j + 1], pt[3 * (size_t)j + 2]};
-            double K[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) K[k] = Kc[k];
-            for (int o = o0 + sub; o < o1; o += LPL) {
-                const double* x = pose + 12 * (size_t)D.obs_cam[o];
-                double xr[12], r[2];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) xr[k] = x[k];
-                reproj<false>(xr, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], r, nullptr, nullptr, nullptr);
-                e[0] += huber_loss(sqrt(r[0] * r[0] + r[1] * r[1]) / D.nz.pix_sigma, D.nz.pix_huber);
-            }
-            if (sub == 0) {  // the landmark's prior, once
-                const double sg = D.lmprior[2 * j], kh = D.lmprior[2 * j + 1];
-                double n2 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double w = (l[a] - D.pt0[3 * (size_t)j + a]) / sg;
-                    n2 += w * w;
-                }
-                e[0] += huber_loss(sqrt(n2), kh);
-            }
-        }
-    }
-    block_sum<1>(e, sm);
-    if (threadIdx.x == 0) D.err_part[blockIdx.x] = e[0];
-}
-
-// ---- K-G3: fixed-order final sums -> scal[0] = error, scal[1] = linearised cost change -----------------
-// n_lin = workgroups that left a partial of the linearised cost change in lin_part (0: no such term in this pass)
-__global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_cam, const double* lin_cam, int n_lin, double ticket) {
-    __shared__ double sm[(TPB / 64) * 2];
+// ---- K-G3: fixed-order final sums -> scal[0] = error, scal[1] = linearised cost change; one workgroup, all its threads ----
+// n_err / n_lin = workgroups that left a partial in err_part / lin_part (n_lin = 0: no linearised-cost term in this pass)
+__device__ __forceinline__ void final_sums(const BaDev& D, const double* err_cam, const double* lin_cam, int n_err, int n_lin,
+                                           double ticket, double* sm /* [(TPB / 64) * 2] */) {
     double v[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < D.n_ll_blocks; i += TPB) v[0] += D.err_part[i];  // (ba_error_landmarks' grid)
-    for (int i = threadIdx.x; i < n_lin; i += TPB) v[1] += D.lin_part[i];
+    for (int i = threadIdx.x; i < n_err; i += TPB) v[0] += load_wt(&D.err_part[i]);
+    for (int i = threadIdx.x; i < n_lin; i += TPB) v[1] += load_wt(&D.lin_part[i]);
     for (int i = threadIdx.x; i <= D.nc; i += TPB) {
-        v[0] += err_cam[i];
-        if (n_lin) v[1] += lin_cam[i];
+        v[0] += load_wt(&err_cam[i]);
+        if (n_lin) v[1] += load_wt(&lin_cam[i]);
     }
     block_sum<2>(v, sm);
-    // The status word and the hand-off flags of the back-substitution are consumed here, so this kernel also clears
-    // them for the next tryLambda(), and it stores the three scalars a second time into pinned host memory: a memset
-    // node and a device-to-host copy less on the chain of every LM inner iteration.
+    // The status word and the hand-off flags of the back-substitution are consumed here, so they are also cleared here
+    // for the next tryLambda(), and the three scalars go to pinned host memory as well: a memset node and a
+    // device-to-host copy less on the chain of every LM inner iteration.
     if (threadIdx.x == 0) {
         const double st = (double)D.flags[0];
         D.scal[0] = v[0];
@@ -1822,6 +1740,154 @@ __global__ __launch_bounds__(TPB) void ba_final_sums(BaDev D, const double* err_
         }
     }
     for (int k = threadIdx.x; k < N_STATUS + D.sp_npan; k += TPB) D.flags[k] = 0;  // (thread 0 read flags[0] above, in program order)
+}
+
+// nonlinear error of a landmark's reprojection factors (this lane's share of them) + its prior (lane sub == 0).
+// RETRACT: the poses are D.pose (+) delta_c, retracted here; else `pose` as given.
+template <int LPL, bool RETRACT>
+__device__ __forceinline__ double landmark_error(const BaDev& D, int j, int sub, const double* __restrict__ pose, const double (&l)[3],
+                                                 const double (&K)[5]) {
+    const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
+    double e = 0.0;
+    for (int o = o0 + sub; o < o1; o += LPL) {
+        const int cam = (int)D.obs_cam[o];
+        const double* x = pose + 12 * (size_t)cam;
+        double xr[12], r[2];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) xr[k] = x[k];
+        if (RETRACT) {
+            double y[12];
+            retract_pose(xr, D.delta_c + 6 * (size_t)cam, y);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) xr[k] = y[k];
+        }
+        reproj<false>(xr, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], r, nullptr, nullptr, nullptr);
+        e += huber_loss(sqrt(r[0] * r[0] + r[1] * r[1]) / D.nz.pix_sigma, D.nz.pix_huber);
+    }
+    if (sub == 0) {  // the landmark's prior, once
+        const double sg = D.lmprior[2 * j], kh = D.lmprior[2 * j + 1];
+        double n2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double w = (l[a] - D.pt0[3 * (size_t)j + a]) / sg;
+            n2 += w * w;
+        }
+        e += huber_loss(sqrt(n2), kh);
+    }
+    return e;
+}
+
+// The tail of a tryLambda(). Grid = the landmark workgroups, then the workgroups that retract the cameras and K.
+template <int LPL>
+__global__ __launch_bounds__(TPB) void ba_step_landmarks(BaDev D, double lambda, double* err_cam, double* lin_cam, double ticket) {
+    __shared__ double sm[(TPB / 64) * 2];
+    if ((int)blockIdx.x >= D.n_step_blocks) {
+        retract_camera(D, ((int)blockIdx.x - D.n_step_blocks) * TPB + threadIdx.x, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, err_cam, lin_cam);
+    } else {
+        const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
+        double lin[1] = {0.0}, dl[3] = {0.0, 0.0, 0.0};
+        if (j < D.nl) {
+            const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+            if (o1 > o0) {
+                const double* lt = D.lmtry + (size_t)LMLIN * j;
+                double t0 = lt[6], t1 = lt[7], t2 = lt[8];
+                const double* dK = D.delta_c + 6 * D.nc;
+    #pragma unroll
+                for (int a = 0; a < 5; ++a) {
+                    t0 -= lt[9 + 3 * a] * dK[a];
+                    t1 -= lt[10 + 3 * a] * dK[a];
+                    t2 -= lt[11 + 3 * a] * dK[a];
+                }
+                // sum_o Et_o^T dc = Linv sum_o E_o^T dc and E_o^T dc = Al^T (Ap dc): the Jacobians are recomputed at the
+                // linearisation point (pose / pt / Kc do not change inside the lambda loop) from this landmark's own
+                // observation records instead of gathering its ten 144-byte Et rows out of the camera-ordered array
+                // (137 MB of HBM traffic per try, profiles/r02_pmc_ba_traffic.json of the first round-2 build)
+                const double l[3] = {D.pt[3 * (size_t)j], D.pt[3 * (size_t)j + 1], D.pt[3 * (size_t)j + 2]};
+                double K[5];
+    #pragma unroll
+                for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
+                double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+                for (int o = o0 + sub; o < o1; o += LPL) {
+                    const int cam = (int)D.obs_cam[o];
+                    const double* x = D.pose + 12 * (size_t)cam;
+                    const double* dc = D.delta_c + 6 * (size_t)cam;
+                    double xr[12];
+    #pragma unroll
+                    for (int k = 0; k < 12; ++k) xr[k] = x[k];
+                    double Ap[12], Al[6], Ak[10], b[2];
+                    obs_factor(xr, l, K, D.obs_uv[2 * (size_t)o], D.obs_uv[2 * (size_t)o + 1], D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+                    double u0 = 0.0, u1 = 0.0;
+    #pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        u0 += Ap[a] * dc[a];
+                        u1 += Ap[6 + a] * dc[a];
+                    }
+                    w0 += Al[0] * u0 + Al[3] * u1;
+                    w1 += Al[1] * u0 + Al[4] * u1;
+                    w2 += Al[2] * u0 + Al[5] * u1;
+                }
+                if (LPL > 1) w0 = group_sum<LPL>(w0), w1 = group_sum<LPL>(w1), w2 = group_sum<LPL>(w2);  // (a landmark's lanes take this branch together)
+                const double m00 = lt[0], m10 = lt[1], m11 = lt[2], m20 = lt[3], m21 = lt[4], m22 = lt[5];
+                t0 -= m00 * w0;
+                t1 -= m10 * w0 + m11 * w1;
+                t2 -= m20 * w0 + m21 * w1 + m22 * w2;
+                d0 = m00 * t0 + m10 * t1 + m20 * t2;
+                d1 = m11 * t1 + m21 * t2;
+                d2 = m22 * t2;
+                const double* in = D.lmlin + (size_t)LMLIN * j;
+                if (sub == 0)
+                    lin[0] = 0.5 * (d0 * in[6] + d1 * in[7] + d2 * in[8]) +
+                             0.5 * lambda * (clampd(in[0], 1e-6, 1e32) * d0 * d0 + clampd(in[3], 1e-6, 1e32) * d1 * d1 +
+                                             clampd(in[5], 1e-6, 1e32) * d2 * d2);
+            }
+            dl[0] = d0, dl[1] = d1, dl[2] = d2;
+            if (sub == 0) {
+            D.delta_l[3 * (size_t)j] = d0;
+            D.delta_l[3 * (size_t)j + 1] = d1;
+            D.delta_l[3 * (size_t)j + 2] = d2;
+            D.pt_new[3 * (size_t)j] = D.pt[3 * (size_t)j] + d0;
+            D.pt_new[3 * (size_t)j + 1] = D.pt[3 * (size_t)j + 1] + d1;
+            D.pt_new[3 * (size_t)j + 2] = D.pt[3 * (size_t)j + 2] + d2;
+            }
+        }
+        double v[2] = {0.0, lin[0]};
+        if (j < D.nl && D.lm_ptr[j + 1] > D.lm_ptr[j]) {
+            const double lnew[3] = {D.pt[3 * (size_t)j] + dl[0], D.pt[3 * (size_t)j + 1] + dl[1], D.pt[3 * (size_t)j + 2] + dl[2]};
+            double Kn[5];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) Kn[a] = D.Kc[a] + D.delta_c[6 * D.nc + a];
+            v[0] = landmark_error<LPL, true>(D, j, sub, D.pose, lnew, Kn);
+        }
+        block_sum<2>(v, sm);
+        if (threadIdx.x == 0) {
+            store_wt(&D.err_part[blockIdx.x], v[0]);
+            store_wt(&D.lin_part[blockIdx.x], v[1]);
+        }
+    }
+    if (last_workgroup(D.sync_counter)) final_sums(D, err_cam, lin_cam, D.n_step_blocks, D.n_step_blocks, ticket, sm);
+}
+
+// ---- K-G2: nonlinear error at given values (the first error pass of a solve, DogLeg's candidates, the PCG path): the
+// reprojection + landmark-prior factors (thread = landmark); the camera / K prior errors come from ba_retract_cameras,
+// launched before it; the last workgroup makes the final sums.
+template <int LPL>
+__global__ __launch_bounds__(TPB) void ba_error_landmarks(BaDev D, const double* __restrict__ pose, const double* __restrict__ pt,
+                                                          const double* __restrict__ Kc, const double* err_cam, const double* lin_cam,
+                                                          int n_lin, double ticket) {
+    __shared__ double sm[(TPB / 64) * 2];
+    const int gid = blockIdx.x * TPB + threadIdx.x, j = gid / LPL, sub = gid % LPL;
+    double e[1] = {0.0};
+    if (j < D.nl && D.lm_ptr[j + 1] > D.lm_ptr[j]) {
+        const double l[3] = {pt[3 * (size_t)j], pt[3 * (size_t)j + 1], pt[3 * (size_t)j + 2]};
+        double K[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) K[k] = Kc[k];
+        e[0] = landmark_error<LPL, false>(D, j, sub, pose, l, K);
+    }
+    block_sum<1>(e, sm);
+    if (threadIdx.x == 0) store_wt(&D.err_part[blockIdx.x], e[0]);
+    if (last_workgroup(D.sync_counter)) final_sums(D, err_cam, lin_cam, D.n_step_blocks, n_lin, ticket, sm);
 }
 
 // ---- the iterative solve the reference can select: PCG + block-Jacobi (BundleAdjuster.cpp:192-200) -----------------
@@ -2472,6 +2538,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
     D.lpl = nl <= 8192 ? 8 : 1;
     D.n_ll_blocks = std::max(1, (int)(((long long)nl * D.lpl + TPB - 1) / TPB));
+    D.lpl_step = ctx->ba_lpl_step > 0 ? ctx->ba_lpl_step : (nl <= 8192 ? 8 : 2);
+    D.n_step_blocks = std::max(1, (int)(((long long)nl * D.lpl_step + TPB - 1) / TPB));
 
     // ---- structure: observations grouped by landmark (stable), then by camera ----
     std::vector<int> lm_ptr(nl + 1, 0);
@@ -2657,8 +2725,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
         TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
         TRY(dev_alloc(ctx, h, &D.delta_l, 3 * (size_t)nl));
-        TRY(dev_alloc(ctx, h, &D.err_part, (size_t)D.n_ll_blocks));
-        TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)D.n_ll_blocks));
+        TRY(dev_alloc(ctx, h, &D.err_part, (size_t)std::max(D.n_ll_blocks, D.n_step_blocks)));
+        TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)std::max(std::max(D.n_ll_blocks, D.n_step_blocks), D.n_lm_blocks)));
         TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
         TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
         TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
@@ -2678,7 +2746,9 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
             TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
         }
         TRY(dev_alloc(ctx, h, &D.flags, (size_t)N_STATUS + plan.npan));  // [0..3] status, [4 + P] hand-off flag of panel P
-        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (N_STATUS + plan.npan) * sizeof(int), ctx->stream));  // (ba_final_sums leaves them cleared)
+        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (N_STATUS + plan.npan) * sizeof(int), ctx->stream));  // (final_sums leaves them cleared)
+        TRY(dev_alloc(ctx, h, &D.sync_counter, 4));
+        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.sync_counter, 0, 4 * sizeof(int), ctx->stream));
         if (!h->planning) {
             h->scal_host = ctx->ba_pool[h->block].pinned;
             EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
@@ -2741,27 +2811,39 @@ static int ba_reset(eacham_ctx* ctx, eacham_ba_handle* h) {
 
 // graph.error at (pose, pt, K) -> scal[0]
 // the three kernels that walk a landmark's observations, in the lanes-per-landmark variant of the problem (BaDev::lpl)
-static void launch_error_landmarks(eacham_ctx* ctx, const BaDev& D, const double* pose, const double* pt, const double* Kc) {
-    if (D.lpl == 8) ba_error_landmarks<8><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
-    else ba_error_landmarks<1><<<D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc);
+// error at (pose, pt, Kc) + the final sums (made by the launch's last workgroup): ba_retract_cameras ran before it
+static void launch_error_landmarks(eacham_ctx* ctx, eacham_ba_handle* h, const double* pose, const double* pt, const double* Kc, int n_lin) {
+    const BaDev& D = h->D;
+    const double ticket = (double)++h->ticket;
+    switch (D.lpl_step) {
+        case 8: ba_error_landmarks<8><<<D.n_step_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc, h->err_cam, h->lin_cam, n_lin, ticket); break;
+        case 4: ba_error_landmarks<4><<<D.n_step_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc, h->err_cam, h->lin_cam, n_lin, ticket); break;
+        case 2: ba_error_landmarks<2><<<D.n_step_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc, h->err_cam, h->lin_cam, n_lin, ticket); break;
+        default: ba_error_landmarks<1><<<D.n_step_blocks, TPB, 0, ctx->stream>>>(D, pose, pt, Kc, h->err_cam, h->lin_cam, n_lin, ticket);
+    }
 }
 static void launch_linearize_both(eacham_ctx* ctx, const BaDev& D, double* clpart) {
     const int ncb = D.nc * LSEG;
     if (D.lpl == 8) ba_linearize<8><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
     else ba_linearize<1><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
 }
-static void launch_backsub_landmarks(eacham_ctx* ctx, const BaDev& D, double lambda, double* err_cam, double* lin_cam) {
-    const int grid = D.n_ll_blocks + (D.nc + 1 + TPB - 1) / TPB;  // + the camera retraction
-    if (D.lpl == 8) ba_backsub_landmarks<8><<<grid, TPB, 0, ctx->stream>>>(D, lambda, err_cam, lin_cam);
-    else ba_backsub_landmarks<1><<<grid, TPB, 0, ctx->stream>>>(D, lambda, err_cam, lin_cam);
+static void launch_step_landmarks(eacham_ctx* ctx, eacham_ba_handle* h, double lambda) {
+    const BaDev& D = h->D;
+    const int grid = D.n_step_blocks + (D.nc + 1 + TPB - 1) / TPB;  // + the camera retraction
+    const double ticket = (double)++h->ticket;
+    switch (D.lpl_step) {
+        case 8: ba_step_landmarks<8><<<grid, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam, ticket); break;
+        case 4: ba_step_landmarks<4><<<grid, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam, ticket); break;
+        case 2: ba_step_landmarks<2><<<grid, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam, ticket); break;
+        default: ba_step_landmarks<1><<<grid, TPB, 0, ctx->stream>>>(D, lambda, h->err_cam, h->lin_cam, ticket);
+    }
 }
 
 static void launch_error(eacham_ctx* ctx, eacham_ba_handle* h, const double* pose, const double* pt, const double* Kc) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
     ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, pose, D.pose_new, Kc, D.K_new, 0, h->err_cam, h->lin_cam);
-    launch_error_landmarks(ctx, D, pose, pt, Kc);
-    ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0, (double)++h->ticket);
+    launch_error_landmarks(ctx, h, pose, pt, Kc, 0);
 }
 
 static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
@@ -2822,9 +2904,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     }
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
-        launch_backsub_landmarks(ctx, D, lambda, h->err_cam, h->lin_cam);
-        launch_error_landmarks(ctx, D, D.pose_new, D.pt_new, D.K_new);
-        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, D.n_ll_blocks, (double)++h->ticket);
+        launch_step_landmarks(ctx, h, lambda);  // back-substitution, retraction, error at the tentative values, final sums
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     return EACHAM_OK;
@@ -2858,8 +2938,7 @@ static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, l
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_ERROR);
         pcg_landmark_step<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
         ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, lambda, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
-        launch_error_landmarks(ctx, D, D.pose_new, D.pt_new, D.K_new);
-        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, D.n_lm_blocks /* pcg_landmark_step's grid */, (double)++h->ticket);
+        launch_error_landmarks(ctx, h, D.pose_new, D.pt_new, D.K_new, D.n_lm_blocks /* pcg_landmark_step's grid */);
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     return EACHAM_OK;
@@ -2990,8 +3069,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
                         const int na = std::max(3 * D.nl, D.n);
                         ba_dl_apply<<<(na + TPB - 1) / TPB, TPB, 0, ctx->stream>>>(D, cu * alpha, cn);
                         ba_retract_cameras<<<(D.nc + 1 + 63) / 64, 64, 0, ctx->stream>>>(D, 0.0, D.pose, D.pose_new, D.Kc, D.K_new, 1, h->err_cam, h->lin_cam);
-                        launch_error_landmarks(ctx, D, D.pose_new, D.pt_new, D.K_new);
-                        ba_final_sums<<<1, TPB, 0, ctx->stream>>>(D, h->err_cam, h->lin_cam, 0, (double)++h->ticket);
+                        launch_error_landmarks(ctx, h, D.pose_new, D.pt_new, D.K_new, 0);
                     }
                     rc = read_scal(ctx, h, sc);
                     if (rc) return rc;
