@@ -317,6 +317,15 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     const int wg_tile0 = rb * (ROWS_WG / 32);
     const bool split = wg_tile0 < A_even && wg_tile0 + ROWS_WG / 32 > A_even;  // workgroup-uniform
     const int slot0 = rb + ((!split && wg_tile0 >= A_even) ? 1 : 0);
+    // The workgroup's part of the partial array as a SCALAR base (two s-registers) + a 32-bit per-lane index: hoisted as a
+    // per-lane 64-bit address it cost two VGPRs across the whole sweep on a kernel that sits at the 256-register limit of two
+    // waves per SIMD (and was the value the compiler spilled).
+    uint2* colpart_wg;
+    {
+        const unsigned long long u = (unsigned long long)(colpart + ((size_t)p * wb_stride + slot0) * row_stride + 32 * (size_t)tbeg);
+        colpart_wg = (uint2*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)u));
+    }
     // Burst merge of the published tiles [t0, t0 + BURST) by the whole workgroup: thread -> (tile, column).
     auto merge_burst = [&](int t0) {
         const int tt = t0 + 2 * wave + h;  // tid >> 5
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                     m.y = umin(umin(umax(m.x, e.x), m.y), e.y);
                     m.x = umin(m.x, e.x);
                 }
-                colpart[((size_t)p * wb_stride + slot0 + g) * row_stride + 32 * (tbeg + tt) + cl] = m;
+                colpart_wg[(unsigned)(g * row_stride + 32 * tt + cl)] = m;
             }
         }
     };

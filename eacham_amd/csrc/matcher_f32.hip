@@ -74,8 +74,15 @@ __global__ __launch_bounds__(F_THREADS, 2) void match_tile_f32_kernel(
     const bool active = wb < A.ntiles;
     const int wbc = active ? wb : 0;
     const int T = B.ntiles;
-    const gfloat_t Af = (gfloat_t)A.frag, Bf = (gfloat_t)B.frag;
-    const gfloat_t An = (gfloat_t)A.norm, Bn = (gfloat_t)B.norm;
+    // the frame table is read through vector memory: the pointers of the train frame, live for the whole sweep, are moved
+    // to scalar registers (they are workgroup-uniform)
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long u = (unsigned long long)q;
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32 |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)u);
+    };
+    const gfloat_t Af = (gfloat_t)A.frag, Bf = (gfloat_t)uniform_ptr(B.frag);
+    const gfloat_t An = (gfloat_t)A.norm, Bn = (gfloat_t)uniform_ptr(B.norm);
 
     float a[D2];
 #pragma unroll
@@ -105,7 +112,12 @@ __global__ __launch_bounds__(F_THREADS, 2) void match_tile_f32_kernel(
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
-    int4* cp = colpart + ((size_t)p * wb_stride + wb) * row_stride;
+    int4* cp;  // wave-uniform: kept as a scalar base (the kernel sits at the 256-register limit of two waves per SIMD)
+    {
+        const unsigned long long u = (unsigned long long)(colpart + ((size_t)p * wb_stride + wb) * row_stride);
+        cp = (int4*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)u));
+    }
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
         const float nbc = nb_cur;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void match_tile_f32_kernel(
             const bool take = ov1 < cv1 || (ov1 == cv1 && or1 < cr1);
             const float n1 = take ? ov1 : cv1, n2 = take ? fminf(cv1, ov2) : fminf(cv2, ov1);
             const int nr = take ? or1 : cr1;
-            if (h == 0) cp[32 * t + cl] = make_int4(__float_as_int(n1), 32 * wb + nr, __float_as_int(n2), 0);
+            if (h == 0) cp[(unsigned)(32 * t + cl)] = make_int4(__float_as_int(n1), 32 * wb + nr, __float_as_int(n2), 0);
         }
         __syncthreads();
     }
