@@ -178,7 +178,8 @@ class PreparedBA:
         self.ctx._check(self._L.eacham_ba_get_plan_info(self.ctx.handle, self._h, C.byref(info)))
         return {"panels": info.n_panels, "tiles": info.n_tiles, "levels": info.n_levels,
                 "ordering": {v: k for k, v in ORDERINGS.items()}[info.ordering], "nd_leaf": info.nd_leaf,
-                "tile_updates": int(info.tile_updates), "est_us": round(info.est_us, 1)}
+                "tile_updates": int(info.tile_updates), "est_us": round(info.est_us, 1),
+                "prepare_us": [round(v, 1) for v in info.prepare_us]}
 
     def close(self):
         if self._h:

@@ -114,7 +114,7 @@ class BaProblem(C.Structure):
 
 class BaPlanInfo(C.Structure):
     _fields_ = [("n_panels", C.c_int32), ("n_tiles", C.c_int32), ("n_levels", C.c_int32), ("ordering", C.c_int32),
-                ("nd_leaf", C.c_int32), ("reserved", C.c_int32), ("tile_updates", C.c_int64), ("est_us", C.c_double)]
+                ("nd_leaf", C.c_int32), ("reserved", C.c_int32), ("tile_updates", C.c_int64), ("est_us", C.c_double), ("prepare_us", C.c_double * 3)]
 
 
 class BaOptions(C.Structure):

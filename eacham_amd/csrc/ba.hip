@@ -2431,6 +2431,7 @@ struct eacham_ba_handle {
     size_t bytes_linearize = 0, bytes_try = 0;
     // the sparse solve (ba_plan.hpp): the plan stays on the host for the launch sequence and the diagnostic read-back
     eacham::BaPlan plan;
+    double prep_us[3] = {0, 0, 0};  // eacham_ba_prepare: host structures | the plan (ordering + symbolic) | arena + upload + sync
     const int* sp_leaves = nullptr;
     const eacham::BaPlanItem* sp_items = nullptr;
     const eacham::BaPlanSrc* sp_srcs = nullptr;
@@ -2531,6 +2532,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         if (P->obs_cam[o] >= (uint32_t)nc || P->obs_point[o] >= (uint32_t)nl)
             return ctx->fail(EACHAM_ERR_INVALID, "observation %d references a camera/point out of range", o);
     eacham_ba_handle* h = new eacham_ba_handle();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     BaDev& D = h->D;
     memset(&D, 0, sizeof(D));
     D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
@@ -2584,15 +2587,34 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         cam_uv[2 * (size_t)p + 1] = obs_uv[2 * (size_t)cam_obs[p] + 1];
     }
     // ---- camera-pair lists of the Schur complement: block (c <= c') -> (o, o') pairs, landmark order ----
+    // (two passes over every observation pair of every landmark — count, then fill: this loop is most of the host time of
+    // preparing a local window, hence the flat 32-bit index arithmetic; entries are written as Et positions directly)
     const long long nblk_all = (long long)nc * (nc + 1) / 2;
-    auto bid = [nc](int c, int c2) { return (long long)c * nc - (long long)c * (c - 1) / 2 + (c2 - c); };
+    if (nblk_all > 0x7fffffffLL) {
+        delete h;
+        return ctx->fail(EACHAM_ERR_UNSUPPORTED, "too many cameras (%d) for the camera-block index", nc);
+    }
+    std::vector<int> rowoff(std::max(nc, 1));  // block (c, c2 >= c) has index rowoff[c] + c2
+    for (int c = 0; c < nc; ++c) rowoff[c] = (int)((long long)c * nc - (long long)c * (c - 1) / 2 - c);
+    auto bid = [&](int c, int c2) { return rowoff[c] + c2; };
     std::vector<int> bcount((size_t)nblk_all + 1, 0);
-    for (int j = 0; j < nl; ++j)
-        for (int a = lm_ptr[j]; a < lm_ptr[j + 1]; ++a)
-            for (int b = a; b < lm_ptr[j + 1]; ++b) {
-                const int ca = (int)obs_cam[a], cb = (int)obs_cam[b];
-                bcount[(size_t)bid(std::min(ca, cb), std::max(ca, cb)) + 1] += (ca == cb && a != b) ? 2 : 1;
+    {
+        const unsigned* oc = obs_cam.data();
+        int* bc = bcount.data() + 1;
+        for (int j = 0; j < nl; ++j) {
+            const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1];
+            for (int a = a0; a < a1; ++a) {
+                const int ca = (int)oc[a];
+                bc[rowoff[ca] + ca] += 1;  // (a, a)
+                for (int b = a + 1; b < a1; ++b) {
+                    const int cb = (int)oc[b];
+                    if (ca < cb) bc[rowoff[ca] + cb] += 1;
+                    else if (ca > cb) bc[rowoff[cb] + ca] += 1;
+                    else bc[rowoff[ca] + ca] += 2;
+                }
             }
+        }
+    }
     std::vector<long long> bstart((size_t)nblk_all + 1, 0);
     for (long long b = 0; b < nblk_all; ++b) bstart[b + 1] = bstart[b] + bcount[b + 1];
     const long long n_entries = bstart[nblk_all];
@@ -2602,20 +2624,30 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     }
     std::vector<int2> entries((size_t)n_entries);
     {
-        std::vector<long long> pos(bstart.begin(), bstart.end() - 1);
-        for (int j = 0; j < nl; ++j)
-            for (int a = lm_ptr[j]; a < lm_ptr[j + 1]; ++a)
-                for (int b = a; b < lm_ptr[j + 1]; ++b) {
-                    const int ca = (int)obs_cam[a], cb = (int)obs_cam[b];
-                    if (ca < cb) entries[(size_t)pos[bid(ca, cb)]++] = make_int2(a, b);
-                    else if (ca > cb) entries[(size_t)pos[bid(cb, ca)]++] = make_int2(b, a);
+        std::vector<int> pos((size_t)nblk_all);
+        for (long long b = 0; b < nblk_all; ++b) pos[b] = (int)bstart[b];
+        const unsigned* oc = obs_cam.data();
+        const int* op = obs_pos.data();  // Et records live in camera order
+        int2* en = entries.data();
+        int* ps = pos.data();
+        for (int j = 0; j < nl; ++j) {
+            const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1];
+            for (int a = a0; a < a1; ++a) {
+                const int ca = (int)oc[a], pa = op[a];
+                en[ps[rowoff[ca] + ca]++] = make_int2(pa, pa);
+                for (int b = a + 1; b < a1; ++b) {
+                    const int cb = (int)oc[b], pb = op[b];
+                    if (ca < cb) en[ps[rowoff[ca] + cb]++] = make_int2(pa, pb);
+                    else if (ca > cb) en[ps[rowoff[cb] + ca]++] = make_int2(pb, pa);
                     else {
-                        entries[(size_t)pos[bid(ca, ca)]++] = make_int2(a, b);
-                        if (a != b) entries[(size_t)pos[bid(ca, ca)]++] = make_int2(b, a);
+                        int& q = ps[rowoff[ca] + ca];
+                        en[q++] = make_int2(pa, pb);
+                        en[q++] = make_int2(pb, pa);
                     }
                 }
+            }
+        }
     }
-    for (auto& e : entries) e = make_int2(obs_pos[e.x], obs_pos[e.y]);  // Et records live in camera order
     std::vector<int4> chunks, blocks;
     for (int c = 0; c < nc; ++c)
         for (int c2 = c; c2 < nc; ++c2) {
@@ -2631,6 +2663,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     D.n_chunks = (int)chunks.size();
     D.n_blocks = (int)blocks.size();
     // ---- the sparse solve: ordering, panels, symbolic factor, level schedule (ba_plan.hpp) ----
+    const auto t_plan = std::chrono::steady_clock::now();
+    h->prep_us[0] = us_since(t_begin);
     {
         std::vector<std::pair<int, int>> cam_edges;
         cam_edges.reserve(blocks.size());
@@ -2644,6 +2678,8 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         }
         build_ba_plan(nc, cam_edges, hint, h->plan);
     }
+    h->prep_us[1] = us_since(t_plan);
+    const auto t_upload = std::chrono::steady_clock::now();
     const BaPlan& plan = h->plan;
     D.sp_npan = plan.npan; D.sp_ntiles = plan.ntiles; D.sp_posK = plan.posK; D.sp_rhs_row = plan.rhs_row;
     D.sp_n_pad = (int)plan.pad_cols.size();
@@ -2779,12 +2815,16 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         delete h;
         return rc;
     }
-    hipError_t e = hipStreamSynchronize(ctx->stream);  // the host vectors die here
+    // The per-array copies of a large problem read host vectors that die here: wait for them. A small problem was sent as
+    // ONE image out of h->stage, which lives as long as the handle: nothing to wait for (the first kernel of the solve
+    // queues behind the copy on the same stream) — 30-40 us of every local-window call.
+    hipError_t e = h->stage.empty() ? hipStreamSynchronize(ctx->stream) : hipSuccess;
     if (e != hipSuccess) {
         ctx->ba_pool[h->block].busy = false;
         delete h;
         return ctx->fail(EACHAM_ERR_HIP, "BA upload failed: %s", hipGetErrorString(e));
     }
+    h->prep_us[2] = us_since(t_upload);
     // algorithmic HBM bytes; used by the benchmark's roofline line
     h->bytes_linearize = (size_t)no * (24 + 144) + (size_t)no * 24 + (size_t)nl * (24 + LMLIN * 8) + (size_t)nc * (96 + CAMLIN * 8);
     h->bytes_try = (size_t)no * (144 * 2 + 144 + 144) + (size_t)n_entries * 8 + (size_t)nl * (LMLIN * 8 * 3 + 48) +
@@ -3222,6 +3262,9 @@ int eacham_ba_get_plan_info(eacham_ctx* ctx, const eacham_ba_handle* handle, eac
     out->ordering = pl.ordering; out->nd_leaf = pl.nd_leaf; out->reserved = 0;
     out->tile_updates = pl.tile_updates;
     out->est_us = pl.est_us;
+    out->prepare_us[0] = handle->prep_us[0];
+    out->prepare_us[1] = handle->prep_us[1];
+    out->prepare_us[2] = handle->prep_us[2];
     return EACHAM_OK;
 }
 

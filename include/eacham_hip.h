@@ -246,11 +246,14 @@ void eacham_ba_release(eacham_ctx* ctx, eacham_ba_handle* handle);
 /* What the analysis of the reduced camera system decided for a prepared problem (reporting: the benchmark's BA line
  * carries it): panels of 64 columns, tiles of the symbolic factor, height of the elimination tree = number of
  * dependent factorisation launches, the ordering used (EACHAM_BA_ORDER_NATURAL / _RCM / _ND), rank-64 tile updates of
- * one factorisation and the cost model's estimate for factorisation + back-substitution in microseconds. */
+ * one factorisation, the cost model's estimate for factorisation + back-substitution in microseconds, and where the
+ * host time of eacham_ba_prepare went. */
 typedef struct eacham_ba_plan_info {
     int32_t n_panels, n_tiles, n_levels, ordering, nd_leaf, reserved;
     int64_t tile_updates;
     double est_us;
+    double prepare_us[3];  /* host time of eacham_ba_prepare: observation / pair structures | ordering + symbolic
+                            * analysis | arena + upload + synchronisation */
 } eacham_ba_plan_info;
 int eacham_ba_get_plan_info(eacham_ctx* ctx, const eacham_ba_handle* handle, eacham_ba_plan_info* out);
 
