@@ -45,14 +45,8 @@ for k, v in sorted(ba.items()):
     b = (2.0 * v.get("FETCH_SIZE_KB_mean_per_dispatch", 0.0) + v.get("WRITE_SIZE_KB_mean_per_dispatch", 0.0)) * 1024.0 * n
     per_kernel[k] = {"dispatches": n, "hbm_bytes_total": b, "hbm_bytes_per_inner_iteration": b / max(tries, 1)}
     total += b
-# a memset of the reduced system (hipMemsetAsync -> fillBufferAligned), if a build still issues one, belongs to every try
-# as well (since r02 ba_eliminate_landmarks clears S itself)
-for k, v in out.items():
-    if "fillBufferAligned" in k and v.get("WRITE_SIZE_KB_mean_per_dispatch", 0.0) > 1024.0:
-        n = v.get("dispatches_WRITE_SIZE", 0)
-        b = (2.0 * v.get("FETCH_SIZE_KB_mean_per_dispatch", 0.0) + v.get("WRITE_SIZE_KB_mean_per_dispatch", 0.0)) * 1024.0 * n
-        per_kernel[k] = {"dispatches": n, "hbm_bytes_total": b, "hbm_bytes_per_inner_iteration": b / max(tries, 1)}
-        total += b
+# (no memset belongs to a try: ba_eliminate_landmarks clears the tiles of S itself; the fill kernels of the profiled run are
+# the matcher's workspace clears and PyTorch's allocations)
 dst = os.path.join(root, "profiles", f"{rnd}_pmc_ba_traffic.json")
 with open(dst, "w") as f:
     json.dump({"__meta__": meta, "tries": tries,
