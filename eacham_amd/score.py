@@ -36,3 +36,25 @@ def score_hypotheses(ctx, kind: str, a, b, models, K=None, threshold: float = 16
         vp(K4.ctypes.data) if K4 is not None else None, C.c_float(threshold), vp(err.ctypes.data) if want_errors else None,
         vp(counts.ctypes.data), vp(med.ctypes.data)))
     return err, counts, med
+
+
+SOLVERS = {"homography4": (capi.SOLVE_HOMOGRAPHY4, 4, 1), "essential5": (capi.SOLVE_ESSENTIAL5, 5, 10)}
+
+
+def solve_minimal(ctx, kind: str, a, b, samples, K=None):
+    """eacham_solve_minimal: every minimal sample (rows of `samples`: 4 / 5 point indices) -> its model(s).
+    Returns (models [n_samples, max_models, 9] float64, n_models [n_samples] int32); max_models = 1 / 10."""
+    k, m, maxm = SOLVERS[kind]
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, 2)
+    idx = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, m)
+    if a.shape[0] != b.shape[0]:
+        raise ValueError("point lists disagree")
+    K4 = None if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(4)
+    models = np.zeros((idx.shape[0], maxm, 9), dtype=np.float64)
+    counts = np.zeros(idx.shape[0], dtype=np.int32)
+    vp = C.c_void_p
+    ctx._check(capi.lib().eacham_solve_minimal(ctx.handle, k, a.shape[0], vp(a.ctypes.data), vp(b.ctypes.data),
+                                               vp(K4.ctypes.data) if K4 is not None else None, idx.shape[0], vp(idx.ctypes.data),
+                                               vp(models.ctypes.data), vp(counts.ctypes.data)))
+    return models, counts

@@ -329,6 +329,24 @@ int eacham_score_hypotheses(eacham_ctx* ctx, int kind, int n_points, const doubl
                             const double* models, const double* K, float threshold, float* errors,
                             int32_t* inlier_counts, float* medians);
 
+/* ---- minimal solvers of the robust estimators --------------------------------------------
+ * The model-generating half of cv::findHomography / cv::findEssentialMat
+ * (/root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:75, :57-61): every minimal sample of the
+ * caller's list -> its model(s), one launch for the whole list (the reference asks for 100 / 1000 iterations).
+ * OpenCV draws the samples from its own RNG inside the estimator; here the sample INDICES are an argument, so what is
+ * defined — and tested against the CPU restatement bit for bit — is "these correspondences -> these models".
+ *   kind HOMOGRAPHY4  a, b = n_points x 2 (source, destination); 4 indices per sample; 1 model = 9 doubles row-major,
+ *                     H[8] = 1 (HomographyEstimatorCallback::runKernel). K unused.
+ *   kind ESSENTIAL5   a, b = n_points x 2 pixels of view 1 / view 2, K = fx fy cx cy (NULL: already normalised);
+ *                     5 indices per sample; up to 10 models of 9 doubles (unit Frobenius norm, x2' E x1 = 0), the slots
+ *                     beyond n_models[s] are zero (Nister's five-point algorithm, EMEstimatorCallback::runKernel).
+ * models: n_samples x max_models x 9 with max_models = 1 / 10; n_models: n_samples (0 = degenerate sample).
+ * Pair it with eacham_score_hypotheses (all models against all correspondences) for the RANSAC / LMedS choice. */
+#define EACHAM_SOLVE_HOMOGRAPHY4 0
+#define EACHAM_SOLVE_ESSENTIAL5 1
+int eacham_solve_minimal(eacham_ctx* ctx, int kind, int n_points, const double* a, const double* b, const double* K,
+                         int n_samples, const int32_t* sample_idx, double* models, int32_t* n_models);
+
 /* ---- view-graph query on the CSR match graph --------------------------
  * Graph::GetBestPairForValid (/root/reference/modules/sfm/data/Graph.h:59-106) evaluated directly on the
  * wire format of eacham_match_all_pairs: pair p with counts[p] > 0 is the factor f1 -> f2 with matches

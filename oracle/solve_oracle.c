@@ -1,0 +1,424 @@
+/*
+ * solve_oracle.c — CPU restatement of the MINIMAL SOLVERS inside the robust estimators eacham calls
+ * (the scoring half is score_oracle.c).
+ *
+ * TEST INFRASTRUCTURE ONLY. PARITY UNPINNED: the solvers live in OpenCV 4.5.5 (conanfile.txt:3), which is not in the
+ * reference tree; restated from its published sources (modules/calib3d/src/fundam.cpp HomographyEstimatorCallback::runKernel,
+ * five-point.cpp EMEstimatorCallback::runKernel — Nister's five-point algorithm), anchored on the reference's call sites:
+ *   cv::findHomography(pts1, pts2, cv::LMEDS, 4.0, mask2, 100, 0.999)              ReconstructionManager.cpp:75
+ *   cv::findEssentialMat(pts1, pts2, focal, pp, cv::LMEDS, 0.99, 4.0, 1000, mask)  ReconstructionManager.cpp:57-61
+ * OpenCV draws the minimal samples from its own RNG (cv::RNG(-1) state inside RANSACPointSetRegistrator / LMeDS...): the
+ * sample INDICES are an input here, so what can be stated — and is tested — is "these correspondences -> these models";
+ * end-to-end parity with findHomography / findEssentialMat cannot be pinned by anyone without that RNG stream.
+ *   homography4  4 correspondences -> H (3x3 row-major, H[8] = 1): points normalised per set (centroid, mean absolute
+ *                deviation per axis), LtL = sum of the 2 x 9 constraint rows' outer products, eigenvector of the smallest
+ *                eigenvalue (cyclic Jacobi), denormalised, divided by H[8] — fundam.cpp's sequence.
+ *   essential5   5 correspondences (pixels + K, normalised as findEssentialMat does) -> up to 10 E (3x3 row-major, unit
+ *                Frobenius norm, ascending in the hidden variable z): null space of the 5 x 9 epipolar system (Householder),
+ *                E = xX + yY + zZ + W, the ten cubic constraints det E = 0 and 2 E E^T E - tr(E E^T) E = 0 as a 10 x 20
+ *                matrix in Nister's monomial order, Gauss-Jordan, the 3 x 3 polynomial matrix B(z), det B = degree-10
+ *                polynomial, its real roots (Durand-Kerner on the monic polynomial, Newton polish), x and y from B(z).
+ *                five-point.cpp finds the roots with cv::solvePoly and the null space with cv::SVD: same solution set.
+ * Products and sums are NOT contracted into FMAs.
+ */
+#pragma GCC optimize("fp-contract=off")
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* cyclic Jacobi on a symmetric n x n matrix (n <= 12): A is destroyed, V's COLUMNS are the eigenvectors, w the eigenvalues */
+static void jacobi_eig(int n, double* A, double* V, double* w) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < n; ++p) {
+            diag += A[p * n + p] * A[p * n + p];
+            for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {  /* columns p, q */
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {  /* rows p, q */
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
+/* a: 4 x 2 source points, b: 4 x 2 destination points; H: 9 doubles. Returns 1, or 0 for a degenerate sample. */
+int oracle_homography4(const double* a, const double* b, double* H) {
+    const int count = 4;
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < count; ++i) {
+        cM[0] += a[2 * i]; cM[1] += a[2 * i + 1];
+        cm[0] += b[2 * i]; cm[1] += b[2 * i + 1];
+    }
+    for (int k = 0; k < 2; ++k) cM[k] /= count, cm[k] /= count;
+    for (int i = 0; i < count; ++i)
+        for (int k = 0; k < 2; ++k) {
+            sM[k] += fabs(a[2 * i + k] - cM[k]);
+            sm[k] += fabs(b[2 * i + k] - cm[k]);
+        }
+    for (int k = 0; k < 2; ++k)
+        if (fabs(sM[k]) < 2.220446049250313e-16 || fabs(sm[k]) < 2.220446049250313e-16) return 0;
+    for (int k = 0; k < 2; ++k) sM[k] = count / sM[k], sm[k] = count / sm[k];
+    double LtL[81];
+    memset(LtL, 0, sizeof(LtL));
+    for (int i = 0; i < count; ++i) {
+        const double x = (b[2 * i] - cm[0]) * sm[0], y = (b[2 * i + 1] - cm[1]) * sm[1];
+        const double X = (a[2 * i] - cM[0]) * sM[0], Y = (a[2 * i + 1] - cM[1]) * sM[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int j = 0; j < 9; ++j)
+            for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    for (int j = 0; j < 9; ++j)
+        for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
+    double V[81], w[9];
+    jacobi_eig(9, LtL, V, w);
+    int best = 0;
+    for (int i = 1; i < 9; ++i)
+        if (w[i] < w[best]) best = i;
+    double H0[9];
+    for (int k = 0; k < 9; ++k) H0[k] = V[k * 9 + best];
+    /* H = invHnorm * H0 * Hnorm2, invHnorm = [1/sm.x 0 cm.x; 0 1/sm.y cm.y; 0 0 1], Hnorm2 = [sM.x 0 -cM.x sM.x; 0 sM.y -cM.y sM.y; 0 0 1] */
+    const double inv[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double n2[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double T[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[3 * r + c] = inv[3 * r] * H0[c] + inv[3 * r + 1] * H0[3 + c] + inv[3 * r + 2] * H0[6 + c];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H[3 * r + c] = T[3 * r] * n2[c] + T[3 * r + 1] * n2[3 + c] + T[3 * r + 2] * n2[6 + c];
+    if (!(fabs(H[8]) > 0.0)) return 0;
+    const double s = 1.0 / H[8];
+    for (int k = 0; k < 9; ++k) H[k] *= s;
+    return 1;
+}
+
+/* ---- five-point ---------------------------------------------------------------------------------------------- */
+/* column of the monomial x^ex y^ey z^ez (total degree <= 3) in Nister's elimination order */
+static int mono_col(int ex, int ey, int ez) {
+    static const int8_t order[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                                        {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+    for (int k = 0; k < 20; ++k)
+        if (order[k][0] == ex && order[k][1] == ey && order[k][2] == ez) return k;
+    return -1;
+}
+/* row += s * l1 l2 l3, each l a linear form {x, y, z, 1} */
+static void mul3acc(const double* l1, const double* l2, const double* l3, double s, double* row) {
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            for (int c = 0; c < 4; ++c) {
+                const int ex = (a == 0) + (b == 0) + (c == 0), ey = (a == 1) + (b == 1) + (c == 1), ez = (a == 2) + (b == 2) + (c == 2);
+                row[mono_col(ex, ey, ez)] += s * (l1[a] * l2[b]) * l3[c];
+            }
+}
+static void poly_mul(const double* p, int dp, const double* q, int dq, double* out /* dp + dq + 1 */) {
+    for (int k = 0; k <= dp + dq; ++k) out[k] = 0.0;
+    for (int i = 0; i <= dp; ++i)
+        for (int j = 0; j <= dq; ++j) out[i + j] += p[i] * q[j];
+}
+
+/* real roots of c[0] + c[1] z + ... + c[10] z^10 (ascending), sorted ascending; returns their number */
+static int real_roots10(const double* c, double* roots) {
+    int deg = 10;
+    double cmax = 0.0;
+    for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(c[k]));
+    if (!(cmax > 0.0)) return 0;
+    while (deg > 0 && fabs(c[deg]) <= 1e-14 * cmax) --deg;
+    if (deg == 0) return 0;
+    double m[11];  /* monic */
+    for (int k = 0; k <= deg; ++k) m[k] = c[k] / c[deg];
+    double bound = 0.0;
+    for (int k = 0; k < deg; ++k) bound = fmax(bound, fabs(m[k]));
+    bound += 1.0;
+    /* Durand-Kerner from the powers of 0.4 + 0.9 i scaled to the geometric mean of the root magnitudes |m0|^(1/deg)
+     * (Newton's iteration for the deg-th root: only + - * /, so that every build computes the same bits) */
+    double zr[10], zi[10];
+    {
+        double r0 = 1.0;
+        const double a0 = fabs(m[0]);
+        if (a0 > 0.0) {
+            double y = a0 > 1.0 ? a0 : 1.0;
+            for (int it = 0; it < 80; ++it) {
+                double yp = 1.0;
+                for (int j = 0; j < deg - 1; ++j) yp *= y;
+                y = ((deg - 1) * y + a0 / yp) / deg;
+            }
+            r0 = y;
+        }
+        r0 = fmin(fmax(r0, 0.5), bound);
+        double cr = 1.0, ci = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            zr[k] = r0 * cr;
+            zi[k] = r0 * ci;
+            const double tr = cr * 0.4 - ci * 0.9, ti = cr * 0.9 + ci * 0.4;
+            cr = tr, ci = ti;
+        }
+    }
+    for (int it = 0; it < 600; ++it) {
+        double change = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
+            for (int j = deg - 1; j >= 0; --j) {
+                const double tr = pr * zr[k] - pi * zi[k] + m[j], ti = pr * zi[k] + pi * zr[k];
+                pr = tr, pi = ti;
+            }
+            double dr = 1.0, di = 0.0;
+            for (int j = 0; j < deg; ++j)
+                if (j != k) {
+                    const double ar = zr[k] - zr[j], ai = zi[k] - zi[j];
+                    const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+                    dr = tr, di = ti;
+                }
+            const double den = dr * dr + di * di;
+            if (!(den > 0.0)) continue;
+            const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
+            zr[k] -= qr;
+            zi[k] -= qi;
+            change = fmax(change, fabs(qr) + fabs(qi));
+        }
+        if (change <= 1e-15 * bound) break;
+    }
+    int n = 0;
+    for (int k = 0; k < deg; ++k) {
+        if (fabs(zi[k]) > 1e-7 * (1.0 + fabs(zr[k]))) continue;
+        double z = zr[k];
+        for (int it = 0; it < 4; ++it) {  /* Newton polish on the real polynomial */
+            double p = c[deg], d = 0.0;
+            for (int j = deg - 1; j >= 0; --j) {
+                d = d * z + p;
+                p = p * z + c[j];
+            }
+            if (!(fabs(d) > 0.0)) break;
+            z -= p / d;
+        }
+        roots[n++] = z;
+    }
+    for (int i = 1; i < n; ++i) {  /* insertion sort */
+        const double v = roots[i];
+        int j = i - 1;
+        while (j >= 0 && roots[j] > v) roots[j + 1] = roots[j], --j;
+        roots[j + 1] = v;
+    }
+    return n;
+}
+
+/* p1, p2: 5 x 2 pixels of view 1 / view 2; K = fx fy cx cy (NULL: already normalised). E: 10 x 9. Returns the number of models. */
+int oracle_essential5(const double* p1, const double* p2, const double* K, double* E) {
+    double Q[9][5];  /* Q^T: column i = the constraint row of correspondence i */
+    for (int i = 0; i < 5; ++i) {
+        double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        if (K) {
+            x1 = (x1 - K[2]) / K[0]; y1 = (y1 - K[3]) / K[1];
+            x2 = (x2 - K[2]) / K[0]; y2 = (y2 - K[3]) / K[1];
+        }
+        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+        for (int k = 0; k < 9; ++k) Q[k][i] = row[k];
+    }
+    /* Householder QR of Q^T (9 x 5): the last four columns of the orthogonal factor span the null space of Q */
+    double P[9][9];
+    for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 9; ++c) P[r][c] = r == c ? 1.0 : 0.0;
+    for (int k = 0; k < 5; ++k) {
+        double norm = 0.0;
+        for (int r = k; r < 9; ++r) norm += Q[r][k] * Q[r][k];
+        norm = sqrt(norm);
+        if (!(norm > 0.0)) return 0;
+        double v[9];
+        for (int r = 0; r < 9; ++r) v[r] = r < k ? 0.0 : Q[r][k];
+        v[k] += Q[k][k] >= 0.0 ? norm : -norm;
+        double vv = 0.0;
+        for (int r = k; r < 9; ++r) vv += v[r] * v[r];
+        if (!(vv > 0.0)) return 0;
+        for (int c = k; c < 5; ++c) {  /* Q <- (I - 2 v v^T / vv) Q */
+            double d = 0.0;
+            for (int r = k; r < 9; ++r) d += v[r] * Q[r][c];
+            d = 2.0 * d / vv;
+            for (int r = k; r < 9; ++r) Q[r][c] -= d * v[r];
+        }
+        for (int r = 0; r < 9; ++r) {  /* P <- P (I - 2 v v^T / vv) */
+            double d = 0.0;
+            for (int c = k; c < 9; ++c) d += P[r][c] * v[c];
+            d = 2.0 * d / vv;
+            for (int c = k; c < 9; ++c) P[r][c] -= d * v[c];
+        }
+    }
+    double lin[9][4];  /* entry e of E as a linear form in (x, y, z, 1) */
+    for (int e = 0; e < 9; ++e)
+        for (int b = 0; b < 4; ++b) lin[e][b] = P[e][5 + b];
+    double A[10][20];
+    memset(A, 0, sizeof(A));
+    {   /* det E */
+        static const int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+        for (int p = 0; p < 6; ++p)
+            mul3acc(lin[perm[p][0]], lin[3 + perm[p][1]], lin[6 + perm[p][2]], p < 3 ? 1.0 : -1.0, A[0]);
+    }
+    for (int i = 0; i < 3; ++i)      /* 2 E E^T E - tr(E E^T) E */
+        for (int j = 0; j < 3; ++j) {
+            double* row = A[1 + 3 * i + j];
+            for (int k = 0; k < 3; ++k)
+                for (int l = 0; l < 3; ++l) {
+                    mul3acc(lin[3 * i + l], lin[3 * k + l], lin[3 * k + j], 2.0, row);
+                    mul3acc(lin[3 * k + l], lin[3 * k + l], lin[3 * i + j], -1.0, row);
+                }
+        }
+    double A0[10][20];  /* the constraints as assembled: the polish below evaluates them */
+    for (int r = 0; r < 10; ++r)
+        for (int c = 0; c < 20; ++c) A0[r][c] = A[r][c];
+    for (int col = 0; col < 10; ++col) {  /* Gauss-Jordan, partial pivoting */
+        int piv = col;
+        for (int r = col + 1; r < 10; ++r)
+            if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+        if (!(fabs(A[piv][col]) > 1e-300)) return 0;
+        if (piv != col)
+            for (int c = 0; c < 20; ++c) {
+                const double t = A[piv][c];
+                A[piv][c] = A[col][c];
+                A[col][c] = t;
+            }
+        const double inv = 1.0 / A[col][col];
+        for (int c = 0; c < 20; ++c) A[col][c] *= inv;
+        for (int r = 0; r < 10; ++r)
+            if (r != col) {
+                const double f = A[r][col];
+                if (f != 0.0)
+                    for (int c = 0; c < 20; ++c) A[r][c] -= f * A[col][c];
+            }
+    }
+    /* B(z): rows k = e - z f, l = g - z h, m = i - z j; entries = polynomials in z (ascending), degrees 3, 3, 4 */
+    double B[3][3][5];
+    for (int r = 0; r < 3; ++r) {
+        const double* e = &A[4 + 2 * r][10];
+        const double* f = &A[5 + 2 * r][10];
+        B[r][0][0] = e[2];  B[r][0][1] = e[1] - f[2];  B[r][0][2] = e[0] - f[1];  B[r][0][3] = -f[0];  B[r][0][4] = 0.0;
+        B[r][1][0] = e[5];  B[r][1][1] = e[4] - f[5];  B[r][1][2] = e[3] - f[4];  B[r][1][3] = -f[3];  B[r][1][4] = 0.0;
+        B[r][2][0] = e[9];  B[r][2][1] = e[8] - f[9];  B[r][2][2] = e[7] - f[8];  B[r][2][3] = e[6] - f[7];  B[r][2][4] = -f[6];
+    }
+    double poly[11];
+    for (int k = 0; k <= 10; ++k) poly[k] = 0.0;
+    {
+        static const int cyc[3][2] = {{1, 2}, {2, 0}, {0, 1}};  /* cofactor expansion along row 0: columns (c1, c2) of rows 1, 2 */
+        for (int c0 = 0; c0 < 3; ++c0) {
+            const int c1 = cyc[c0][0], c2 = cyc[c0][1];
+            const int d1 = c1 == 2 ? 4 : 3, d2 = c2 == 2 ? 4 : 3, d0 = c0 == 2 ? 4 : 3;
+            double m1[9], m2[9], minor[9], term[13];
+            poly_mul(B[1][c1], d1, B[2][c2], d2, m1);
+            poly_mul(B[1][c2], d2, B[2][c1], d1, m2);
+            for (int k = 0; k <= d1 + d2; ++k) minor[k] = m1[k] - m2[k];
+            poly_mul(B[0][c0], d0, minor, d1 + d2, term);
+            for (int k = 0; k <= d0 + d1 + d2 && k <= 10; ++k) poly[k] += term[k];
+        }
+    }
+    double roots[10];
+    const int nr = real_roots10(poly, roots);
+    int n = 0;
+    for (int r = 0; r < nr; ++r) {
+        const double z = roots[r];
+        double b[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double v = B[i][j][4];
+                for (int k = 3; k >= 0; --k) v = v * z + B[i][j][k];
+                b[i][j] = v;
+            }
+        /* [x y 1]^T spans the null space of b: two of its rows, the pair with the largest 2 x 2 determinant */
+        static const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+        int bp = 0;
+        double bd = 0.0;
+        for (int p = 0; p < 3; ++p) {
+            const double d = b[pr[p][0]][0] * b[pr[p][1]][1] - b[pr[p][0]][1] * b[pr[p][1]][0];
+            if (fabs(d) > fabs(bd)) bd = d, bp = p;
+        }
+        if (!(fabs(bd) > 0.0)) continue;
+        const int r0 = pr[bp][0], r1 = pr[bp][1];
+        double x = (b[r0][1] * b[r1][2] - b[r0][2] * b[r1][1]) / bd;
+        double y = (b[r0][2] * b[r1][0] - b[r0][0] * b[r1][2]) / bd;
+        double zz = z;
+        /* The root of a degree-10 polynomial carries the conditioning of the whole elimination (1e-4 seen on samples of a
+         * short baseline): three Gauss-Newton steps on the ten constraints themselves, in (x, y, z), bring the solution
+         * back to the accuracy of the input. (five-point.cpp returns the unpolished root.) */
+        for (int it = 0; it < 3; ++it) {
+            const double px[4] = {1.0, x, x * x, x * x * x}, py[4] = {1.0, y, y * y, y * y * y}, pz[4] = {1.0, zz, zz * zz, zz * zz * zz};
+            double JtJ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jtr[3] = {0, 0, 0};
+            for (int row = 0; row < 10; ++row) {
+                double rv = 0.0, g[3] = {0, 0, 0};
+                for (int ex = 0; ex <= 3; ++ex)
+                    for (int ey = 0; ex + ey <= 3; ++ey)
+                        for (int ez = 0; ex + ey + ez <= 3; ++ez) {
+                            const double cf = A0[row][mono_col(ex, ey, ez)];
+                            rv += cf * (px[ex] * py[ey]) * pz[ez];
+                            if (ex) g[0] += cf * (ex * px[ex - 1] * py[ey]) * pz[ez];
+                            if (ey) g[1] += cf * (px[ex] * (ey * py[ey - 1])) * pz[ez];
+                            if (ez) g[2] += cf * (px[ex] * py[ey]) * (ez * pz[ez - 1]);
+                        }
+                for (int u = 0; u < 3; ++u) {
+                    Jtr[u] += g[u] * rv;
+                    for (int v = 0; v < 3; ++v) JtJ[u][v] += g[u] * g[v];
+                }
+            }
+            /* 3 x 3 solve by cofactors */
+            const double c00 = JtJ[1][1] * JtJ[2][2] - JtJ[1][2] * JtJ[2][1], c01 = JtJ[1][2] * JtJ[2][0] - JtJ[1][0] * JtJ[2][2],
+                         c02 = JtJ[1][0] * JtJ[2][1] - JtJ[1][1] * JtJ[2][0];
+            const double dt = JtJ[0][0] * c00 + JtJ[0][1] * c01 + JtJ[0][2] * c02;
+            if (!(fabs(dt) > 0.0)) break;
+            const double c10 = JtJ[0][2] * JtJ[2][1] - JtJ[0][1] * JtJ[2][2], c11 = JtJ[0][0] * JtJ[2][2] - JtJ[0][2] * JtJ[2][0],
+                         c12 = JtJ[0][1] * JtJ[2][0] - JtJ[0][0] * JtJ[2][1];
+            const double c20 = JtJ[0][1] * JtJ[1][2] - JtJ[0][2] * JtJ[1][1], c21 = JtJ[0][2] * JtJ[1][0] - JtJ[0][0] * JtJ[1][2],
+                         c22 = JtJ[0][0] * JtJ[1][1] - JtJ[0][1] * JtJ[1][0];
+            const double dx = (c00 * Jtr[0] + c10 * Jtr[1] + c20 * Jtr[2]) / dt;
+            const double dy = (c01 * Jtr[0] + c11 * Jtr[1] + c21 * Jtr[2]) / dt;
+            const double dz = (c02 * Jtr[0] + c12 * Jtr[1] + c22 * Jtr[2]) / dt;
+            if (!(fabs(dx) + fabs(dy) + fabs(dz) < 1e300)) break;
+            x -= dx, y -= dy, zz -= dz;
+        }
+        double Ev[9], nrm = 0.0;
+        for (int e = 0; e < 9; ++e) {
+            Ev[e] = lin[e][0] * x + lin[e][1] * y + lin[e][2] * zz + lin[e][3];
+            nrm += Ev[e] * Ev[e];
+        }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0) || !(nrm < 1e300)) continue;
+        for (int e = 0; e < 9; ++e) E[9 * n + e] = Ev[e] / nrm;
+        ++n;
+    }
+    return n;
+}
+
+/* batch form with caller-supplied sample indices: kind 0 = homography4 (a -> b), kind 1 = essential5 (a = view 1, b = view 2).
+ * models: n_samples x max_models x 9 (max_models = 1 / 10), n_models per sample. */
+void oracle_solve_minimal(int kind, const double* a, const double* b, const double* K, int n_samples, const int32_t* idx,
+                          double* models, int32_t* n_models) {
+    const int m = kind == 0 ? 4 : 5, maxm = kind == 0 ? 1 : 10;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int s = 0; s < n_samples; ++s) {
+        double pa[10], pb[10];
+        for (int k = 0; k < m; ++k) {
+            pa[2 * k] = a[2 * idx[s * m + k]]; pa[2 * k + 1] = a[2 * idx[s * m + k] + 1];
+            pb[2 * k] = b[2 * idx[s * m + k]]; pb[2 * k + 1] = b[2 * idx[s * m + k] + 1];
+        }
+        double* out = models + (size_t)s * maxm * 9;
+        for (int k = 0; k < maxm * 9; ++k) out[k] = 0.0;
+        n_models[s] = kind == 0 ? oracle_homography4(pa, pb, out) : oracle_essential5(pa, pb, K, out);
+    }
+}

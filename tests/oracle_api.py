@@ -255,3 +255,20 @@ def score_hypotheses(kind, a, b, models, K=None, threshold=16.0):
                               vp(K4.ctypes.data) if K4 is not None else None, C.c_float(threshold), vp(err.ctypes.data),
                               vp(counts.ctypes.data), vp(med.ctypes.data))
     return err, counts, med
+
+
+def solve_minimal(kind, a, b, samples, K=None):
+    """oracle_solve_minimal (oracle/solve_oracle.c): kind "homography4" / "essential5"; same contract as eacham_solve_minimal."""
+    L = oracle.lib()
+    k, m, maxm = {"homography4": (0, 4, 1), "essential5": (1, 5, 10)}[kind]
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, 2)
+    idx = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, m)
+    K4 = None if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(4)
+    models = np.zeros((idx.shape[0], maxm, 9), dtype=np.float64)
+    counts = np.zeros(idx.shape[0], dtype=np.int32)
+    vp = C.c_void_p
+    L.oracle_solve_minimal.restype = None
+    L.oracle_solve_minimal(C.c_int(k), vp(a.ctypes.data), vp(b.ctypes.data), vp(K4.ctypes.data) if K4 is not None else None,
+                           C.c_int(idx.shape[0]), vp(idx.ctypes.data), vp(models.ctypes.data), vp(counts.ctypes.data))
+    return models, counts

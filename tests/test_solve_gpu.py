@@ -1,0 +1,63 @@
+"""GPU: eacham_solve_minimal (eacham_amd/csrc/solve.hip) — the minimal solvers of cv::findHomography / cv::findEssentialMat
+(ReconstructionManager.cpp:75, :57-61) for caller-supplied sample indices — against oracle/solve_oracle.c, BIT FOR BIT
+(both sides use only + - * / sqrt and no fused multiply-adds), and end to end with eacham_score_hypotheses as an LMedS /
+RANSAC loop whose sampling is this test's own (OpenCV's RNG stream is not reproducible: parity unpinned)."""
+import numpy as np
+import pytest
+
+from eacham_amd import capi, score, EachamError
+import oracle_api as O
+import score_cases as SC
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(rng, n, m, count):
+    return np.array([rng.choice(n, m, replace=False) for _ in range(count)], np.int32)
+
+
+def test_homography4_bit_identical_and_the_lmeds_loop_finds_the_plane(hip_ctx):
+    c = SC.two_view_case(n=600, seed=13, outliers=0.3, planar=True)
+    rng = np.random.default_rng(13)
+    samples = draw(rng, 600, 4, 100)                      # findHomography(..., LMEDS, 4.0, mask, 100, 0.999): 100 iterations
+    models, counts = score.solve_minimal(hip_ctx, "homography4", c["uv1"], c["uv2"], samples)
+    want, wcounts = O.solve_minimal("homography4", c["uv1"], c["uv2"], samples)
+    assert np.array_equal(counts, wcounts) and np.array_equal(models, want)
+    # the LMedS choice over those models: the winner is the plane's homography up to the pixel noise
+    _, inl, med = score.score_hypotheses(hip_ctx, "homography", c["uv1"], c["uv2"], models[:, 0], threshold=16.0, want_errors=False)
+    best = models[int(np.argmin(med)), 0].reshape(3, 3)
+    truth = c["H"][0].reshape(3, 3)
+    p = np.c_[c["uv1"], np.ones(600)] @ best.T
+    q = np.c_[c["uv1"], np.ones(600)] @ truth.T
+    good = ~c["bad"]
+    assert np.median(np.linalg.norm(p[good, :2] / p[good, 2:] - q[good, :2] / q[good, 2:], axis=1)) < 3.0
+    assert inl.max() > 0.5 * good.sum()
+
+
+def test_essential5_bit_identical_at_the_reference_iteration_count(hip_ctx):
+    c = SC.two_view_case(n=700, seed=21, outliers=0.25)
+    rng = np.random.default_rng(21)
+    samples = draw(rng, 700, 5, 1000)                     # findEssentialMat(..., LMEDS, 0.99, 4.0, 1000, mask): 1000 iterations
+    models, counts = score.solve_minimal(hip_ctx, "essential5", c["uv1"], c["uv2"], samples, c["K"])
+    want, wcounts = O.solve_minimal("essential5", c["uv1"], c["uv2"], samples, c["K"])
+    assert np.array_equal(counts, wcounts) and (counts % 2 == 0).all() and counts.max() <= 10
+    assert np.array_equal(models, want)
+    # every candidate of every sample scored in one call; the LMedS winner agrees with the true E on the inliers
+    cand = np.concatenate([m[:n] for m, n in zip(models, counts)])
+    _, inl, med = score.score_hypotheses(hip_ctx, "essential", c["uv1"], c["uv2"], cand, c["K"], threshold=16.0 / c["K"][0] ** 2,
+                                         want_errors=False)
+    best = cand[int(np.argmin(med))].reshape(3, 3)
+    Et = c["E"][0].reshape(3, 3) / np.linalg.norm(c["E"][0])
+    assert min(np.abs(best - Et).max(), np.abs(best + Et).max()) < 0.05
+    assert len(cand) > 2000
+
+
+def test_solver_arguments(hip_ctx):
+    pts = np.zeros((6, 2))
+    with pytest.raises(EachamError) as e:
+        score.solve_minimal(hip_ctx, "homography4", pts, pts, np.array([[0, 1, 2, 6]], np.int32))   # index out of range
+    assert e.value.code == capi.ERR_INVALID
+    m, k = score.solve_minimal(hip_ctx, "essential5", pts, pts, np.array([[0, 1, 2, 3, 4]], np.int32))  # degenerate: no model
+    assert k[0] == 0 and not m.any()
+    m, k = score.solve_minimal(hip_ctx, "homography4", pts, pts, np.zeros((0, 4), np.int32))
+    assert m.shape == (0, 1, 9)
