@@ -1,0 +1,307 @@
+// TwoViewHip.hpp — the rest of RecoverPoseTwoView's OpenCV calls on top of the C-ABI
+// (/root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:47-183):
+//
+//   cv::findEssentialMat(pts1, pts2, focal, pp, cv::LMEDS, 0.99, 4.0, 1000, mask)   :57-61   -> FindEssentialMat
+//   cv::findHomography(pts1, pts2, cv::LMEDS, 4.0, mask2, 100, 0.999)               :75      -> FindHomography
+//   cv::decomposeHomographyMat(H, K, Rs, ts, normals)                               :92      -> DecomposeHomographyMat
+//   cv::recoverPose(E, pts1, pts2, K, R, t, 50.0f, mask)                            :150     -> RecoverPose
+//
+// The robust estimators are the pair (eacham_solve_minimal: every minimal sample -> its models, one launch) +
+// (eacham_score_hypotheses: every model against every correspondence, one launch) with the LMedS rule of
+// LMeDSPointSetRegistrator::run in between: smallest median wins, sigma = 2.5 * 1.4826 * (1 + 5 / (n - m)) * sqrt(median),
+// inliers = err <= sigma^2 (ptsetreg.cpp). WHAT CANNOT BE REPRODUCED is OpenCV's sampling: getSubset draws from the
+// estimator's own cv::RNG stream; here the samples come from a counter-based generator seeded by the caller, so the
+// models offered to the median test differ from OpenCV's and only the STATISTICS of the result can agree (parity
+// unpinned; the tests hold the result against ground truth). Neither estimator is followed by OpenCV's final
+// Levenberg-Marquardt polish on the inliers (findHomography does one; findEssentialMat does not).
+// DecomposeHomographyMat returns the four {R, t, n} of the Faugeras decomposition — the solution set of
+// cv::decomposeHomographyMat (OpenCV computes it with the Malis-Vargas closed form and in another order: the reference
+// keeps "the first solution with the strictly largest number of good points", so the order only matters on ties).
+// RecoverPose follows cv::recoverPose: the four (R, t) of decomposeEssentialMat, every point triangulated for each
+// (eacham_two_view_points), a point is good iff its depth is positive and below distanceThresh in BOTH cameras, the
+// candidate with the most good points wins (first on ties).
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "TriangulatorHip.hpp"
+
+namespace eacham {
+namespace hip {
+
+typedef std::array<double, 9> Mat3;   // row-major
+typedef std::array<double, 3> Vec3;
+
+namespace twoview_detail {
+
+inline Mat3 mul(const Mat3& A, const Mat3& B) {
+    Mat3 C{};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+    return C;
+}
+inline Mat3 transpose(const Mat3& A) { return {A[0], A[3], A[6], A[1], A[4], A[7], A[2], A[5], A[8]}; }
+inline double det(const Mat3& A) {
+    return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+inline Vec3 cross(const Vec3& a, const Vec3& b) { return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; }
+inline double norm(const Vec3& a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+// A = U diag(S) V^T, S descending, U and V orthogonal (columns). One-sided Jacobi on the columns of A.
+inline void svd3(const Mat3& A, Mat3& U, Vec3& S, Mat3& V) {
+    double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) a[r][c] = A[3 * r + c];
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < 3; ++r) alpha += a[r][p] * a[r][p], beta += a[r][q] * a[r][q], gamma += a[r][p] * a[r][q];
+                off = std::max(off, std::fabs(gamma) / std::sqrt(alpha * beta + 1e-300));
+                if (gamma == 0.0) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    const double x = a[r][p], y = a[r][q];
+                    a[r][p] = c * x - s * y, a[r][q] = s * x + c * y;
+                    const double vx = v[r][p], vy = v[r][q];
+                    v[r][p] = c * vx - s * vy, v[r][q] = s * vx + c * vy;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double s[3];
+    int ord[3] = {0, 1, 2};
+    for (int c = 0; c < 3; ++c) s[c] = std::sqrt(a[0][c] * a[0][c] + a[1][c] * a[1][c] + a[2][c] * a[2][c]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (s[ord[j]] > s[ord[i]]) std::swap(ord[i], ord[j]);
+    Vec3 u[3];
+    for (int k = 0; k < 3; ++k) {
+        const int c = ord[k];
+        S[k] = s[c];
+        for (int r = 0; r < 3; ++r) V[3 * r + k] = v[r][c];
+        if (s[c] > 1e-12 * s[ord[0]] && s[c] > 0.0)
+            u[k] = {a[0][c] / s[c], a[1][c] / s[c], a[2][c] / s[c]};
+        else if (k == 2)
+            u[k] = cross(u[0], u[1]);  // a rank-2 matrix (an essential matrix): complete the basis
+        else
+            u[k] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, 0.0};
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 3; ++r) U[3 * r + k] = u[k][r];
+}
+
+// counter-based sample indices (splitmix64): sample s = m distinct indices out of n
+inline uint64_t mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+inline std::vector<int32_t> draw_samples(int n, int m, int count, uint64_t seed) {
+    std::vector<int32_t> idx((size_t)count * m);
+    for (int s = 0; s < count; ++s) {
+        uint64_t ctr = 0;
+        for (int k = 0; k < m;) {
+            const int v = (int)(mix(seed * 0x100000001B3ull + ((uint64_t)s << 20) + ctr++) % (uint64_t)n);
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup = dup || idx[(size_t)s * m + j] == v;
+            if (!dup) idx[(size_t)s * m + k++] = v;
+        }
+    }
+    return idx;
+}
+
+struct RobustModel {
+    Mat3 model{};
+    std::vector<uint8_t> mask;   // inliers of the LMedS rule
+    int inliers = 0;
+    float median = std::numeric_limits<float>::quiet_NaN();
+    bool ok = false;
+};
+
+// the LMedS loop: solve all samples, score all models, keep the smallest median, classify by sigma
+inline RobustModel lmeds(Context& ctx, int solve_kind, int score_kind, int m, const std::vector<double>& uv1, const std::vector<double>& uv2,
+                         const double* K4, int iterations, uint64_t seed) {
+    RobustModel out;
+    const int n = (int)(uv1.size() / 2), maxm = solve_kind == EACHAM_SOLVE_ESSENTIAL5 ? 10 : 1;
+    if (n < m || uv2.size() != uv1.size()) return out;
+    const std::vector<int32_t> idx = draw_samples(n, m, iterations, seed);
+    std::vector<double> models((size_t)iterations * maxm * 9);
+    std::vector<int32_t> counts(iterations);
+    ctx.check(eacham_solve_minimal(ctx.get(), solve_kind, n, uv1.data(), uv2.data(), K4, iterations, idx.data(), models.data(), counts.data()));
+    std::vector<double> cand;
+    for (int s = 0; s < iterations; ++s)
+        for (int k = 0; k < counts[s]; ++k) cand.insert(cand.end(), &models[((size_t)s * maxm + k) * 9], &models[((size_t)s * maxm + k) * 9] + 9);
+    const int nm = (int)(cand.size() / 9);
+    if (nm == 0) return out;
+    std::vector<float> med(nm);
+    std::vector<int32_t> inl(nm);
+    ctx.check(eacham_score_hypotheses(ctx.get(), score_kind, n, uv1.data(), uv2.data(), nm, cand.data(), K4, 0.0f, nullptr, inl.data(), med.data()));
+    int best = -1;
+    for (int k = 0; k < nm; ++k)
+        if (med[k] == med[k] && (best < 0 || med[k] < med[best])) best = k;
+    if (best < 0) return out;
+    for (int e = 0; e < 9; ++e) out.model[e] = cand[(size_t)best * 9 + e];
+    out.median = med[best];
+    // sigma of LMeDSPointSetRegistrator::run, then the errors of the winner alone
+    const double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / std::max(n - m, 1)) * std::sqrt((double)med[best]);
+    const float thr = (float)std::max(sigma * sigma, 1e-300);
+    std::vector<float> err(n);
+    int32_t cnt = 0;
+    float m1 = 0;
+    ctx.check(eacham_score_hypotheses(ctx.get(), score_kind, n, uv1.data(), uv2.data(), 1, out.model.data(), K4, thr, err.data(), &cnt, &m1));
+    out.mask.resize(n);
+    for (int i = 0; i < n; ++i) out.mask[i] = err[i] <= thr ? 1 : 0;
+    out.inliers = cnt;
+    out.ok = true;
+    return out;
+}
+
+}  // namespace twoview_detail
+
+using twoview_detail::RobustModel;
+
+// cv::findEssentialMat(pts1, pts2, focal, pp, LMEDS, prob, threshold, maxIters, mask): pixels in, K4 = fx fy cx cy
+// (the reference passes focal = K(0,0) and pp = (K(0,2), K(1,2)): fx = fy = focal). The model is a unit-norm E.
+inline RobustModel FindEssentialMat(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2, const double* K4,
+                                    int maxIters = 1000, uint64_t seed = 12345) {
+    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_ESSENTIAL5, EACHAM_SCORE_ESSENTIAL, 5, uv1, uv2, K4, maxIters, seed);
+}
+// cv::findHomography(pts1, pts2, LMEDS, ransacReprojThreshold, mask, maxIters, confidence). The model has H[8] = 1.
+inline RobustModel FindHomography(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2, int maxIters = 100,
+                                  uint64_t seed = 12345) {
+    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_HOMOGRAPHY4, EACHAM_SCORE_HOMOGRAPHY, 4, uv1, uv2, nullptr, maxIters, seed);
+}
+
+// cv::decomposeEssentialMat: E = U diag(1, 1, 0) V^T -> R1 = U W V^T, R2 = U W^T V^T, t = U[:, 2] (|t| = 1)
+inline void DecomposeEssentialMat(const Mat3& E, Mat3& R1, Mat3& R2, Vec3& t) {
+    using namespace twoview_detail;
+    Mat3 U, V;
+    Vec3 S;
+    svd3(E, U, S, V);
+    if (det(U) < 0) for (double& x : U) x = -x;
+    if (det(V) < 0) for (double& x : V) x = -x;
+    const Mat3 W{0, 1, 0, -1, 0, 0, 0, 0, 1}, Vt = transpose(V);
+    R1 = mul(mul(U, W), Vt);
+    R2 = mul(mul(U, transpose(W)), Vt);
+    t = {U[2], U[5], U[8]};
+}
+
+struct RecoveredPose {
+    Mat3 R{};
+    Vec3 t{};
+    int good = 0;
+    std::vector<uint8_t> mask;
+    std::array<double, 16> transform() const {  // camera-1 -> camera-2, row-major 4x4 (ConvertToTransform of the reference)
+        return {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2], 0, 0, 0, 1};
+    }
+};
+
+// cv::recoverPose(E, pts1, pts2, K, R, t, distanceThresh, mask): K = 3x3 row-major
+inline RecoveredPose RecoverPose(Context& ctx, const Mat3& E, const std::vector<double>& uv1, const std::vector<double>& uv2,
+                                 const double* K, double distanceThresh = 50.0, const std::vector<uint8_t>* maskIn = nullptr) {
+    Mat3 R1, R2;
+    Vec3 t;
+    DecomposeEssentialMat(E, R1, R2, t);
+    const Mat3* Rs[4] = {&R1, &R2, &R1, &R2};
+    const double sg[4] = {1, 1, -1, -1};
+    std::vector<double> T(4 * 16);
+    for (int k = 0; k < 4; ++k) {
+        RecoveredPose p;
+        p.R = *Rs[k];
+        p.t = {sg[k] * t[0], sg[k] * t[1], sg[k] * t[2]};
+        const auto M = p.transform();
+        std::copy(M.begin(), M.end(), T.begin() + 16 * k);
+    }
+    const int n = (int)(uv1.size() / 2);
+    const double K4[4] = {K[0], K[4], K[2], K[5]};
+    std::vector<double> pts((size_t)12 * n + 3);
+    std::vector<uint8_t> keep((size_t)4 * n + 1);
+    std::vector<int32_t> counts(5);
+    // every (candidate, point) triangulated on the device; the cheirality rule of recoverPose is applied here
+    ctx.check(eacham_two_view_points(ctx.get(), n, uv1.data(), uv2.data(), K4, 4, T.data(), std::numeric_limits<float>::max(), 0.0f, 0,
+                                     pts.data(), keep.data(), counts.data()));
+    RecoveredPose best;
+    for (int k = 0; k < 4; ++k) {
+        const double* M = &T[16 * k];
+        std::vector<uint8_t> mask(n);
+        int good = 0;
+        for (int i = 0; i < n; ++i) {
+            const double* X = &pts[3 * ((size_t)k * n + i)];
+            const double z1 = X[2], z2 = M[8] * X[0] + M[9] * X[1] + M[10] * X[2] + M[11];
+            const bool ok = (!maskIn || (*maskIn)[i]) && z1 > 0 && z1 < distanceThresh && z2 > 0 && z2 < distanceThresh;
+            mask[i] = ok;
+            good += ok;
+        }
+        if (k == 0 || good > best.good) {
+            best.R = *Rs[k];
+            best.t = {sg[k] * t[0], sg[k] * t[1], sg[k] * t[2]};
+            best.good = good;
+            best.mask = std::move(mask);
+        }
+    }
+    return best;
+}
+
+struct HomographyMotion {
+    Mat3 R{};
+    Vec3 t{}, n{};   // H_normalised ~ R + t n^T, |n| = 1, t scaled by the plane distance
+};
+
+// cv::decomposeHomographyMat(H, K, rotations, translations, normals): K = 3x3 row-major. Up to four solutions.
+inline std::vector<HomographyMotion> DecomposeHomographyMat(const Mat3& H, const double* K) {
+    using namespace twoview_detail;
+    const Mat3 Km{K[0], K[1], K[2], K[3], K[4], K[5], K[6], K[7], K[8]};
+    // K^-1 for an upper-triangular camera matrix
+    const double fx = K[0], s = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const Mat3 Ki{1 / fx, -s / (fx * fy), (s * cy - cx * fy) / (fx * fy), 0, 1 / fy, -cy / fy, 0, 0, 1};
+    Mat3 Hn = mul(mul(Ki, H), Km);
+    Mat3 U, V;
+    Vec3 S;
+    svd3(Hn, U, S, V);
+    std::vector<HomographyMotion> out;
+    if (!(S[1] > 0)) return out;
+    for (double& x : Hn) x /= S[1];                 // the middle singular value of a Euclidean homography is 1
+    const double s1 = S[0] / S[1], s3 = S[2] / S[1];
+    // H is only known up to scale AND sign: a Euclidean homography has det > 0 (both cameras see the plane from the same
+    // side), so a negative determinant means the scale was negative — flip Hn and, with it, U (Hn = U S V^T stays true)
+    if (det(U) * det(V) < 0) {
+        for (double& x : Hn) x = -x;
+        for (double& x : U) x = -x;
+    }
+    const Mat3 Vt = transpose(V);
+    if (s1 - s3 < 1e-12) {  // pure rotation: one solution, t = 0
+        HomographyMotion m;
+        m.R = Hn;
+        m.n = {0, 0, 1};
+        out.push_back(m);
+        return out;
+    }
+    const double a = std::sqrt(std::max(0.0, (s1 * s1 - 1.0) / (s1 * s1 - s3 * s3)));
+    const double b = std::sqrt(std::max(0.0, (1.0 - s3 * s3) / (s1 * s1 - s3 * s3)));
+    const double sth = std::sqrt(std::max(0.0, (s1 * s1 - 1.0) * (1.0 - s3 * s3))) / (s1 + s3);
+    const double cth = (1.0 + s1 * s3) / (s1 + s3);
+    for (int e1 = 1; e1 >= -1; e1 -= 2)
+        for (int e3 = 1; e3 >= -1; e3 -= 2) {
+            const double x1 = e1 * a, x3 = e3 * b, st = e1 * e3 * sth;
+            const Mat3 Rp{cth, 0, -st, 0, 1, 0, st, 0, cth};
+            const Vec3 tp{(s1 - s3) * x1, 0, -(s1 - s3) * x3}, np{x1, 0, x3};
+            HomographyMotion m;
+            m.R = mul(mul(U, Rp), Vt);              // det U det V = +1 here: a proper rotation
+            m.t = {U[0] * tp[0] + U[1] * tp[1] + U[2] * tp[2], U[3] * tp[0] + U[4] * tp[1] + U[5] * tp[2], U[6] * tp[0] + U[7] * tp[1] + U[8] * tp[2]};
+            m.n = {V[0] * np[0] + V[1] * np[1] + V[2] * np[2], V[3] * np[0] + V[4] * np[1] + V[5] * np[2], V[6] * np[0] + V[7] * np[1] + V[8] * np[2]};
+            out.push_back(m);
+        }
+    return out;
+}
+
+}  // namespace hip
+}  // namespace eacham

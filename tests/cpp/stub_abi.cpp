@@ -191,4 +191,21 @@ int eacham_score_hypotheses(eacham_ctx*, int kind, int n, const double* a, const
     return EACHAM_OK;
 }
 
+
+int eacham_solve_minimal(eacham_ctx* c, int kind, int n_points, const double* a, const double* b, const double*, int n_samples,
+                         const int32_t* idx, double* models, int32_t* n_models) {
+    // one fake model per sample, built from the sample's first correspondence (content-dependent, deterministic)
+    const int m = kind == 0 ? 4 : 5, maxm = kind == 0 ? 1 : 10;
+    for (int s = 0; s < n_samples; ++s) {
+        for (int k = 0; k < m; ++k)
+            if (idx[s * m + k] < 0 || idx[s * m + k] >= n_points) return fail(c, EACHAM_ERR_INVALID, "sample index out of range");
+        double* out = models + (size_t)s * maxm * 9;
+        for (int k = 0; k < maxm * 9; ++k) out[k] = 0.0;
+        const int i = idx[s * m];
+        const double v[9] = {1, 0, a[2 * i] - b[2 * i], 0, 1, a[2 * i + 1] - b[2 * i + 1], 0, 0, 1};
+        for (int k = 0; k < 9; ++k) out[k] = v[k];
+        n_models[s] = 1;
+    }
+    return EACHAM_OK;
+}
 }  // extern "C"

@@ -1,0 +1,98 @@
+// Test driver for include/eacham/TwoViewHip.hpp.
+//   twoview_driver decompose   < "H(9) K(9)" or "E(9)" lines     -> prints the decompositions (host-only math)
+//   twoview_driver pipeline <in.bin> <out.bin>                    -> FindEssentialMat / FindHomography / RecoverPose /
+//                                                                    DecomposeHomographyMat through the C-ABI (GPU)
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "eacham/TwoViewHip.hpp"
+
+using namespace eacham::hip;
+
+template <class T> static std::vector<T> rd(std::ifstream& f, size_t n) {
+    std::vector<T> v(n);
+    f.read((char*)v.data(), sizeof(T) * n);
+    return v;
+}
+template <class T> static void wr(std::ofstream& f, const std::vector<T>& v) {
+    int64_t n = (int64_t)v.size();
+    f.write((char*)&n, sizeof(n));
+    f.write((const char*)v.data(), sizeof(T) * v.size());
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && !strcmp(argv[1], "decompose")) {
+        std::string kind;
+        while (std::cin >> kind) {
+            if (kind == "H") {
+                Mat3 H;
+                double K[9];
+                for (double& x : H) std::cin >> x;
+                for (double& x : K) std::cin >> x;
+                const auto sols = DecomposeHomographyMat(H, K);
+                std::printf("H %zu\n", sols.size());
+                for (const auto& m : sols) {
+                    for (double x : m.R) std::printf("%.17g ", x);
+                    for (double x : m.t) std::printf("%.17g ", x);
+                    for (double x : m.n) std::printf("%.17g ", x);
+                    std::printf("\n");
+                }
+            } else {
+                Mat3 E, R1, R2;
+                Vec3 t;
+                for (double& x : E) std::cin >> x;
+                DecomposeEssentialMat(E, R1, R2, t);
+                std::printf("E\n");
+                for (double x : R1) std::printf("%.17g ", x);
+                for (double x : R2) std::printf("%.17g ", x);
+                for (double x : t) std::printf("%.17g ", x);
+                std::printf("\n");
+            }
+        }
+        return 0;
+    }
+    if (argc < 4) return 2;
+    std::ifstream in(argv[2], std::ios::binary);
+    std::ofstream out(argv[3], std::ios::binary);
+    Context ctx(0);
+    for (int scene = 0; scene < 2; ++scene) {   // a general scene (E branch), a planar one (H branch)
+        int32_t n;
+        in.read((char*)&n, sizeof(n));
+        const auto uv1 = rd<double>(in, 2 * (size_t)n), uv2 = rd<double>(in, 2 * (size_t)n), K9 = rd<double>(in, 9);
+        const double K4[4] = {K9[0], K9[4], K9[2], K9[5]};
+        const RobustModel Em = FindEssentialMat(ctx, uv1, uv2, K4, 1000, 7);
+        const RobustModel Hm = FindHomography(ctx, uv1, uv2, 100, 7);
+        std::vector<double> meta{(double)Em.ok, (double)Em.inliers, (double)Em.median, (double)Hm.ok, (double)Hm.inliers, (double)Hm.median};
+        wr(out, meta);
+        wr(out, std::vector<double>(Em.model.begin(), Em.model.end()));
+        wr(out, std::vector<double>(Hm.model.begin(), Hm.model.end()));
+        wr(out, Em.mask);
+        wr(out, Hm.mask);
+        const RecoveredPose rp = RecoverPose(ctx, Em.model, uv1, uv2, K9.data(), 50.0, &Em.mask);
+        std::vector<double> pose(rp.R.begin(), rp.R.end());
+        pose.insert(pose.end(), rp.t.begin(), rp.t.end());
+        pose.push_back(rp.good);
+        wr(out, pose);
+        // the homography branch of RecoverPoseTwoView (:92-150): decompose, triangulate every match under each solution, best count
+        const auto sols = DecomposeHomographyMat(Hm.model, K9.data());
+        std::vector<double> T;
+        for (const auto& m : sols) {
+            const double M[16] = {m.R[0], m.R[1], m.R[2], m.t[0], m.R[3], m.R[4], m.R[5], m.t[1], m.R[6], m.R[7], m.R[8], m.t[2], 0, 0, 0, 1};
+            T.insert(T.end(), M, M + 16);
+        }
+        const auto tv = TwoViewPoints(ctx, uv1, uv2, K9.data(), T, 4.0f, 0.0174533f, true);
+        const int best = BestTwoViewSolution(tv);
+        std::vector<double> hb{(double)sols.size(), (double)best};
+        for (const auto& s : tv) hb.push_back((double)s.matches.size());
+        for (const auto& m : sols) {
+            hb.insert(hb.end(), m.R.begin(), m.R.end());
+            hb.insert(hb.end(), m.t.begin(), m.t.end());
+        }
+        wr(out, hb);
+    }
+    std::printf("twoview driver ok\n");
+    return 0;
+}

@@ -8,7 +8,7 @@ def skew(t):
     return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
 
 
-def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False):
+def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False, facing=False):
     """Two cameras of a synth scene seeing n landmarks: pixel correspondences (float32-valued, as cv::Point2f),
     the true E / H and n_models candidates around them (the first is the truth, the rest perturbed, some garbage)."""
     sc = synth.make_scene(2, n, 2, seed=seed, pixel_noise=0.7)
@@ -16,7 +16,10 @@ def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False):
     T1, T2 = sc["T_true"][0], sc["T_true"][1]
     X = sc["points_true"].copy()
     if planar:
-        X[:, 2] = 0.05 * X[:, 0] - 0.03 * X[:, 1]          # points on a plane: a homography maps view 1 to view 2
+        if facing:                                          # a plane both cameras (at x = 4) see from the same side
+            X[:, 0] = 0.05 * X[:, 1] - 0.03 * X[:, 2]
+        else:                                               # points on a plane: a homography maps view 1 to view 2
+            X[:, 2] = 0.05 * X[:, 0] - 0.03 * X[:, 1]       # (the cameras sit on opposite sides of this one: fine for scoring only)
     rng = np.random.default_rng(seed)
 
     def proj(T):
@@ -46,7 +49,7 @@ def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False):
         Es.append(E + s * rng.normal(size=(3, 3)) if m % 7 else rng.normal(size=(3, 3)))
         Hm = H + s * rng.normal(size=(3, 3)) * np.array([[1, 1, 50], [1, 1, 50], [1e-3, 1e-3, 0]])
         Hs.append(Hm / Hm[2, 2])
-    return {"K": K, "uv1": uv1, "uv2": uv2, "E": np.array(Es).reshape(-1, 9), "H": np.array(Hs).reshape(-1, 9), "bad": bad}
+    return {"K": K, "uv1": uv1, "uv2": uv2, "E": np.array(Es).reshape(-1, 9), "H": np.array(Hs).reshape(-1, 9), "bad": bad, "T21": T21}
 
 
 def pnp_case(n=500, n_models=64, seed=11, outliers=0.3):
