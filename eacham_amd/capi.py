@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
     L.eacham_two_view_points.argtypes = [vp, i32, vp, vp, vp, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp]
     L.eacham_score_hypotheses.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp]
     L.eacham_solve_minimal.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.eacham_solve_pnp.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
     L.eacham_graph_best_pair.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.eacham_reprojection_errors.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.eacham_profile_enable.argtypes = [vp, i32]

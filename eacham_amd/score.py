@@ -58,3 +58,19 @@ def solve_minimal(ctx, kind: str, a, b, samples, K=None):
                                                vp(K4.ctypes.data) if K4 is not None else None, idx.shape[0], vp(idx.ctypes.data),
                                                vp(models.ctypes.data), vp(counts.ctypes.data)))
     return models, counts
+
+
+def solve_pnp(ctx, object_points, image_points, K, samples):
+    """eacham_solve_pnp: EPnP on every row of `samples` (>= 5 point indices per row) -> (models [n_samples, 12] = R | t, ok [n_samples])."""
+    X = np.ascontiguousarray(object_points, dtype=np.float64).reshape(-1, 3)
+    uv = np.ascontiguousarray(image_points, dtype=np.float64).reshape(-1, 2)
+    idx = np.ascontiguousarray(samples, dtype=np.int32)
+    if idx.ndim != 2 or X.shape[0] != uv.shape[0]:
+        raise ValueError("samples must be [n_samples, sample_size]; point lists must agree")
+    K4 = np.ascontiguousarray(K, dtype=np.float64).reshape(4)
+    models = np.zeros((idx.shape[0], 12), dtype=np.float64)
+    ok = np.zeros(idx.shape[0], dtype=np.int32)
+    vp = C.c_void_p
+    ctx._check(capi.lib().eacham_solve_pnp(ctx.handle, X.shape[0], vp(X.ctypes.data), vp(uv.ctypes.data), vp(K4.ctypes.data), idx.shape[1],
+                                           idx.shape[0], vp(idx.ctypes.data), vp(models.ctypes.data), vp(ok.ctypes.data)))
+    return models, ok

@@ -347,6 +347,17 @@ int eacham_score_hypotheses(eacham_ctx* ctx, int kind, int n_points, const doubl
 int eacham_solve_minimal(eacham_ctx* ctx, int kind, int n_points, const double* a, const double* b, const double* K,
                          int n_samples, const int32_t* sample_idx, double* models, int32_t* n_models);
 
+/* EPnP, the solver inside cv::solvePnPRansac(..., 10000, 4.0f, 0.999f, inliers, cv::SOLVEPNP_EPNP)
+ * (/root/reference/modules/sfm/reconstruction/ReconstructionManager.cpp:227-228): OpenCV runs it on 5-point samples inside
+ * the RANSAC loop and once more on the inliers of the winning model. Here every row of sample_idx (sample_size >= 5 indices
+ * into the n_points object / image points) is one EPnP problem, one launch for the whole list: 10 000 rows of 5 for the
+ * loop, one row of all inliers for the refit. models: n_samples x 12 = R (row-major) | t with x_cam = R X + t — the layout
+ * eacham_score_hypotheses(kind PNP) scores; n_models[s] = 1, or 0 (model zeroed) for a degenerate sample (coplanar or
+ * coincident points: the four-control-point form needs volume). K = fx fy cx cy, no distortion (the reference passes zeros).
+ * Bit-identical with oracle/solve_oracle.c's oracle_solve_pnp. */
+int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* object_points, const double* image_points, const double* K,
+                     int sample_size, int n_samples, const int32_t* sample_idx, double* models, int32_t* n_models);
+
 /* ---- view-graph query on the CSR match graph --------------------------
  * Graph::GetBestPairForValid (/root/reference/modules/sfm/data/Graph.h:59-106) evaluated directly on the
  * wire format of eacham_match_all_pairs: pair p with counts[p] > 0 is the factor f1 -> f2 with matches

@@ -19,6 +19,15 @@
  *                matrix in Nister's monomial order, Gauss-Jordan, the 3 x 3 polynomial matrix B(z), det B = degree-10
  *                polynomial, its real roots (Durand-Kerner on the monic polynomial, Newton polish), x and y from B(z).
  *                five-point.cpp finds the roots with cv::solvePoly and the null space with cv::SVD: same solution set.
+ *   epnp         m >= 5 object points + pixels + K -> R | t: the minimal-set kernel (5 points) and the all-inlier refit of
+ *                cv::solvePnPRansac(..., 10000, 4.0f, 0.999f, inliers, cv::SOLVEPNP_EPNP)   ReconstructionManager.cpp:227-228
+ *                restated from the EPnP paper (Lepetit, Moreno-Noguer, Fua, IJCV 2009) and the structure of OpenCV's epnp.cpp:
+ *                four control points (centroid + principal axes), barycentric coordinates, M^T M of the 2m x 12 projection
+ *                system, its four smallest eigenvectors, the 6 x 10 control-point distance system, three linearised starts
+ *                (4 / 3 / 5 unknown products) each polished by five Gauss-Newton steps, absolute orientation, and the start
+ *                with the smallest reprojection error wins. Own choices where the result set is the same: Jacobi instead of
+ *                cv::SVD, Householder least squares, Horn's quaternion form for the absolute orientation (epnp.cpp: SVD of
+ *                the 3 x 3 correlation with a row flip for det < 0); coplanar sets are reported degenerate (n_models = 0).
  * Products and sums are NOT contracted into FMAs.
  */
 #pragma GCC optimize("fp-contract=off")
@@ -403,6 +412,241 @@ int oracle_essential5(const double* p1, const double* p2, const double* K, doubl
         ++n;
     }
     return n;
+}
+
+/* least squares min |A x - b| for an r x c system (r <= 6, c <= 5), Householder QR on a copy; returns 0 if a column collapses */
+static int lsq_small(int r, int c, const double* A, const double* b, double* x) {
+    double Q[6 * 6];  /* the r x (c + 1) working array [A | b] */
+    for (int i = 0; i < r; ++i) {
+        for (int j = 0; j < c; ++j) Q[i * 6 + j] = A[i * c + j];
+        Q[i * 6 + c] = b[i];
+    }
+    for (int j = 0; j < c; ++j) {
+        double nrm = 0.0;
+        for (int i = j; i < r; ++i) nrm += Q[i * 6 + j] * Q[i * 6 + j];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0)) return 0;
+        const double alpha = Q[j * 6 + j] > 0.0 ? -nrm : nrm;
+        double v[6];
+        for (int i = j; i < r; ++i) v[i] = Q[i * 6 + j];
+        v[j] -= alpha;
+        double vv = 0.0;
+        for (int i = j; i < r; ++i) vv += v[i] * v[i];
+        if (!(vv > 0.0)) return 0;
+        for (int k = j; k <= c; ++k) {
+            double d = 0.0;
+            for (int i = j; i < r; ++i) d += v[i] * Q[i * 6 + k];
+            d = 2.0 * d / vv;
+            for (int i = j; i < r; ++i) Q[i * 6 + k] -= d * v[i];
+        }
+        Q[j * 6 + j] = alpha;
+    }
+    for (int j = c - 1; j >= 0; --j) {
+        double s = Q[j * 6 + c];
+        for (int k = j + 1; k < c; ++k) s -= Q[j * 6 + k] * x[k];
+        x[j] = s / Q[j * 6 + j];
+    }
+    for (int j = 0; j < c; ++j)
+        if (!(fabs(x[j]) < 1e300)) return 0;
+    return 1;
+}
+
+/* EPnP (Lepetit, Moreno-Noguer, Fua 2009) on the m >= 4 points idx[0..m) of obj (n x 3) / img (n x 2), K = fx fy cx cy.
+ * Rt = R (row-major) | t of x_cam = R X + t. Every pass over the points recomputes the barycentric coordinates, so the
+ * working set does not grow with m (the RANSAC kernel calls it with m = 5, the final refit with all inliers).
+ * Returns 1, or 0 for a degenerate point set (coplanar / coincident points: the 4-control-point form needs volume). */
+int oracle_epnp(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt) {
+    if (m < 4) return 0;
+    const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
+    /* control points: centroid + principal axes scaled by the spread along them */
+    double c0[3] = {0, 0, 0};
+    for (int k = 0; k < m; ++k)
+        for (int e = 0; e < 3; ++e) c0[e] += obj[3 * (size_t)idx[k] + e];
+    for (int e = 0; e < 3; ++e) c0[e] /= (double)m;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9], w3[3];
+    for (int k = 0; k < m; ++k) {
+        double d[3];
+        for (int e = 0; e < 3; ++e) d[e] = obj[3 * (size_t)idx[k] + e] - c0[e];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) C[3 * i + j] += d[i] * d[j];
+    }
+    jacobi_eig(3, C, V3, w3);
+    double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
+    wmax = wmax > w3[2] ? wmax : w3[2];
+    double ax[3][3], sc[3];  /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
+    for (int k = 0; k < 3; ++k) {
+        if (!(w3[k] > 1e-12 * wmax) || !(wmax > 0.0)) return 0;
+        sc[k] = sqrt(w3[k] / (double)m);
+        for (int e = 0; e < 3; ++e) ax[k][e] = V3[3 * e + k];
+    }
+#define EPNP_ALPHAS(i, al)                                                                        \
+    {                                                                                             \
+        double d_[3];                                                                             \
+        for (int e_ = 0; e_ < 3; ++e_) d_[e_] = obj[3 * (size_t)(i) + e_] - c0[e_];               \
+        for (int k_ = 0; k_ < 3; ++k_) (al)[k_ + 1] = (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
+        (al)[0] = 1.0 - (al)[1] - (al)[2] - (al)[3];                                              \
+    }
+    /* M^T M of the 2m x 12 projection system  sum_j alpha_j (fu Xc_j + (uc - u) Zc_j) = 0, same with v */
+    double MtM[144], V[144], w[12];
+    for (int i = 0; i < 144; ++i) MtM[i] = 0.0;
+    for (int k = 0; k < m; ++k) {
+        double al[4], r1[12], r2[12];
+        EPNP_ALPHAS(idx[k], al);
+        const double du = uc - img[2 * (size_t)idx[k]], dv = vc - img[2 * (size_t)idx[k] + 1];
+        for (int j = 0; j < 4; ++j) {
+            r1[3 * j] = al[j] * fu, r1[3 * j + 1] = 0.0, r1[3 * j + 2] = al[j] * du;
+            r2[3 * j] = 0.0, r2[3 * j + 1] = al[j] * fv, r2[3 * j + 2] = al[j] * dv;
+        }
+        for (int i = 0; i < 12; ++i)
+            for (int j = i; j < 12; ++j) MtM[12 * i + j] += r1[i] * r1[j] + r2[i] * r2[j];
+    }
+    for (int i = 0; i < 12; ++i)
+        for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
+    jacobi_eig(12, MtM, V, w);
+    int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
+    for (int k = 0; k < 4; ++k) {
+        int best = -1;
+        for (int i = 0; i < 12; ++i) {
+            int used = 0;
+            for (int q = 0; q < k; ++q) used |= ord[q] == i;
+            if (!used && (best < 0 || w[i] < w[best])) best = i;
+        }
+        ord[k] = best;
+    }
+    double ev[4][12];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 12; ++i) ev[k][i] = V[12 * i + ord[k]];
+    /* the six control-point distance constraints, quadratic in beta: L (6 x 10) over [b00 b01 b11 b02 b12 b22 b03 b13 b23 b33] */
+    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    double cw[4][3];
+    for (int e = 0; e < 3; ++e) {
+        cw[0][e] = c0[e];
+        for (int k = 0; k < 3; ++k) cw[k + 1][e] = c0[e] + sc[k] * ax[k][e];
+    }
+    double L[6][10], rho[6];
+    for (int p = 0; p < 6; ++p) {
+        double dv[4][3];
+        for (int k = 0; k < 4; ++k)
+            for (int e = 0; e < 3; ++e) dv[k][e] = ev[k][3 * pa[p] + e] - ev[k][3 * pb[p] + e];
+        int col = 0;
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i <= j; ++i) {
+                const double d = dv[i][0] * dv[j][0] + dv[i][1] * dv[j][1] + dv[i][2] * dv[j][2];
+                L[p][col++] = i == j ? d : 2.0 * d;
+            }
+        rho[p] = 0.0;
+        for (int e = 0; e < 3; ++e) rho[p] += (cw[pa[p]][e] - cw[pb[p]][e]) * (cw[pa[p]][e] - cw[pb[p]][e]);
+    }
+    double best_err = -1.0;
+    for (int variant = 0; variant < 3; ++variant) {
+        /* linearised start: the products b_i b_j that involve only the first 1 / 2 / 3 null vectors' leading terms */
+        const int ncol[3] = {4, 3, 5};
+        const int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
+        double A[30], x[5], beta[4] = {0, 0, 0, 0};
+        for (int p = 0; p < 6; ++p)
+            for (int j = 0; j < ncol[variant]; ++j) A[p * ncol[variant] + j] = L[p][cols[variant][j]];
+        if (!lsq_small(6, ncol[variant], A, rho, x)) continue;
+        if (variant == 0) {  /* x = b00 b01 b02 b03 */
+            const double s = x[0] < 0.0 ? -1.0 : 1.0;
+            beta[0] = sqrt(s * x[0]);
+            if (!(beta[0] > 0.0)) continue;
+            for (int k = 1; k < 4; ++k) beta[k] = s * x[k] / beta[0];
+        } else {             /* x = b00 b01 b11 (b02 b12) */
+            const double s = x[0] < 0.0 ? -1.0 : 1.0;
+            beta[0] = sqrt(s * x[0]);
+            beta[1] = s * x[2] > 0.0 ? sqrt(s * x[2]) : 0.0;
+            if (x[1] < 0.0) beta[0] = -beta[0];
+            if (!(beta[0] != 0.0)) continue;
+            if (variant == 2) beta[2] = x[3] / beta[0];
+        }
+        for (int it = 0; it < 5; ++it) {  /* Gauss-Newton on the six distance equations */
+            double J[24], r[6], dx[4];
+            for (int p = 0; p < 6; ++p) {
+                const double* l = L[p];
+                J[4 * p + 0] = 2.0 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
+                J[4 * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1] + l[4] * beta[2] + l[7] * beta[3];
+                J[4 * p + 2] = l[3] * beta[0] + l[4] * beta[1] + 2.0 * l[5] * beta[2] + l[8] * beta[3];
+                J[4 * p + 3] = l[6] * beta[0] + l[7] * beta[1] + l[8] * beta[2] + 2.0 * l[9] * beta[3];
+                r[p] = rho[p] - (l[0] * beta[0] * beta[0] + l[1] * beta[0] * beta[1] + l[2] * beta[1] * beta[1] + l[3] * beta[0] * beta[2] +
+                                 l[4] * beta[1] * beta[2] + l[5] * beta[2] * beta[2] + l[6] * beta[0] * beta[3] + l[7] * beta[1] * beta[3] +
+                                 l[8] * beta[2] * beta[3] + l[9] * beta[3] * beta[3]);
+            }
+            if (!lsq_small(6, 4, J, r, dx)) break;
+            for (int k = 0; k < 4; ++k) beta[k] += dx[k];
+        }
+        /* control points in the camera frame, sign from the first point's depth */
+        double cc[4][3];
+        for (int j = 0; j < 4; ++j)
+            for (int e = 0; e < 3; ++e) cc[j][e] = beta[0] * ev[0][3 * j + e] + beta[1] * ev[1][3 * j + e] + beta[2] * ev[2][3 * j + e] + beta[3] * ev[3][3 * j + e];
+        {
+            double al[4];
+            EPNP_ALPHAS(idx[0], al);
+            const double z0 = al[0] * cc[0][2] + al[1] * cc[1][2] + al[2] * cc[2][2] + al[3] * cc[3][2];
+            if (z0 < 0.0)
+                for (int j = 0; j < 4; ++j)
+                    for (int e = 0; e < 3; ++e) cc[j][e] = -cc[j][e];
+        }
+        /* absolute orientation world -> camera (Horn's quaternion form): S = sum pc (pw - c0)^T */
+        double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pcm[3] = {0, 0, 0};
+        for (int k = 0; k < m; ++k) {
+            double al[4], pc[3];
+            EPNP_ALPHAS(idx[k], al);
+            for (int e = 0; e < 3; ++e) {
+                pc[e] = al[0] * cc[0][e] + al[1] * cc[1][e] + al[2] * cc[2][e] + al[3] * cc[3][e];
+                pcm[e] += pc[e];
+            }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) S[3 * i + j] += pc[i] * (obj[3 * (size_t)idx[k] + j] - c0[j]);
+        }
+        for (int e = 0; e < 3; ++e) pcm[e] /= (double)m;
+        /* S[i][j] = sum camera_i world_j; the rotation maximising tr(R^T S) is the top eigenvector of Horn's 4 x 4 matrix
+         * written for the map world -> camera (its "left" set is the world points: Sxy = sum world_x camera_y = S[y][x]) */
+        const double Sxx = S[0], Sxy = S[3], Sxz = S[6], Syx = S[1], Syy = S[4], Syz = S[7], Szx = S[2], Szy = S[5], Szz = S[8];
+        double N[16] = {Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx,
+                        Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz,
+                        Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy,
+                        Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz};
+        double V4[16], w4[4];
+        jacobi_eig(4, N, V4, w4);
+        int top = 0;
+        for (int k = 1; k < 4; ++k)
+            if (w4[k] > w4[top]) top = k;
+        const double q0 = V4[top], qx = V4[4 + top], qy = V4[8 + top], qz = V4[12 + top];
+        double cand[12];
+        cand[0] = q0 * q0 + qx * qx - qy * qy - qz * qz, cand[1] = 2.0 * (qx * qy - q0 * qz), cand[2] = 2.0 * (qx * qz + q0 * qy);
+        cand[3] = 2.0 * (qy * qx + q0 * qz), cand[4] = q0 * q0 - qx * qx + qy * qy - qz * qz, cand[5] = 2.0 * (qy * qz - q0 * qx);
+        cand[6] = 2.0 * (qz * qx - q0 * qy), cand[7] = 2.0 * (qz * qy + q0 * qx), cand[8] = q0 * q0 - qx * qx - qy * qy + qz * qz;
+        for (int i = 0; i < 3; ++i) cand[9 + i] = pcm[i] - (cand[3 * i] * c0[0] + cand[3 * i + 1] * c0[1] + cand[3 * i + 2] * c0[2]);
+        double err = 0.0;
+        for (int k = 0; k < m; ++k) {
+            const double* X = obj + 3 * (size_t)idx[k];
+            const double xc = cand[0] * X[0] + cand[1] * X[1] + cand[2] * X[2] + cand[9];
+            const double yc = cand[3] * X[0] + cand[4] * X[1] + cand[5] * X[2] + cand[10];
+            const double zc = cand[6] * X[0] + cand[7] * X[1] + cand[8] * X[2] + cand[11];
+            const double eu = uc + fu * xc / zc - img[2 * (size_t)idx[k]], evv = vc + fv * yc / zc - img[2 * (size_t)idx[k] + 1];
+            err += sqrt(eu * eu + evv * evv);
+        }
+        if (!(err < 1e300)) continue;
+        if (best_err < 0.0 || err < best_err) {
+            best_err = err;
+            for (int i = 0; i < 12; ++i) Rt[i] = cand[i];
+        }
+    }
+#undef EPNP_ALPHAS
+    return best_err >= 0.0 ? 1 : 0;
+}
+
+/* batch form: n_samples index lists of sample_size points each -> one pose (R row-major | t) per sample, n_models[s] = 0 / 1 */
+void oracle_solve_pnp(const double* obj, const double* img, const double* K, int sample_size, int n_samples, const int32_t* idx,
+                      double* models, int32_t* n_models) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int s = 0; s < n_samples; ++s) {
+        double* out = models + 12 * (size_t)s;
+        for (int k = 0; k < 12; ++k) out[k] = 0.0;
+        n_models[s] = oracle_epnp(sample_size, idx + (size_t)s * sample_size, obj, img, K, out);
+        if (!n_models[s])
+            for (int k = 0; k < 12; ++k) out[k] = 0.0;
+    }
 }
 
 /* batch form with caller-supplied sample indices: kind 0 = homography4 (a -> b), kind 1 = essential5 (a = view 1, b = view 2).

@@ -208,4 +208,18 @@ int eacham_solve_minimal(eacham_ctx* c, int kind, int n_points, const double* a,
     }
     return EACHAM_OK;
 }
+
+int eacham_solve_pnp(eacham_ctx* c, int n_points, const double* obj, const double*, const double*, int sample_size, int n_samples,
+                     const int32_t* idx, double* models, int32_t* n_models) {
+    if (sample_size < 5) return fail(c, EACHAM_ERR_INVALID, "EPnP needs at least 5 points per sample");
+    for (int s = 0; s < n_samples; ++s) {   // a fake pose per sample: identity rotation, t = -first object point
+        for (int k = 0; k < sample_size; ++k)
+            if (idx[(size_t)s * sample_size + k] < 0 || idx[(size_t)s * sample_size + k] >= n_points) return fail(c, EACHAM_ERR_INVALID, "sample index out of range");
+        const int i = idx[(size_t)s * sample_size];
+        const double v[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, -obj[3 * i], -obj[3 * i + 1], -obj[3 * i + 2]};
+        for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = v[k];
+        n_models[s] = 1;
+    }
+    return EACHAM_OK;
+}
 }  // extern "C"

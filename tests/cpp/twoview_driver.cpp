@@ -1,5 +1,6 @@
-// Test driver for include/eacham/TwoViewHip.hpp.
-//   twoview_driver decompose   < "H(9) K(9)" or "E(9)" lines     -> prints the decompositions (host-only math)
+// Test driver for include/eacham/TwoViewHip.hpp and PnPHip.hpp.
+//   twoview_driver decompose   < "H(9) K(9)", "E(9)" or "R(9)" lines -> prints the decompositions / the Rodrigues vector (host-only math)
+//   twoview_driver pnp <in.bin> <out.bin>                          -> SolvePnPRansac through the C-ABI (GPU)
 //   twoview_driver pipeline <in.bin> <out.bin>                    -> FindEssentialMat / FindHomography / RecoverPose /
 //                                                                    DecomposeHomographyMat through the C-ABI (GPU)
 #include <cstdio>
@@ -8,6 +9,7 @@
 #include <iostream>
 #include <vector>
 
+#include "eacham/PnPHip.hpp"
 #include "eacham/TwoViewHip.hpp"
 
 using namespace eacham::hip;
@@ -40,6 +42,11 @@ int main(int argc, char** argv) {
                     for (double x : m.n) std::printf("%.17g ", x);
                     std::printf("\n");
                 }
+            } else if (kind == "R") {
+                Mat3 R;
+                for (double& x : R) std::cin >> x;
+                const Vec3 r = RodriguesFromMatrix(R);
+                std::printf("R %.17g %.17g %.17g\n", r[0], r[1], r[2]);
             } else {
                 Mat3 E, R1, R2;
                 Vec3 t;
@@ -58,6 +65,20 @@ int main(int argc, char** argv) {
     std::ifstream in(argv[2], std::ios::binary);
     std::ofstream out(argv[3], std::ios::binary);
     Context ctx(0);
+    if (!strcmp(argv[1], "pnp")) {   // n, object (n x 3), image (n x 2), K9 -> ok, iterations, R, rvec, t, inliers
+        int32_t n;
+        in.read((char*)&n, sizeof(n));
+        const auto obj = rd<double>(in, 3 * (size_t)n), img = rd<double>(in, 2 * (size_t)n), K9 = rd<double>(in, 9);
+        const PnPResult r = SolvePnPRansac(ctx, obj, img, K9.data(), 10000, 4.0f, 0.999, 5);
+        std::vector<double> pose{(double)r.ok, (double)r.opencv_iterations};
+        pose.insert(pose.end(), r.R.begin(), r.R.end());
+        pose.insert(pose.end(), r.rvec.begin(), r.rvec.end());
+        pose.insert(pose.end(), r.t.begin(), r.t.end());
+        wr(out, pose);
+        wr(out, std::vector<int32_t>(r.inliers.begin(), r.inliers.end()));
+        std::printf("twoview driver ok\n");
+        return 0;
+    }
     for (int scene = 0; scene < 2; ++scene) {   // a general scene (E branch), a planar one (H branch)
         int32_t n;
         in.read((char*)&n, sizeof(n));

@@ -272,3 +272,19 @@ def solve_minimal(kind, a, b, samples, K=None):
     L.oracle_solve_minimal(C.c_int(k), vp(a.ctypes.data), vp(b.ctypes.data), vp(K4.ctypes.data) if K4 is not None else None,
                            C.c_int(idx.shape[0]), vp(idx.ctypes.data), vp(models.ctypes.data), vp(counts.ctypes.data))
     return models, counts
+
+
+def solve_pnp(object_points, image_points, K, samples):
+    """oracle_solve_pnp (oracle/solve_oracle.c): EPnP per row of `samples`; same contract as eacham_solve_pnp."""
+    L = oracle.lib()
+    X = np.ascontiguousarray(object_points, dtype=np.float64).reshape(-1, 3)
+    uv = np.ascontiguousarray(image_points, dtype=np.float64).reshape(-1, 2)
+    idx = np.ascontiguousarray(samples, dtype=np.int32)
+    K4 = np.ascontiguousarray(K, dtype=np.float64).reshape(4)
+    models = np.zeros((idx.shape[0], 12), dtype=np.float64)
+    ok = np.zeros(idx.shape[0], dtype=np.int32)
+    vp = C.c_void_p
+    L.oracle_solve_pnp.restype = None
+    L.oracle_solve_pnp(vp(X.ctypes.data), vp(uv.ctypes.data), vp(K4.ctypes.data), C.c_int(idx.shape[1]), C.c_int(idx.shape[0]),
+                       vp(idx.ctypes.data), vp(models.ctypes.data), vp(ok.ctypes.data))
+    return models, ok

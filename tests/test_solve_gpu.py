@@ -61,3 +61,37 @@ def test_solver_arguments(hip_ctx):
     assert k[0] == 0 and not m.any()
     m, k = score.solve_minimal(hip_ctx, "homography4", pts, pts, np.zeros((0, 4), np.int32))
     assert m.shape == (0, 1, 9)
+
+
+def test_epnp_bit_identical_at_the_reference_iteration_count_and_the_ransac_loop_finds_the_pose(hip_ctx):
+    """cv::solvePnPRansac(pts3d, pts2d, K, dist, rvec, t, false, 10000, 4.0f, 0.999f, inliers, SOLVEPNP_EPNP) (:227-228) as three
+    launches: EPnP on 10 000 five-point samples, every model against every point (4 px), EPnP on the winner's inliers."""
+    c = SC.pnp_case(n=500, seed=11, outliers=0.3)
+    X, uv, K, T = c["X"][1:], c["uv"][1:], c["K"], c["models"][0]
+    rng = np.random.default_rng(11)
+    samples = draw(rng, len(X), 5, 10000)
+    models, ok = score.solve_pnp(hip_ctx, X, uv, K, samples)
+    want, wok = O.solve_pnp(X, uv, K, samples)
+    assert np.array_equal(ok, wok) and np.array_equal(models, want) and ok.mean() > 0.99
+    err, inl, _ = score.score_hypotheses(hip_ctx, "pnp", X, uv, models, K, threshold=16.0)
+    best = int(np.argmax(inl))
+    good = ~c["bad"][1:]
+    assert inl[best] > 0.9 * good.sum()
+    inliers = np.flatnonzero(err[best] <= 16.0).astype(np.int32)[None, :]
+    refit, rok = score.solve_pnp(hip_ctx, X, uv, K, inliers)                       # the all-inlier refit: one row of ~350 indices
+    wrefit, _ = O.solve_pnp(X, uv, K, inliers)
+    assert rok[0] == 1 and np.array_equal(refit, wrefit)
+    assert np.abs(refit[0] - T).max() < 5e-3 and np.abs(refit[0] - T).max() < np.abs(models[best] - T).max()
+
+
+def test_epnp_arguments(hip_ctx):
+    X, uv, K = np.zeros((8, 3)), np.zeros((8, 2)), np.array([500.0, 500.0, 320.0, 240.0])
+    with pytest.raises(EachamError) as e:
+        score.solve_pnp(hip_ctx, X, uv, K, np.array([[0, 1, 2, 3]], np.int32))                 # EPnP needs five points
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(EachamError):
+        score.solve_pnp(hip_ctx, X, uv, K, np.array([[0, 1, 2, 3, 8]], np.int32))              # index out of range
+    m, ok = score.solve_pnp(hip_ctx, X, uv, K, np.array([[0, 1, 2, 3, 4]], np.int32))          # coincident points: degenerate
+    assert ok[0] == 0 and not m.any()
+    m, ok = score.solve_pnp(hip_ctx, X, uv, K, np.zeros((0, 5), np.int32))
+    assert m.shape == (0, 12)

@@ -108,3 +108,43 @@ def test_essential5_noisy_samples_and_degenerate_input():
     same = np.zeros((5, 2))                                              # five identical points: no model, no crash
     m, k = O.solve_minimal("essential5", same, same, np.array([[0, 1, 2, 3, 4]], np.int32), None)
     assert k[0] == 0 and not m.any()
+
+
+def exact_pnp(n=300, seed=11):
+    """Object points, their EXACT pixels under a known pose (no noise, no rounding to float32), K and that pose."""
+    c = SC.pnp_case(n=n, seed=seed, outliers=0.0)
+    X, T, K = np.ascontiguousarray(c["X"][1:]), c["models"][0], np.asarray(c["K"], float)
+    pc = X @ T[:9].reshape(3, 3).T + T[9:]
+    uv = np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1)
+    return X, uv, K, T
+
+
+def test_epnp_recovers_the_pose_exactly_and_averages_noise_down():
+    """EPnP (cv::solvePnPRansac(..., SOLVEPNP_EPNP), ReconstructionManager.cpp:227-228): exact pixels -> the exact pose from
+    5 points up to all of them; noisy pixels -> an error that shrinks with the sample size (the all-inlier refit)."""
+    X, uv, K, T = exact_pnp()
+    rng = np.random.default_rng(2)
+    for m in (5, 6, 12, 299):
+        samples = np.array([rng.choice(len(X), m, replace=False) for _ in range(100)], np.int32)
+        models, ok = O.solve_pnp(X, uv, K, samples)
+        assert ok.all() and np.abs(models - T).max() < 1e-9
+        R = models[:, :9].reshape(-1, 3, 3)
+        assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(R) - 1).max() < 1e-12
+    noisy = uv + 0.5 * rng.normal(size=uv.shape)
+    med = []
+    for m in (5, 20, 299):
+        samples = np.array([rng.choice(len(X), m, replace=False) for _ in range(100)], np.int32)
+        models, ok = O.solve_pnp(X, noisy, K, samples)
+        assert ok.all()
+        med.append(np.median(np.abs(models - T).max(1)))
+    assert med[0] > med[1] > med[2] and med[2] < 2e-3 and med[0] < 0.05
+
+
+def test_epnp_reports_degenerate_samples():
+    X, uv, K, _ = exact_pnp(n=40, seed=3)
+    flat = X.copy()
+    flat[:, 2] = 0.3 * flat[:, 0] - 0.2 * flat[:, 1] + 1.0            # coplanar object points: no volume for four control points
+    same = np.repeat(X[:1], 40, axis=0)                               # one point forty times
+    for pts in (flat, same):
+        models, ok = O.solve_pnp(pts, uv, K, np.arange(10, dtype=np.int32).reshape(2, 5))
+        assert not ok.any() and not models.any()

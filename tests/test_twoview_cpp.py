@@ -42,6 +42,10 @@ def test_decompositions_satisfy_their_equations_and_contain_the_truth(tmp_path):
         lines.append("E " + " ".join(f"{x:.17g}" for x in (E / np.linalg.norm(E)).ravel()))
         truth.append((R, t / d, n, Hn, t / np.linalg.norm(t)))
     lines.append("H " + " ".join(f"{x:.17g}" for x in (K @ rot([0.1, -0.2, 0.05]) @ np.linalg.inv(K)).ravel()) + " " + " ".join(f"{x:.17g}" for x in K.ravel()))
+    rvecs = [np.array([0.3, -0.2, 0.9]), np.zeros(3), np.array([1e-11, 0, 0]), np.pi * np.array([0.6, -0.8, 0.0]), np.pi * np.array([0, 0, 1.0]),
+             (np.pi - 1e-7) * np.array([1.0, 2.0, -2.0]) / 3.0]
+    for rv in rvecs:                                                                        # cv::Rodrigues(R) of PnPHip.hpp
+        lines.append("R " + " ".join(f"{x:.17g}" for x in rot(rv).ravel()))
     out = subprocess.run([exe, "decompose"], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
     i = k = 0
     for k in range(12):
@@ -65,6 +69,11 @@ def test_decompositions_satisfy_their_equations_and_contain_the_truth(tmp_path):
     assert out[i].split() == ["H", "1"]                                                   # a pure rotation: one solution, t = 0
     s = np.array(out[i + 1].split(), float)
     assert np.abs(s[:9].reshape(3, 3) - rot([0.1, -0.2, 0.05])).max() < 1e-12 and not s[9:12].any()
+    i += 2
+    for rv in rvecs:
+        got = np.array(out[i].split()[1:], float)
+        assert np.abs(rot(got) - rot(rv)).max() < 1e-6 and abs(np.linalg.norm(got) - np.linalg.norm(rv)) < 1e-6   # (the axis of a half turn has no sign)
+        i += 1
 
 
 def _vec(f, dtype):
@@ -121,3 +130,29 @@ def test_two_view_pipeline_recovers_the_relative_pose(tmp_path):
                 err = [np.abs(s_[:9].reshape(3, 3) - Rt).max() + np.abs(s_[9:] / np.linalg.norm(s_[9:]) - tt).max() for s_ in sols]
                 near = int(np.argmin(err))
                 assert err[near] < 0.2 and counts[near] > 0.5 * good.sum()
+
+
+@pytest.mark.gpu
+def test_solve_pnp_ransac_recovers_the_camera_pose(tmp_path):
+    """SolvePnPRansac (PnPHip.hpp) = cv::solvePnPRansac(..., 10000, 4.0f, 0.999f, inliers, SOLVEPNP_EPNP) of RecoverPosePnP
+    (ReconstructionManager.cpp:227-238): 30 % gross outliers, 0.8 px noise."""
+    exe = str(tmp_path / "twoview_driver")
+    lib = os.path.join(ROOT, "eacham_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(CPP, "twoview_driver.cpp"), "-o", exe,
+                    "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"], check=True, capture_output=True)
+    c = SC.pnp_case(n=500, seed=11, outliers=0.3)
+    X, uv, K, T, bad = c["X"][1:], c["uv"][1:], c["K"], c["models"][0], c["bad"][1:]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("i", len(X))); f.write(np.ascontiguousarray(X).tobytes()); f.write(np.ascontiguousarray(uv).tobytes())
+        f.write(np.array([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1.0]).tobytes())
+    r = subprocess.run([exe, "pnp", fin, fout], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(fout, "rb") as f:
+        pose, inliers = _vec(f, np.float64), _vec(f, np.int32)
+    ok, iters, R, rvec, t = pose[0], pose[1], pose[2:11].reshape(3, 3), pose[11:14], pose[14:17]
+    assert ok == 1 and 5 <= iters < 200                       # 70 % inliers: OpenCV's adaptive budget stops after a few dozen samples
+    assert np.abs(R - T[:9].reshape(3, 3)).max() < 2e-3 and np.abs(t - T[9:]).max() < 5e-3
+    assert np.abs(rot(rvec) - R).max() < 1e-9
+    mask = np.zeros(len(X), bool); mask[inliers] = True
+    assert mask[~bad].mean() > 0.95 and mask[bad].mean() < 0.05
