@@ -26,46 +26,83 @@
 namespace eacham {
 namespace {
 
-/* cyclic Jacobi on a symmetric n x n matrix (n <= 12): A is destroyed, V's COLUMNS are the eigenvectors, w the eigenvalues */
-__device__ static void jacobi_eig(int n, double* A, double* V, double* w) {
+// A thread's large work arrays live in LDS, element e of thread t at arena[e * NT + t] (conflict-free when the lanes of a
+// wave use the same e, which they do outside data-dependent branches): as private arrays they are indexed at run time, i.e.
+// they sit in scratch memory, and a solve is then a chain of ~10^5 dependent scratch round trips (14.7 ms for a five-point
+// sample, 4.2 ms for EPnP, measured) — the arithmetic itself is a few hundred microseconds.
+__device__ __forceinline__ void wave_sync_lds() {  // a wave's own LDS traffic: order its writes before its reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NT>
+struct PV {
+    double* p;
+    __device__ __forceinline__ double& operator[](int i) const { return p[i * NT]; }
+    __device__ __forceinline__ PV sub(int off) const { return PV{p + off * NT}; }
+};
+
+/* cyclic Jacobi on a symmetric N x N matrix (N <= 12): A is destroyed, V's COLUMNS are the eigenvectors, w the eigenvalues.
+ * Small N (3, 4) unrolls completely and stays in registers. */
+template <int N, class MA, class MV>
+__device__ __forceinline__ void jacobi_eig(MA A, MV V, double* w) {
+    constexpr int n = N;
+#pragma unroll
     for (int i = 0; i < n; ++i)
+#pragma unroll
         for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    auto rotate = [&](int p, int q) {
+        const double apq = A[p * n + q];
+        if (apq == 0.0) return;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {  /* columns p, q */
+            const double akp = A[k * n + p], akq = A[k * n + q];
+            A[k * n + p] = c * akp - s * akq;
+            A[k * n + q] = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < n; ++k) {  /* rows p, q */
+            const double apk = A[p * n + k], aqk = A[q * n + k];
+            A[p * n + k] = c * apk - s * aqk;
+            A[q * n + k] = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const double vkp = V[k * n + p], vkq = V[k * n + q];
+            V[k * n + p] = c * vkp - s * vkq;
+            V[k * n + q] = s * vkp + c * vkq;
+        }
+    };
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0, diag = 0.0;
+#pragma unroll
         for (int p = 0; p < n; ++p) {
             diag += A[p * n + p] * A[p * n + p];
+#pragma unroll
             for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
         }
         if (off <= 1e-60 || off <= 1e-32 * diag) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; ++k) {  /* columns p, q */
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {  /* rows p, q */
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
-                }
-            }
+        if constexpr (N <= 4) {
+#pragma unroll
+            for (int p = 0; p < n - 1; ++p)
+#pragma unroll
+                for (int q = p + 1; q < n; ++q) rotate(p, q);
+        } else {
+            for (int p = 0; p < n - 1; ++p)
+                for (int q = p + 1; q < n; ++q) rotate(p, q);
+        }
     }
+#pragma unroll
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
 }
 
 /* a: 4 x 2 source points, b: 4 x 2 destination points; H: 9 doubles. Returns 1, or 0 for a degenerate sample. */
-__device__ static int homography4(const double* a, const double* b, double* H) {
+template <class MA>
+__device__ static int homography4(const double* a, const double* b, double* H, MA LtL, MA V) {
     const int count = 4;
     double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
     for (int i = 0; i < count; ++i) {
@@ -81,7 +118,6 @@ __device__ static int homography4(const double* a, const double* b, double* H) {
     for (int k = 0; k < 2; ++k)
         if (fabs(sM[k]) < 2.220446049250313e-16 || fabs(sm[k]) < 2.220446049250313e-16) return 0;
     for (int k = 0; k < 2; ++k) sM[k] = count / sM[k], sm[k] = count / sm[k];
-    double LtL[81];
     for (int k = 0; k < 81; ++k) LtL[k] = 0.0;
     for (int i = 0; i < count; ++i) {
         const double x = (b[2 * i] - cm[0]) * sm[0], y = (b[2 * i + 1] - cm[1]) * sm[1];
@@ -93,8 +129,8 @@ __device__ static int homography4(const double* a, const double* b, double* H) {
     }
     for (int j = 0; j < 9; ++j)
         for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
-    double V[81], w[9];
-    jacobi_eig(9, LtL, V, w);
+    double w[9];
+    jacobi_eig<9>(LtL, V, w);
     int best = 0;
     for (int i = 1; i < 9; ++i)
         if (w[i] < w[best]) best = i;
@@ -124,9 +160,13 @@ __device__ static int mono_col(int ex, int ey, int ez) {
     return -1;
 }
 /* row += s * l1 l2 l3, each l a linear form {x, y, z, 1} */
-__device__ static void mul3acc(const double* l1, const double* l2, const double* l3, double s, double* row) {
+/* (unrolled: the monomial column of every term is then a compile-time constant and `row` can be a register array) */
+__device__ __forceinline__ void mul3acc(const double* l1, const double* l2, const double* l3, double s, double* row) {
+#pragma unroll
     for (int a = 0; a < 4; ++a)
+#pragma unroll
         for (int b = 0; b < 4; ++b)
+#pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ex = (a == 0) + (b == 0) + (c == 0), ey = (a == 1) + (b == 1) + (c == 1), ez = (a == 2) + (b == 2) + (c == 2);
                 row[mono_col(ex, ey, ez)] += s * (l1[a] * l2[b]) * l3[c];
@@ -175,6 +215,43 @@ __device__ static int real_roots10(const double* c, double* roots) {
             cr = tr, ci = ti;
         }
     }
+    if (deg == 10) {
+        // the usual case, with every index a compile-time constant: the ten iterates and the coefficients stay in registers
+        // (with run-time indices they are scratch arrays and one sweep is ~200 dependent scratch round trips)
+        double xr[10], xi[10], mm[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xr[k] = zr[k], xi[k] = zi[k], mm[k] = m[k];
+        for (int it = 0; it < 600; ++it) {
+            double change = 0.0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                double pr = 1.0, pi = 0.0;
+#pragma unroll
+                for (int j = 9; j >= 0; --j) {
+                    const double tr = pr * xr[k] - pi * xi[k] + mm[j], ti = pr * xi[k] + pi * xr[k];
+                    pr = tr, pi = ti;
+                }
+                double dr = 1.0, di = 0.0;
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+                    if (j != k) {
+                        const double ar = xr[k] - xr[j], ai = xi[k] - xi[j];
+                        const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+                        dr = tr, di = ti;
+                    }
+                const double den = dr * dr + di * di;
+                if (den > 0.0) {
+                    const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
+                    xr[k] -= qr;
+                    xi[k] -= qi;
+                    change = fmax(change, fabs(qr) + fabs(qi));
+                }
+            }
+            if (change <= 1e-15 * bound) break;
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) zr[k] = xr[k], zi[k] = xi[k];
+    } else
     for (int it = 0; it < 600; ++it) {
         double change = 0.0;
         for (int k = 0; k < deg; ++k) {
@@ -224,7 +301,8 @@ __device__ static int real_roots10(const double* c, double* roots) {
 }
 
 /* p1, p2: 5 x 2 pixels of view 1 / view 2; K = fx fy cx cy (NULL: already normalised). E: 10 x 9. Returns the number of models. */
-__device__ static int essential5(const double* p1, const double* p2, const double* K, double* E) {
+template <class MA>
+__device__ static int essential5(const double* p1, const double* p2, const double* K, double* E, MA A, MA A0) {
     double Q[9][5];  /* Q^T: column i = the constraint row of correspondence i */
     for (int i = 0; i < 5; ++i) {
         double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
@@ -266,51 +344,59 @@ __device__ static int essential5(const double* p1, const double* p2, const doubl
     double lin[9][4];  /* entry e of E as a linear form in (x, y, z, 1) */
     for (int e = 0; e < 9; ++e)
         for (int b = 0; b < 4; ++b) lin[e][b] = P[e][5 + b];
-    double A[10][20];
-    for (int r = 0; r < 10; ++r)
-        for (int c = 0; c < 20; ++c) A[r][c] = 0.0;
     {   /* det E */
         constexpr int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+        double row[20];
+#pragma unroll
+        for (int c = 0; c < 20; ++c) row[c] = 0.0;
+#pragma unroll
         for (int p = 0; p < 6; ++p)
-            mul3acc(lin[perm[p][0]], lin[3 + perm[p][1]], lin[6 + perm[p][2]], p < 3 ? 1.0 : -1.0, A[0]);
+            mul3acc(lin[perm[p][0]], lin[3 + perm[p][1]], lin[6 + perm[p][2]], p < 3 ? 1.0 : -1.0, row);
+#pragma unroll
+        for (int c = 0; c < 20; ++c) A[c] = row[c];
     }
-    for (int i = 0; i < 3; ++i)      /* 2 E E^T E - tr(E E^T) E */
+    for (int i = 0; i < 3; ++i)      /* 2 E E^T E - tr(E E^T) E: a row is accumulated in registers and stored once */
         for (int j = 0; j < 3; ++j) {
-            double* row = A[1 + 3 * i + j];
+            double row[20];
+#pragma unroll
+            for (int c = 0; c < 20; ++c) row[c] = 0.0;
+#pragma unroll
             for (int k = 0; k < 3; ++k)
+#pragma unroll
                 for (int l = 0; l < 3; ++l) {
                     mul3acc(lin[3 * i + l], lin[3 * k + l], lin[3 * k + j], 2.0, row);
                     mul3acc(lin[3 * k + l], lin[3 * k + l], lin[3 * i + j], -1.0, row);
                 }
+#pragma unroll
+            for (int c = 0; c < 20; ++c) A[(1 + 3 * i + j) * 20 + c] = row[c];
         }
-    double A0[10][20];  /* the constraints as assembled: the polish below evaluates them */
-    for (int r = 0; r < 10; ++r)
-        for (int c = 0; c < 20; ++c) A0[r][c] = A[r][c];
+    for (int r = 0; r < 10; ++r)  /* A0: the constraints as assembled, the polish below evaluates them */
+        for (int c = 0; c < 20; ++c) A0[r * 20 + c] = A[r * 20 + c];
     for (int col = 0; col < 10; ++col) {  /* Gauss-Jordan, partial pivoting */
         int piv = col;
         for (int r = col + 1; r < 10; ++r)
-            if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
-        if (!(fabs(A[piv][col]) > 1e-300)) return 0;
+            if (fabs(A[(r) * 20 + col]) > fabs(A[(piv) * 20 + col])) piv = r;
+        if (!(fabs(A[(piv) * 20 + col]) > 1e-300)) return 0;
         if (piv != col)
             for (int c = 0; c < 20; ++c) {
-                const double t = A[piv][c];
-                A[piv][c] = A[col][c];
-                A[col][c] = t;
+                const double t = A[(piv) * 20 + c];
+                A[(piv) * 20 + c] = A[(col) * 20 + c];
+                A[(col) * 20 + c] = t;
             }
-        const double inv = 1.0 / A[col][col];
-        for (int c = 0; c < 20; ++c) A[col][c] *= inv;
+        const double inv = 1.0 / A[(col) * 20 + col];
+        for (int c = 0; c < 20; ++c) A[(col) * 20 + c] *= inv;
         for (int r = 0; r < 10; ++r)
             if (r != col) {
-                const double f = A[r][col];
+                const double f = A[(r) * 20 + col];
                 if (f != 0.0)
-                    for (int c = 0; c < 20; ++c) A[r][c] -= f * A[col][c];
+                    for (int c = 0; c < 20; ++c) A[(r) * 20 + c] -= f * A[(col) * 20 + c];
             }
     }
     /* B(z): rows k = e - z f, l = g - z h, m = i - z j; entries = polynomials in z (ascending), degrees 3, 3, 4 */
     double B[3][3][5];
     for (int r = 0; r < 3; ++r) {
-        const double* e = &A[4 + 2 * r][10];
-        const double* f = &A[5 + 2 * r][10];
+        const MA e = A.sub((4 + 2 * r) * 20 + 10);
+        const MA f = A.sub((5 + 2 * r) * 20 + 10);
         B[r][0][0] = e[2];  B[r][0][1] = e[1] - f[2];  B[r][0][2] = e[0] - f[1];  B[r][0][3] = -f[0];  B[r][0][4] = 0.0;
         B[r][1][0] = e[5];  B[r][1][1] = e[4] - f[5];  B[r][1][2] = e[3] - f[4];  B[r][1][3] = -f[3];  B[r][1][4] = 0.0;
         B[r][2][0] = e[9];  B[r][2][1] = e[8] - f[9];  B[r][2][2] = e[7] - f[8];  B[r][2][3] = e[6] - f[7];  B[r][2][4] = -f[6];
@@ -366,7 +452,7 @@ __device__ static int essential5(const double* p1, const double* p2, const doubl
                 for (int ex = 0; ex <= 3; ++ex)
                     for (int ey = 0; ex + ey <= 3; ++ey)
                         for (int ez = 0; ex + ey + ez <= 3; ++ez) {
-                            const double cf = A0[row][mono_col(ex, ey, ez)];
+                            const double cf = A0[(row) * 20 + mono_col(ex, ey, ez)];
                             rv += cf * (px[ex] * py[ey]) * pz[ez];
                             if (ex) g[0] += cf * (ex * px[ex - 1] * py[ey]) * pz[ez];
                             if (ey) g[1] += cf * (px[ex] * (ey * py[ey - 1])) * pz[ez];
@@ -447,22 +533,42 @@ __device__ static int lsq_small(int r, int c, const double* A, const double* b, 
  * Rt = R (row-major) | t of x_cam = R X + t. Every pass over the points recomputes the barycentric coordinates, so the
  * working set does not grow with m (the RANSAC kernel calls it with m = 5, the final refit with all inliers).
  * Returns 1, or 0 for a degenerate point set (coplanar / coincident points: the 4-control-point form needs volume). */
-__device__ static int epnp_solve(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt) {
+// Sum of one value per lane in LANE ORDER, ((v0 + v1) + v2) + ... + v63, returned to every lane. With at most 64 points (one
+// per lane, the others 0) this is the sequential sum over the points, bit for bit: the one-thread-per-sample form below.
+__device__ __forceinline__ double ordered_wave_sum(double v, double* red) {
+    red[threadIdx.x] = v;
+    wave_sync_lds();
+    double t = red[0];
+    for (int l = 1; l < 64; ++l) t += red[l];
+    wave_sync_lds();
+    return t;
+}
+
+// WAVE = false: one thread solves the sample (the RANSAC kernel: thousands of 5-point samples). WAVE = true: one wave solves it
+// — lane l accumulates the points l, l + 64, ... of every pass over the points, the 64 partial sums are added in lane order, and
+// every lane then runs the small dense algebra on identical values (the all-inlier refit: one sample of thousands of points,
+// 5.2 ms on one thread). The CPU restatement defines the sums the same way (64 strided partials when m > 64), so both
+// forms agree with it bit for bit.
+template <bool WAVE, class MA>
+__device__ static int epnp_solve(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt, MA MtM, MA V, double* red) {
     if (m < 4) return 0;
+    const int kfirst = WAVE ? (int)threadIdx.x : 0, kstep = WAVE ? 64 : 1;
+    auto total = [&](double v) { return WAVE ? ordered_wave_sum(v, red) : v; };
     const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
     /* control points: centroid + principal axes scaled by the spread along them */
     double c0[3] = {0, 0, 0};
-    for (int k = 0; k < m; ++k)
+    for (int k = kfirst; k < m; k += kstep)
         for (int e = 0; e < 3; ++e) c0[e] += obj[3 * (size_t)idx[k] + e];
-    for (int e = 0; e < 3; ++e) c0[e] /= (double)m;
+    for (int e = 0; e < 3; ++e) c0[e] = total(c0[e]) / (double)m;
     double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9], w3[3];
-    for (int k = 0; k < m; ++k) {
+    for (int k = kfirst; k < m; k += kstep) {
         double d[3];
         for (int e = 0; e < 3; ++e) d[e] = obj[3 * (size_t)idx[k] + e] - c0[e];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) C[3 * i + j] += d[i] * d[j];
     }
-    jacobi_eig(3, C, V3, w3);
+    for (int i = 0; i < 9; ++i) C[i] = total(C[i]);
+    jacobi_eig<3>(C, V3, w3);
     double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
     wmax = wmax > w3[2] ? wmax : w3[2];
     double ax[3][3], sc[3];  /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
@@ -479,9 +585,9 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         (al)[0] = 1.0 - (al)[1] - (al)[2] - (al)[3];                                              \
     }
     /* M^T M of the 2m x 12 projection system  sum_j alpha_j (fu Xc_j + (uc - u) Zc_j) = 0, same with v */
-    double MtM[144], V[144], w[12];
+    double w[12];
     for (int i = 0; i < 144; ++i) MtM[i] = 0.0;
-    for (int k = 0; k < m; ++k) {
+    for (int k = kfirst; k < m; k += kstep) {
         double al[4], r1[12], r2[12];
         EPNP_ALPHAS(idx[k], al);
         const double du = uc - img[2 * (size_t)idx[k]], dv = vc - img[2 * (size_t)idx[k] + 1];
@@ -492,9 +598,12 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         for (int i = 0; i < 12; ++i)
             for (int j = i; j < 12; ++j) MtM[12 * i + j] += r1[i] * r1[j] + r2[i] * r2[j];
     }
+    if (WAVE)
+        for (int i = 0; i < 12; ++i)
+            for (int j = i; j < 12; ++j) MtM[12 * i + j] = total(MtM[12 * i + j]);
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
-    jacobi_eig(12, MtM, V, w);
+    jacobi_eig<12>(MtM, V, w);
     int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
     for (int k = 0; k < 4; ++k) {
         int best = -1;
@@ -580,7 +689,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         }
         /* absolute orientation world -> camera (Horn's quaternion form): S = sum pc (pw - c0)^T */
         double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pcm[3] = {0, 0, 0};
-        for (int k = 0; k < m; ++k) {
+        for (int k = kfirst; k < m; k += kstep) {
             double al[4], pc[3];
             EPNP_ALPHAS(idx[k], al);
             for (int e = 0; e < 3; ++e) {
@@ -590,7 +699,8 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) S[3 * i + j] += pc[i] * (obj[3 * (size_t)idx[k] + j] - c0[j]);
         }
-        for (int e = 0; e < 3; ++e) pcm[e] /= (double)m;
+        for (int i = 0; i < 9; ++i) S[i] = total(S[i]);
+        for (int e = 0; e < 3; ++e) pcm[e] = total(pcm[e]) / (double)m;
         /* S[i][j] = sum camera_i world_j; the rotation maximising tr(R^T S) is the top eigenvector of Horn's 4 x 4 matrix
          * written for the map world -> camera (its "left" set is the world points: Sxy = sum world_x camera_y = S[y][x]) */
         const double Sxx = S[0], Sxy = S[3], Sxz = S[6], Syx = S[1], Syy = S[4], Syz = S[7], Szx = S[2], Szy = S[5], Szz = S[8];
@@ -599,7 +709,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
                         Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy,
                         Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz};
         double V4[16], w4[4];
-        jacobi_eig(4, N, V4, w4);
+        jacobi_eig<4>(N, V4, w4);
         int top = 0;
         for (int k = 1; k < 4; ++k)
             if (w4[k] > w4[top]) top = k;
@@ -610,7 +720,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         cand[6] = 2.0 * (qz * qx - q0 * qy), cand[7] = 2.0 * (qz * qy + q0 * qx), cand[8] = q0 * q0 - qx * qx - qy * qy + qz * qz;
         for (int i = 0; i < 3; ++i) cand[9 + i] = pcm[i] - (cand[3 * i] * c0[0] + cand[3 * i + 1] * c0[1] + cand[3 * i + 2] * c0[2]);
         double err = 0.0;
-        for (int k = 0; k < m; ++k) {
+        for (int k = kfirst; k < m; k += kstep) {
             const double* X = obj + 3 * (size_t)idx[k];
             const double xc = cand[0] * X[0] + cand[1] * X[1] + cand[2] * X[2] + cand[9];
             const double yc = cand[3] * X[0] + cand[4] * X[1] + cand[5] * X[2] + cand[10];
@@ -618,6 +728,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
             const double eu = uc + fu * xc / zc - img[2 * (size_t)idx[k]], evv = vc + fv * yc / zc - img[2 * (size_t)idx[k] + 1];
             err += sqrt(eu * eu + evv * evv);
         }
+        err = total(err);
         if (!(err < 1e300)) continue;
         if (best_err < 0.0 || err < best_err) {
             best_err = err;
@@ -628,40 +739,81 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
     return best_err >= 0.0 ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void solve_pnp_kernel(const double* __restrict__ obj, const double* __restrict__ img,
-                                                       const double* __restrict__ K, int sample_size, int n_samples,
-                                                       const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+constexpr int PNP_NT = 64, H4_NT = 64, E5_NT = 32;   // threads per workgroup = samples per workgroup
+
+__global__ __launch_bounds__(PNP_NT) void solve_pnp_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                           const double* __restrict__ K, int sample_size, int n_samples,
+                                                           const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
+    __shared__ double arena[2 * 144 * PNP_NT];   // M^T M and its eigenvectors per thread: 144 KiB
+    const int s = blockIdx.x * PNP_NT + threadIdx.x;
     if (s >= n_samples) return;
+    const PV<PNP_NT> MtM{arena + threadIdx.x}, V = MtM.sub(144);
     double K4[4], out[12];
     for (int k = 0; k < 4; ++k) K4[k] = K[k];
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_solve(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out);
+    const int n = epnp_solve<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, nullptr);
     for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
     n_models[s] = n;
 }
 
-__global__ __launch_bounds__(64) void solve_minimal_kernel(int kind, const double* __restrict__ a, const double* __restrict__ b,
-                                                           const double* __restrict__ K, int has_K, int n_samples,
-                                                           const int* __restrict__ idx, double* __restrict__ models,
-                                                           int* __restrict__ n_models) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+// one WAVE per sample (sample_size > 64)
+__global__ __launch_bounds__(PNP_NT) void solve_pnp_wave_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                                const double* __restrict__ K, int sample_size, const int* __restrict__ idx,
+                                                                double* __restrict__ models, int* __restrict__ n_models) {
+    static_assert(PNP_NT == 64, "one wave");
+    __shared__ double arena[2 * 144 * PNP_NT];
+    __shared__ double red[64];
+    const int s = blockIdx.x;
+    const PV<PNP_NT> MtM{arena + threadIdx.x}, V = MtM.sub(144);
+    double K4[4], out[12];
+    for (int k = 0; k < 4; ++k) K4[k] = K[k];
+    for (int k = 0; k < 12; ++k) out[k] = 0.0;
+    const int n = epnp_solve<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, red);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
+        n_models[s] = n;
+    }
+}
+
+__global__ __launch_bounds__(H4_NT) void solve_h4_kernel(const double* __restrict__ a, const double* __restrict__ b, int n_samples,
+                                                         const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
+    __shared__ double arena[2 * 81 * H4_NT];     // L^T L and its eigenvectors per thread: 81 KiB
+    const int s = blockIdx.x * H4_NT + threadIdx.x;
     if (s >= n_samples) return;
-    const int m = kind == EACHAM_SOLVE_HOMOGRAPHY4 ? 4 : 5, maxm = kind == EACHAM_SOLVE_HOMOGRAPHY4 ? 1 : 10;
+    const PV<H4_NT> LtL{arena + threadIdx.x}, V = LtL.sub(81);
+    double pa[8], pb[8], out[9];
+    for (int k = 0; k < 4; ++k) {
+        const int i = idx[s * 4 + k];
+        pa[2 * k] = a[2 * (size_t)i]; pa[2 * k + 1] = a[2 * (size_t)i + 1];
+        pb[2 * k] = b[2 * (size_t)i]; pb[2 * k + 1] = b[2 * (size_t)i + 1];
+    }
+    for (int k = 0; k < 9; ++k) out[k] = 0.0;
+    const int n = homography4(pa, pb, out, LtL, V);
+    for (int k = 0; k < 9; ++k) models[9 * (size_t)s + k] = out[k];
+    n_models[s] = n;
+}
+
+__global__ __launch_bounds__(E5_NT) void solve_e5_kernel(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ K,
+                                                         int has_K, int n_samples, const int* __restrict__ idx, double* __restrict__ models,
+                                                         int* __restrict__ n_models) {
+    __shared__ double arena[2 * 200 * E5_NT];    // the 10 x 20 constraint matrix, as assembled and as eliminated, per thread: 100 KiB
+    const int s = blockIdx.x * E5_NT + threadIdx.x;
+    if (s >= n_samples) return;
+    const PV<E5_NT> A{arena + threadIdx.x}, A0 = A.sub(200);
     double pa[10], pb[10];
-    for (int k = 0; k < m; ++k) {
-        const int i = idx[s * m + k];
+    for (int k = 0; k < 5; ++k) {
+        const int i = idx[s * 5 + k];
         pa[2 * k] = a[2 * (size_t)i]; pa[2 * k + 1] = a[2 * (size_t)i + 1];
         pb[2 * k] = b[2 * (size_t)i]; pb[2 * k + 1] = b[2 * (size_t)i + 1];
     }
     double out[90];
-    for (int k = 0; k < maxm * 9; ++k) out[k] = 0.0;
+    for (int k = 0; k < 90; ++k) out[k] = 0.0;
     double K4[4] = {1, 1, 0, 0};
     if (has_K)
         for (int k = 0; k < 4; ++k) K4[k] = K[k];
-    const int n = kind == EACHAM_SOLVE_HOMOGRAPHY4 ? homography4(pa, pb, out) : essential5(pa, pb, has_K ? K4 : nullptr, out);
-    double* dst = models + (size_t)s * maxm * 9;
-    for (int k = 0; k < maxm * 9; ++k) dst[k] = out[k];
+    const int n = essential5(pa, pb, has_K ? K4 : nullptr, out, A, A0);
+    double* dst = models + (size_t)s * 90;
+    for (int k = 0; k < 90; ++k) dst[k] = out[k];
     n_models[s] = n;
 }
 
@@ -698,9 +850,13 @@ extern "C" int eacham_solve_minimal(eacham_ctx* ctx, int kind, int n_points, con
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)n_samples * m, hipMemcpyHostToDevice, st));
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
-        solve_minimal_kernel<<<(unsigned)((n_samples + 63) / 64), 64, 0, st>>>(kind, (const double*)(base + o_a), (const double*)(base + o_b),
-                                                                              (const double*)(base + o_K), K ? 1 : 0, n_samples,
-                                                                              (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+        if (kind == EACHAM_SOLVE_HOMOGRAPHY4)
+            solve_h4_kernel<<<(unsigned)((n_samples + H4_NT - 1) / H4_NT), H4_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), n_samples,
+                                                                                       (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+        else
+            solve_e5_kernel<<<(unsigned)((n_samples + E5_NT - 1) / E5_NT), E5_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b),
+                                                                                       (const double*)(base + o_K), K ? 1 : 0, n_samples,
+                                                                                       (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(models, base + o_m, sizeof(double) * 9 * (size_t)maxm * n_samples, hipMemcpyDeviceToHost, st));
@@ -736,7 +892,11 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
-        solve_pnp_kernel<<<(unsigned)((n_samples + 63) / 64), 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b),
+        if (sample_size > 64)
+            solve_pnp_wave_kernel<<<(unsigned)n_samples, PNP_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
+                                                                          sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+        else
+            solve_pnp_kernel<<<(unsigned)((n_samples + PNP_NT - 1) / PNP_NT), PNP_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b),
                                                                           (const double*)(base + o_K), sample_size, n_samples,
                                                                           (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }

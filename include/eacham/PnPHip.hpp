@@ -5,13 +5,14 @@
 //   cv::Rodrigues(rvec, R); factor.transform = ConvertToTransform(R, t);                                          :236-238
 //
 // OpenCV's loop is sequential: draw 5 points, EPnP, count the points within 4 px, shrink the iteration budget from the
-// best inlier ratio and the confidence, and at the end run EPnP once more on the inliers of the winner. Here the three
-// steps are three launches over ALL candidate samples: eacham_solve_pnp on `iterations` five-point rows, one
-// eacham_score_hypotheses(kind PNP) call for every model against every point, eacham_solve_pnp on the one row of the
-// winner's inliers. The early exit is only a cost saving in OpenCV (a model found later can only have MORE inliers), so
-// evaluating the full budget returns a model at least as good; the iteration count OpenCV WOULD have stopped at is
-// reported for reference (`opencv_iterations`). The samples come from a counter-based generator seeded by the caller —
-// OpenCV's own RNG stream is not reproduced (parity unpinned; tests hold the result against the ground truth).
+// best inlier ratio and the confidence (RANSACUpdateNumIters), stop when the budget is used up, and run EPnP once more on
+// the inliers of the winner. Here the samples are processed in CHUNKS of 256 — eacham_solve_pnp on the chunk's five-point
+// rows, one eacham_score_hypotheses(kind PNP) call for its models against every point — and the sequential rule is replayed
+// over the chunk's inlier counts in sample order, so the loop ends at exactly the sample OpenCV's would (`iterations`) and
+// the winner is the best model among the samples before it; with 70 % inliers that is one chunk instead of the 10 000
+// samples asked for. The last launch is EPnP on the one row of the winner's inliers. The samples come from a counter-based
+// generator seeded by the caller — OpenCV's own RNG stream is not reproduced (parity unpinned; tests hold the result
+// against the ground truth).
 #pragma once
 
 #include <algorithm>
@@ -28,7 +29,7 @@ struct PnPResult {
     Vec3 rvec{};                  // axis * angle, what solvePnPRansac hands back
     Vec3 t{};
     std::vector<int> inliers;     // indices within 4 px of the RANSAC winner (OpenCV's `inliers` output)
-    int opencv_iterations = 0;    // where RANSACUpdateNumIters would have stopped the sequential loop
+    int iterations = 0;           // samples the sequential rule consumed before RANSACUpdateNumIters stopped it
 };
 
 inline Vec3 RodriguesFromMatrix(const Mat3& R) {   // rotation matrix -> axis * angle
@@ -58,30 +59,33 @@ inline PnPResult SolvePnPRansac(Context& ctx, const std::vector<double>& object,
     const int n = (int)(image.size() / 2), m = 5;
     if (n < m || object.size() != (size_t)3 * n || iterations <= 0) return out;
     const double K4[4] = {K9[0], K9[4], K9[2], K9[5]};
-    const std::vector<int32_t> idx = twoview_detail::draw_samples(n, m, iterations, seed);
-    std::vector<double> models((size_t)iterations * 12);
-    std::vector<int32_t> okv(iterations), inl(iterations);
-    ctx.check(eacham_solve_pnp(ctx.get(), n, object.data(), image.data(), K4, m, iterations, idx.data(), models.data(), okv.data()));
     const float thr = reprojectionError * reprojectionError;   // PnPRansacCallback::computeError returns squared pixels
-    ctx.check(eacham_score_hypotheses(ctx.get(), EACHAM_SCORE_PNP, n, object.data(), image.data(), iterations, models.data(), K4, thr, nullptr,
-                                      inl.data(), nullptr));
-    int best = -1, budget = iterations;
-    for (int s = 0; s < iterations; ++s) {
-        if (!okv[s]) continue;
-        if (best < 0 || inl[s] > inl[best]) {   // strictly more inliers replaces the model, as in RANSACPointSetRegistrator::run
-            best = s;
-            // RANSACUpdateNumIters(confidence, outlier ratio, model points, budget)
-            const double ep = std::min(1.0, std::max(0.0, (double)(n - inl[s]) / n));
-            const double num = std::log(std::max(1.0 - confidence, 1e-300)), denom = std::log(std::max(1.0 - std::pow(1.0 - ep, m), 1e-300));
-            if (denom < 0.0 && -num < (double)budget * -denom) budget = (int)std::lround(num / denom);
+    const int chunk = 256;
+    std::vector<double> models((size_t)chunk * 12), best_model(12, 0.0);
+    std::vector<int32_t> okv(chunk), inl(chunk);
+    int best_inl = -1, budget = iterations, done = 0;
+    for (int first = 0; first < budget; first += chunk) {
+        const int cnt = std::min(chunk, iterations - first);
+        // sample s of the whole run is row (s - first) of this chunk: the generator is indexed by the global sample number
+        const std::vector<int32_t> idx = twoview_detail::draw_samples(n, m, cnt, seed, first);
+        ctx.check(eacham_solve_pnp(ctx.get(), n, object.data(), image.data(), K4, m, cnt, idx.data(), models.data(), okv.data()));
+        ctx.check(eacham_score_hypotheses(ctx.get(), EACHAM_SCORE_PNP, n, object.data(), image.data(), cnt, models.data(), K4, thr, nullptr,
+                                          inl.data(), nullptr));
+        for (int k = 0; k < cnt && first + k < budget; ++k) {
+            done = first + k + 1;
+            if (!okv[k]) continue;
+            if (inl[k] > std::max(best_inl, m - 1)) {   // strictly more inliers (and at least a sample's worth) replaces the model
+                best_inl = inl[k];
+                std::copy(&models[(size_t)k * 12], &models[(size_t)k * 12] + 12, best_model.begin());
+                budget = twoview_detail::ransac_update_num_iters(confidence, (double)(n - inl[k]) / n, m, budget);
+            }
         }
-        if (out.opencv_iterations == 0 && s + 1 >= budget) out.opencv_iterations = s + 1;
     }
-    if (out.opencv_iterations == 0) out.opencv_iterations = iterations;
-    if (best < 0 || inl[best] < m) return out;
+    out.iterations = done;
+    if (best_inl < m) return out;
     std::vector<float> err(n);
     int32_t cnt = 0;
-    ctx.check(eacham_score_hypotheses(ctx.get(), EACHAM_SCORE_PNP, n, object.data(), image.data(), 1, &models[(size_t)best * 12], K4, thr,
+    ctx.check(eacham_score_hypotheses(ctx.get(), EACHAM_SCORE_PNP, n, object.data(), image.data(), 1, best_model.data(), K4, thr,
                                       err.data(), &cnt, nullptr));
     std::vector<int32_t> rows;
     for (int i = 0; i < n; ++i)
@@ -90,7 +94,7 @@ inline PnPResult SolvePnPRansac(Context& ctx, const std::vector<double>& object,
     double refit[12];
     int32_t rok = 0;
     ctx.check(eacham_solve_pnp(ctx.get(), n, object.data(), image.data(), K4, (int)rows.size(), 1, rows.data(), refit, &rok));
-    const double* pose = rok ? refit : &models[(size_t)best * 12];   // (a coplanar inlier set cannot be refitted: keep the winner)
+    const double* pose = rok ? refit : best_model.data();   // (a coplanar inlier set cannot be refitted: keep the winner)
     for (int e = 0; e < 9; ++e) out.R[e] = pose[e];
     for (int e = 0; e < 3; ++e) out.t[e] = pose[9 + e];
     out.rvec = RodriguesFromMatrix(out.R);

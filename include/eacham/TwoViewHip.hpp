@@ -105,12 +105,12 @@ inline uint64_t mix(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-inline std::vector<int32_t> draw_samples(int n, int m, int count, uint64_t seed) {
+inline std::vector<int32_t> draw_samples(int n, int m, int count, uint64_t seed, int first = 0) {   // samples first .. first + count - 1
     std::vector<int32_t> idx((size_t)count * m);
     for (int s = 0; s < count; ++s) {
         uint64_t ctr = 0;
         for (int k = 0; k < m;) {
-            const int v = (int)(mix(seed * 0x100000001B3ull + ((uint64_t)s << 20) + ctr++) % (uint64_t)n);
+            const int v = (int)(mix(seed * 0x100000001B3ull + ((uint64_t)(first + s) << 20) + ctr++) % (uint64_t)n);
             bool dup = false;
             for (int j = 0; j < k; ++j) dup = dup || idx[(size_t)s * m + j] == v;
             if (!dup) idx[(size_t)s * m + k++] = v;
@@ -124,15 +124,33 @@ struct RobustModel {
     std::vector<uint8_t> mask;   // inliers of the LMedS rule
     int inliers = 0;
     float median = std::numeric_limits<float>::quiet_NaN();
+    int iterations = 0;          // minimal samples drawn (see lmeds)
     bool ok = false;
 };
 
-// the LMedS loop: solve all samples, score all models, keep the smallest median, classify by sigma
+// RANSACUpdateNumIters (ptsetreg.cpp): iterations after which a sample of m inliers has been drawn with probability p at
+// outlier ratio ep, capped by maxIters
+inline int ransac_update_num_iters(double p, double ep, int m, int maxIters) {
+    p = std::min(std::max(p, 0.0), 1.0);
+    ep = std::min(std::max(ep, 0.0), 1.0);
+    const double num = std::max(1.0 - p, std::numeric_limits<double>::min());
+    const double denom = 1.0 - std::pow(1.0 - ep, m);
+    if (denom < std::numeric_limits<double>::min()) return 0;
+    const double ln = std::log(num), ld = std::log(denom);
+    return ld >= 0 || -ln >= maxIters * (-ld) ? maxIters : (int)std::lround(ln / ld);
+}
+
+// the LMedS loop: solve all samples, score all models, keep the smallest median, classify by sigma.
+// LMeDSPointSetRegistrator::run fixes its iteration count up front from the confidence at an assumed outlier ratio of 0.45
+// (at least 3, at most maxIters): 1000 asked for with confidence 0.99 and 5-point samples are 89 iterations, 100 asked for
+// with 0.999 and 4-point samples are 72.
 inline RobustModel lmeds(Context& ctx, int solve_kind, int score_kind, int m, const std::vector<double>& uv1, const std::vector<double>& uv2,
-                         const double* K4, int iterations, uint64_t seed) {
+                         const double* K4, int maxIters, double confidence, uint64_t seed) {
     RobustModel out;
     const int n = (int)(uv1.size() / 2), maxm = solve_kind == EACHAM_SOLVE_ESSENTIAL5 ? 10 : 1;
-    if (n < m || uv2.size() != uv1.size()) return out;
+    if (n < m || uv2.size() != uv1.size() || maxIters <= 0) return out;
+    const int iterations = std::min(maxIters, std::max(ransac_update_num_iters(confidence, 0.45, m, maxIters), 3));
+    out.iterations = iterations;
     const std::vector<int32_t> idx = draw_samples(n, m, iterations, seed);
     std::vector<double> models((size_t)iterations * maxm * 9);
     std::vector<int32_t> counts(iterations);
@@ -172,13 +190,135 @@ using twoview_detail::RobustModel;
 // cv::findEssentialMat(pts1, pts2, focal, pp, LMEDS, prob, threshold, maxIters, mask): pixels in, K4 = fx fy cx cy
 // (the reference passes focal = K(0,0) and pp = (K(0,2), K(1,2)): fx = fy = focal). The model is a unit-norm E.
 inline RobustModel FindEssentialMat(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2, const double* K4,
-                                    int maxIters = 1000, uint64_t seed = 12345) {
-    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_ESSENTIAL5, EACHAM_SCORE_ESSENTIAL, 5, uv1, uv2, K4, maxIters, seed);
+                                    int maxIters = 1000, uint64_t seed = 12345, double prob = 0.99) {
+    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_ESSENTIAL5, EACHAM_SCORE_ESSENTIAL, 5, uv1, uv2, K4, maxIters, prob, seed);
 }
-// cv::findHomography(pts1, pts2, LMEDS, ransacReprojThreshold, mask, maxIters, confidence). The model has H[8] = 1.
+// What cv::findHomography does with the inliers of the robust stage (fundam.cpp, "if (result && npoints > 4 ...)"): the
+// normalised DLT over ALL inliers (HomographyEstimatorCallback::runKernel with count = inliers), then at most 10
+// Levenberg-Marquardt iterations on the 8 free entries (H[8] = 1) of the forward transfer error. Host arithmetic: a 9 x 9
+// eigenproblem and 8 x 8 solves over a few thousand points. false: fewer than 4 inliers or a degenerate configuration.
+inline bool RefitHomography(const std::vector<double>& uv1, const std::vector<double>& uv2, const std::vector<uint8_t>& mask, Mat3& H) {
+    const int n = (int)(uv1.size() / 2);
+    std::vector<int> in;
+    for (int i = 0; i < n; ++i)
+        if (mask.empty() || mask[i]) in.push_back(i);
+    const int m = (int)in.size();
+    if (m < 4) return false;
+    double cm[2] = {0, 0}, cM[2] = {0, 0}, sm[2] = {0, 0}, sM[2] = {0, 0};
+    for (int i : in) { cM[0] += uv1[2 * i], cM[1] += uv1[2 * i + 1], cm[0] += uv2[2 * i], cm[1] += uv2[2 * i + 1]; }
+    for (int e = 0; e < 2; ++e) cM[e] /= m, cm[e] /= m;
+    for (int i : in) {
+        sM[0] += std::fabs(uv1[2 * i] - cM[0]), sM[1] += std::fabs(uv1[2 * i + 1] - cM[1]);
+        sm[0] += std::fabs(uv2[2 * i] - cm[0]), sm[1] += std::fabs(uv2[2 * i + 1] - cm[1]);
+    }
+    for (int e = 0; e < 2; ++e)
+        if (!(sM[e] > 1e-12) || !(sm[e] > 1e-12)) return false;
+    for (int e = 0; e < 2; ++e) sM[e] = m / sM[e], sm[e] = m / sm[e];
+    double LtL[81] = {0};
+    for (int i : in) {
+        const double x = (uv2[2 * i] - cm[0]) * sm[0], y = (uv2[2 * i + 1] - cm[1]) * sm[1];
+        const double X = (uv1[2 * i] - cM[0]) * sM[0], Y = (uv1[2 * i + 1] - cM[1]) * sM[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x}, Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int j = 0; j < 9; ++j)
+            for (int k = j; k < 9; ++k) LtL[9 * j + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    for (int j = 0; j < 9; ++j)
+        for (int k = 0; k < j; ++k) LtL[9 * j + k] = LtL[9 * k + j];
+    // eigenvector of the smallest eigenvalue: cyclic Jacobi
+    double V[81];
+    for (int i = 0; i < 81; ++i) V[i] = (i % 10 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, diag = 0;
+        for (int p = 0; p < 9; ++p) {
+            diag += LtL[10 * p] * LtL[10 * p];
+            for (int q = p + 1; q < 9; ++q) off += LtL[9 * p + q] * LtL[9 * p + q];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = LtL[9 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (LtL[10 * q] - LtL[10 * p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 9; ++k) { const double a = LtL[9 * k + p], b = LtL[9 * k + q]; LtL[9 * k + p] = c * a - sn * b, LtL[9 * k + q] = sn * a + c * b; }
+                for (int k = 0; k < 9; ++k) { const double a = LtL[9 * p + k], b = LtL[9 * q + k]; LtL[9 * p + k] = c * a - sn * b, LtL[9 * q + k] = sn * a + c * b; }
+                for (int k = 0; k < 9; ++k) { const double a = V[9 * k + p], b = V[9 * k + q]; V[9 * k + p] = c * a - sn * b, V[9 * k + q] = sn * a + c * b; }
+            }
+    }
+    int lo = 0;
+    for (int k = 1; k < 9; ++k)
+        if (LtL[10 * k] < LtL[10 * lo]) lo = k;
+    Mat3 H0;
+    for (int k = 0; k < 9; ++k) H0[k] = V[9 * k + lo];
+    const Mat3 invHnorm{1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1}, Hnorm2{sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    Mat3 Hd = twoview_detail::mul(twoview_detail::mul(invHnorm, H0), Hnorm2);
+    if (!(std::fabs(Hd[8]) > 1e-300)) return false;
+    for (double& v : Hd) v /= Hd[8];
+    // Levenberg-Marquardt on h[0..7], residuals = projected - observed
+    auto cost = [&](const Mat3& G) {
+        double c = 0;
+        for (int i : in) {
+            const double X = uv1[2 * i], Y = uv1[2 * i + 1], w = G[6] * X + G[7] * Y + 1.0, iw = std::fabs(w) > 1e-300 ? 1.0 / w : 0.0;
+            const double ex = (G[0] * X + G[1] * Y + G[2]) * iw - uv2[2 * i], ey = (G[3] * X + G[4] * Y + G[5]) * iw - uv2[2 * i + 1];
+            c += ex * ex + ey * ey;
+        }
+        return c;
+    };
+    double lambda = 1e-3, c0 = cost(Hd);
+    for (int it = 0; it < 10; ++it) {
+        double JtJ[64] = {0}, Jte[8] = {0};
+        for (int i : in) {
+            const double X = uv1[2 * i], Y = uv1[2 * i + 1], w = Hd[6] * X + Hd[7] * Y + 1.0, iw = std::fabs(w) > 1e-300 ? 1.0 / w : 0.0;
+            const double xi = (Hd[0] * X + Hd[1] * Y + Hd[2]) * iw, yi = (Hd[3] * X + Hd[4] * Y + Hd[5]) * iw;
+            const double Jx[8] = {X * iw, Y * iw, iw, 0, 0, 0, -X * iw * xi, -Y * iw * xi}, Jy[8] = {0, 0, 0, X * iw, Y * iw, iw, -X * iw * yi, -Y * iw * yi};
+            const double ex = xi - uv2[2 * i], ey = yi - uv2[2 * i + 1];
+            for (int j = 0; j < 8; ++j) {
+                Jte[j] += Jx[j] * ex + Jy[j] * ey;
+                for (int k = j; k < 8; ++k) JtJ[8 * j + k] += Jx[j] * Jx[k] + Jy[j] * Jy[k];
+            }
+        }
+        for (int j = 0; j < 8; ++j)
+            for (int k = 0; k < j; ++k) JtJ[8 * j + k] = JtJ[8 * k + j];
+        bool improved = false;
+        for (int attempt = 0; attempt < 8 && !improved; ++attempt) {
+            double A[64], b[8];   // (JtJ + lambda diag) d = -Jte by Cholesky
+            for (int j = 0; j < 64; ++j) A[j] = JtJ[j];
+            for (int j = 0; j < 8; ++j) A[9 * j] *= 1.0 + lambda, b[j] = -Jte[j];
+            bool spd = true;
+            for (int j = 0; j < 8 && spd; ++j) {
+                for (int k = 0; k <= j; ++k) {
+                    double v = A[8 * j + k];
+                    for (int q = 0; q < k; ++q) v -= A[8 * j + q] * A[8 * k + q];
+                    if (j == k) { spd = v > 0; A[9 * j] = spd ? std::sqrt(v) : 1.0; } else A[8 * j + k] = v / A[9 * k];
+                }
+            }
+            if (spd) {
+                for (int j = 0; j < 8; ++j) { for (int q = 0; q < j; ++q) b[j] -= A[8 * j + q] * b[q]; b[j] /= A[9 * j]; }
+                for (int j = 7; j >= 0; --j) { for (int q = j + 1; q < 8; ++q) b[j] -= A[8 * q + j] * b[q]; b[j] /= A[9 * j]; }
+                Mat3 G = Hd;
+                for (int j = 0; j < 8; ++j) G[j] += b[j];
+                const double c1 = cost(G);
+                if (c1 < c0) { Hd = G, c0 = c1, lambda *= 0.1, improved = true; }
+            }
+            if (!improved) lambda *= 10.0;
+        }
+        if (!improved) break;
+    }
+    H = Hd;
+    return true;
+}
+
+// cv::findHomography(pts1, pts2, LMEDS, ransacReprojThreshold, mask, maxIters, confidence). The model has H[8] = 1:
+// the LMedS winner refitted on its inliers as above (the mask stays the winner's).
 inline RobustModel FindHomography(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2, int maxIters = 100,
-                                  uint64_t seed = 12345) {
-    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_HOMOGRAPHY4, EACHAM_SCORE_HOMOGRAPHY, 4, uv1, uv2, nullptr, maxIters, seed);
+                                  uint64_t seed = 12345, double confidence = 0.999) {
+    RobustModel r = twoview_detail::lmeds(ctx, EACHAM_SOLVE_HOMOGRAPHY4, EACHAM_SCORE_HOMOGRAPHY, 4, uv1, uv2, nullptr, maxIters, confidence, seed);
+    if (r.ok && uv1.size() / 2 > 4) {
+        Mat3 H;
+        if (RefitHomography(uv1, uv2, r.mask, H)) r.model = H;
+    }
+    return r;
 }
 
 // cv::decomposeEssentialMat: E = U diag(1, 1, 0) V^T -> R1 = U W V^T, R2 = U W^T V^T, t = U[:, 2] (|t| = 1)

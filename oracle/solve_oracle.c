@@ -457,18 +457,30 @@ static int lsq_small(int r, int c, const double* A, const double* b, double* x) 
  * Returns 1, or 0 for a degenerate point set (coplanar / coincident points: the 4-control-point form needs volume). */
 int oracle_epnp(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt) {
     if (m < 4) return 0;
+    /* Sums over the points: sequential for m <= 64; beyond that W = 64 strided partial sums (points l, l + 64, ... in
+     * partial l), added in the order of l — the order a 64-lane wave produces, and for m <= 64 the same bits as the
+     * sequential sum (every partial then holds at most one term). */
+    const int W = m > 64 ? 64 : 1;
     const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
     /* control points: centroid + principal axes scaled by the spread along them */
     double c0[3] = {0, 0, 0};
-    for (int k = 0; k < m; ++k)
-        for (int e = 0; e < 3; ++e) c0[e] += obj[3 * (size_t)idx[k] + e];
+    for (int l = 0; l < W; ++l) {
+        double part[3] = {0, 0, 0};
+        for (int k = l; k < m; k += W)
+            for (int e = 0; e < 3; ++e) part[e] += obj[3 * (size_t)idx[k] + e];
+        for (int e = 0; e < 3; ++e) c0[e] = l ? c0[e] + part[e] : part[e];
+    }
     for (int e = 0; e < 3; ++e) c0[e] /= (double)m;
     double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9], w3[3];
-    for (int k = 0; k < m; ++k) {
-        double d[3];
-        for (int e = 0; e < 3; ++e) d[e] = obj[3 * (size_t)idx[k] + e] - c0[e];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) C[3 * i + j] += d[i] * d[j];
+    for (int l = 0; l < W; ++l) {
+        double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = l; k < m; k += W) {
+            double d[3];
+            for (int e = 0; e < 3; ++e) d[e] = obj[3 * (size_t)idx[k] + e] - c0[e];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) part[3 * i + j] += d[i] * d[j];
+        }
+        for (int i = 0; i < 9; ++i) C[i] = l ? C[i] + part[i] : part[i];
     }
     jacobi_eig(3, C, V3, w3);
     double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
@@ -489,16 +501,21 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
     /* M^T M of the 2m x 12 projection system  sum_j alpha_j (fu Xc_j + (uc - u) Zc_j) = 0, same with v */
     double MtM[144], V[144], w[12];
     for (int i = 0; i < 144; ++i) MtM[i] = 0.0;
-    for (int k = 0; k < m; ++k) {
-        double al[4], r1[12], r2[12];
-        EPNP_ALPHAS(idx[k], al);
-        const double du = uc - img[2 * (size_t)idx[k]], dv = vc - img[2 * (size_t)idx[k] + 1];
-        for (int j = 0; j < 4; ++j) {
-            r1[3 * j] = al[j] * fu, r1[3 * j + 1] = 0.0, r1[3 * j + 2] = al[j] * du;
-            r2[3 * j] = 0.0, r2[3 * j + 1] = al[j] * fv, r2[3 * j + 2] = al[j] * dv;
+    for (int l = 0; l < W; ++l) {
+        double part[144];
+        for (int i = 0; i < 144; ++i) part[i] = 0.0;
+        for (int k = l; k < m; k += W) {
+            double al[4], r1[12], r2[12];
+            EPNP_ALPHAS(idx[k], al);
+            const double du = uc - img[2 * (size_t)idx[k]], dv = vc - img[2 * (size_t)idx[k] + 1];
+            for (int j = 0; j < 4; ++j) {
+                r1[3 * j] = al[j] * fu, r1[3 * j + 1] = 0.0, r1[3 * j + 2] = al[j] * du;
+                r2[3 * j] = 0.0, r2[3 * j + 1] = al[j] * fv, r2[3 * j + 2] = al[j] * dv;
+            }
+            for (int i = 0; i < 12; ++i)
+                for (int j = i; j < 12; ++j) part[12 * i + j] += r1[i] * r1[j] + r2[i] * r2[j];
         }
-        for (int i = 0; i < 12; ++i)
-            for (int j = i; j < 12; ++j) MtM[12 * i + j] += r1[i] * r1[j] + r2[i] * r2[j];
+        for (int i = 0; i < 144; ++i) MtM[i] = l ? MtM[i] + part[i] : part[i];
     }
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
@@ -588,15 +605,20 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
         }
         /* absolute orientation world -> camera (Horn's quaternion form): S = sum pc (pw - c0)^T */
         double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pcm[3] = {0, 0, 0};
-        for (int k = 0; k < m; ++k) {
-            double al[4], pc[3];
-            EPNP_ALPHAS(idx[k], al);
-            for (int e = 0; e < 3; ++e) {
-                pc[e] = al[0] * cc[0][e] + al[1] * cc[1][e] + al[2] * cc[2][e] + al[3] * cc[3][e];
-                pcm[e] += pc[e];
+        for (int l = 0; l < W; ++l) {
+            double Sp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pp[3] = {0, 0, 0};
+            for (int k = l; k < m; k += W) {
+                double al[4], pc[3];
+                EPNP_ALPHAS(idx[k], al);
+                for (int e = 0; e < 3; ++e) {
+                    pc[e] = al[0] * cc[0][e] + al[1] * cc[1][e] + al[2] * cc[2][e] + al[3] * cc[3][e];
+                    pp[e] += pc[e];
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) Sp[3 * i + j] += pc[i] * (obj[3 * (size_t)idx[k] + j] - c0[j]);
             }
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) S[3 * i + j] += pc[i] * (obj[3 * (size_t)idx[k] + j] - c0[j]);
+            for (int i = 0; i < 9; ++i) S[i] = l ? S[i] + Sp[i] : Sp[i];
+            for (int e = 0; e < 3; ++e) pcm[e] = l ? pcm[e] + pp[e] : pp[e];
         }
         for (int e = 0; e < 3; ++e) pcm[e] /= (double)m;
         /* S[i][j] = sum camera_i world_j; the rotation maximising tr(R^T S) is the top eigenvector of Horn's 4 x 4 matrix
@@ -618,13 +640,17 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
         cand[6] = 2.0 * (qz * qx - q0 * qy), cand[7] = 2.0 * (qz * qy + q0 * qx), cand[8] = q0 * q0 - qx * qx - qy * qy + qz * qz;
         for (int i = 0; i < 3; ++i) cand[9 + i] = pcm[i] - (cand[3 * i] * c0[0] + cand[3 * i + 1] * c0[1] + cand[3 * i + 2] * c0[2]);
         double err = 0.0;
-        for (int k = 0; k < m; ++k) {
-            const double* X = obj + 3 * (size_t)idx[k];
-            const double xc = cand[0] * X[0] + cand[1] * X[1] + cand[2] * X[2] + cand[9];
-            const double yc = cand[3] * X[0] + cand[4] * X[1] + cand[5] * X[2] + cand[10];
-            const double zc = cand[6] * X[0] + cand[7] * X[1] + cand[8] * X[2] + cand[11];
-            const double eu = uc + fu * xc / zc - img[2 * (size_t)idx[k]], evv = vc + fv * yc / zc - img[2 * (size_t)idx[k] + 1];
-            err += sqrt(eu * eu + evv * evv);
+        for (int l = 0; l < W; ++l) {
+            double ep = 0.0;
+            for (int k = l; k < m; k += W) {
+                const double* X = obj + 3 * (size_t)idx[k];
+                const double xc = cand[0] * X[0] + cand[1] * X[1] + cand[2] * X[2] + cand[9];
+                const double yc = cand[3] * X[0] + cand[4] * X[1] + cand[5] * X[2] + cand[10];
+                const double zc = cand[6] * X[0] + cand[7] * X[1] + cand[8] * X[2] + cand[11];
+                const double eu = uc + fu * xc / zc - img[2 * (size_t)idx[k]], evv = vc + fv * yc / zc - img[2 * (size_t)idx[k] + 1];
+                ep += sqrt(eu * eu + evv * evv);
+            }
+            err = l ? err + ep : ep;
         }
         if (!(err < 1e300)) continue;
         if (best_err < 0.0 || err < best_err) {

@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
         in.read((char*)&n, sizeof(n));
         const auto obj = rd<double>(in, 3 * (size_t)n), img = rd<double>(in, 2 * (size_t)n), K9 = rd<double>(in, 9);
         const PnPResult r = SolvePnPRansac(ctx, obj, img, K9.data(), 10000, 4.0f, 0.999, 5);
-        std::vector<double> pose{(double)r.ok, (double)r.opencv_iterations};
+        std::vector<double> pose{(double)r.ok, (double)r.iterations};
         pose.insert(pose.end(), r.R.begin(), r.R.end());
         pose.insert(pose.end(), r.rvec.begin(), r.rvec.end());
         pose.insert(pose.end(), r.t.begin(), r.t.end());
@@ -86,7 +86,8 @@ int main(int argc, char** argv) {
         const double K4[4] = {K9[0], K9[4], K9[2], K9[5]};
         const RobustModel Em = FindEssentialMat(ctx, uv1, uv2, K4, 1000, 7);
         const RobustModel Hm = FindHomography(ctx, uv1, uv2, 100, 7);
-        std::vector<double> meta{(double)Em.ok, (double)Em.inliers, (double)Em.median, (double)Hm.ok, (double)Hm.inliers, (double)Hm.median};
+        std::vector<double> meta{(double)Em.ok, (double)Em.inliers, (double)Em.median, (double)Hm.ok, (double)Hm.inliers, (double)Hm.median,
+                                 (double)Em.iterations, (double)Hm.iterations};
         wr(out, meta);
         wr(out, std::vector<double>(Em.model.begin(), Em.model.end()));
         wr(out, std::vector<double>(Hm.model.begin(), Hm.model.end()));

@@ -108,6 +108,7 @@ def test_two_view_pipeline_recovers_the_relative_pose(tmp_path):
             T21 = c["T21"]
             Rt, tt = T21[:3, :3], T21[:3, 3] / np.linalg.norm(T21[:3, 3])
             assert meta[0] == 1 and meta[3] == 1
+            assert meta[6] == 89 and meta[7] == 72          # LMedS' fixed budgets: 1000 asked at 0.99 / 5 points, 100 at 0.999 / 4 points
             if k == 0:                                                       # general scene: the essential matrix and its pose
                 Et = c["E"][0].reshape(3, 3) / np.linalg.norm(c["E"][0])
                 assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 0.02

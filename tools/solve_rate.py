@@ -1,0 +1,94 @@
+"""Robust-estimator building blocks at the reference's iteration counts (ReconstructionManager.cpp:57-61, :75, :227-228):
+  findHomography     100 LMedS iterations   -> 100 four-point solves + 100 models scored
+  findEssentialMat  1000 LMedS iterations   -> 1000 five-point solves (<= 10 models each) + all of them scored
+  solvePnPRansac   10000 RANSAC iterations  -> 10 000 EPnP(5) solves + 10 000 models scored + the all-inlier refit
+Device time from the C-ABI's HIP-event slot (solve and score kernels share EACHAM_KERNEL_SCORE), end-to-end time
+through the host-pointer entry points, the CPU restatement (OpenMP, all host cores) beside it, and bit-parity.
+Run on the GPU box:  python tools/solve_rate.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from eacham_amd import HipContext, capi, score  # noqa: E402
+import oracle_api as O  # noqa: E402
+import score_cases as SC  # noqa: E402
+
+
+def draw(rng, n, m, count):
+    return np.array([rng.choice(n, m, replace=False) for _ in range(count)], np.int32)
+
+
+def timed(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    return (time.perf_counter() - t0) / reps, r
+
+
+def main():
+    rng = np.random.default_rng(1)
+    n = 2000                                                  # matches of a pair / 2D-3D correspondences of a frame
+    tv = SC.two_view_case(n=n, seed=5, outliers=0.25)
+    pl = SC.two_view_case(n=n, seed=6, outliers=0.25, planar=True, facing=True)
+    pn = SC.pnp_case(n=n + 1, seed=7, outliers=0.3)
+    X, uv = pn["X"][1:], pn["uv"][1:]
+    sH, sE, sP = draw(rng, n, 4, 100), draw(rng, n, 5, 1000), draw(rng, n, 5, 10000)
+    out = {"points": n, "cpu_cores": os.cpu_count()}
+    with HipContext(0) as ctx:
+        def gpu_h():
+            m, c = score.solve_minimal(ctx, "homography4", pl["uv1"], pl["uv2"], sH)
+            return m, c, score.score_hypotheses(ctx, "homography", pl["uv1"], pl["uv2"], m[:, 0], threshold=16.0, want_errors=False)
+
+        def gpu_e():
+            m, c = score.solve_minimal(ctx, "essential5", tv["uv1"], tv["uv2"], sE, tv["K"])
+            cand = np.concatenate([a[:k] for a, k in zip(m, c)])
+            return m, c, score.score_hypotheses(ctx, "essential", tv["uv1"], tv["uv2"], cand, tv["K"], threshold=16.0 / tv["K"][0] ** 2, want_errors=False)
+
+        def gpu_p():
+            m, ok = score.solve_pnp(ctx, X, uv, pn["K"], sP)
+            err, inl, _ = score.score_hypotheses(ctx, "pnp", X, uv, m, pn["K"], threshold=16.0)
+            rows = np.flatnonzero(err[int(np.argmax(inl))] <= 16.0).astype(np.int32)[None, :]
+            return m, ok, inl, score.solve_pnp(ctx, X, uv, pn["K"], rows)
+
+        def cpu_h():
+            m, c = O.solve_minimal("homography4", pl["uv1"], pl["uv2"], sH)
+            return m, c, O.score_hypotheses("homography", pl["uv1"], pl["uv2"], m[:, 0], None, 16.0)
+
+        def cpu_e():
+            m, c = O.solve_minimal("essential5", tv["uv1"], tv["uv2"], sE, tv["K"])
+            cand = np.concatenate([a[:k] for a, k in zip(m, c)])
+            return m, c, O.score_hypotheses("essential", tv["uv1"], tv["uv2"], cand, tv["K"], 16.0 / tv["K"][0] ** 2)
+
+        def cpu_p():
+            m, ok = O.solve_pnp(X, uv, pn["K"], sP)
+            err, inl, _ = O.score_hypotheses("pnp", X, uv, m, pn["K"], 16.0)
+            rows = np.flatnonzero(err[int(np.argmax(inl))] <= 16.0).astype(np.int32)[None, :]
+            return m, ok, inl, O.solve_pnp(X, uv, pn["K"], rows)
+
+        for name, g, c, iters in (("findHomography_100", gpu_h, cpu_h, 100), ("findEssentialMat_1000", gpu_e, cpu_e, 1000),
+                                  ("solvePnPRansac_10000", gpu_p, cpu_p, 10000)):
+            g()
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            reps = 10
+            dt, rg = timed(g, reps)
+            _, ms = ctx.profile_get(capi.KERNEL_SCORE)
+            ctx.profile_enable(False)
+            dc, rc = timed(c, 2)
+            same = bool(np.array_equal(rg[0], rc[0]) and np.array_equal(rg[1], rc[1]))
+            out[name] = {"kernels_ms": round(ms / (reps + 1), 4), "end_to_end_ms": round(dt * 1e3, 3), "cpu_ms": round(dc * 1e3, 2),
+                         "iterations_per_s_end_to_end": round(iters / dt), "cpu_iterations_per_s": round(iters / dc),
+                         "models_bit_identical": same}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
