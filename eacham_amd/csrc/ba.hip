@@ -242,7 +242,7 @@ struct BaDev {
     // stream, not by bandwidth: a landmark's ~8 observations cost ~3 k fp64 instructions in one lane, ~10 us per kernel
     // whatever the landmark count. There the three kernels that loop over a landmark's observations spread it over
     // lpl = 8 adjacent lanes (observation o0 + sub, o0 + sub + 8, ...; xor-shuffle sums in a fixed order), on a grid of
-    // n_ll_blocks workgroups; large problems keep lpl = 1 (n_ll_blocks = n_lm_blocks): their time is traffic.
+    // n_ll_blocks workgroups; large problems use lpl = 2 (50 k landmarks are 782 waves on 1024 SIMDs with one lane each).
     int lpl, n_ll_blocks;
     // the same idea for the kernels of the step's tail (back-substitution + error: two passes of dependent gathers per
     // observation): their own lanes-per-landmark count and grid (measured on S200 / config 4: 2 lanes 35.6 / 72 us,
@@ -2539,7 +2539,7 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
     D.nz = make_noise();
     D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
-    D.lpl = nl <= 8192 ? 8 : 1;
+    D.lpl = ctx->ba_lpl_lin > 0 ? ctx->ba_lpl_lin : (nl <= 8192 ? 8 : 2);  // (S200: 45.7 / 40.4 / 41.0 / 45.6 us for 1 / 2 / 4 / 8, tools/ba_lpl_lin.sh)
     D.n_ll_blocks = std::max(1, (int)(((long long)nl * D.lpl + TPB - 1) / TPB));
     D.lpl_step = ctx->ba_lpl_step > 0 ? ctx->ba_lpl_step : (nl <= 8192 ? 8 : 2);
     D.n_step_blocks = std::max(1, (int)(((long long)nl * D.lpl_step + TPB - 1) / TPB));
@@ -2864,8 +2864,12 @@ static void launch_error_landmarks(eacham_ctx* ctx, eacham_ba_handle* h, const d
 }
 static void launch_linearize_both(eacham_ctx* ctx, const BaDev& D, double* clpart) {
     const int ncb = D.nc * LSEG;
-    if (D.lpl == 8) ba_linearize<8><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
-    else ba_linearize<1><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
+    switch (D.lpl) {
+        case 8: ba_linearize<8><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb); break;
+        case 4: ba_linearize<4><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb); break;
+        case 2: ba_linearize<2><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb); break;
+        default: ba_linearize<1><<<ncb + D.n_ll_blocks, TPB, 0, ctx->stream>>>(D, clpart, ncb);
+    }
 }
 static void launch_step_landmarks(eacham_ctx* ctx, eacham_ba_handle* h, double lambda) {
     const BaDev& D = h->D;

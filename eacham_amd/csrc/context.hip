@@ -227,6 +227,10 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
         const int v = atoi(l);
         if (v == 1 || v == 2 || v == 4 || v == 8) ctx->ba_lpl_step = v;
     }
+    if (const char* l = getenv("EACHAM_BA_LPL_LIN")) {
+        const int v = atoi(l);
+        if (v == 1 || v == 2 || v == 4 || v == 8) ctx->ba_lpl_lin = v;
+    }
     if (const char* o = getenv("EACHAM_BA_ORDERING"))
         ctx->ba_ordering = !strcmp(o, "natural") ? EACHAM_BA_ORDER_NATURAL : !strcmp(o, "rcm") ? EACHAM_BA_ORDER_RCM : !strcmp(o, "nd") ? EACHAM_BA_ORDER_ND : EACHAM_BA_ORDER_AUTO;
     if (hipSetDevice(device_id) != hipSuccess ||

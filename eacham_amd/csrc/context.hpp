@@ -98,6 +98,7 @@ struct eacham_ctx {
     std::vector<eacham::BaBlock> ba_pool;  // arenas of released BA problems, reused by the next eacham_ba_prepare
     int ba_ordering = 0;  // EACHAM_BA_ORDERING=natural|rcm|nd read ONCE at eacham_ctx_create (diagnostic override of
                           // eacham_ba_problem.ordering == AUTO); nothing on the solve path reads the environment
+    int ba_lpl_lin = 0;             // EACHAM_BA_LPL_LIN=1|2|4|8 (diagnostic: lanes per landmark of the linearisation), read at create
     int ba_lpl_step = 0;            // EACHAM_BA_LPL_STEP=1|2|4|8 (diagnostic: lanes per landmark of the step's tail kernels), read at create
     bool match_no_overlap = false;  // EACHAM_NO_OVERLAP (diagnostic: finalize on the tile kernel's stream), read at create
 
