@@ -429,10 +429,9 @@ __global__ __launch_bounds__(TPB) void ba_linearize(BaDev D, double* __restrict_
 // Second stage, one launch: blocks [0, KLIN) sum the calibration parts over every (camera, segment) in fixed order
 // (strided partial sums, then a shuffle tree) and add the Cal3_S2 prior -> klin; blocks [KLIN, KLIN + nc) add a
 // camera's segments in order and its pose prior -> camlin.
-__global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double* __restrict__ clpart) {
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x < KLIN) {
-        const int i = blockIdx.x;
+__device__ __forceinline__ void finish_linearize_block(const BaDev& D, const double* __restrict__ clpart, int block, int lane) {
+    if (block < KLIN) {
+        const int i = block;
         const int src = i < 25 ? 16 * (6 + min(i / 5, i % 5)) + 6 + max(i / 5, i % 5) : 16 * (6 + (i - 25)) + 11;  // upper triangle
         double s = 0.0;
         for (int e = lane; e < D.nc * LSEG; e += 64) s += clpart[(size_t)CLP * e + src];
@@ -449,7 +448,7 @@ __global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double*
         }
         return;
     }
-    const int c = blockIdx.x - KLIN;
+    const int c = block - KLIN;
     if (lane >= 57) return;
     int a, bb;  // entry of the accumulator image this lane finishes: Hcc upper triangle (21), HcK (30), gc (6)
     if (lane < 21) {
@@ -486,18 +485,30 @@ __global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double*
     }
 }
 
+__global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double* __restrict__ clpart) {
+    finish_linearize_block(D, clpart, (int)blockIdx.x, (int)threadIdx.x);
+}
+
 // ---- K-C: per-landmark elimination for one lambda (thread = landmark) -------------------------------
 // Hd = Hll + lambda clamp(diag), Hd = L L^T, Linv; EKt = ElK Linv^T, gt = Linv gl (Et_o = E_o Linv^T: K-C2).
 // Also this block's share of the (K,K) Schur term: sum EKt EKt^T (25) and EKt gt (5) -> kk_part.
 // The launch also clears the tiles of S for the assembly kernels behind it (the factorisation works in place, so S is
 // rebuilt for every lambda): the stores are issued first and drain under the arithmetic — no fill node per try.
-__global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double lambda) {
+// The FIRST try after a linearisation also carries that linearisation's second stage (finish_linearize_block: n_finish
+// extra workgroups, one wave of each at work): it depends on the linearisation only, like this kernel, and as a launch of its own
+// it was 4.6 (window) / 6.9 us (S200) on the chain of the iteration.
+__global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double lambda, const double* __restrict__ clpart, int n_finish) {
     __shared__ double sm[(TPB / 64) * 30];
+    const int n_lm_blocks = (int)gridDim.x - n_finish;
+    if ((int)blockIdx.x >= n_lm_blocks) {  // workgroup-uniform
+        if (threadIdx.x < 64) finish_linearize_block(D, clpart, (int)blockIdx.x - n_lm_blocks, (int)threadIdx.x);
+        return;
+    }
     const int j = blockIdx.x * TPB + threadIdx.x;
     {
         double2* S2 = reinterpret_cast<double2*>(D.T);
         const size_t total = (size_t)D.sp_ntiles * (PB * PB / 2);
-        for (size_t e = (size_t)j; e < total; e += (size_t)gridDim.x * TPB) S2[e] = make_double2(0.0, 0.0);
+        for (size_t e = (size_t)j; e < total; e += (size_t)n_lm_blocks * TPB) S2[e] = make_double2(0.0, 0.0);
     }
     double kk[30];
 #pragma unroll
@@ -2424,6 +2435,7 @@ struct eacham_ba_handle {
     std::vector<char> stage;   // small problems: host image of the uploaded arrays, sent with ONE copy
     std::vector<int> lm_order;  // landmark-sorted observation index -> caller's observation index
     double *kpart = nullptr, *err_cam = nullptr, *lin_cam = nullptr;
+    bool finish_pending = false;  // the linearisation's second stage has not run yet: the next try's first launch carries it
     double* scal_host = nullptr;  // pinned: the per-try scalar read-back sits on the LM loop's critical path
     long long ticket = 0;         // number of the last ba_final_sums launch (it stores it behind the scalars)
     double *pose_init = nullptr, *pt_init = nullptr, *K_init = nullptr;
@@ -2842,6 +2854,7 @@ static void ba_release(eacham_ctx* ctx, eacham_ba_handle* h) {
 
 // resets the values to the uploaded initial state
 static int ba_reset(eacham_ctx* ctx, eacham_ba_handle* h) {
+    h->finish_pending = false;
     BaDev& D = h->D;
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.pose, h->pose_init, sizeof(double) * 12 * (size_t)D.nc, hipMemcpyDeviceToDevice, ctx->stream));
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(D.pt, h->pt_init, sizeof(double) * 3 * (size_t)D.nl, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2894,7 +2907,13 @@ static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
     launch_linearize_both(ctx, D, h->kpart);
-    ba_finish_linearize<<<KLIN + D.nc, 64, 0, ctx->stream>>>(D, h->kpart);
+    h->finish_pending = true;  // rides in the next ba_eliminate_landmarks (launch_try) or is flushed by finish_linearize_now
+}
+static void finish_linearize_now(eacham_ctx* ctx, eacham_ba_handle* h) {
+    if (!h->finish_pending) return;
+    ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
+    ba_finish_linearize<<<KLIN + h->D.nc, 64, 0, ctx->stream>>>(h->D, h->kpart);
+    h->finish_pending = false;
 }
 
 // one tryLambda(): builds and solves the damped system, writes tentative values and
@@ -2904,7 +2923,9 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     const int n = D.n;
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
-        ba_eliminate_landmarks<<<D.n_lm_blocks, TPB, 0, ctx->stream>>>(D, lambda);
+        const int n_finish = h->finish_pending ? KLIN + D.nc : 0;
+        ba_eliminate_landmarks<<<D.n_lm_blocks + n_finish, TPB, 0, ctx->stream>>>(D, lambda, h->kpart, n_finish);
+        h->finish_pending = false;
         if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
         if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
         const unsigned nbg = (unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB);
@@ -2958,6 +2979,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
 // (needs E: the linearisation ran with store_E). Same outputs as launch_try. *pcg_iterations (optional) += iterations.
 static int launch_try_pcg(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, long long* pcg_iterations) {
     BaDev& D = h->D;
+    finish_linearize_now(ctx, h);
     const int n_update_blocks = (D.nl + D.nc + 1 + TPB - 1) / TPB;
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SOLVE);
