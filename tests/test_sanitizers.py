@@ -139,3 +139,34 @@ def test_adapters_under_asan_ubsan(tmp_path):
     open(os.path.join(bad, "config.json"), "w").write('{"root_path": "x", "feature": {"min_features_count": [1, 2, {"a": "\\u00e9\\n"}]}, "t": tru')
     r = subprocess.run([exe, bad, "config-only"], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV))
     assert r.returncode == 1 and "ERROR: " not in r.stderr and "runtime error" not in r.stderr   # a parse error, reported, no UB
+
+
+def test_two_view_and_pnp_adapters_under_asan_ubsan(tmp_path):
+    """TwoViewHip.hpp / PnPHip.hpp — the LMedS and RANSAC loops, the sample generator, the homography refit, the
+    decompositions and the Rodrigues vector — with the stub standing in for the device calls (it reads every input array it
+    is handed and fills every output array: a wrong size in the adapters is an ASAN report)."""
+    import struct
+    tmp = str(tmp_path)
+    exe = _build(tmp, "twoview_driver", ASAN, "asan")
+    rng = np.random.default_rng(4)
+    K = np.array([[700.0, 0, 320], [0, 700, 240], [0, 0, 1]])
+    H = K @ (np.eye(3) + 0.1 * rng.normal(size=(3, 3))) @ np.linalg.inv(K)
+    lines = ["H " + " ".join(f"{x:.17g}" for x in np.r_[H.ravel(), K.ravel()]),
+             "H " + " ".join(f"{x:.17g}" for x in np.r_[np.eye(3).ravel(), K.ravel()]),       # no motion at all
+             "H " + " ".join(f"{x:.17g}" for x in np.r_[np.zeros(9), K.ravel()]),             # not a homography
+             "E " + " ".join(f"{x:.17g}" for x in rng.normal(size=9)), "E " + " ".join(["0"] * 9),
+             "R " + " ".join(f"{x:.17g}" for x in np.eye(3).ravel()), "R " + " ".join(f"{x:.17g}" for x in np.diag([1.0, -1, -1]).ravel())]
+    r = _run([exe, "decompose"], input="\n".join(lines) + "\n")
+    assert r.stdout.count("\n") >= 7
+    fin, fout = os.path.join(tmp, "tv_in.bin"), os.path.join(tmp, "tv_out.bin")
+    with open(fin, "wb") as f:
+        for n in (37, 5):                                           # two scenes; the second at the five-point minimum
+            f.write(struct.pack("i", n))
+            f.write(rng.uniform(0, 640, size=(n, 2)).tobytes()); f.write(rng.uniform(0, 640, size=(n, 2)).tobytes())
+            f.write(K.tobytes())
+    assert "twoview driver ok" in _run([exe, "pipeline", fin, fout]).stdout
+    for n in (300, 5, 3):                                            # more than a chunk's worth of points, the minimum, too few
+        with open(fin, "wb") as f:
+            f.write(struct.pack("i", n))
+            f.write(rng.normal(size=(n, 3)).tobytes()); f.write(rng.uniform(0, 640, size=(n, 2)).tobytes()); f.write(K.tobytes())
+        assert "twoview driver ok" in _run([exe, "pnp", fin, fout]).stdout
