@@ -6,6 +6,8 @@
 //   Graph::GetNodes / Get / IsFixed, Node::IsValid / GetTransform / SetTransform / GetFeatures / GetPoints3d /
 //   SetPoint3d / GetFactors (Factor::matches), Map::Get / GetStatus / GetObservers / GetAll / Add / UpdatePoint /
 //   UpdateStatus / AddObserver / RemoveObserver, OptimizerConfig's five fields
+//   and for ReconstructionHip.hpp: Node::GetFactor / GetKeyPoint / HasPoint3d / IsPoint3dTwoView / GetPoint3d / SetValid,
+//   Factor::quality / transform, Graph::Connect / Size, Map::Add(point, colour)
 //       modules/sfm/data/Graph.h:44-57,108-116, Node.h:24-31,57-71,100-103,126-134,146-149,204-207,
 //       Map.h:15-23,40-49,59-71,87-99,101-127,129-177,179-196, modules/sfm/config/SfmConfig.h:15-22 (under /root/reference)
 // These classes carry those names with the smallest bodies that make them work, plus a few Test* methods the drivers use
@@ -59,7 +61,10 @@ using match_t = std::unordered_map<unsigned, unsigned>;
 
 struct Factor {
     unsigned id = 0;
+    float quality = 0;
     match_t matches;
+    unsigned points3dCount = 0;
+    Eigen::Matrix4d transform;
 };
 
 struct OptimizerConfig {
@@ -81,7 +86,17 @@ public:
     void SetPoint3d(unsigned id2d, unsigned id3d, bool isTwoView) { points3d_[id2d] = id3d; twoView_[id2d] = isTwoView; }
     const std::unordered_map<unsigned, Factor>& GetFactors() { return factors_; }
     bool IsValid() const { return valid_; }
+    void SetValid(bool v) { valid_ = v; }
     unsigned GetId() const { return id_; }
+    Factor& GetFactor(unsigned id) {
+        auto it = factors_.find(id);
+        if (it == factors_.end()) throw std::runtime_error("Node::GetFactor: factor is not found");
+        return it->second;
+    }
+    const cv::Point2f& GetKeyPoint(unsigned id) const { return keypoints_.at(id); }
+    bool HasPoint3d(unsigned id2d) const { return points3d_.count(id2d) > 0; }
+    bool IsPoint3dTwoView(unsigned id2d) const { return twoView_.at(id2d); }
+    unsigned GetPoint3d(unsigned id2d) const { return points3d_.at(id2d); }
     // test-only loaders
     void TestSetValid(bool v) { valid_ = v; }
     void TestSetFeatures(FT k) { keypoints_ = std::move(k); }
@@ -105,6 +120,12 @@ public:
         return it == nodes_.end() ? nullptr : it->second;
     }
     const std::map<unsigned, Node<FT, DT>*>& GetNodes() { return nodes_; }
+    void Connect(Node<FT, DT>* node1, Node<FT, DT>* node2, match_t&& matches) {
+        Factor& f = node1->TestFactor(node2->GetId());
+        f.quality = (float)matches.size();
+        f.matches = std::move(matches);
+    }
+    size_t Size() const { return nodes_.size(); }
     void FixNode(unsigned id) { fixed_.insert(id); }
     bool IsFixed(unsigned id) { return fixed_.count(id) > 0; }
     Node<FT, DT>* TestCreate(unsigned id) {
@@ -137,6 +158,7 @@ public:
         points_[counter_] = d;
         return counter_;
     }
+    unsigned Add(const Eigen::Vector3d& p, const Eigen::Vector3d& /*colour*/) { return Add(p); }
     void UpdatePoint(unsigned id, const Eigen::Vector3d& p) { at(id).point3d = p; }
     void UpdateStatus(unsigned id, bool valid) { at(id).isValid = valid; }
     Eigen::Vector3d Get(unsigned id) const { return at(id).point3d; }

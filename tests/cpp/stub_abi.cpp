@@ -106,11 +106,19 @@ int eacham_match_pair(eacham_ctx* c, int f1, int f2, double, uint32_t* q, uint32
 }
 
 int eacham_graph_best_pair(eacham_ctx*, int, const int32_t* pairs, int npairs, const int32_t* counts, const int64_t*, const uint32_t*,
-                           const uint32_t*, const uint8_t*, const uint8_t*, const int64_t*, const uint8_t*, uint32_t* edge_counts, uint32_t* best) {
+                           const uint32_t*, const uint8_t* valid, const uint8_t* excluded, const int64_t*, const uint8_t*, uint32_t* edge_counts,
+                           uint32_t* best) {
+    // a fake of the query that keeps its CONTRACT: an edge from a valid node to a not-yet-valid, not-excluded one (either way round)
     best[0] = best[1] = 0xffffffffu; best[2] = 0;
     for (int p = 0; p < npairs; ++p) {
         if (edge_counts) edge_counts[2 * p] = edge_counts[2 * p + 1] = 0;
-        if (counts[p] >= (int32_t)best[2]) { best[0] = (uint32_t)pairs[2 * p]; best[1] = (uint32_t)pairs[2 * p + 1]; best[2] = (uint32_t)counts[p]; }
+        if (counts[p] <= 0) continue;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int a = pairs[2 * p + dir], b = pairs[2 * p + 1 - dir];
+            if (valid[a] && !valid[b] && !(excluded && excluded[b]) && counts[p] >= (int32_t)best[2]) {
+                best[0] = (uint32_t)a; best[1] = (uint32_t)b; best[2] = (uint32_t)counts[p];
+            }
+        }
     }
     return EACHAM_OK;
 }

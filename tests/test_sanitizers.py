@@ -170,3 +170,24 @@ def test_two_view_and_pnp_adapters_under_asan_ubsan(tmp_path):
             f.write(struct.pack("i", n))
             f.write(rng.normal(size=(n, 3)).tobytes()); f.write(rng.uniform(0, 640, size=(n, 2)).tobytes()); f.write(K.tobytes())
         assert "twoview driver ok" in _run([exe, "pnp", fin, fout]).stdout
+
+
+def test_sfm_loop_driver_builds_and_walks_its_graph_under_asan_ubsan(tmp_path):
+    """tests/cpp/sfm_loop_driver.cpp (the loop of apps/sfm/main.cpp on ReferenceGlue.hpp + ReconstructionHip.hpp) compiled
+    -Wall -Wextra -Werror against the stub: the graph / map walks of FindBestPair, RecoverPoseTwoView and RecoverPosePnP run
+    on fake device results; whichever way the loop ends (a reconstruction or 'no initial pair'), there is no sanitizer report."""
+    tmp = str(tmp_path)
+    exe = _build(tmp, "sfm_loop_driver", ASAN, "asan")
+    rng = np.random.default_rng(9)
+    F, n, dim = 4, 60, 16
+    fin, fout = os.path.join(tmp, "sfm_in.bin"), os.path.join(tmp, "sfm_out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("ii", F, dim))
+        base = rng.integers(0, 255, size=(n, dim)).astype(np.float32)
+        for _ in range(F):
+            f.write(struct.pack("i", n)); f.write(rng.uniform(0, 640, size=(n, 2)).astype(np.float32).tobytes()); f.write(base.tobytes())
+        f.write(np.array([700.0, 0, 320, 0, 700, 240, 0, 0, 1]).tobytes())
+        f.write(np.array([0.8, 3.5, 0.05, 8.0, 0.05, 15, 10], dtype=np.float32).tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV), timeout=600)
+    assert r.returncode in (0, 3) and "ERROR: " not in r.stderr and "runtime error" not in r.stderr, (r.returncode, r.stdout[-1000:], r.stderr[-3000:])
+    assert "sfm loop" in r.stdout

@@ -1,0 +1,84 @@
+"""GPU: the incremental loop of apps/sfm/main.cpp:76-240 run end to end on the library — pair matching, FindBestPair
+(RecoverPoseTwoView both ways: findEssentialMat / findHomography / recoverPose or decomposeHomographyMat), then
+GetBestPairForValid -> RecoverPosePnP (solvePnPRansac) -> TriangulateFrame -> RefineBA -> TriangulateFrame per frame and the
+global RefineBA — through the reference-typed entry points (ReferenceGlue.hpp, ReconstructionHip.hpp) on stand-ins of
+Graph / Node / Map (tests/cpp/sfm_loop_driver.cpp). Nothing but keypoints, descriptors and K goes in; the recovered
+cameras are held against the synthetic scene's ground truth up to the similarity the reconstruction is free in."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from eacham_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+pytestmark = pytest.mark.gpu
+
+
+def _vec(f, dtype=np.float64):
+    n = struct.unpack("q", f.read(8))[0]
+    return np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype).copy()
+
+
+def umeyama(src, dst):
+    """Similarity (s, R, t) minimising |s R src + t - dst|."""
+    ms, md = src.mean(0), dst.mean(0)
+    a, b = src - ms, dst - md
+    U, S, Vt = np.linalg.svd(b.T @ a / len(src))
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt
+    s = np.trace(np.diag(S) @ D) / (a ** 2).sum() * len(src)
+    return s, R, md - s * R @ ms
+
+
+def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path):
+    n_frames, kpts, dim = 12, 700, 128
+    sc = synth.make_scene(n_frames, 2200, 6, seed=21, pixel_noise=0.5)
+    descs, ids = synth.make_frame_descriptors(sc, kpts, dim, seed=21)
+    uv_of = {(int(c), int(l)): sc["obs_uv"][o] for o, (c, l) in enumerate(zip(sc["obs_cam"], sc["obs_lm"]))}
+    rnd = synth.rng_uniform(21, 900, (n_frames, kpts, 2)) * 800.0
+    kp = np.array([[uv_of.get((f, int(ids[f][k])), rnd[f, k]) for k in range(kpts)] for f in range(n_frames)], dtype=np.float32)
+    K = sc["K"]
+    exe = str(tmp_path / "sfm_loop_driver")
+    lib = os.path.join(ROOT, "eacham_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + CPP, os.path.join(CPP, "sfm_loop_driver.cpp"), "-o", exe,
+                    "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"], check=True, capture_output=True)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    deg = 3.141592 / 180.0
+    with open(fin, "wb") as f:
+        f.write(struct.pack("ii", n_frames, dim))
+        for fr in range(n_frames):
+            f.write(struct.pack("i", kpts)); f.write(kp[fr].tobytes()); f.write(descs[fr].tobytes())
+        f.write(np.array([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1.0]).tobytes())
+        # inliers_ratio, initial max reprojection error / min angle, processing max reprojection error / min angle, min_pnp_inliers
+        # (config/SfmConfigNerf.json), initial min_inliers scaled to this scene's ~300 shared keypoints per pair (350 there)
+        f.write(np.array([0.8, 3.5, 3.0 * deg, 8.0, 3.0 * deg, 15, 100], dtype=np.float32).tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    print(r.stdout.strip())
+    with open(fout, "rb") as f:
+        log, poses, pts = _vec(f), _vec(f).reshape(n_frames, 17), _vec(f).reshape(-1, 6)
+    valid = poses[:, 0] == 1
+    assert valid.sum() >= n_frames - 1, (r.stdout, valid)                       # every frame (at most one lost) joined the reconstruction
+    T = poses[:, 1:].reshape(n_frames, 4, 4)
+    # camera centres against the truth, up to the gauge (first camera = identity, |t| of the first pair = 1)
+    C_est = np.array([-T[f, :3, :3].T @ T[f, :3, 3] for f in range(n_frames)])
+    Tt = sc["T_true"]
+    C_true = np.array([-Tt[f, :3, :3].T @ Tt[f, :3, 3] for f in range(n_frames)])
+    s, R, t = umeyama(C_est[valid], C_true[valid])
+    err = np.linalg.norm((s * (R @ C_est[valid].T)).T + t - C_true[valid], axis=1)
+    assert err.max() < 0.05, err                                                 # cameras sit on a helix of radius 4
+    for f in np.flatnonzero(valid):                                              # orientations: R_est = R_true R^T in the aligned frame
+        dR = T[f, :3, :3] @ R.T @ Tt[f, :3, :3].T
+        assert np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))) < 0.5, f
+    # the map: thousands of points, the valid ones consistent with the scene after the same alignment
+    good = pts[pts[:, 4] == 1]
+    assert len(good) > 1000
+    X = (s * (R @ good[:, 1:4].T)).T + t
+    d = np.abs(X[:, None, :] - sc["points_true"][None, :, :]).max(-1).min(1)     # distance to the nearest true landmark
+    assert np.median(d) < 0.01 and (d < 0.05).mean() > 0.95
