@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdio>
 #include <limits>
 #include <memory>
 #include <tuple>
@@ -39,10 +40,16 @@ struct MatchTwoViewHip {   // MatchTwoView of modules/sfm/data/Types.h: (id2d in
 template <class GraphT, class MapT>
 class ReconstructionManagerHip {
 public:
+    // inlierThresholdPx = 0 (default) is the reference: E_Inliers / H_Inliers are the LMedS masks. Those masks are SCALE-FREE
+    // (inlier = error below 2.5 * 1.4826 * sqrt(median), whatever the median is), so the best homography of a thoroughly
+    // non-planar pair still calls nearly every match an inlier, H_E_ratio is ~1 for almost any pair, and the reference
+    // initialises through decomposeHomographyMat, leaving it to FindBestPair's min_inliers gate to throw such pairs out.
+    // inlierThresholdPx > 0 counts the inliers of the two winning models at that pixel threshold instead (what the `4.0`
+    // the reference passes to both estimators would mean under RANSAC; LMEDS ignores it): an option, not the reference's behaviour.
     ReconstructionManagerHip(Context& ctx, std::shared_ptr<GraphT> graph, std::shared_ptr<MapT> map, float maxReprError, float minTriAngle,
-                             int minPnpInliers, uint64_t seed = 12345)
+                             int minPnpInliers, uint64_t seed = 12345, float inlierThresholdPx = 0.0f)
         : ctx_(ctx), graph_(std::move(graph)), map_(std::move(map)), maxReprError_(maxReprError), minTriAngle_(minTriAngle),
-          minPnpInliers_(minPnpInliers), seed_(seed) {}
+          minPnpInliers_(minPnpInliers), seed_(seed), inlierThresholdPx_(inlierThresholdPx) {}
 
     // ReconstructionManager.cpp:47-183
     template <class MatT>
@@ -68,7 +75,24 @@ public:
         // :75 findHomography(pts1, pts2, LMEDS, 4.0, mask2, 100, 0.999)
         const RobustModel H = FindHomography(ctx_, pts1, pts2, 100, s + 1, 0.999);
         if (!E.ok) return result;
-        const float ratio = H.ok && H.inliers > 0 ? (float)H.inliers / (float)E.inliers : 0.0f;   // :87
+        int eInliers = E.inliers, hInliers = H.ok ? H.inliers : 0;
+        if (inlierThresholdPx_ > 0.0f) {
+            const int n = (int)ms.size();
+            int32_t c = 0;
+            const float te = (inlierThresholdPx_ / (float)K9[0]) * (inlierThresholdPx_ / (float)K9[0]);   // Sampson error lives in normalised coordinates
+            ctx_.check(eacham_score_hypotheses(ctx_.get(), EACHAM_SCORE_ESSENTIAL, n, pts1.data(), pts2.data(), 1, E.model.data(), K4, te, nullptr, &c, nullptr));
+            eInliers = c;
+            if (H.ok) {
+                ctx_.check(eacham_score_hypotheses(ctx_.get(), EACHAM_SCORE_HOMOGRAPHY, n, pts1.data(), pts2.data(), 1, H.model.data(), nullptr,
+                                                  inlierThresholdPx_ * inlierThresholdPx_, nullptr, &c, nullptr));
+                hInliers = c;
+            }
+        }
+        const float ratio = hInliers > 0 && eInliers > 0 ? (float)hInliers / (float)eInliers : 0.0f;   // :87
+#ifdef EACHAM_RECON_DEBUG
+        std::fprintf(stderr, "two-view %u-%u: %zu matches, E inliers %d (median %g), H inliers %d (median %g), ratio %.3f\n", id1, id2, ms.size(), eInliers,
+                     (double)E.median, hInliers, (double)H.median, (double)ratio);
+#endif
         if (ratio > 0.9f) {                                                                        // :89-150
             const auto sols = DecomposeHomographyMat(H.model, K9);
             std::vector<double> T;
@@ -139,6 +163,7 @@ private:
     float maxReprError_, minTriAngle_;
     int minPnpInliers_;
     uint64_t seed_;
+    float inlierThresholdPx_;
 };
 
 // utils::FindBestPair (Utils.h:24-70): the first pair of connected nodes whose two-view reconstruction passes in BOTH directions;

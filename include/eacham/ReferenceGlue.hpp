@@ -21,6 +21,8 @@
 #pragma once
 
 #include <memory>
+#include <set>
+#include <stdexcept>
 #include <type_traits>
 #include <utility>
 
@@ -61,8 +63,19 @@ inline RefineBAReport RefineBA(const int currentFrameId, const std::shared_ptr<G
                                MatT& K, const ConfigT& config) {
     GraphView gv;
     MapView mv;
+    // Only what the adapter reads is converted: the local window is the current frame and its factor neighbours
+    // (BundleAdjuster.cpp:123-145), the global problem (currentFrameId = -1) every node. Converting the whole graph and map per
+    // call made the incremental loop quadratic in the sequence length (7.9 ms per TriangulateFrame at 100 frames).
+    std::set<unsigned> needed;
+    if (currentFrameId > -1) {
+        auto* start = graph->Get((unsigned)currentFrameId);
+        if (!start) throw std::runtime_error("Node is null");
+        needed.insert((unsigned)currentFrameId);
+        for (const auto& f : start->GetFactors()) needed.insert(f.first);
+    }
     for (const auto& entry : graph->GetNodes()) {
         const unsigned id = entry.first;
+        if (currentFrameId > -1 && !needed.count(id)) continue;
         auto* node = entry.second;
         NodeView nv;
         nv.id = id;
@@ -139,7 +152,15 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
                                                const float maxReprError, const float minTriAngle) {
     TriGraphView gv;
     TriMapView mv;
+    // the walk reads the frame, the nodes it has factors to, and the map points those nodes reference (Triangulator.cpp:204-296)
+    std::set<unsigned> needed{frameId};
+    {
+        auto* start = graph->Get(frameId);
+        if (!start) throw std::runtime_error("Node is null");
+        for (const auto& f : start->GetFactors()) needed.insert(f.first);
+    }
     for (const auto& entry : graph->GetNodes()) {
+        if (!needed.count(entry.first)) continue;
         auto* node = entry.second;
         TriNodeView nv;
         nv.valid = node->IsValid();
@@ -157,14 +178,20 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
             }
         gv.nodes[entry.first] = std::move(nv);
     }
-    for (const auto& kv : map->GetAll()) {
-        TriMapPoint mp;
-        mp.point3d[0] = kv.second.point3d(0), mp.point3d[1] = kv.second.point3d(1), mp.point3d[2] = kv.second.point3d(2);
-        mp.isValid = kv.second.isValid;
-        for (const auto& ob : kv.second.observers) mp.observers[ob.first] = ob.second;
-        mv.points[kv.first] = std::move(mp);
+    const auto& all = map->GetAll();
+    for (const auto& kv : all)
         if (kv.first > mv.mapPointId) mv.mapPointId = kv.first;  // Map never removes a point: its counter is the largest id
-    }
+    for (const auto& nk : gv.nodes)
+        for (const auto& p : nk.second.points3d) {
+            if (mv.points.count(p.second)) continue;
+            const auto it = all.find(p.second);
+            if (it == all.end()) throw std::runtime_error("Map: point is not found");
+            TriMapPoint mp;
+            mp.point3d[0] = it->second.point3d(0), mp.point3d[1] = it->second.point3d(1), mp.point3d[2] = it->second.point3d(2);
+            mp.isValid = it->second.isValid;
+            for (const auto& ob : it->second.observers) mp.observers[ob.first] = ob.second;
+            mv.points[p.second] = std::move(mp);
+        }
     const TriGraphView before_g = gv;
     const TriMapView before_m = mv;
     const double K9[9] = {K.template at<double>(0, 0), 0.0, K.template at<double>(0, 2), 0.0, K.template at<double>(1, 1),

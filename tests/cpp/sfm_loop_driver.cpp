@@ -6,6 +6,7 @@
 // in the image); the functions called are the drop-in definitions of ReferenceGlue.hpp / ReconstructionHip.hpp.
 //   sfm_loop_driver <in.bin> <out.bin>
 // in : F, dim; per frame n, keypoints (float n x 2), descriptors (float n x dim); K (9 doubles); seven config floats
+//      [+ an eighth: pixel threshold for the H / E inlier counts of RecoverPoseTwoView, 0 = the reference's LMedS masks]
 // out: per frame valid flag + 16 doubles (world -> camera); map: n points x (id, x, y, z, valid, observers); log counters
 #include <chrono>
 #include <cstdio>
@@ -55,6 +56,9 @@ int main(int argc, char** argv) {
     const float maxReprError = rd1<float>(in), minTriAngle = rd1<float>(in);
     const int minPnpInliers = (int)rd1<float>(in);
     const unsigned initialMinInliers = (unsigned)rd1<float>(in);
+    float inlierPx = 0.0f;
+    in.read((char*)&inlierPx, sizeof(float));
+    if (!in) inlierPx = 0.0f;
     cv::Mat K;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) K.at<double>(r, c) = K9[3 * r + c];
@@ -78,7 +82,7 @@ int main(int argc, char** argv) {
         ++edges;
     }
     // ---- two view (:157-176)
-    glue::ReconstructionManagerHip<graph_t, Map> reconstructor(ctx, graph, globalMap, initialMaxReprError, initialMinTriAngle, minPnpInliers);
+    glue::ReconstructionManagerHip<graph_t, Map> reconstructor(ctx, graph, globalMap, initialMaxReprError, initialMinTriAngle, minPnpInliers, 12345, inlierPx);
     auto [prevId, currentId] = glue::FindBestPair(graph, globalMap, reconstructor, K, initialMinInliers);
     std::vector<double> log{(double)edges, (double)prevId, (double)currentId, (double)globalMap->GetAll().size()};
     if (prevId > graph->Size() || currentId > graph->Size()) {
@@ -102,22 +106,37 @@ int main(int argc, char** argv) {
     std::set<unsigned> excluded{prevId, currentId};
     BestPair bp = best_pair(excluded);
     int pnp_ok = 0, pnp_failed = 0;
+    double ms_pnp = 0, ms_tri = 0, ms_ba = 0, ms_query = 0;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     while (bp.id <= graph->Size() && bp.id2 <= graph->Size()) {
-        if (reconstructor.RecoverPosePnP(bp.id, bp.id2, K)) {
+        auto ta = std::chrono::steady_clock::now();
+        const bool posed = reconstructor.RecoverPosePnP(bp.id, bp.id2, K);
+        ms_pnp += since(ta);
+        if (posed) {
+            ta = std::chrono::steady_clock::now();
             eacham::TriangulateFrame(bp.id2, graph, globalMap, K, 2, maxReprError, minTriAngle);   // :203
+            ms_tri += since(ta);
+            ta = std::chrono::steady_clock::now();
             eacham::RefineBA((int)bp.id2, graph, globalMap, K, refineOpt);                           // :207
+            ms_ba += since(ta);
+            ta = std::chrono::steady_clock::now();
             eacham::TriangulateFrame(bp.id2, graph, globalMap, K, 3, maxReprError, minTriAngle);   // :209
+            ms_tri += since(ta);
             excluded = {};
             ++pnp_ok;
         } else {
             ++pnp_failed;
         }
+        ta = std::chrono::steady_clock::now();
         bp = best_pair(excluded);
+        ms_query += since(ta);
         if (bp.id > graph->Size() || bp.id2 > graph->Size()) break;
         excluded.insert(bp.id);
         excluded.insert(bp.id2);
     }
+    const auto tg = std::chrono::steady_clock::now();
     eacham::RefineBA(-1, graph, globalMap, K, globalOpt);                                            // :216-220
+    const double ms_global = since(tg);
     const auto t2 = std::chrono::steady_clock::now();
     const double match_ms = std::chrono::duration<double, std::milli>(t1 - t0).count(), sfm_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
     // ---- results
@@ -141,7 +160,7 @@ int main(int argc, char** argv) {
         pts.push_back((double)kv.second.observers.size());
     }
     wr(out, pts);
-    std::printf("sfm loop ok: %zu edges, initial pair %u-%u, %d frames added, %d PnP failures, %zu map points; [Match] %.1f ms (upload + %zu pairs), [SfM] %.1f ms\n",
-                edges, prevId, currentId, pnp_ok, pnp_failed, globalMap->GetAll().size(), match_ms, pairs.size(), sfm_ms);
+    std::printf("sfm loop ok: %zu edges, initial pair %u-%u, %d frames added, %d PnP failures, %zu map points; [Match] %.1f ms (upload + %zu pairs), [SfM] %.1f ms = PnP %.1f + TriangulateFrame %.1f + RefineBA %.1f + GetBestPairForValid %.1f + global BA %.1f + two-view\n",
+                edges, prevId, currentId, pnp_ok, pnp_failed, globalMap->GetAll().size(), match_ms, pairs.size(), sfm_ms, ms_pnp, ms_tri, ms_ba, ms_query, ms_global);
     return 0;
 }

@@ -36,11 +36,15 @@ def umeyama(src, dst):
     return s, R, md - s * R @ ms
 
 
-def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path):
-    n_frames, kpts, dim = 12, 700, 128
-    sc = synth.make_scene(n_frames, 2200, 6, seed=21, pixel_noise=0.5)
+@pytest.mark.parametrize("n_frames,kpts,n_lm,k_obs,inlier_px,tol", [
+    (12, 700, 2200, 6, 0.0, 0.05),      # the reference's own rule for the H / E branch (LMedS masks)
+    (60, 600, 3600, 10, 4.0, 0.05),     # a longer sequence with narrow baselines: H / E inliers counted at 4 px (ReconstructionHip.hpp)
+])
+def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path, n_frames, kpts, n_lm, k_obs, inlier_px, tol):
+    dim = 128
+    sc = synth.make_scene(n_frames, n_lm, k_obs, seed=21, pixel_noise=0.5)
     descs, ids = synth.make_frame_descriptors(sc, kpts, dim, seed=21)
-    uv_of = {(int(c), int(l)): sc["obs_uv"][o] for o, (c, l) in enumerate(zip(sc["obs_cam"], sc["obs_lm"]))}
+    uv_of = {(int(c), int(l)): sc["obs_uv"][o] for o, (c, l) in enumerate(zip(sc["obs_cam"].tolist(), sc["obs_lm"].tolist()))}
     rnd = synth.rng_uniform(21, 900, (n_frames, kpts, 2)) * 800.0
     kp = np.array([[uv_of.get((f, int(ids[f][k])), rnd[f, k]) for k in range(kpts)] for f in range(n_frames)], dtype=np.float32)
     K = sc["K"]
@@ -57,7 +61,7 @@ def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path):
         f.write(np.array([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1.0]).tobytes())
         # inliers_ratio, initial max reprojection error / min angle, processing max reprojection error / min angle, min_pnp_inliers
         # (config/SfmConfigNerf.json), initial min_inliers scaled to this scene's ~300 shared keypoints per pair (350 there)
-        f.write(np.array([0.8, 3.5, 3.0 * deg, 8.0, 3.0 * deg, 15, 100], dtype=np.float32).tobytes())
+        f.write(np.array([0.8, 3.5, 3.0 * deg, 8.0, 3.0 * deg, 15, 100, inlier_px], dtype=np.float32).tobytes())
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     print(r.stdout.strip())
@@ -72,13 +76,13 @@ def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path):
     C_true = np.array([-Tt[f, :3, :3].T @ Tt[f, :3, 3] for f in range(n_frames)])
     s, R, t = umeyama(C_est[valid], C_true[valid])
     err = np.linalg.norm((s * (R @ C_est[valid].T)).T + t - C_true[valid], axis=1)
-    assert err.max() < 0.05, err                                                 # cameras sit on a helix of radius 4
+    assert err.max() < tol, err                                                  # cameras sit on a helix of radius 4
     for f in np.flatnonzero(valid):                                              # orientations: R_est = R_true R^T in the aligned frame
         dR = T[f, :3, :3] @ R.T @ Tt[f, :3, :3].T
         assert np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))) < 0.5, f
     # the map: thousands of points, the valid ones consistent with the scene after the same alignment
     good = pts[pts[:, 4] == 1]
-    assert len(good) > 1000
+    assert len(good) > 0.45 * n_lm
     X = (s * (R @ good[:, 1:4].T)).T + t
     d = np.abs(X[:, None, :] - sc["points_true"][None, :, :]).max(-1).min(1)     # distance to the nearest true landmark
     assert np.median(d) < 0.01 and (d < 0.05).mean() > 0.95
