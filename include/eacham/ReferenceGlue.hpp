@@ -165,11 +165,17 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
         TriNodeView nv;
         nv.valid = node->IsValid();
         matrix_to_rows(node->GetTransform(), nv.transform);
+        nv.keypoints.reserve(2 * node->GetFeatures().size());
         for (const auto& kp : node->GetFeatures()) {
             nv.keypoints.push_back(kp.x);
             nv.keypoints.push_back(kp.y);
         }
-        for (const auto& p : node->GetPoints3d()) nv.points3d[p.first] = p.second;
+        {
+            std::vector<FlatMap::value_type> items;
+            items.reserve(node->GetPoints3d().size());
+            for (const auto& p : node->GetPoints3d()) items.emplace_back(p.first, p.second);
+            nv.points3d.assign_unsorted(std::move(items));
+        }
         if (entry.first == frameId)   // the walk only reads the factors of the frame being inserted (:204)
             for (const auto& f : node->GetFactors()) {
                 auto& dst = nv.factors[f.first];
@@ -189,7 +195,12 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
             TriMapPoint mp;
             mp.point3d[0] = it->second.point3d(0), mp.point3d[1] = it->second.point3d(1), mp.point3d[2] = it->second.point3d(2);
             mp.isValid = it->second.isValid;
-            for (const auto& ob : it->second.observers) mp.observers[ob.first] = ob.second;
+            {
+                std::vector<FlatMap::value_type> items;
+                items.reserve(it->second.observers.size());
+                for (const auto& ob : it->second.observers) items.emplace_back(ob.first, ob.second);
+                mp.observers.assign_unsorted(std::move(items));
+            }
             mv.points[p.second] = std::move(mp);
         }
     const TriGraphView before_g = gv;

@@ -19,6 +19,7 @@
 // this adapter visits neighbours in ascending id and matches in the order given.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <map>
@@ -151,11 +152,49 @@ inline HypothesisScores ScoreHypotheses(Context& ctx, int kind, const std::vecto
 
 // ---- views for TriangulateFrame ---------------------------------------------------------------
 
+// unsigned -> unsigned map as a sorted vector: the views below are rebuilt for every call, and as std::map they were one heap
+// allocation per keypoint-with-a-point and per observer (tens of thousands per TriangulateFrame of a 100-frame sequence).
+// Iterates in ascending key order like std::map; the interface is the part of std::map the walk and the glue use.
+struct FlatMap {
+    typedef std::pair<unsigned, unsigned> value_type;
+    typedef std::vector<value_type>::iterator iterator;
+    typedef std::vector<value_type>::const_iterator const_iterator;
+    std::vector<value_type> v;
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+    void clear() { v.clear(); }
+    iterator begin() { return v.begin(); }
+    iterator end() { return v.end(); }
+    const_iterator begin() const { return v.begin(); }
+    const_iterator end() const { return v.end(); }
+    iterator lower(unsigned k) { return std::lower_bound(v.begin(), v.end(), k, [](const value_type& a, unsigned b) { return a.first < b; }); }
+    const_iterator lower(unsigned k) const { return std::lower_bound(v.begin(), v.end(), k, [](const value_type& a, unsigned b) { return a.first < b; }); }
+    iterator find(unsigned k) { auto it = lower(k); return it != v.end() && it->first == k ? it : v.end(); }
+    const_iterator find(unsigned k) const { auto it = lower(k); return it != v.end() && it->first == k ? it : v.end(); }
+    size_t count(unsigned k) const { return find(k) != v.end() ? 1 : 0; }
+    unsigned& operator[](unsigned k) {
+        auto it = lower(k);
+        if (it == v.end() || it->first != k) it = v.insert(it, value_type(k, 0u));
+        return it->second;
+    }
+    size_t erase(unsigned k) {
+        auto it = find(k);
+        if (it == v.end()) return 0;
+        v.erase(it);
+        return 1;
+    }
+    void assign_unsorted(std::vector<value_type>&& items) {   // bulk build: keys unique
+        v = std::move(items);
+        std::sort(v.begin(), v.end());
+    }
+    bool operator==(const FlatMap& o) const { return v == o.v; }
+};
+
 struct TriNodeView {
     bool valid = false;                                   // Node::IsValid()
     double transform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::vector<float> keypoints;                         // x0 y0 x1 y1 ... (cv::Point2f)
-    std::map<unsigned, unsigned> points3d;                // keypoint -> map point (Node::SetPoint3d / HasPoint3d)
+    FlatMap points3d;                                     // keypoint -> map point (Node::SetPoint3d / HasPoint3d)
     std::map<unsigned, std::vector<std::pair<unsigned, unsigned>>> factors;  // neighbour id -> (m1, m2) matches
 };
 struct TriGraphView {
@@ -164,7 +203,7 @@ struct TriGraphView {
 struct TriMapPoint {
     double point3d[3] = {0, 0, 0};
     bool isValid = false;
-    std::map<unsigned, unsigned> observers;               // frame -> keypoint (MapPointData::observers)
+    FlatMap observers;                                    // frame -> keypoint (MapPointData::observers)
 };
 struct TriMapView {                                       // the operations of modules/sfm/data/Map.h the walk uses
     std::map<unsigned, TriMapPoint> points;
@@ -229,7 +268,7 @@ inline TriangulateFrameReport TriangulateFrame(Context& ctx, const unsigned fram
     ctx.check(eacham_reprojection_errors(ctx.get(), current.transform, 1, (int)cands.size(), cframe.data(), cpts.data(),
                                          cuv.data(), K4, cerr.data()));
 
-    std::map<unsigned, std::map<unsigned, unsigned>> observersFull;
+    std::map<unsigned, FlatMap> observersFull;
     size_t ci = 0;
     for (const auto& f : current.factors) {
         const TriNodeView& other = node_at(f.first);
@@ -255,7 +294,7 @@ inline TriangulateFrameReport TriangulateFrame(Context& ctx, const unsigned fram
     std::vector<double> transforms, uv;
     std::vector<int32_t> trackPtr{0};
     std::vector<uint32_t> obsFrame;
-    std::vector<const std::map<unsigned, unsigned>*> trackObs;
+    std::vector<const FlatMap*> trackObs;
     for (const auto& kv : observersFull) {
         if (kv.second.size() < minObservers) continue;
         for (const auto& ob : kv.second) {
