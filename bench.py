@@ -549,6 +549,18 @@ def main():
                                 "BASELINE configs[2] stand-in (TUM fr1/desk sizes): 500 frames x 600 kpts x 128-D, 124750 pairs",
                                 "match_tile_kernel<4, 2>")
         out["ba"] = bench_local_windows(D, ctx, tum, range(100, 140), ba.OptimizerConfig.refine_ba())
+        if D.rank == 0:
+            # the whole incremental loop of apps/sfm/main.cpp:76-240 (match -> FindBestPair -> per frame PnP / TriangulateFrame /
+            # RefineBA / TriangulateFrame -> global BA) through the reference-typed entry points, 100 frames x 600 kpts from
+            # keypoints + descriptors alone, held against the scene's ground truth (tests/cpp/sfm_loop_driver.cpp)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import sfm_loop_rate
+                loop = sfm_loop_rate.run(100, 600, 6000, 10, 4.0)
+                loop.pop("driver", None)
+                out["sfm_loop"] = loop
+            except Exception as e:  # a missing host compiler must not take the bench down
+                out["sfm_loop"] = {"error": repr(e)[:300]}
         return out
     leg("c3_tum", tum_line)
     leg("c4_ba", lambda: bench_ba(D, ctx, synth.make_scene(500, 100_000, 10, seed=4), max(3, args.ba_solves // 10),
@@ -620,6 +632,8 @@ def main():
                     c["ms_per_inner_iter"] = round(v["ms_per_inner_iter"], 5)
                 if "ba" in v:
                     c["ba_windows_per_s"] = v["ba"]["windows_per_s"]
+                if "sfm_loop" in v and "frames_per_s" in v["sfm_loop"]:
+                    c["sfm_loop_frames_per_s"] = v["sfm_loop"]["frames_per_s"]
                 if "all_gather" in v:
                     c["all_gather_ok"] = v["all_gather"]["gathered_equals_local_shard"]
                 out["lines"][name] = c
