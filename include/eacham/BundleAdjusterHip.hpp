@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../eacham_hip.h"
+#include "FlatMap.hpp"
 
 namespace eacham {
 namespace hip {
@@ -40,7 +41,7 @@ struct NodeView {
     bool fixed = false;                                // Graph::IsFixed(id)
     double transform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // Node::GetTransform(), row-major world->camera
     std::vector<float> keypoints;                      // x0 y0 x1 y1 ... (Node::GetKeyPoint(id2d), cv::Point2f)
-    std::map<unsigned, unsigned> points3d;             // Node::GetPoints3d(): keypoint index -> landmark id
+    FlatMap points3d;                                  // Node::GetPoints3d(): keypoint index -> landmark id (ascending keypoint order)
     std::vector<unsigned> neighbours;                  // keys of Node::GetFactors()
 };
 

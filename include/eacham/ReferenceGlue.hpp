@@ -82,18 +82,26 @@ inline RefineBAReport RefineBA(const int currentFrameId, const std::shared_ptr<G
         nv.valid = node->IsValid();
         nv.fixed = graph->IsFixed(id);
         matrix_to_rows(node->GetTransform(), nv.transform);
+        nv.keypoints.reserve(2 * node->GetFeatures().size());
         for (const auto& kp : node->GetFeatures()) {   // Node::GetKeyPoint(id2d) of every keypoint (cv::Point2f)
             nv.keypoints.push_back(kp.x);
             nv.keypoints.push_back(kp.y);
         }
-        for (const auto& p : node->GetPoints3d()) {
-            nv.points3d[p.first] = p.second;
+        {
+            std::vector<FlatMap::value_type> items;
+            items.reserve(node->GetPoints3d().size());
+            for (const auto& p : node->GetPoints3d()) items.emplace_back(p.first, p.second);
+            nv.points3d.assign_unsorted(std::move(items));
+        }
+        const auto& all = map->GetAll();
+        for (const auto& p : nv.points3d) {
             if (mv.points.find(p.second) == mv.points.end()) {
+                const auto it = all.find(p.second);   // (Map::Get / GetStatus / GetObservers of the reference each take a lock and the last one copies the map)
+                if (it == all.end()) throw std::runtime_error("Map: point is not found");
                 MapPointView mp;
-                const auto X = map->Get(p.second);
-                mp.point3d[0] = X(0), mp.point3d[1] = X(1), mp.point3d[2] = X(2);
-                mp.status = map->GetStatus(p.second);
-                mp.observers = (unsigned)map->GetObservers(p.second).size();
+                mp.point3d[0] = it->second.point3d(0), mp.point3d[1] = it->second.point3d(1), mp.point3d[2] = it->second.point3d(2);
+                mp.status = it->second.isValid;
+                mp.observers = (unsigned)it->second.observers.size();
                 mv.points[p.second] = mp;
             }
         }
