@@ -211,41 +211,51 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
             }
             mv.points[p.second] = std::move(mp);
         }
-    const TriGraphView before_g = gv;
-    const TriMapView before_m = mv;
+    const unsigned lastId = mv.mapPointId;   // ids above it after the call are new map points
     const double K9[9] = {K.template at<double>(0, 0), 0.0, K.template at<double>(0, 2), 0.0, K.template at<double>(1, 1),
                           K.template at<double>(1, 2), 0.0, 0.0, 1.0};
     const TriangulateFrameReport rep =
         eacham::hip::TriangulateFrame(shared_context(), frameId, gv, mv, K9, minObservers, maxReprError, minTriAngle);
-    // ---- write-back, in the order the reference mutates its objects ----
+    // ---- write-back, in the order the reference mutates its objects; the views are compared with the LIVE objects (which the
+    //      adapter never touched) instead of with copies taken before the call ----
     using Vec3 = std::decay_t<decltype(map->Get(0u))>;
     for (auto& kv : mv.points) {           // new map points: Map::Add hands out the ids the view counted up
-        if (before_m.points.count(kv.first)) continue;
+        if (kv.first <= lastId) continue;
         Vec3 X;
         X(0) = kv.second.point3d[0], X(1) = kv.second.point3d[1], X(2) = kv.second.point3d[2];
         const unsigned id = map->Add(X);
         if (id != kv.first) throw std::runtime_error("TriangulateFrame glue: Map::Add returned an unexpected id");
     }
     for (const auto& kv : mv.points) {     // observers and validity
-        const auto was_it = before_m.points.find(kv.first);
-        static const TriMapPoint none;
-        const TriMapPoint& was = was_it == before_m.points.end() ? none : was_it->second;
-        for (const auto& ob : was.observers) {
-            const auto still = kv.second.observers.find(ob.first);
-            if (still == kv.second.observers.end()) map->RemoveObserver(ob.first, ob.second, kv.first);
+        const bool isNew = kv.first > lastId;
+        std::vector<std::pair<unsigned, unsigned>> gone, come;
+        bool wasValid = false;
+        {
+            const auto live = map->GetAll().find(kv.first);
+            if (live == map->GetAll().end()) throw std::runtime_error("Map: point is not found");
+            wasValid = live->second.isValid;
+            for (const auto& ob : live->second.observers)
+                if (kv.second.observers.find(ob.first) == kv.second.observers.end()) gone.emplace_back(ob.first, ob.second);
+            for (const auto& ob : kv.second.observers) {
+                const auto had = live->second.observers.find(ob.first);
+                if (had == live->second.observers.end() || had->second != ob.second) come.emplace_back(ob.first, ob.second);
+            }
         }
-        for (const auto& ob : kv.second.observers) {
-            const auto had = was.observers.find(ob.first);
-            if (had == was.observers.end() || had->second != ob.second) map->AddObserver(ob.first, ob.second, kv.first);
-        }
-        if (kv.second.isValid != was.isValid || was_it == before_m.points.end()) map->UpdateStatus(kv.first, kv.second.isValid);
+        for (const auto& ob : gone) map->RemoveObserver(ob.first, ob.second, kv.first);
+        for (const auto& ob : come) map->AddObserver(ob.first, ob.second, kv.first);
+        if (kv.second.isValid != wasValid || isNew) map->UpdateStatus(kv.first, kv.second.isValid);
     }
     for (const auto& kv : gv.nodes) {      // Node::SetPoint3d(id2d, id3d, false) for every keypoint that changed its point
-        const TriNodeView& was = before_g.nodes.at(kv.first);
-        for (const auto& p : kv.second.points3d) {
-            const auto had = was.points3d.find(p.first);
-            if (had == was.points3d.end() || had->second != p.second) graph->Get(kv.first)->SetPoint3d(p.first, p.second, false);
+        auto* node = graph->Get(kv.first);
+        std::vector<std::pair<unsigned, unsigned>> changed;
+        {
+            const auto& live = node->GetPoints3d();
+            for (const auto& p : kv.second.points3d) {
+                const auto had = live.find(p.first);
+                if (had == live.end() || had->second != p.second) changed.push_back(p);
+            }
         }
+        for (const auto& p : changed) node->SetPoint3d(p.first, p.second, false);
     }
     return rep;
 }
