@@ -529,6 +529,59 @@ __device__ static int lsq_small(int r, int c, const double* A, const double* b, 
     return 1;
 }
 
+/* lsq_small for 6 rows and a compile-time number of columns, every loop unrolled: the working array and the callers' matrices stay in
+ * registers (as run-time-indexed arrays they are scratch memory, and the eighteen small solves of a sample were most of EPnP's
+ * 1.2 ms). Same operations in the same order as lsq_small(6, C, ...). */
+template <int C>
+__device__ __forceinline__ int lsq6(const double* A, const double* b, double* x) {
+    constexpr int r = 6, c = C;
+    double Q[6][C + 1];
+#pragma unroll
+    for (int i = 0; i < r; ++i) {
+#pragma unroll
+        for (int j = 0; j < c; ++j) Q[i][j] = A[i * c + j];
+        Q[i][c] = b[i];
+    }
+#pragma unroll
+    for (int j = 0; j < c; ++j) {
+        double nrm = 0.0;
+#pragma unroll
+        for (int i = j; i < r; ++i) nrm += Q[i][j] * Q[i][j];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0)) return 0;
+        const double alpha = Q[j][j] > 0.0 ? -nrm : nrm;
+        double v[6];
+#pragma unroll
+        for (int i = j; i < r; ++i) v[i] = Q[i][j];
+        v[j] -= alpha;
+        double vv = 0.0;
+#pragma unroll
+        for (int i = j; i < r; ++i) vv += v[i] * v[i];
+        if (!(vv > 0.0)) return 0;
+#pragma unroll
+        for (int k = j; k <= c; ++k) {
+            double d = 0.0;
+#pragma unroll
+            for (int i = j; i < r; ++i) d += v[i] * Q[i][k];
+            d = 2.0 * d / vv;
+#pragma unroll
+            for (int i = j; i < r; ++i) Q[i][k] -= d * v[i];
+        }
+        Q[j][j] = alpha;
+    }
+#pragma unroll
+    for (int j = c - 1; j >= 0; --j) {
+        double s = Q[j][c];
+#pragma unroll
+        for (int k = j + 1; k < c; ++k) s -= Q[j][k] * x[k];
+        x[j] = s / Q[j][j];
+    }
+#pragma unroll
+    for (int j = 0; j < c; ++j)
+        if (!(fabs(x[j]) < 1e300)) return 0;
+    return 1;
+}
+
 /* EPnP (Lepetit, Moreno-Noguer, Fua 2009) on the m >= 4 points idx[0..m) of obj (n x 3) / img (n x 2), K = fx fy cx cy.
  * Rt = R (row-major) | t of x_cam = R X + t. Every pass over the points recomputes the barycentric coordinates, so the
  * working set does not grow with m (the RANSAC kernel calls it with m = 5, the final refit with all inliers).
@@ -639,14 +692,19 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         for (int e = 0; e < 3; ++e) rho[p] += (cw[pa[p]][e] - cw[pb[p]][e]) * (cw[pa[p]][e] - cw[pb[p]][e]);
     }
     double best_err = -1.0;
+#pragma unroll
     for (int variant = 0; variant < 3; ++variant) {
         /* linearised start: the products b_i b_j that involve only the first 1 / 2 / 3 null vectors' leading terms */
-        const int ncol[3] = {4, 3, 5};
-        const int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
+        constexpr int ncol[3] = {4, 3, 5};
+        constexpr int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
         double A[30], x[5], beta[4] = {0, 0, 0, 0};
+#pragma unroll
         for (int p = 0; p < 6; ++p)
-            for (int j = 0; j < ncol[variant]; ++j) A[p * ncol[variant] + j] = L[p][cols[variant][j]];
-        if (!lsq_small(6, ncol[variant], A, rho, x)) continue;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (j < ncol[variant]) A[p * ncol[variant] + j] = L[p][cols[variant][j]];
+        const int solved = variant == 0 ? lsq6<4>(A, rho, x) : (variant == 1 ? lsq6<3>(A, rho, x) : lsq6<5>(A, rho, x));
+        if (!solved) continue;
         if (variant == 0) {  /* x = b00 b01 b02 b03 */
             const double s = x[0] < 0.0 ? -1.0 : 1.0;
             beta[0] = sqrt(s * x[0]);
@@ -662,6 +720,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         }
         for (int it = 0; it < 5; ++it) {  /* Gauss-Newton on the six distance equations */
             double J[24], r[6], dx[4];
+#pragma unroll
             for (int p = 0; p < 6; ++p) {
                 const double* l = L[p];
                 J[4 * p + 0] = 2.0 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
@@ -672,7 +731,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
                                  l[4] * beta[1] * beta[2] + l[5] * beta[2] * beta[2] + l[6] * beta[0] * beta[3] + l[7] * beta[1] * beta[3] +
                                  l[8] * beta[2] * beta[3] + l[9] * beta[3] * beta[3]);
             }
-            if (!lsq_small(6, 4, J, r, dx)) break;
+            if (!lsq6<4>(J, r, dx)) break;
             for (int k = 0; k < 4; ++k) beta[k] += dx[k];
         }
         /* control points in the camera frame, sign from the first point's depth */
