@@ -4,7 +4,7 @@
   solvePnPRansac   10000 RANSAC iterations  -> 10 000 EPnP(5) solves + 10 000 models scored + the all-inlier refit
 Device time from the C-ABI's HIP-event slot (solve and score kernels share EACHAM_KERNEL_SCORE), end-to-end time
 through the host-pointer entry points, the CPU restatement (OpenMP, all host cores) beside it, and bit-parity.
-Run on the GPU box:  python tools/solve_rate.py"""
+Run on the GPU box:  python tests/rate_solve.py"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives in tests/: it times the CPU oracle beside the device path, which only tests may do)
 
 from eacham_amd import HipContext, capi, score  # noqa: E402
 import oracle_api as O  # noqa: E402

@@ -1,6 +1,6 @@
 """Triangulation throughput on the S200 scene (50,000 tracks, 2..10 observers each): device kernel
 time from the C-ABI's HIP-event slots, end-to-end rate through the host-pointer entry point, and the
-CPU oracle beside it. Run on the GPU box:  python tools/tri_rate.py"""
+CPU oracle beside it. Run on the GPU box:  python tests/rate_tri.py"""
 import json
 import os
 import sys
@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives in tests/: it times the CPU oracle beside the device path, which only tests may do)
 
 from eacham_amd import HipContext, capi, synth  # noqa: E402
 from eacham_amd import triangulate as tri  # noqa: E402
