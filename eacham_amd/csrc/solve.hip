@@ -597,13 +597,59 @@ __device__ __forceinline__ double ordered_wave_sum(double v, double* red) {
     return t;
 }
 
+// The 12 x 12 eigenproblem by ONE WAVE on one shared copy of A and V: the three loops of a rotation (columns p, q; rows p, q; V) run
+// over their index k on the lanes 0..11, every lane forms the rotation itself from the same three entries. Element by element the
+// arithmetic is that of jacobi_eig<12> (a rotation's loop iterations are independent), so the result is the same bits; the rotations
+// stay in their cyclic order. A wave's LDS operations execute in program order: the barriers only pin the compiler.
+// (One thread walking these loops was two thirds of an EPnP solve: 0.73 of 1.1 ms, measured with a one-sweep build.)
+__device__ __forceinline__ void jacobi12_wave(double* A, double* V, double* w) {
+    constexpr int n = 12;
+    const int k = threadIdx.x & 63;
+    for (int e = k; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+    wave_sync_lds();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < n; ++p) {
+            diag += A[p * n + p] * A[p * n + p];
+            for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;  // (wave-uniform)
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                wave_sync_lds();
+                if (k < n) {  /* columns p, q */
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                wave_sync_lds();
+                if (k < n) {  /* rows p, q; V */
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+                wave_sync_lds();
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
 // WAVE = false: one thread solves the sample (the RANSAC kernel: thousands of 5-point samples). WAVE = true: one wave solves it
 // — lane l accumulates the points l, l + 64, ... of every pass over the points, the 64 partial sums are added in lane order, and
 // every lane then runs the small dense algebra on identical values (the all-inlier refit: one sample of thousands of points,
 // 5.2 ms on one thread). The CPU restatement defines the sums the same way (64 strided partials when m > 64), so both
 // forms agree with it bit for bit.
 template <bool WAVE, class MA>
-__device__ static int epnp_solve(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt, MA MtM, MA V, double* red) {
+__device__ static int epnp_solve(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt, MA MtM, MA V, double* red,
+                                 double* jac /* WAVE: 2 x 144 doubles shared by the wave */) {
     if (m < 4) return 0;
     const int kfirst = WAVE ? (int)threadIdx.x : 0, kstep = WAVE ? 64 : 1;
     auto total = [&](double v) { return WAVE ? ordered_wave_sum(v, red) : v; };
@@ -656,7 +702,14 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
             for (int j = i; j < 12; ++j) MtM[12 * i + j] = total(MtM[12 * i + j]);
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
-    jacobi_eig<12>(MtM, V, w);
+    if (WAVE) {   // every lane holds the same M^T M: one shared copy, the eigenproblem by the whole wave, V back into the lane's array
+        for (int e = (int)threadIdx.x; e < 144; e += 64) jac[e] = MtM[e];
+        wave_sync_lds();
+        jacobi12_wave(jac, jac + 144, w);
+        for (int e = 0; e < 144; ++e) V[e] = jac[144 + e];
+    } else {
+        jacobi_eig<12>(MtM, V, w);
+    }
     int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
     for (int k = 0; k < 4; ++k) {
         int best = -1;
@@ -810,24 +863,25 @@ __global__ __launch_bounds__(PNP_NT) void solve_pnp_kernel(const double* __restr
     double K4[4], out[12];
     for (int k = 0; k < 4; ++k) K4[k] = K[k];
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_solve<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, nullptr);
+    const int n = epnp_solve<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, nullptr, nullptr);
     for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
     n_models[s] = n;
 }
 
-// one WAVE per sample (sample_size > 64)
+// one WAVE per sample
 __global__ __launch_bounds__(PNP_NT) void solve_pnp_wave_kernel(const double* __restrict__ obj, const double* __restrict__ img,
                                                                 const double* __restrict__ K, int sample_size, const int* __restrict__ idx,
                                                                 double* __restrict__ models, int* __restrict__ n_models) {
     static_assert(PNP_NT == 64, "one wave");
     __shared__ double arena[2 * 144 * PNP_NT];
     __shared__ double red[64];
+    __shared__ double jac[2 * 144];
     const int s = blockIdx.x;
     const PV<PNP_NT> MtM{arena + threadIdx.x}, V = MtM.sub(144);
     double K4[4], out[12];
     for (int k = 0; k < 4; ++k) K4[k] = K[k];
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_solve<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, red);
+    const int n = epnp_solve<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, red, jac);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
         n_models[s] = n;
@@ -951,7 +1005,11 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
-        if (sample_size > 64)
+        // One wave per sample (0.45 ms whatever the sample size: the eigenproblem runs on twelve lanes) holds 144 KiB of LDS, i.e. one
+        // sample per CU at a time: it serves the all-inlier refit and batches of up to two rounds of the chip (the 256-sample chunks of the
+        // RANSAC loop); larger batches of minimal samples take the one-thread-per-sample kernel (1.1 ms, 64 samples per workgroup). Both
+        // produce the bits of the CPU restatement.
+        if (sample_size > 64 || n_samples <= 512)
             solve_pnp_wave_kernel<<<(unsigned)n_samples, PNP_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
                                                                           sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
         else

@@ -83,7 +83,8 @@ def test_epnp_bit_identical_at_the_reference_iteration_count_and_the_ransac_loop
     assert rok[0] == 1 and np.array_equal(refit, wrefit)
     assert np.abs(refit[0] - T).max() < 5e-3 and np.abs(refit[0] - T).max() < np.abs(models[best] - T).max()
     # sample sizes on both sides of the one-thread / one-wave split (64) and not a multiple of the wave
-    for m, count in ((12, 40), (64, 3), (65, 3), (200, 2)):
+    # (batches of <= 512 samples take the one-wave-per-sample kernel whatever their size, larger ones of <= 64 points the one-thread kernel)
+    for m, count in ((12, 40), (64, 3), (65, 3), (200, 2), (5, 256), (5, 513), (30, 600)):
         rows = draw(rng, len(X), m, count)
         got, gok = score.solve_pnp(hip_ctx, X, uv, K, rows)
         want, wok = O.solve_pnp(X, uv, K, rows)
