@@ -21,6 +21,10 @@
 #pragma once
 
 #include <memory>
+#ifdef EACHAM_GLUE_TIMING
+#include <chrono>
+#include <cstdio>
+#endif
 #include <set>
 #include <stdexcept>
 #include <type_traits>
@@ -158,6 +162,11 @@ template <class GraphT, class MapT, class MatT>
 inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std::shared_ptr<GraphT>& graph,
                                                const std::shared_ptr<MapT>& map, const MatT& K, const unsigned minObservers,
                                                const float maxReprError, const float minTriAngle) {
+#ifdef EACHAM_GLUE_TIMING
+    struct Tm { double conv = 0, call = 0, back = 0; long n = 0; ~Tm() { std::fprintf(stderr, "TriangulateFrame glue: %ld calls, convert %.3f ms, adapter %.3f ms, write-back %.3f ms per call\n", n, conv / n, call / n, back / n); } };
+    static Tm tm;
+    const auto t_a = std::chrono::steady_clock::now();
+#endif
     TriGraphView gv;
     TriMapView mv;
     // the walk reads the frame, the nodes it has factors to, and the map points those nodes reference (Triangulator.cpp:204-296)
@@ -214,8 +223,14 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
     const unsigned lastId = mv.mapPointId;   // ids above it after the call are new map points
     const double K9[9] = {K.template at<double>(0, 0), 0.0, K.template at<double>(0, 2), 0.0, K.template at<double>(1, 1),
                           K.template at<double>(1, 2), 0.0, 0.0, 1.0};
+#ifdef EACHAM_GLUE_TIMING
+    const auto t_b = std::chrono::steady_clock::now();
+#endif
     const TriangulateFrameReport rep =
         eacham::hip::TriangulateFrame(shared_context(), frameId, gv, mv, K9, minObservers, maxReprError, minTriAngle);
+#ifdef EACHAM_GLUE_TIMING
+    const auto t_c = std::chrono::steady_clock::now();
+#endif
     // ---- write-back, in the order the reference mutates its objects; the views are compared with the LIVE objects (which the
     //      adapter never touched) instead of with copies taken before the call ----
     using Vec3 = std::decay_t<decltype(map->Get(0u))>;
@@ -257,6 +272,15 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
         }
         for (const auto& p : changed) node->SetPoint3d(p.first, p.second, false);
     }
+#ifdef EACHAM_GLUE_TIMING
+    {
+        const auto t_d = std::chrono::steady_clock::now();
+        tm.conv += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+        tm.call += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+        tm.back += std::chrono::duration<double, std::milli>(t_d - t_c).count();
+        ++tm.n;
+    }
+#endif
     return rep;
 }
 

@@ -23,7 +23,7 @@ def run(F=100, kpts=600, nl=6000, kobs=10, inlier_px=4.0, debug=False, seed=3):
     exe = os.path.join(tmp, "sfm_loop_driver")
     lib = os.path.join(ROOT, "eacham_amd", "lib")
     cpp = os.path.join(ROOT, "tests", "cpp")
-    subprocess.run(["g++", "-std=c++17", "-O2", *(["-DEACHAM_RECON_DEBUG"] if debug else []), "-I" + os.path.join(ROOT, "include"), "-I" + cpp,
+    subprocess.run(["g++", "-std=c++17", "-O2", *(["-DEACHAM_RECON_DEBUG", "-DEACHAM_GLUE_TIMING"] if debug else []), "-I" + os.path.join(ROOT, "include"), "-I" + cpp,
                     os.path.join(cpp, "sfm_loop_driver.cpp"), "-o", exe, "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"], check=True)
     fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
     deg = 3.141592 / 180.0
