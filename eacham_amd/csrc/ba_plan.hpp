@@ -30,6 +30,7 @@
 #include <functional>
 #include <numeric>
 #include <utility>
+#include <thread>
 #include <vector>
 
 namespace eacham {
@@ -490,32 +491,56 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     std::vector<int> all(nc);
     std::iota(all.begin(), all.end(), 0);
     const int cams_per_panel = PLAN_PANEL / PLAN_CAM;  // 10
-    // the natural order is always a candidate: (it is what a window of a sequence already is)
-    BaPlan best;
-    plan_from_nodes(nc, adj, {all}, best, cm);
-    best.ordering = BA_ORDER_NATURAL;
-    auto consider = [&](const std::vector<std::vector<int>>& nodes, int ordering, int leaf, bool force) {
-        BaPlan cand;
-        plan_from_nodes(nc, adj, nodes, cand, cm);
-        cand.ordering = ordering;
-        cand.nd_leaf = leaf;
-        if (force || cand.est_us < best.est_us - 1e-9) best = std::move(cand);
+    // The candidates — the natural order (what a window of a sequence already is), reverse Cuthill-McKee, nested dissection
+    // with four leaf sizes and one / several roots per bisection — are independent of each other: on a scene of some size
+    // (more than four panels) each is dissected, laid out and priced on its own host thread (S200: ten candidates of
+    // ~0.17 ms each, 1.7 ms in sequence), and the choice is then made in the fixed candidate order — first strictly
+    // cheaper — exactly as the sequential loop makes it.
+    struct Cand {
+        int ordering, leaf, variants;
+        bool force;
+        BaPlan plan;
     };
+    std::vector<Cand> cands;
+    cands.push_back({BA_ORDER_NATURAL, 0, 0, false, BaPlan()});
     const bool small = nc <= 2 * cams_per_panel;  // two panels: nothing to reorder
-    if (hint == BA_ORDER_RCM || (hint == BA_ORDER_AUTO && !small)) consider({plan_detail::rcm(adj)}, BA_ORDER_RCM, 0, hint == BA_ORDER_RCM);
+    if (hint == BA_ORDER_RCM || (hint == BA_ORDER_AUTO && !small)) cands.push_back({BA_ORDER_RCM, 0, 0, hint == BA_ORDER_RCM, BaPlan()});
     if (hint == BA_ORDER_ND || (hint == BA_ORDER_AUTO && !small)) {
         bool first = true;
         for (int variants : {0, 3})
             for (int leaf : {cams_per_panel, 2 * cams_per_panel + 1, 3 * cams_per_panel + 2, 4 * cams_per_panel + 2}) {
-                std::vector<std::vector<int>> nodes;
-                std::vector<int> mark(nc, 0), lev(nc, -1);
-                int tag = 1;
-                plan_detail::dissect(adj, mark, tag, all, leaf, nodes, lev, variants);
-                consider(nodes, BA_ORDER_ND, leaf, hint == BA_ORDER_ND && first);
+                cands.push_back({BA_ORDER_ND, leaf, variants, hint == BA_ORDER_ND && first, BaPlan()});
                 first = false;
             }
     }
-    P = std::move(best);
+    auto evaluate = [&](Cand& c) {
+        std::vector<std::vector<int>> nodes;
+        if (c.ordering == BA_ORDER_NATURAL) {
+            nodes = {all};
+        } else if (c.ordering == BA_ORDER_RCM) {
+            nodes = {plan_detail::rcm(adj)};
+        } else {
+            std::vector<int> mark(nc, 0), lev(nc, -1);
+            int tag = 1;
+            plan_detail::dissect(adj, mark, tag, all, c.leaf, nodes, lev, c.variants);
+        }
+        plan_from_nodes(nc, adj, nodes, c.plan, cm);
+        c.plan.ordering = c.ordering;
+        c.plan.nd_leaf = c.leaf;
+    };
+    if (cands.size() > 2 && nc > 4 * cams_per_panel) {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < cands.size(); ++k) th.emplace_back([&, k] { evaluate(cands[k]); });
+        evaluate(cands[0]);
+        for (auto& t : th) t.join();
+    } else {
+        for (Cand& c : cands) evaluate(c);
+    }
+    size_t best = 0;
+    for (size_t k = 1; k < cands.size(); ++k)
+        if (cands[k].force || cands[k].plan.est_us < cands[best].plan.est_us - 1e-9) best = k;
+    BaPlan& bestp = cands[best].plan;
+    P = std::move(bestp);
 }
 
 }  // namespace eacham

@@ -32,6 +32,11 @@ struct eacham_comm {
     // per device: pairs | counts | offsets | total | edges, and the gathered counts / edges
     struct Buf { void* dev = nullptr; size_t bytes = 0; };
     std::vector<Buf> work, gathered;
+    // what the last eacham_comm_match_run left resident (eacham_comm_match_fetch reads it)
+    int run_npairs = -1, run_shard_cap = 0;
+    long long run_edge_cap = 0, run_total = 0;
+    size_t run_gc = 0;
+    std::vector<int32_t> run_order, run_bounds;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -65,19 +70,61 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" {
 
+// Work-balanced contiguous cut of the ordered pair list: bounds[r] = first pair of shard r, bounds[world] = npairs.
+// With weights w_k >= 0 (the matcher's cost of pair k is its distance matrix, rows(f1) x rows(f2)) and prefix sums
+// P[k] = w_0 + .. + w_{k-1}, shard r starts at the smallest k with P[k] * world >= r * P[npairs]: every shard's work is
+// within one pair of the mean, whatever the mix of frame sizes. weights == NULL (or all zero) = equal pair COUNTS, the cut
+// of eacham_shard_bounds.
+int eacham_shard_bounds_weighted(int npairs, int world, const int64_t* weights, int32_t* bounds) {
+    if (npairs < 0 || world <= 0 || !bounds) return EACHAM_ERR_INVALID;
+    long long W = 0;
+    if (weights)
+        for (int k = 0; k < npairs; ++k) {
+            if (weights[k] < 0 || weights[k] > ((long long)1 << 40)) return EACHAM_ERR_INVALID;
+            W += weights[k];
+        }
+    if (!weights || W == 0) {
+        for (int r = 0; r < world; ++r) {
+            int b = 0, e = 0;
+            (void)eacham_shard_bounds(npairs, world, r, &b, &e);
+            bounds[r] = b;
+        }
+        bounds[world] = npairs;
+        return EACHAM_OK;
+    }
+    if (W > (long long)0x7fffffffffffffffLL / world) return EACHAM_ERR_UNSUPPORTED;
+    long long P = 0;
+    int k = 0;
+    for (int r = 0; r < world; ++r) {
+        while (k < npairs && P * world < (long long)r * W) P += weights[k++];
+        bounds[r] = k;
+    }
+    bounds[world] = npairs;
+    return EACHAM_OK;
+}
+
 // Host-side assembly of gathered shards (no device needed): g_counts = world x shard_cap per-pair counts (zero padded),
-// g_edges = world x edge_cap x {q, t}; the shards are the contiguous ranges of eacham_shard_bounds over the SORTED pair
-// list, sorted_index[k] = position of sorted pair k in the caller's list. Writes the CSR over the caller's pair order.
-int eacham_assemble_match_graph(const int32_t* g_counts, const uint32_t* g_edges, int npairs, int world, int shard_cap,
-                                int64_t edge_cap, const int32_t* sorted_index, int32_t* counts, int64_t* offsets,
-                                uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total) {
+// g_edges = world x edge_cap x {q, t}; shard r = pairs [bounds[r], bounds[r + 1]) of the SORTED pair list (bounds == NULL:
+// the equal-count cut of eacham_shard_bounds), sorted_index[k] = position of sorted pair k in the caller's list. Writes
+// the CSR over the caller's pair order.
+int eacham_assemble_match_graph_bounds(const int32_t* g_counts, const uint32_t* g_edges, int npairs, int world, int shard_cap,
+                                       int64_t edge_cap, const int32_t* bounds, const int32_t* sorted_index, int32_t* counts,
+                                       int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total) {
     if (npairs < 0 || world <= 0 || shard_cap < 0 || edge_cap < 0 || !out_total || (npairs > 0 && (!g_counts || !counts || !offsets)))
         return EACHAM_ERR_INVALID;
+    if (bounds && (bounds[0] != 0 || bounds[world] != npairs)) return EACHAM_ERR_INVALID;
     std::vector<int64_t> src_off((size_t)npairs, 0);  // offset of sorted pair k inside its shard's edge list
     std::vector<int> src_rank((size_t)npairs, 0);
     for (int r = 0; r < world; ++r) {
         int b = 0, e = 0;
-        if (eacham_shard_bounds(npairs, world, r, &b, &e) != EACHAM_OK || e - b > shard_cap) return EACHAM_ERR_INVALID;
+        if (bounds) {
+            b = bounds[r];
+            e = bounds[r + 1];
+            if (b < 0 || e < b || e > npairs) return EACHAM_ERR_INVALID;
+        } else if (eacham_shard_bounds(npairs, world, r, &b, &e) != EACHAM_OK) {
+            return EACHAM_ERR_INVALID;
+        }
+        if (e - b > shard_cap) return EACHAM_ERR_INVALID;
         int64_t run = 0;
         for (int k = b; k < e; ++k) {
             const int32_t cnt = g_counts[(size_t)r * shard_cap + (k - b)];
@@ -106,6 +153,13 @@ int eacham_assemble_match_graph(const int32_t* g_counts, const uint32_t* g_edges
         }
     }
     return EACHAM_OK;
+}
+
+int eacham_assemble_match_graph(const int32_t* g_counts, const uint32_t* g_edges, int npairs, int world, int shard_cap,
+                                int64_t edge_cap, const int32_t* sorted_index, int32_t* counts, int64_t* offsets,
+                                uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total) {
+    return eacham_assemble_match_graph_bounds(g_counts, g_edges, npairs, world, shard_cap, edge_cap, nullptr, sorted_index, counts,
+                                              offsets, out_q, out_t, cap, out_total);
 }
 
 int eacham_comm_init(int ndev, const int* devices, eacham_comm** out) {
@@ -207,63 +261,110 @@ int eacham_comm_upload_descriptors(eacham_comm* c, int frame_id, const float* ro
     return EACHAM_OK;
 }
 
-int eacham_match_all_pairs_sharded(eacham_comm* c, const int32_t* pairs, int npairs, double ratio, int min_dir, int min_mutual,
-                                   int32_t* counts, int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap,
-                                   int64_t* out_total) {
-    if (!c || npairs < 0 || !out_total || (npairs > 0 && (!pairs || !counts || !offsets)) || cap < 0 || (cap > 0 && (!out_q || !out_t)))
-        return EACHAM_ERR_INVALID;
+// Sizes of the edge region of every rank's send buffer (host logic, exported for the CPU tests): a shard can produce at
+// most the rows of its query frames, and because ncclAllGather sends the SAME number of elements from every rank — the
+// largest exact total — every rank's region must hold the largest bound, not just its own.
+int eacham_comm_edge_region(int world, const int64_t* shard_bound, int64_t* region) {
+    if (world <= 0 || !shard_bound || !region) return EACHAM_ERR_INVALID;
+    int64_t m = 1;
+    for (int r = 0; r < world; ++r) {
+        if (shard_bound[r] < 0) return EACHAM_ERR_INVALID;
+        m = std::max<int64_t>(m, shard_bound[r]);
+    }
+    *region = m;
+    return EACHAM_OK;
+}
+
+// The device part: ordering, work-balanced shards, matching on every device, the two all-gathers. The gathered graph
+// stays resident on EVERY device (c->gathered[r]); eacham_comm_match_fetch reads device 0's copy.
+int eacham_comm_match_run(eacham_comm* c, const int32_t* pairs, int npairs, double ratio, int min_dir, int min_mutual,
+                          int balance, int64_t* out_total) {
+    if (!c || npairs < 0 || !out_total || (npairs > 0 && !pairs)) return EACHAM_ERR_INVALID;
     std::lock_guard<std::mutex> lock(c->mu);
     *out_total = 0;
+    c->run_npairs = -1;
     if (npairs == 0) {
-        if (offsets) offsets[0] = 0;
+        c->run_npairs = 0;
         return EACHAM_OK;
     }
     const int world = c->ndev;
     // every device sees the same order: by train frame, then query frame (eacham_order_pairs), remembered for the way back
-    std::vector<int32_t> order((size_t)npairs);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return pairs[2 * a + 1] != pairs[2 * b + 1] ? pairs[2 * a + 1] < pairs[2 * b + 1] : pairs[2 * a] < pairs[2 * b];
-    });
-    std::vector<int32_t> sorted(2 * (size_t)npairs);
-    for (int k = 0; k < npairs; ++k) sorted[2 * k] = pairs[2 * order[k]], sorted[2 * k + 1] = pairs[2 * order[k] + 1];
-    const int shard_cap = (npairs + world - 1) / world;
-    std::vector<int> lo(world), hi(world);
-    std::vector<long long> bound(world, 1);  // edges a shard can produce at most: the rows of its query frames
-    for (int r = 0; r < world; ++r) {
-        (void)eacham_shard_bounds(npairs, world, r, &lo[r], &hi[r]);
-        for (int k = lo[r]; k < hi[r]; ++k) {
-            const int rows = eacham_frame_rows(c->ctx[r], sorted[2 * k]);
-            if (rows < 0 || eacham_frame_rows(c->ctx[r], sorted[2 * k + 1]) < 0)
-                return c->fail(EACHAM_ERR_INVALID, "pair %d names a frame (%d, %d) that is not resident", order[k], sorted[2 * k], sorted[2 * k + 1]);
-            bound[r] += rows;
+    std::vector<int32_t>& order = c->run_order;
+    order.resize((size_t)npairs);
+    int max_frame = 0;
+    for (int i = 0; i < 2 * npairs; ++i) {
+        if (pairs[i] < 0 || pairs[i] >= (1 << 20)) return c->fail(EACHAM_ERR_INVALID, "pair %d names frame %d", i / 2, pairs[i]);
+        max_frame = std::max(max_frame, (int)pairs[i]);
+    }
+    {   // two stable counting passes (query frame, then train frame) = the order of eacham_order_pairs, O(npairs + frames)
+        std::vector<int32_t> tmp((size_t)npairs), head((size_t)max_frame + 2);
+        for (int col = 0; col < 2; ++col) {
+            std::fill(head.begin(), head.end(), 0);
+            for (int k = 0; k < npairs; ++k) head[pairs[2 * (col ? tmp[k] : k) + col] + 1]++;
+            for (int f = 0; f <= max_frame; ++f) head[f + 1] += head[f];
+            for (int k = 0; k < npairs; ++k) {
+                const int32_t src = col ? tmp[k] : k;
+                (col ? order : tmp)[head[pairs[2 * src + col]]++] = src;
+            }
         }
+    }
+    std::vector<int> rows((size_t)max_frame + 1, -2);  // one locked query per frame, not per pair
+    auto rows_of = [&](int f) {
+        if (rows[f] == -2) rows[f] = eacham_frame_rows(c->ctx[0], f);
+        return rows[f];
+    };
+    std::vector<int32_t> sorted(2 * (size_t)npairs);
+    std::vector<int64_t> weight((size_t)npairs), rows_q((size_t)npairs);
+    for (int k = 0; k < npairs; ++k) {
+        sorted[2 * k] = pairs[2 * order[k]], sorted[2 * k + 1] = pairs[2 * order[k] + 1];
+        const int r1 = rows_of(sorted[2 * k]), r2 = rows_of(sorted[2 * k + 1]);
+        if (r1 < 0 || r2 < 0)
+            return c->fail(EACHAM_ERR_INVALID, "pair %d names a frame (%d, %d) that is not resident", order[k], sorted[2 * k], sorted[2 * k + 1]);
+        rows_q[k] = r1;
+        weight[k] = (int64_t)r1 * r2;  // the pair's distance matrix: what the tile kernel's time is proportional to
+    }
+    std::vector<int32_t>& bnd = c->run_bounds;
+    bnd.assign((size_t)world + 1, 0);
+    int rc = eacham_shard_bounds_weighted(npairs, world, balance ? weight.data() : nullptr, bnd.data());
+    if (rc) return c->fail(rc, "cutting %d pairs into %d shards failed", npairs, world);
+    int shard_cap = 1;
+    std::vector<int64_t> bound(world, 1);  // edges a shard can produce at most: the rows of its query frames
+    for (int r = 0; r < world; ++r) {
+        shard_cap = std::max(shard_cap, bnd[r + 1] - bnd[r]);
+        for (int k = bnd[r]; k < bnd[r + 1]; ++k) bound[r] += rows_q[k];
+    }
+    int64_t region = 1;
+    (void)eacham_comm_edge_region(world, bound.data(), &region);
+    // ---- phase 0: every allocation of every rank, before anything is enqueued (a rank that fails here fails the call
+    // while no other rank has entered a collective) ----
+    const size_t o_counts = align256((size_t)shard_cap * 2 * sizeof(int32_t));
+    const size_t o_offsets = align256(o_counts + (size_t)shard_cap * sizeof(int32_t));
+    const size_t o_total = align256(o_offsets + (size_t)(shard_cap + 1) * sizeof(int64_t));
+    const size_t o_edges = align256(o_total + sizeof(int64_t));
+    for (int r = 0; r < world; ++r) {
+        (void)hipSetDevice(c->ctx[r]->device);
+        if (grow(c, r, c->work[r], o_edges + (size_t)region * 2 * sizeof(uint32_t)))
+            return c->fail(EACHAM_ERR_HIP, "device %d: allocating the shard workspace failed", r);
     }
     // ---- phase 1: every device matches its shard; the exact totals size the padded edge lists of the gather ----
     std::vector<int> rcs(world, EACHAM_OK);
     std::vector<long long> totals(world, 0);
-    std::vector<size_t> o_counts(world), o_offsets(world), o_total(world), o_edges(world);
     auto phase1 = [&](int r) {
         eacham_ctx* x = c->ctx[r];
         (void)hipSetDevice(x->device);
-        const int n = hi[r] - lo[r];
-        o_counts[r] = align256((size_t)shard_cap * 2 * sizeof(int32_t));
-        o_offsets[r] = align256(o_counts[r] + (size_t)shard_cap * sizeof(int32_t));
-        o_total[r] = align256(o_offsets[r] + (size_t)(shard_cap + 1) * sizeof(int64_t));
-        o_edges[r] = align256(o_total[r] + sizeof(int64_t));
-        if (grow(c, r, c->work[r], o_edges[r] + (size_t)bound[r] * 2 * sizeof(uint32_t))) { rcs[r] = EACHAM_ERR_HIP; return; }
+        const int n = bnd[r + 1] - bnd[r];
         char* w = (char*)c->work[r].dev;
-        if (hipMemsetAsync(w + o_counts[r], 0, (size_t)shard_cap * sizeof(int32_t), x->stream) != hipSuccess ||
-            hipMemsetAsync(w + o_total[r], 0, sizeof(int64_t), x->stream) != hipSuccess ||
-            (n > 0 && hipMemcpyAsync(w, sorted.data() + 2 * (size_t)lo[r], (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, x->stream) != hipSuccess)) {
+        if (hipMemsetAsync(w + o_counts, 0, (size_t)shard_cap * sizeof(int32_t), x->stream) != hipSuccess ||
+            hipMemsetAsync(w + o_total, 0, sizeof(int64_t), x->stream) != hipSuccess ||
+            (n > 0 && hipMemcpyAsync(w, sorted.data() + 2 * (size_t)bnd[r], (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, x->stream) != hipSuccess)) {
             rcs[r] = EACHAM_ERR_HIP;
             return;
         }
         if (n > 0)
-            rcs[r] = eacham_match_all_pairs_dev(x, (const int32_t*)w, n, ratio, min_dir, min_mutual, (int32_t*)(w + o_counts[r]),
-                                                (int64_t*)(w + o_offsets[r]), (uint32_t*)(w + o_edges[r]), bound[r],
-                                                (int64_t*)(w + o_total[r]), nullptr);
-        if (rcs[r] == EACHAM_OK && (hipMemcpyAsync(&totals[r], w + o_total[r], sizeof(long long), hipMemcpyDeviceToHost, x->stream) != hipSuccess ||
+            rcs[r] = eacham_match_all_pairs_dev(x, (const int32_t*)w, n, ratio, min_dir, min_mutual, (int32_t*)(w + o_counts),
+                                                (int64_t*)(w + o_offsets), (uint32_t*)(w + o_edges), bound[r],
+                                                (int64_t*)(w + o_total), nullptr);
+        if (rcs[r] == EACHAM_OK && (hipMemcpyAsync(&totals[r], w + o_total, sizeof(long long), hipMemcpyDeviceToHost, x->stream) != hipSuccess ||
                                     hipStreamSynchronize(x->stream) != hipSuccess))
             rcs[r] = EACHAM_ERR_HIP;
     };
@@ -276,24 +377,27 @@ int eacham_match_all_pairs_sharded(eacham_comm* c, const int32_t* pairs, int npa
     for (int r = 0; r < world; ++r)
         if (rcs[r]) return c->fail(rcs[r], "device %d: %s", r, rcs[r] == EACHAM_ERR_HIP ? "HIP call failed while matching a shard" : eacham_last_error(c->ctx[r]));
     const long long edge_cap = std::max<long long>(1, *std::max_element(totals.begin(), totals.end()));
-    // ---- phase 2: the RCCL all-gathers, on every context's own stream (one host thread per device) ----
-    std::vector<int32_t> g_counts((size_t)world * shard_cap);
-    std::vector<uint32_t> g_edges((size_t)world * edge_cap * 2);
+    if (edge_cap > region) return c->fail(EACHAM_ERR_HIP, "a shard reports %lld matches, more than its query rows (%lld)", edge_cap, (long long)region);
+    // ---- phase 2: the receive buffers of every rank first, then the RCCL all-gathers on every context's own stream ----
+    const size_t gc = align256((size_t)world * shard_cap * sizeof(int32_t));
+    for (int r = 0; r < world; ++r) {
+        (void)hipSetDevice(c->ctx[r]->device);
+        if (grow(c, r, c->gathered[r], gc + (size_t)world * edge_cap * 2 * sizeof(uint32_t)))
+            return c->fail(EACHAM_ERR_HIP, "device %d: allocating the gathered match graph failed", r);
+    }
     auto phase2 = [&](int r) {
         eacham_ctx* x = c->ctx[r];
         (void)hipSetDevice(x->device);
-        const size_t gc = align256((size_t)world * shard_cap * sizeof(int32_t));
-        if (grow(c, r, c->gathered[r], gc + (size_t)world * edge_cap * 2 * sizeof(uint32_t))) { rcs[r] = EACHAM_ERR_HIP; return; }
         char* w = (char*)c->work[r].dev;
         char* g = (char*)c->gathered[r].dev;
-        ncclResult_t nr = c->AllGather(w + o_counts[r], g, (size_t)shard_cap, ncclInt32, c->comms[r], x->stream);
-        if (nr == ncclSuccess) nr = c->AllGather(w + o_edges[r], g + gc, (size_t)edge_cap * 2, ncclUint32, c->comms[r], x->stream);
-        if (nr != ncclSuccess) { rcs[r] = EACHAM_ERR_HIP; return; }
-        if (r == 0) {  // every device holds the graph now; the host reads device 0's copy
-            if (hipMemcpyAsync(g_counts.data(), g, g_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, x->stream) != hipSuccess ||
-                hipMemcpyAsync(g_edges.data(), g + gc, g_edges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream) != hipSuccess)
-                rcs[r] = EACHAM_ERR_HIP;
+        // the slots between this rank's total and the common edge_cap travel too: cleared, never stale
+        if (totals[r] < edge_cap &&
+            hipMemsetAsync(w + o_edges + (size_t)totals[r] * 2 * sizeof(uint32_t), 0, (size_t)(edge_cap - totals[r]) * 2 * sizeof(uint32_t), x->stream) != hipSuccess) {
+            rcs[r] = EACHAM_ERR_HIP;  // (still joins the collectives below: nobody may be left waiting)
         }
+        ncclResult_t nr = c->AllGather(w + o_counts, g, (size_t)shard_cap, ncclInt32, c->comms[r], x->stream);
+        if (nr == ncclSuccess) nr = c->AllGather(w + o_edges, g + gc, (size_t)edge_cap * 2, ncclUint32, c->comms[r], x->stream);
+        if (nr != ncclSuccess) rcs[r] = EACHAM_ERR_HIP;
         if (hipStreamSynchronize(x->stream) != hipSuccess) rcs[r] = EACHAM_ERR_HIP;
     };
     {
@@ -304,10 +408,55 @@ int eacham_match_all_pairs_sharded(eacham_comm* c, const int32_t* pairs, int npa
     }
     for (int r = 0; r < world; ++r)
         if (rcs[r]) return c->fail(rcs[r], "device %d: the all-gather of the match graph failed", r);
-    const int rc = eacham_assemble_match_graph(g_counts.data(), g_edges.data(), npairs, world, shard_cap, edge_cap, order.data(), counts,
-                                               offsets, out_q, out_t, cap, out_total);
+    long long total = 0;
+    for (int r = 0; r < world; ++r) total += totals[r];
+    c->run_npairs = npairs;
+    c->run_shard_cap = shard_cap;
+    c->run_edge_cap = edge_cap;
+    c->run_gc = gc;
+    c->run_total = total;
+    *out_total = total;
+    return EACHAM_OK;
+}
+
+// Downloads the graph gathered by the last eacham_comm_match_run from device 0 and assembles the CSR in the caller's
+// pair order.
+int eacham_comm_match_fetch(eacham_comm* c, int32_t* counts, int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap,
+                            int64_t* out_total) {
+    if (!c || !out_total || cap < 0 || (cap > 0 && (!out_q || !out_t))) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->run_npairs < 0) return c->fail(EACHAM_ERR_INVALID, "no gathered match graph: eacham_comm_match_run has not succeeded");
+    *out_total = 0;
+    const int npairs = c->run_npairs, world = c->ndev;
+    if (npairs == 0) {
+        if (offsets) offsets[0] = 0;
+        return EACHAM_OK;
+    }
+    if (!counts || !offsets) return EACHAM_ERR_INVALID;
+    std::vector<int32_t> g_counts((size_t)world * c->run_shard_cap);
+    std::vector<uint32_t> g_edges((size_t)world * c->run_edge_cap * 2);
+    eacham_ctx* x = c->ctx[0];
+    (void)hipSetDevice(x->device);
+    const char* g = (const char*)c->gathered[0].dev;
+    if (hipMemcpyAsync(g_counts.data(), g, g_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, x->stream) != hipSuccess ||
+        hipMemcpyAsync(g_edges.data(), g + c->run_gc, g_edges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream) != hipSuccess ||
+        hipStreamSynchronize(x->stream) != hipSuccess)
+        return c->fail(EACHAM_ERR_HIP, "reading the gathered match graph back failed");
+    const int rc = eacham_assemble_match_graph_bounds(g_counts.data(), g_edges.data(), npairs, world, c->run_shard_cap, c->run_edge_cap,
+                                                      c->run_bounds.data(), c->run_order.data(), counts, offsets, out_q, out_t, cap, out_total);
     if (rc) return c->fail(rc, rc == EACHAM_ERR_CAPACITY ? "output capacity %lld too small" : "gathered match graph is inconsistent", (long long)cap);
     return EACHAM_OK;
+}
+
+int eacham_match_all_pairs_sharded(eacham_comm* c, const int32_t* pairs, int npairs, double ratio, int min_dir, int min_mutual,
+                                   int32_t* counts, int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap,
+                                   int64_t* out_total) {
+    if (!c || npairs < 0 || !out_total || (npairs > 0 && (!pairs || !counts || !offsets)) || cap < 0 || (cap > 0 && (!out_q || !out_t)))
+        return EACHAM_ERR_INVALID;
+    int64_t total = 0;
+    int rc = eacham_comm_match_run(c, pairs, npairs, ratio, min_dir, min_mutual, /*balance=*/1, &total);
+    if (rc) return rc;
+    return eacham_comm_match_fetch(c, counts, offsets, out_q, out_t, cap, out_total);
 }
 
 }  // extern "C"

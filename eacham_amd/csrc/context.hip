@@ -223,6 +223,12 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     if (!ctx) return EACHAM_ERR_INVALID;
     ctx->device = device_id;
     ctx->match_no_overlap = getenv("EACHAM_NO_OVERLAP") != nullptr;
+    ctx->exp_no_coltop2 = getenv("EACHAM_EXP_NO_COLTOP2") != nullptr;
+    ctx->match_full_columns = getenv("EACHAM_MATCH_FULL_COLUMNS") != nullptr;
+    if (const char* b = getenv("EACHAM_MATCH_BUDGET_MB")) {
+        const int v = atoi(b);
+        if (v >= 16 && v <= 65536) ctx->match_budget_mb = v;
+    }
     if (const char* l = getenv("EACHAM_BA_LPL_STEP")) {
         const int v = atoi(l);
         if (v == 1 || v == 2 || v == 4 || v == 8) ctx->ba_lpl_step = v;

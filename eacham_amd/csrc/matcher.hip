@@ -204,10 +204,20 @@ __device__ __forceinline__ void lds_read_frag(V& dst, unsigned addr, int offset_
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offset_bytes));
 }
 
-template <int KS, int NSUB>
+// GATHER (the candidate-only column pass, see match_rows_kernel): the stationary operand is not a frame's row block but the
+// CANDIDATE columns of frame pairs[p].y — row i of the block is stored column rowcand[candlist[i]].x, its fragments gathered
+// in the prologue — and the streamed frame is pairs[p].x: the same sweep then yields, per candidate column, the top-2 over
+// all rows of the query frame ("rowres" of the swapped roles), i.e. exactly what the mutual check asks of that column.
+struct CandView {
+    const uint2* rowcand;
+    const int* candlist;
+    const int4* state;
+};
+template <int KS, int NSUB, bool COL, bool GATHER>
 __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair, int col_chunks,
-    uint4* __restrict__ rowres, uint2* __restrict__ colpart, int wb_stride, int row_stride) {
+    uint4* __restrict__ rowres, uint2* __restrict__ colpart, int wb_stride, int row_stride, CandView cand) {
+    static_assert(!(COL && GATHER), "the gathered sweep has no column direction");
     constexpr int TILE_V4 = KS * 64;          // int4 per B tile
     constexpr int ROWS_WAVE = 32 * NSUB;      // query rows a wave keeps in registers
     constexpr int ROWS_WG = WAVES * ROWS_WAVE;
@@ -231,9 +241,17 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     const int rb = (blockIdx.x / col_chunks) % wgs_per_pair;
     const int p = blockIdx.x / (col_chunks * wgs_per_pair);
     const int2 pr = pairs[p];
-    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    const FrameDev A = frames[GATHER ? pr.y : pr.x], B = frames[GATHER ? pr.x : pr.y];
     const int tbeg = cc * CHUNK_TILES;
-    const int A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];  // tiles of the even class / in use
+    int A_even, A_tiles, ncand = 0;
+    if constexpr (GATHER) {
+        const int4 st = cand.state[p];
+        ncand = st.x;
+        A_even = 0;
+        A_tiles = st.y ? (ncand + ROWS_WAVE - 1) / ROWS_WAVE * NSUB : 0;  // whole wave-blocks of candidates of a live pair
+    } else {
+        A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];  // tiles of the even class / in use
+    }
     const int B_even = ((gint_t)B.meta)[0], B_tiles = ((gint_t)B.meta)[1];
     if (rb * (ROWS_WG / 32) >= A_tiles || tbeg >= B_tiles) return;  // workgroup-uniform
     const int wb = rb * WAVES + wave;                  // wave-block (ROWS_WAVE rows) of frame A
@@ -246,14 +264,26 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     v16i cinit[NSUB];                 // floor(|a|^2/2) of this lane's 16 rows per sub-tile: the MFMA C-init
     unsigned rm1[NSUB][16], rm2[NSUB][16];
     const int wbc = active ? wb : 0;  // inactive waves load a valid block and never use it
+    // candidate i of the pair -> its stored column in the candidates' frame (slots past the list repeat the first candidate:
+    // their results are never read)
+    auto cand_col = [&](int i) {
+        const uint2* rc = cand.rowcand + (size_t)p * row_stride;
+        return (int)rc[cand.candlist[(size_t)p * row_stride + (i < ncand ? i : 0)]].x;
+    };
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
+        if constexpr (GATHER) {
+            const int c = cand_col(ROWS_WAVE * wbc + 32 * s + cl);  // this lane's operand row: (c >> 5, c & 31) of the frame
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
+            for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(c >> 5) * KS + ks) * 64 + 32 * h + (c & 31)];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int lrow = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
-            cinit[s][r] = Aca[ROWS_WAVE * wbc + lrow];
+            cinit[s][r] = GATHER ? Aca[cand_col(ROWS_WAVE * wbc + lrow)] : Aca[ROWS_WAVE * wbc + lrow];
             rm1[s][r] = 0xffffffffu;
             rm2[s][r] = 0xffffffffu;
         }
@@ -357,7 +387,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
         const unsigned lowc = ((unsigned)hb_cur << (KEY_SHIFT + 1)) | (unsigned)((tbeg + t >= B_even ? (1 << KEY_SHIFT) : 0) | t);
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
         hb_cur = Bhb[32 * t1 + cl];
-        if (t > 0 && t % BURST == 0) merge_burst(t - BURST);  // tiles t-8 .. t-1 are published; their buffer is rewritten from tile t+8 on
+        if (COL && t > 0 && t % BURST == 0) merge_burst(t - BURST);  // tiles t-8 .. t-1 are published; their buffer is rewritten from tile t+8 on
         stage_tile(t2, slot_new);  // lands during this iteration; the barrier below publishes it
         unsigned cm1[NSUB], cm2[NSUB], pend[3] = {0, 0, 0};  // column top-2 per sub-tile (a sub-tile has one parity)
         if (active) {
@@ -392,20 +422,22 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
                     // are taken three at a time — {min3, med3} of a triple (2 ops) then one sorted-pair
                     // insert (3 ops) = 5 ops per 3 keys instead of 6 (and the first triple needs no insert).
                     const int eg = ks * EPK + e;  // 0..15 within the sub-tile, compile-time after unrolling
-                    pend[eg % 3] = key;
-                    if (eg % 3 == 2) {
-                        const unsigned s1 = umin(umin(pend[0], pend[1]), pend[2]);
-                        const unsigned s2 = vmed3(pend[0], pend[1], pend[2]);
-                        if (eg == 2) {
-                            cm1[ph] = s1;
-                            cm2[ph] = s2;
-                        } else {
-                            cm2[ph] = umin(umin(umax(cm1[ph], s1), cm2[ph]), s2);
-                            cm1[ph] = umin(cm1[ph], s1);
+                    if constexpr (COL) {
+                        pend[eg % 3] = key;
+                        if (eg % 3 == 2) {
+                            const unsigned s1 = umin(umin(pend[0], pend[1]), pend[2]);
+                            const unsigned s2 = vmed3(pend[0], pend[1], pend[2]);
+                            if (eg == 2) {
+                                cm1[ph] = s1;
+                                cm2[ph] = s2;
+                            } else {
+                                cm2[ph] = umin(umin(umax(cm1[ph], s1), cm2[ph]), s2);
+                                cm1[ph] = umin(cm1[ph], s1);
+                            }
+                        } else if (eg == 15) {  // 16 = 5 triples + 1
+                            cm2[ph] = vmed3(cm1[ph], cm2[ph], key);
+                            cm1[ph] = umin(cm1[ph], key);
                         }
-                    } else if (eg == 15) {  // 16 = 5 triples + 1
-                        cm2[ph] = vmed3(cm1[ph], cm2[ph], key);
-                        cm1[ph] = umin(cm1[ph], key);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -417,7 +449,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             // straddles the even/odd boundary of frame A, which keeps the two parities apart.
             unsigned g1[2] = {0xffffffffu, 0xffffffffu}, g2[2] = {0xffffffffu, 0xffffffffu};
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
+            for (int s = 0; COL && s < NSUB; ++s) {
                 const int g = (split && NSUB * wb + s >= A_even) ? 1 : 0;  // wave-uniform
                 if (g == 0) {
                     g2[0] = umin(umin(umax(g1[0], cm1[s]), g2[0]), cm2[s]);
@@ -429,21 +461,21 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             }
             // lanes l and l+32 hold the same column, rows 4h.. of each 8-row group: merge halves
             // (v_permlane32_swap: lanes 0-31 of the 2nd operand <-> lanes 32-63 of the 1st, pure VALU)
-            {
+            if constexpr (COL) {
                 auto w1 = __builtin_amdgcn_permlane32_swap(g1[0], g1[0], false, false);
                 auto w2 = __builtin_amdgcn_permlane32_swap(g2[0], g2[0], false, false);
                 const unsigned n1 = umin(w1[0], w1[1]);
                 const unsigned n2 = umin(umax(w1[0], w1[1]), umin(w2[0], w2[1]));
                 if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][0][wave][cl] = make_uint2(n1, n2);
             }
-            if (split) {
+            if (COL && split) {
                 auto w1 = __builtin_amdgcn_permlane32_swap(g1[1], g1[1], false, false);
                 auto w2 = __builtin_amdgcn_permlane32_swap(g2[1], g2[1], false, false);
                 const unsigned n1 = umin(w1[0], w1[1]);
                 const unsigned n2 = umin(umax(w1[0], w1[1]), umin(w2[0], w2[1]));
                 if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][1][wave][cl] = make_uint2(n1, n2);
             }
-        } else {  // a wave beyond the frame's rows contributes nothing
+        } else if constexpr (COL) {  // a wave beyond the frame's rows contributes nothing
             if (h == 0) sU.c.e[(t / BURST) & 1][t % BURST][0][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
             if (split && h == 0) sU.c.e[(t / BURST) & 1][t % BURST][1][wave][cl] = make_uint2(0xffffffffu, 0xffffffffu);
         }
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
             if (t + 1 < T) tile(P1{}, S1{}, t + 1);
         }
     }
-    if (T > 0) merge_burst((T - 1) / BURST * BURST);  // the last 1..8 tiles, published by the loop's last barrier
+    if (COL && T > 0) merge_burst((T - 1) / BURST * BURST);  // the last 1..8 tiles, published by the loop's last barrier
     __syncthreads();                                  // the region becomes the row slab
     if (!active) return;
 
@@ -631,6 +663,149 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The candidate-only column pass (round 4). The tile sweep is bound by the VALU issue port and its column direction is
+// 1.67 of the 4.67 operations it spends per distance (profiles/r04_coltop_knockout.txt: the sweep alone is 26 % / 39 %
+// faster at 256-D / 128-D). But the pair loop of apps/sfm/main.cpp:111,133-142 only ever looks at column t = m12[q] of a
+// row q that passed the ratio test: with |mutual| > min_mutual >= min_dir - 1 the two direction thresholds are implied
+// (every mutual match is in m12 and in m21), so a pair with no more than min_mutual passing rows is dead, and for the
+// others the column top-2 is needed for the passing rows' best columns only. Three small kernels replace K2:
+//   R  match_rows_kernel       per pair: merge the row results, ratio test, ordered list of the passing rows (candidates)
+//   V  match_tile_kernel<.., GATHER>  the SAME sweep with the roles swapped: the candidate columns of a live pair, gathered
+//                              as the stationary operand, against all rows of the query frame streamed through LDS; its
+//                              row results are the top-2 of every candidate column (dead pairs' workgroups exit at once)
+//   F  match_finalize2_kernel  per pair: keep candidate (q, t) iff column t passes the ratio test with minimum d2(q, t);
+//                              ordered compaction in the caller's row order, threshold
+// ------------------------------------------------------------------------------------------------
+
+// exclusive rank of this thread's flag among the workgroup's flags (thread order) + the workgroup's total
+__device__ __forceinline__ int block_rank(bool flag, int tid, int* s_wave /* [FIN_THREADS / 64] */, int& total) {
+    const unsigned long long bal = __ballot(flag);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < FIN_THREADS / 64; ++w) {
+        const int c = s_wave[w];
+        before += w < wave ? c : 0;
+        all += c;
+    }
+    __syncthreads();
+    total = all;
+    return before + in_wave;
+}
+
+// rowcand[p][j] = {stored column of row j's best, d2} if stored row j passes the ratio test, else {~0, 0};
+// candlist[p][i] = stored row of the i-th passing row (ascending j); state[p] = {passing rows, live, 0, 0}
+__global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint4* __restrict__ rowres, int col_chunks,
+    int row_stride, double ratio, int min_dir, int min_mutual, int mode, uint2* __restrict__ rowcand,
+    int* __restrict__ candlist, int4* __restrict__ state) {
+    __shared__ int s_wave[FIN_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    const int A_even = A.meta[0], A_tiles = A.meta[1], B_tiles = B.meta[1];
+    constexpr unsigned PAD_V = 2u * PADH;
+    const int nchunks = (B_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
+    uint2* rc = rowcand + (size_t)p * row_stride;
+    int* cl = candlist + (size_t)p * row_stride;
+    int base = 0;
+    for (int j0 = 0; j0 < 32 * A_tiles; j0 += FIN_THREADS) {
+        const int j = j0 + tid;
+        bool ok = false;
+        unsigned col = 0;
+        int d2 = 0;
+        if (j < 32 * A_tiles && A.orig[j] >= 0) {
+            unsigned v1 = 0xffffffffu, v2 = 0xffffffffu;
+            for (int ch = 0; ch < nchunks; ++ch) {  // ascending columns; strict '<' keeps the lower column on ties
+                const uint4 e = rowres[((size_t)p * col_chunks + ch) * row_stride + j];
+                if (e.x < v1) {
+                    v2 = umin(v1, e.z);
+                    v1 = e.x;
+                    col = e.y;
+                } else {
+                    v2 = umin(v2, e.x);
+                }
+            }
+            const unsigned pa = (j >> 5) >= A_even ? 1u : 0u;
+            d2 = (int)(v1 + pa) - 2;
+            ok = v2 < PAD_V && ratio_pass(d2, (int)(v2 + pa) - 2, ratio);  // pad second => < 2 train rows
+        }
+        if (j < 32 * A_tiles) rc[j] = ok ? make_uint2(col, (unsigned)d2) : make_uint2(0xffffffffu, 0u);
+        int total;
+        const int rank = block_rank(ok, tid, s_wave, total);
+        if (ok) cl[base + rank] = j;
+        base += total;
+    }
+    // main.cpp:111,142: an edge needs |m12| >= min_dir and |mutual| > min_mutual, and mutual is a subset of m12
+    const bool live = mode == 0 && base >= min_dir && base > min_mutual;
+    if (tid == 0) state[p] = make_int4(base, live ? 1 : 0, 0, 0);
+}
+
+// out_matches[p][k] = {q, t} sorted by q; counts[p] (mode 0: |mutual| if it exceeds min_mutual, else 0; mode 1: |m12|)
+__global__ __launch_bounds__(FIN_THREADS) void match_finalize2_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint2* __restrict__ rowcand,
+    const int* __restrict__ candlist, const uint4* __restrict__ colres, const int4* __restrict__ state, int col_chunks,
+    int row_stride, double ratio, int min_mutual, int mode, uint2* __restrict__ out_matches, int* __restrict__ counts) {
+    extern __shared__ int smem[];
+    __shared__ int s_wave[FIN_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const int4 st = state[p];
+    if (st.x == 0 || (mode == 0 && !st.y)) {  // workgroup-uniform: no passing row, or a pair that cannot reach the thresholds
+        if (tid == 0) counts[p] = 0;
+        return;
+    }
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    const int A_tiles = A.meta[1], B_even = B.meta[0];
+    constexpr unsigned PAD_V = 2u * PADH;
+    int* keepcol = smem;  // [row_stride] by stored row: stored column of the kept match or -1
+    const uint2* rc = rowcand + (size_t)p * row_stride;
+    const int* cl = candlist + (size_t)p * row_stride;
+    for (int j = tid; j < 32 * A_tiles; j += FIN_THREADS) keepcol[j] = -1;
+    __syncthreads();
+    const int nchunks = (A_tiles + CHUNK_TILES - 1) / CHUNK_TILES;  // the gathered sweep streams frame A
+    for (int i = tid; i < st.x; i += FIN_THREADS) {
+        const int j = cl[i];
+        const uint2 c = rc[j];  // {stored column of row j's best, d2}
+        int keep = (int)c.x;
+        if (mode == 0) {
+            // main.cpp:133-140: q is kept iff t's own best match is q, i.e. iff column t passes the ratio test (a unique
+            // minimum for any ratio <= 1) and its minimum is d2(q, t). Candidate slot i of the gathered sweep holds the
+            // top-2 of column c.x over the rows of frame A, per chunk of streamed rows.
+            unsigned v1 = 0xffffffffu, v2 = 0xffffffffu;
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const uint4 e = colres[((size_t)p * col_chunks + ch) * row_stride + i];
+                v2 = umin(umin(umax(v1, e.x), v2), e.z);  // (e.x <= e.z) merged into (v1 <= v2): values only
+                v1 = umin(v1, e.x);
+            }
+            // v = 2H + pa of the streamed row: d2 = v + pb - 2 with pb the candidate column's parity... the key's parity bit
+            // is the STREAMED row's, so the constant left to add is the stationary (candidate) side's
+            const unsigned pb = (c.x >> 5) >= (unsigned)B_even ? 1u : 0u;
+            const int d1 = (int)(v1 + pb) - 2;
+            if (!(d1 == (int)c.y && v2 < PAD_V && ratio_pass(d1, (int)(v2 + pb) - 2, ratio))) keep = -1;
+        }
+        keepcol[j] = keep;
+    }
+    __syncthreads();
+    uint2* out = out_matches + (size_t)p * row_stride;
+    int base = 0;
+    for (int q0 = 0; q0 < A.n; q0 += FIN_THREADS) {  // ordered compaction over the caller's q
+        const int q = q0 + tid;
+        const int t = q < A.n ? keepcol[A.pos[q]] : -1;
+        int total;
+        const int rank = block_rank(t >= 0, tid, s_wave, total);
+        if (t >= 0) out[base + rank] = make_uint2((unsigned)q, (unsigned)B.orig[t]);
+        base += total;
+    }
+    if (tid == 0) counts[p] = mode == 1 ? base : (base > min_mutual ? base : 0);  // main.cpp:142
+}
+
 // offsets[first + i] = running total; single workgroup, sequential over chunks (npairs is small)
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ counts, int n,
                                                            long long* __restrict__ offsets,
@@ -757,9 +932,11 @@ struct MatchPlan {
     int col_chunks;  // sweeps of <= 4096 train rows per pair
     int slots;       // workspace copies: batch i+1's tile kernel overlaps batch i's finalize
     size_t off_rowres, off_colpart, off_matches, slot_bytes, total;
+    // the candidate-only column pass: rowcand | candlist | colres (the gathered sweep's row results) | state
+    size_t off_rowcand, off_candlist, off_colres, off_state;
 };
 
-static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
+static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
     int max_tiles = std::max(4, GROUP_TILES);
     for (const auto& f : ctx->frames)
         if (f.n >= 0) max_tiles = std::max(max_tiles, f.tiles_used);
@@ -768,10 +945,12 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
     pl.wb_stride = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32) + 1;  // column-partial slots per pair: one per workgroup + 1
     pl.wgs_per_pair = (max_tiles + (ROWS_PER_WG / 32) - 1) / (ROWS_PER_WG / 32);
     pl.col_chunks = (max_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
-    size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) +
-                      (size_t)pl.row_stride * sizeof(uint2);
+    // per pair: row results + match list, and EITHER the column partials of the full sweep OR the arrays of the candidate pass
+    const size_t colpart_pp = full_cols ? (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) : 0;
+    const size_t cand_pp = full_cols ? 0 : (size_t)pl.row_stride * (sizeof(uint2) + sizeof(int) + (size_t)pl.col_chunks * sizeof(uint4)) + sizeof(int4);
+    size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.row_stride * sizeof(uint2) + colpart_pp + cand_pp;
     // bound a slot near 1 GiB so the column partials of one batch stay cache-friendly
-    size_t budget = (size_t)1 << 30;
+    size_t budget = (size_t)ctx->match_budget_mb << 20;
     int batch = (int)std::min<size_t>(std::max<size_t>(budget / per_pair, 1), (size_t)npairs);
     // whole rounds of workgroups (2 per CU x 256 CUs) keep the tail of a launch short
     const int wgs = pl.wgs_per_pair * pl.col_chunks;
@@ -787,17 +966,36 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     pl.off_rowres = 0;
     pl.off_colpart = align(pl.off_rowres + (size_t)pl.batch * pl.col_chunks * pl.row_stride * sizeof(int4));
-    pl.off_matches = align(pl.off_colpart + (size_t)pl.batch * pl.wb_stride * pl.row_stride * sizeof(int2));
-    pl.slot_bytes = align(pl.off_matches + (size_t)pl.batch * pl.row_stride * sizeof(uint2));
+    pl.off_matches = align(pl.off_colpart + (full_cols ? (size_t)pl.batch * pl.wb_stride * pl.row_stride * sizeof(int2) : 0));
+    pl.off_rowcand = align(pl.off_matches + (size_t)pl.batch * pl.row_stride * sizeof(uint2));
+    const size_t cb = full_cols ? 0 : (size_t)pl.batch;  // the candidate arrays exist in the other form only
+    pl.off_candlist = align(pl.off_rowcand + cb * pl.row_stride * sizeof(uint2));
+    pl.off_colres = align(pl.off_candlist + cb * pl.row_stride * sizeof(int));
+    pl.off_state = align(pl.off_colres + cb * pl.col_chunks * pl.row_stride * sizeof(uint4));
+    pl.slot_bytes = align(pl.off_state + cb * sizeof(int4) + 256);
     pl.total = pl.slot_bytes * pl.slots;
     return pl;
 }
 
 template <int KS>
-static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws) {
-    match_tile_kernel<KS, MATCH_NSUB><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
-        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_rowres),
-        (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
+static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws, bool col) {
+    const CandView none{nullptr, nullptr, nullptr};
+    if (!col)  // the sweep without its column direction: the candidate-only pass follows (or nothing, for directed lists)
+        match_tile_kernel<KS, MATCH_NSUB, false, false><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
+            ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_rowres),
+            (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride, none);
+    else
+        match_tile_kernel<KS, MATCH_NSUB, true, false><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
+            ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_rowres),
+            (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride, none);
+}
+// the gathered sweep of the candidate columns (roles swapped; results in the colres region, laid out like rowres)
+template <int KS>
+static void launch_verify(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws, hipStream_t st) {
+    const CandView cv{(const uint2*)(ws + pl.off_rowcand), (const int*)(ws + pl.off_candlist), (const int4*)(ws + pl.off_state)};
+    match_tile_kernel<KS, MATCH_NSUB, false, true><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, st>>>(
+        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_colres), nullptr, pl.wb_stride,
+        pl.row_stride, cv);
 }
 
 // Core driver. mode 0 = mutual (CSR out), mode 1 = directed single pair (fixed-stride out in ws).
@@ -814,13 +1012,20 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
     if (ctx->kind_common == 1)
         return run_match_f32(ctx, pairs_dev, npairs, ratio, min_dir, min_mutual, mode, counts_dev, offsets_dev, edges_dev,
                              edge_cap, total_dev, stats_dev);
-    MatchPlan pl = make_plan(ctx, npairs);
+    // Which form of the column direction: the reference's thresholds (30 / 30, main.cpp:111,142) make the direction counts
+    // redundant once |mutual| > min_mutual >= min_dir - 1, so only the columns that are some passing row's best are ever
+    // looked at (candidate-only pass); directed lists need no column at all. Callers that ask for the per-pair statistics
+    // (|m12|, |m21|) or use other thresholds get every column's top-2 from the sweep itself, as before.
+    const bool full_cols = ctx->match_full_columns || (mode == 0 && (stats_dev != nullptr || (long long)min_mutual < (long long)min_dir - 1));
+    MatchPlan pl = make_plan(ctx, npairs, full_cols);
     rc = ensure_workspace(ctx, pl.total);
     if (rc) return rc;
     ctx->last_matches = (char*)ctx->ws + pl.off_matches;
-    const size_t fin_smem = (size_t)2 * pl.row_stride * sizeof(int);
-    if (fin_smem > 48 * 1024)
-        EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)match_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_smem));
+    const size_t fin_smem = (size_t)(full_cols ? 2 : 1) * pl.row_stride * sizeof(int);
+    if (fin_smem > 48 * 1024) {
+        if (full_cols) EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)match_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_smem));
+        else EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)match_finalize2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_smem));
+    }
     // Two streams: the tile kernels run back to back on the context stream; finalize, scan and
     // compaction of a batch run on stream2 beside the next batch's tile kernel (they are bound by
     // HBM/L2, the tile kernel by the vector ALU), each batch in its own workspace slot.
@@ -836,10 +1041,11 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
         if (b >= pl.slots) EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st1, ctx->ev_fin[slot], 0));  // slot free again
         {
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_TILE, st1);
+            const bool col = full_cols && !ctx->exp_no_coltop2;
             switch (ctx->ks_common) {
-                case 2: launch_tile<2>(ctx, pl, pb, nb, ws); break;
-                case 4: launch_tile<4>(ctx, pl, pb, nb, ws); break;
-                default: launch_tile<8>(ctx, pl, pb, nb, ws); break;
+                case 2: launch_tile<2>(ctx, pl, pb, nb, ws, col); break;
+                case 4: launch_tile<4>(ctx, pl, pb, nb, ws, col); break;
+                default: launch_tile<8>(ctx, pl, pb, nb, ws, col); break;
             }
         }
         EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_tile[slot], st1));
@@ -848,11 +1054,30 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
         int* cnt = csr ? counts_dev + first : counts_dev;
         {
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_FINALIZE, st2);
-            match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(
-                ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres),
-                (const uint2*)(ws + pl.off_colpart), pl.col_chunks, pl.wb_stride, pl.row_stride, ratio, min_dir,
-                min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt,
-                stats_dev ? stats_dev + first : nullptr);
+            if (full_cols) {
+                match_finalize_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(
+                    ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres),
+                    (const uint2*)(ws + pl.off_colpart), pl.col_chunks, pl.wb_stride, pl.row_stride, ratio, min_dir,
+                    min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt,
+                    stats_dev ? stats_dev + first : nullptr);
+            } else {
+                uint2* rowcand = (uint2*)(ws + pl.off_rowcand);
+                int* candlist = (int*)(ws + pl.off_candlist);
+                uint4* colres = (uint4*)(ws + pl.off_colres);
+                int4* state = (int4*)(ws + pl.off_state);
+                match_rows_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.col_chunks,
+                                                               pl.row_stride, ratio, min_dir, min_mutual, mode, rowcand, candlist, state);
+                if (mode == 0) {
+                    switch (ctx->ks_common) {
+                        case 2: launch_verify<2>(ctx, pl, pb, nb, ws, st2); break;
+                        case 4: launch_verify<4>(ctx, pl, pb, nb, ws, st2); break;
+                        default: launch_verify<8>(ctx, pl, pb, nb, ws, st2); break;
+                    }
+                }
+                match_finalize2_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(ctx->frame_table_dev, pb, rowcand, candlist, (const uint4*)colres, state,
+                                                                          pl.col_chunks, pl.row_stride, ratio, min_mutual, mode,
+                                                                          (uint2*)(ws + pl.off_matches), cnt);
+            }
             if (csr) {
                 scan_counts_kernel<<<1, 1024, 0, st2>>>(cnt, nb, offsets_dev, total_dev, first, first + nb == npairs);
                 compact_edges_kernel<<<nb, 256, 0, st2>>>((const uint2*)(ws + pl.off_matches), cnt, offsets_dev + first,

@@ -101,8 +101,10 @@ class HipContext:
         return q[:cnt.value].copy(), t[:cnt.value].copy()
 
     def match_all_pairs(self, pairs: np.ndarray, ratio: float = RATIO, min_dir: int = MIN_DIRECTED,
-                        min_mutual: int = MIN_MUTUAL, cap: int | None = None):
-        """Returns (counts, offsets, q, t, stats): CSR over pairs, see include/eacham_hip.h."""
+                        min_mutual: int = MIN_MUTUAL, cap: int | None = None, stats: bool = True):
+        """Returns (counts, offsets, q, t, stats): CSR over pairs, see include/eacham_hip.h. stats=False passes NULL for the
+        per-pair statistics (what the pair loop of apps/sfm/main.cpp needs: the library then evaluates the column direction
+        for candidate columns only) and returns None in their place."""
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
         npairs = pairs.shape[0]
         if cap is None:
@@ -111,12 +113,12 @@ class HipContext:
         offsets = np.zeros(npairs + 1, dtype=np.int64)
         q = np.empty(max(cap, 1), dtype=np.uint32)
         t = np.empty(max(cap, 1), dtype=np.uint32)
-        stats = np.zeros((npairs, 4), dtype=np.int32)
+        st = np.zeros((npairs, 4), dtype=np.int32) if stats else None
         total = C.c_int64(0)
         self._check(self._L.eacham_match_all_pairs(
             self._h, pairs.ctypes.data, npairs, ratio, min_dir, min_mutual, counts.ctypes.data,
-            offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total), stats.ctypes.data))
-        return counts, offsets, q[:total.value].copy(), t[:total.value].copy(), stats
+            offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total), st.ctypes.data if stats else None))
+        return counts, offsets, q[:total.value].copy(), t[:total.value].copy(), st
 
     def match_pairs_directed(self, frames, ordered_pairs, ratio: float = RATIO, f32: bool = False) -> list:
         """Uploads `frames` (list of N x D matrices) as frames 0.. and runs every ordered pair (i, j) as one directed

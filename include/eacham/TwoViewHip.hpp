@@ -170,8 +170,10 @@ inline RobustModel lmeds(Context& ctx, int solve_kind, int score_kind, int m, co
     for (int e = 0; e < 9; ++e) out.model[e] = cand[(size_t)best * 9 + e];
     out.median = med[best];
     // sigma of LMeDSPointSetRegistrator::run, then the errors of the winner alone
-    const double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / std::max(n - m, 1)) * std::sqrt((double)med[best]);
-    const float thr = (float)std::max(sigma * sigma, 1e-300);
+    // (`sigma = MAX(sigma, 0.001)` before findInliers squares it: on noise-free data the median is ~0 and without the floor
+    // the mask would shrink to the below-median half; for E the unit is the K-normalised one OpenCV uses too)
+    const double sigma = std::max(2.5 * 1.4826 * (1.0 + 5.0 / std::max(n - m, 1)) * std::sqrt((double)med[best]), 0.001);
+    const float thr = (float)(sigma * sigma);
     std::vector<float> err(n);
     int32_t cnt = 0;
     float m1 = 0;

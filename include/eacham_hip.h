@@ -404,6 +404,12 @@ int eacham_profile_get(eacham_ctx* ctx, int kernel_id, int64_t* launches, double
 int eacham_order_pairs(int32_t* pairs, int npairs);
 /* Contiguous shard of rank `rank` of `world`: [*begin, *end), sizes differ by at most one. */
 int eacham_shard_bounds(int npairs, int world, int rank, int* begin, int* end);
+/* Work-balanced contiguous cut of the ordered list: bounds[r] = first pair of shard r, bounds[world] = npairs. weights[k] =
+ * cost of ordered pair k — the matcher's is the pair's distance matrix, rows(f1) * rows(f2), which is what makes shards of
+ * ragged frames take equal time (equal pair COUNTS do not: apps/sfm/main.cpp:98-109 hands every pair to whichever thread is
+ * free, a static cut has to weigh them). Shard r starts at the smallest k whose prefix weight P[k] satisfies
+ * P[k] * world >= r * P[npairs]. weights == NULL (or all zero): the equal-count cut of eacham_shard_bounds. */
+int eacham_shard_bounds_weighted(int npairs, int world, const int64_t* weights, int32_t* bounds);
 
 /* ---- single-process multi-GPU form of the pair loop -----------------------
  * The reference app is ONE C++ process (apps/sfm/main.cpp:31) whose pair loop (:84-147) fans out over host threads
@@ -426,6 +432,17 @@ int eacham_comm_upload_descriptors(eacham_comm* comm, int frame_id, const float*
 int eacham_match_all_pairs_sharded(eacham_comm* comm, const int32_t* pairs, int npairs, double ratio,
                                    int min_dir, int min_mutual, int32_t* counts, int64_t* offsets,
                                    uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total);
+/* The two halves of eacham_match_all_pairs_sharded. run: order the pairs, cut them into shards (balance != 0: by work,
+ * eacham_shard_bounds_weighted with rows(f1) * rows(f2); 0: by count), match every shard on its device and all-gather; the
+ * gathered graph stays resident on EVERY device, *out_total = matches in it. fetch: read device 0's copy back and assemble
+ * the CSR in the caller's pair order (any number of times until the next run). */
+int eacham_comm_match_run(eacham_comm* comm, const int32_t* pairs, int npairs, double ratio, int min_dir, int min_mutual,
+                          int balance, int64_t* out_total);
+int eacham_comm_match_fetch(eacham_comm* comm, int32_t* counts, int64_t* offsets, uint32_t* out_q, uint32_t* out_t,
+                            int64_t cap, int64_t* out_total);
+/* Host logic of the gather's send buffers (no device needed; exported for the CPU tests): ncclAllGather sends the same
+ * number of elements from every rank, so the edge region of EVERY rank's buffer holds the largest shard bound. */
+int eacham_comm_edge_region(int world, const int64_t* shard_bound, int64_t* region);
 /* Host-side assembly of gathered shards (what eacham_match_all_pairs_sharded does after its all-gather; also for callers
  * that run one process per GPU and gather with their own collective): g_counts = world x shard_cap per-pair counts,
  * g_edges = world x edge_cap x {q, t}; shard r holds pairs [eacham_shard_bounds(npairs, world, r)) of the ORDERED list,
@@ -433,6 +450,12 @@ int eacham_match_all_pairs_sharded(eacham_comm* comm, const int32_t* pairs, int 
 int eacham_assemble_match_graph(const int32_t* g_counts, const uint32_t* g_edges, int npairs, int world, int shard_cap,
                                 int64_t edge_cap, const int32_t* sorted_index, int32_t* counts, int64_t* offsets,
                                 uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total);
+
+/* Same with explicit shard boundaries (bounds[world + 1] over the ordered list, as eacham_shard_bounds_weighted returns
+ * them; NULL = the equal-count cut). */
+int eacham_assemble_match_graph_bounds(const int32_t* g_counts, const uint32_t* g_edges, int npairs, int world, int shard_cap,
+                                       int64_t edge_cap, const int32_t* bounds, const int32_t* sorted_index, int32_t* counts,
+                                       int64_t* offsets, uint32_t* out_q, uint32_t* out_t, int64_t cap, int64_t* out_total);
 
 #ifdef __cplusplus
 }

@@ -79,9 +79,9 @@ int main(int argc, char** argv) {
         std::printf("twoview driver ok\n");
         return 0;
     }
-    for (int scene = 0; scene < 2; ++scene) {   // a general scene (E branch), a planar one (H branch)
+    for (;;) {   // one scene per record (a general one: E branch, a planar one: H branch, ...)
         int32_t n;
-        in.read((char*)&n, sizeof(n));
+        if (!in.read((char*)&n, sizeof(n))) break;
         const auto uv1 = rd<double>(in, 2 * (size_t)n), uv2 = rd<double>(in, 2 * (size_t)n), K9 = rd<double>(in, 9);
         const double K4[4] = {K9[0], K9[4], K9[2], K9[5]};
         const RobustModel Em = FindEssentialMat(ctx, uv1, uv2, K4, 1000, 7);

@@ -8,7 +8,7 @@ def skew(t):
     return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
 
 
-def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False, facing=False):
+def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False, facing=False, noise=0.5):
     """Two cameras of a synth scene seeing n landmarks: pixel correspondences (float32-valued, as cv::Point2f),
     the true E / H and n_models candidates around them (the first is the truth, the rest perturbed, some garbage)."""
     sc = synth.make_scene(2, n, 2, seed=seed, pixel_noise=0.7)
@@ -25,8 +25,8 @@ def two_view_case(n=700, n_models=40, seed=7, outliers=0.25, planar=False, facin
     def proj(T):
         pc = X @ T[:3, :3].T + T[:3, 3]
         return np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1)
-    uv1 = proj(T1) + 0.5 * rng.normal(size=(n, 2))
-    uv2 = proj(T2) + 0.5 * rng.normal(size=(n, 2))
+    uv1 = proj(T1) + noise * rng.normal(size=(n, 2))
+    uv2 = proj(T2) + noise * rng.normal(size=(n, 2))
     bad = rng.random(n) < outliers
     uv2[bad] += rng.normal(0, 60, size=(int(bad.sum()), 2))
     uv1, uv2 = uv1.astype(np.float32).astype(np.float64), uv2.astype(np.float32).astype(np.float64)

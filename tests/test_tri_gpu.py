@@ -30,6 +30,11 @@ def _compare(ctx, tr, max_err=MAX_ERR, min_angle=MIN_ANGLE):
     diff = np.nonzero(status != ostatus)[0]
     assert diff.size == 0, f"verdicts differ on tracks {diff[:8]}"
     assert np.array_equal(masks, omasks)
+    # the select kernel re-derives the winning pair's mask: it must agree with the count the pair kernel decided on
+    # (status bit 1 = every observation an inlier), for tracks of any length
+    ptr = np.asarray(tr["track_ptr"])
+    full = np.array([masks[a:b].all() if b > a else False for a, b in zip(ptr[:-1], ptr[1:])])
+    assert np.array_equal((status & 2) != 0, full), "mask and status disagree"
     fin = np.isfinite(opts).all(1)
     assert np.array_equal(np.isfinite(pts).all(1), fin)
     assert np.allclose(pts[fin], opts[fin], rtol=1e-9, atol=1e-11)

@@ -90,7 +90,10 @@ def test_two_view_pipeline_recovers_the_relative_pose(tmp_path):
     lib = os.path.join(ROOT, "eacham_amd", "lib")
     subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(CPP, "twoview_driver.cpp"), "-o", exe,
                     "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"], check=True, capture_output=True)
-    cases = [SC.two_view_case(n=800, seed=31, outliers=0.25), SC.two_view_case(n=800, seed=32, outliers=0.25, planar=True, facing=True)]
+    cases = [SC.two_view_case(n=800, seed=31, outliers=0.25), SC.two_view_case(n=800, seed=32, outliers=0.25, planar=True, facing=True),
+             # noise-free pixels (only their float rounding is left): the median is ~0 and the inlier rule rests on OpenCV's
+             # `sigma = MAX(sigma, 0.001)` — without it the masks would shrink to the below-median half of the good matches
+             SC.two_view_case(n=800, seed=33, outliers=0.25, noise=0.0), SC.two_view_case(n=800, seed=34, outliers=0.25, planar=True, facing=True, noise=0.0)]
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
         for c in cases:
@@ -109,6 +112,12 @@ def test_two_view_pipeline_recovers_the_relative_pose(tmp_path):
             Rt, tt = T21[:3, :3], T21[:3, 3] / np.linalg.norm(T21[:3, 3])
             assert meta[0] == 1 and meta[3] == 1
             assert meta[6] == 89 and meta[7] == 72          # LMedS' fixed budgets: 1000 asked at 0.99 / 5 points, 100 at 0.999 / 4 points
+            if k == 2:                                                       # noise-free, general: EVERY good match is an inlier of E
+                assert emask[good].all() and int(emask.sum()) == int(good.sum()) + int(emask[c["bad"]].sum()) and emask[c["bad"]].mean() < 0.05
+                continue
+            if k == 3:                                                       # noise-free, planar: every good match is an inlier of H
+                assert hmask[good].all() and hmask[c["bad"]].mean() < 0.05
+                continue
             if k == 0:                                                       # general scene: the essential matrix and its pose
                 Et = c["E"][0].reshape(3, 3) / np.linalg.norm(c["E"][0])
                 assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 0.02
