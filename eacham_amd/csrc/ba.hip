@@ -26,6 +26,7 @@
 // (HBM-bound); see DESIGN.md for the per-kernel byte counts.
 #include "context.hpp"
 #include "ba_plan.hpp"
+#include "devprim.hpp"
 
 #include <cstdlib>
 
@@ -2428,6 +2429,7 @@ using namespace eacham;
 struct eacham_ba_handle {
     BaDev D;
     int block = -1;            // index into ctx->ba_pool: the arena all device arrays of this problem live in
+    int block2 = -1;           // device-built problems: a second arena for what is sized by the pair lists and the plan
     char* arena = nullptr;
     size_t arena_off = 0;      // bump pointer (planning pass: the total)
     bool planning = false;     // first pass over the allocation sequence: sizes only
@@ -2534,7 +2536,92 @@ static int ba_block_acquire(eacham_ctx* ctx, size_t bytes, int* index) {
     return EACHAM_OK;
 }
 
-static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
+// The allocation sequence of a problem's device arrays, in three parts (each runs twice: sizes first, then pointers):
+// the plan's tables (uploads), the work arrays sized by (nc, nl, no), and those sized by the pair lists and the plan.
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+static int ba_upload_plan(eacham_ctx* ctx, eacham_ba_handle* h, const BaPlan& plan, const std::vector<int2>& bs_ent) {
+    BaDev& D = h->D;
+    TRY(dev_upload(ctx, h, &D.sp_pos, plan.pos));
+    TRY(dev_upload(ctx, h, &D.sp_tile_map, plan.tile_map));
+    TRY(dev_upload(ctx, h, &D.sp_pad_cols, plan.pad_cols));
+    TRY(dev_upload(ctx, h, &D.sp_diag_tile, plan.diag_tile));
+    TRY(dev_upload(ctx, h, &h->sp_leaves, plan.leaves));
+    TRY(dev_upload(ctx, h, &h->sp_items, plan.items));
+    TRY(dev_upload(ctx, h, &h->sp_srcs, plan.srcs));
+    TRY(dev_upload(ctx, h, &h->bs_order, plan.bs_order));
+    TRY(dev_upload(ctx, h, &h->bs_ptr, plan.bs_ptr));
+    TRY(dev_upload(ctx, h, &h->bs_ent, bs_ent));
+    TRY(dev_upload(ctx, h, &h->sp_col_dest, plan.col_dest));
+    return EACHAM_OK;
+}
+static int ba_alloc_work_a(eacham_ctx* ctx, eacham_ba_handle* h) {
+    BaDev& D = h->D;
+    const int nc = D.nc, nl = D.nl, no = D.no;
+    TRY(dev_alloc(ctx, h, &D.pose, 12 * (size_t)nc));
+    TRY(dev_alloc(ctx, h, &D.pose_new, 12 * (size_t)nc));
+    TRY(dev_alloc(ctx, h, &D.pt, 3 * (size_t)nl));
+    TRY(dev_alloc(ctx, h, &D.pt_new, 3 * (size_t)nl));
+    TRY(dev_alloc(ctx, h, &D.Kc, 8));
+    TRY(dev_alloc(ctx, h, &D.K_new, 8));
+    TRY(dev_alloc(ctx, h, &D.E, 18 * (size_t)no));
+    TRY(dev_alloc(ctx, h, &D.Et, 18 * (size_t)no));
+    TRY(dev_alloc(ctx, h, &D.lmlin, (size_t)LMLIN * nl));
+    TRY(dev_alloc(ctx, h, &D.lmtry, (size_t)LMLIN * nl));
+    TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
+    TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
+    TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
+    TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
+    TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
+    TRY(dev_alloc(ctx, h, &D.delta_l, 3 * (size_t)nl));
+    TRY(dev_alloc(ctx, h, &D.err_part, (size_t)std::max(D.n_ll_blocks, D.n_step_blocks)));
+    TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)std::max(std::max(D.n_ll_blocks, D.n_step_blocks), D.n_lm_blocks)));
+    TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
+    TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
+    TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
+    TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
+    TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
+    TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
+    {
+        const size_t nn = (size_t)D.n + 8, n3 = 3 * (size_t)std::max(nl, 1);
+        TRY(dev_alloc(ctx, h, &D.pcg_rc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_zc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_pc, nn));
+        TRY(dev_alloc(ctx, h, &D.pcg_qc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_Dc, nn));
+        TRY(dev_alloc(ctx, h, &D.pcg_rl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_zl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_pl, n3));
+        TRY(dev_alloc(ctx, h, &D.pcg_ql, n3)); TRY(dev_alloc(ctx, h, &D.pcg_Dl, n3));
+        TRY(dev_alloc(ctx, h, &D.pcg_Mc, (size_t)36 * std::max(nc, 1))); TRY(dev_alloc(ctx, h, &D.pcg_MK, 32));
+        TRY(dev_alloc(ctx, h, &D.pcg_Ml, 3 * n3));
+        TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks));
+        TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
+    }
+    TRY(dev_alloc(ctx, h, &D.sync_counter, 4));
+    if (!h->planning) {
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.sync_counter, 0, 4 * sizeof(int), ctx->stream));
+        h->scal_host = ctx->ba_pool[h->block].pinned;
+        EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
+        for (int k = 0; k < SCAL; ++k) h->scal_host[k] = 0.0;  // (tickets start at 1; the block may have served another problem)
+    }
+    return EACHAM_OK;
+}
+static int ba_alloc_work_b(eacham_ctx* ctx, eacham_ba_handle* h) {
+    BaDev& D = h->D;
+    const BaPlan& plan = h->plan;
+    TRY(dev_alloc(ctx, h, &D.T, (size_t)plan.ntiles * TILE));
+    TRY(dev_alloc(ctx, h, &D.Winv, (size_t)2 * plan.npan * NB * NB));   // W_a, W_b of every panel, row-major
+    TRY(dev_alloc(ctx, h, &D.Xrow, (size_t)plan.npan * NB * NB));       // X = -W_b L_ba W_a, row-major
+    TRY(dev_alloc(ctx, h, &D.Wops, (size_t)plan.npan * TILE_OPS));      // W_a, W_b, X of every panel in MFMA operand order
+    TRY(dev_alloc(ctx, h, &D.zsol, (size_t)plan.npan * PB));
+    TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * std::max(D.n_chunks, 1)));
+    TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * std::max(D.n_cam_chunks, 1)));
+    TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
+    TRY(dev_alloc(ctx, h, &D.flags, (size_t)N_STATUS + plan.npan));  // [0..3] status, [4 + P] hand-off flag of panel P
+    if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (N_STATUS + plan.npan) * sizeof(int), ctx->stream));  // (final_sums leaves them cleared)
+    return EACHAM_OK;
+}
+#undef TRY
+
+// The structure built by host loops (the round-1..3 form): what a local window of a few thousand observations still uses —
+// a dozen dependent launches and three read-backs cost more than these loops on a problem that small — and the reference
+// the device-built structure is held against bit for bit (EACHAM_BA_PREPARE=host|device forces either form).
+static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
     if (!P || P->n_cams < 0 || P->n_points < 0 || P->n_obs < 0) return ctx->fail(EACHAM_ERR_INVALID, "bad BA problem");
     const int nc = P->n_cams, nl = P->n_points, no = P->n_obs;
     if (no > 0 && (!P->obs_cam || !P->obs_point || !P->obs_uv)) return ctx->fail(EACHAM_ERR_INVALID, "null observation arrays");
@@ -2740,68 +2827,9 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
         TRY(dev_upload(ctx, h, &D.pair_entries, entries));
         TRY(dev_upload(ctx, h, &D.pair_chunks, chunks));
         TRY(dev_upload(ctx, h, &D.blocks, blocks));
-        TRY(dev_upload(ctx, h, &D.sp_pos, plan.pos));
-        TRY(dev_upload(ctx, h, &D.sp_tile_map, plan.tile_map));
-        TRY(dev_upload(ctx, h, &D.sp_pad_cols, plan.pad_cols));
-        TRY(dev_upload(ctx, h, &D.sp_diag_tile, plan.diag_tile));
-        TRY(dev_upload(ctx, h, &h->sp_leaves, plan.leaves));
-        TRY(dev_upload(ctx, h, &h->sp_items, plan.items));
-        TRY(dev_upload(ctx, h, &h->sp_srcs, plan.srcs));
-        TRY(dev_upload(ctx, h, &h->bs_order, plan.bs_order));
-        TRY(dev_upload(ctx, h, &h->bs_ptr, plan.bs_ptr));
-        TRY(dev_upload(ctx, h, &h->bs_ent, bs_ent));
-        TRY(dev_upload(ctx, h, &h->sp_col_dest, plan.col_dest));
-        TRY(dev_alloc(ctx, h, &D.pose, 12 * (size_t)nc));
-        TRY(dev_alloc(ctx, h, &D.pose_new, 12 * (size_t)nc));
-        TRY(dev_alloc(ctx, h, &D.pt, 3 * (size_t)nl));
-        TRY(dev_alloc(ctx, h, &D.pt_new, 3 * (size_t)nl));
-        TRY(dev_alloc(ctx, h, &D.Kc, 8));
-        TRY(dev_alloc(ctx, h, &D.K_new, 8));
-        TRY(dev_alloc(ctx, h, &D.E, 18 * (size_t)no));
-        TRY(dev_alloc(ctx, h, &D.Et, 18 * (size_t)no));
-        TRY(dev_alloc(ctx, h, &D.lmlin, (size_t)LMLIN * nl));
-        TRY(dev_alloc(ctx, h, &D.lmtry, (size_t)LMLIN * nl));
-        TRY(dev_alloc(ctx, h, &D.camlin, (size_t)CAMLIN * nc));
-        TRY(dev_alloc(ctx, h, &D.klin, (size_t)KLIN));
-        TRY(dev_alloc(ctx, h, &h->kpart, (size_t)CLP * LSEG * std::max(nc, 1)));
-        TRY(dev_alloc(ctx, h, &D.T, (size_t)plan.ntiles * TILE));
-        TRY(dev_alloc(ctx, h, &D.Winv, (size_t)2 * plan.npan * NB * NB));   // W_a, W_b of every panel, row-major
-        TRY(dev_alloc(ctx, h, &D.Xrow, (size_t)plan.npan * NB * NB));       // X = -W_b L_ba W_a, row-major
-        TRY(dev_alloc(ctx, h, &D.Wops, (size_t)plan.npan * TILE_OPS));      // W_a, W_b, X of every panel in MFMA operand order
-        TRY(dev_alloc(ctx, h, &D.zsol, (size_t)plan.npan * PB));
-        TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * D.n_chunks));
-        TRY(dev_alloc(ctx, h, &D.kk_part, (size_t)30 * D.n_lm_blocks));
-        TRY(dev_alloc(ctx, h, &D.delta_c, (size_t)D.n + 8));
-        TRY(dev_alloc(ctx, h, &D.delta_l, 3 * (size_t)nl));
-        TRY(dev_alloc(ctx, h, &D.err_part, (size_t)std::max(D.n_ll_blocks, D.n_step_blocks)));
-        TRY(dev_alloc(ctx, h, &D.lin_part, (size_t)std::max(std::max(D.n_ll_blocks, D.n_step_blocks), D.n_lm_blocks)));
-        TRY(dev_alloc(ctx, h, &h->err_cam, (size_t)nc + 1));
-        TRY(dev_alloc(ctx, h, &h->lin_cam, (size_t)nc + 1));
-        TRY(dev_alloc(ctx, h, &D.scal, (size_t)SCAL));
-        TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * std::max(D.n_cam_chunks, 1)));
-        TRY(dev_alloc(ctx, h, &D.dl_nc, (size_t)D.n));
-        TRY(dev_alloc(ctx, h, &D.dl_nl, (size_t)3 * D.nl));
-        TRY(dev_alloc(ctx, h, &D.dl_part, (size_t)6 * D.n_lm_blocks));
-        {
-            const size_t nn = (size_t)D.n + 8, n3 = 3 * (size_t)std::max(nl, 1);
-            TRY(dev_alloc(ctx, h, &D.pcg_rc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_zc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_pc, nn));
-            TRY(dev_alloc(ctx, h, &D.pcg_qc, nn)); TRY(dev_alloc(ctx, h, &D.pcg_Dc, nn));
-            TRY(dev_alloc(ctx, h, &D.pcg_rl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_zl, n3)); TRY(dev_alloc(ctx, h, &D.pcg_pl, n3));
-            TRY(dev_alloc(ctx, h, &D.pcg_ql, n3)); TRY(dev_alloc(ctx, h, &D.pcg_Dl, n3));
-            TRY(dev_alloc(ctx, h, &D.pcg_Mc, (size_t)36 * std::max(nc, 1))); TRY(dev_alloc(ctx, h, &D.pcg_MK, 32));
-            TRY(dev_alloc(ctx, h, &D.pcg_Ml, 3 * n3));
-            TRY(dev_alloc(ctx, h, &D.pcg_p1, (size_t)6 * D.n_lm_blocks)); TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
-            TRY(dev_alloc(ctx, h, &D.pcg_p3, (size_t)D.n_lm_blocks + (size_t)(nc + 1 + TPB) / TPB + 2)); TRY(dev_alloc(ctx, h, &D.pcg_s, 16));
-        }
-        TRY(dev_alloc(ctx, h, &D.flags, (size_t)N_STATUS + plan.npan));  // [0..3] status, [4 + P] hand-off flag of panel P
-        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, (N_STATUS + plan.npan) * sizeof(int), ctx->stream));  // (final_sums leaves them cleared)
-        TRY(dev_alloc(ctx, h, &D.sync_counter, 4));
-        if (!h->planning) EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.sync_counter, 0, 4 * sizeof(int), ctx->stream));
-        if (!h->planning) {
-            h->scal_host = ctx->ba_pool[h->block].pinned;
-            EACHAM_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&D.scal_pinned, h->scal_host, 0));
-            for (int k = 0; k < SCAL; ++k) h->scal_host[k] = 0.0;  // (tickets start at 1; the block may have served another problem)
-        }
+        TRY(ba_upload_plan(ctx, h, plan, bs_ent));
+        TRY(ba_alloc_work_a(ctx, h));
+        TRY(ba_alloc_work_b(ctx, h));
         return EACHAM_OK;
     };
 #undef TRY
@@ -2845,10 +2873,487 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     return EACHAM_OK;
 }
 
+// ======================================================================================================================
+// Device-side construction of the problem structure (round 4). RefineBA's graph build is part of the reference's call
+// (modules/sfm/reconstruction/BundleAdjuster.cpp:57-178); as host loops it took 11.6 ms on S200 and 30 ms on config 4 in
+// front of 1.8 / 3.4 ms of Levenberg-Marquardt. Here the caller's arrays are uploaded as they are and everything else is
+// built by sorts and scans (devprim.hpp): observations grouped by landmark and by camera (stable radix sorts: the order of
+// a sequential host loop), the camera-aligned chunk table, the observation pairs of every landmark expanded in (landmark,
+// a, b) order and sorted by camera block (stable: a block's entries stay in landmark order, which is the order every
+// fp64 sum of the Schur complement runs in), the block and chunk tables by a scan over the block histogram. The host
+// keeps what is irregular and small: the elimination ordering + symbolic analysis of the camera graph (ba_plan.hpp), fed by
+// the block table read back. Three read-backs of a few bytes / kilobytes; the result is bit-identical with ba_prepare_host.
+// ======================================================================================================================
+
+struct PrepCounters {   // device-side scalars of the construction, read back by the host
+    long long n_entries;     // expanded observation pairs
+    int n_used;              // landmarks with at least one observation
+    int bad;                 // an observation names a camera / landmark out of range
+    int n_cam_chunks;
+    int pad;
+    prim::I3 totals;         // {entries, blocks, chunks} after the block scan
+};
+
+__device__ __forceinline__ int block_row_start(int c, int nc) {  // index of block (c, c) in the row-major upper triangle
+    return (int)((long long)c * nc - (long long)c * (c - 1) / 2);
+}
+
+__global__ __launch_bounds__(TPB) void prep_values(int nc, int nl, const double* __restrict__ T_wc, const int* __restrict__ observers,
+                                                   double* __restrict__ pose0, double* __restrict__ lmprior, double* __restrict__ K0,
+                                                   double fx, double fy, double cx, double cy) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i == 0) {
+        K0[0] = fx; K0[1] = fy; K0[2] = 0.0; K0[3] = cx; K0[4] = cy;
+    }
+    if (i < nc) {  // pose_from_Twc, operation for operation (no contraction: the host form has none)
+        const double* T = T_wc + 16 * (size_t)i;
+        double* x = pose0 + 12 * (size_t)i;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) x[3 * a + b] = T[4 * b + a];
+        for (int a = 0; a < 3; ++a)
+            x[9 + a] = -__dadd_rn(__dadd_rn(__dmul_rn(T[a], T[3]), __dmul_rn(T[4 + a], T[7])), __dmul_rn(T[8 + a], T[11]));
+    } else if (i - nc < nl) {  // BundleAdjuster.cpp:109-113: sigma = 1.0f/obs, k = 3.0f/obs (float)
+        const int j = i - nc;
+        const float o = (float)(observers[j] > 0 ? observers[j] : 1);
+        lmprior[2 * (size_t)j] = (double)(1.0f / o);
+        lmprior[2 * (size_t)j + 1] = (double)(3.0f / o);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void prep_keys_lm(int no, int nc, int nl, const uint32_t* __restrict__ in_cam,
+                                                    const uint32_t* __restrict__ in_pt, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals, PrepCounters* __restrict__ cnt) {
+    const int o = blockIdx.x * TPB + threadIdx.x;
+    if (o >= no) return;
+    uint32_t pt = in_pt[o];
+    if (pt >= (uint32_t)nl || in_cam[o] >= (uint32_t)nc) {
+        cnt->bad = 1;  // (benign race: every writer stores 1)
+        pt = 0;
+    }
+    keys[o] = pt;
+    vals[o] = (uint32_t)o;
+}
+
+// fills ptr[k] = first position whose key is >= k for the keys (prev, cur] seen at a boundary; sorted keys
+__device__ __forceinline__ void fill_ptr(int* __restrict__ ptr, int pos, int prev_key, int cur_key) {
+    for (int k = prev_key + 1; k <= cur_key; ++k) ptr[k] = pos;
+}
+
+__global__ __launch_bounds__(TPB) void prep_gather_lm(int no, int nl, int nc, const uint32_t* __restrict__ lm_sorted,
+                                                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ in_cam,
+                                                      const double* __restrict__ in_uv, unsigned* __restrict__ obs_cam,
+                                                      unsigned* __restrict__ obs_lm, double* __restrict__ obs_uv, int* __restrict__ lm_ptr,
+                                                      uint32_t* __restrict__ cam_keys, uint32_t* __restrict__ cam_vals,
+                                                      PrepCounters* __restrict__ cnt) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    bool first = false;
+    if (p < no) {
+        const uint32_t o = order[p];
+        const int lm = (int)lm_sorted[p];
+        uint32_t c = in_cam[o];
+        if (c >= (uint32_t)nc) c = 0;  // (flagged by prep_keys_lm: the call fails, the kernels stay in range)
+        obs_cam[p] = c;
+        obs_lm[p] = (unsigned)lm;
+        obs_uv[2 * (size_t)p] = in_uv[2 * (size_t)o];
+        obs_uv[2 * (size_t)p + 1] = in_uv[2 * (size_t)o + 1];
+        cam_keys[p] = c;
+        cam_vals[p] = (uint32_t)p;
+        const int prev = p > 0 ? (int)lm_sorted[p - 1] : -1;
+        first = lm != prev;
+        if (first) fill_ptr(lm_ptr, p, prev, lm);
+        if (p == no - 1) fill_ptr(lm_ptr, no, lm, nl);
+    }
+    const unsigned long long b = __ballot(first);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt->n_used, __popcll(b));
+}
+
+__global__ __launch_bounds__(TPB) void prep_gather_cam(int no, int nc, const uint32_t* __restrict__ cam_sorted,
+                                                       const uint32_t* __restrict__ cam_obs_u, const unsigned* __restrict__ obs_lm,
+                                                       const double* __restrict__ obs_uv, int* __restrict__ cam_obs,
+                                                       int* __restrict__ obs_pos, int* __restrict__ pos_cam, int* __restrict__ cam_lm,
+                                                       double* __restrict__ cam_uv, int* __restrict__ cam_ptr) {
+    const int q = blockIdx.x * TPB + threadIdx.x;
+    if (q >= no) return;
+    const int p = (int)cam_obs_u[q], c = (int)cam_sorted[q];
+    cam_obs[q] = p;
+    obs_pos[p] = q;
+    pos_cam[q] = c;
+    cam_lm[q] = (int)obs_lm[p];
+    cam_uv[2 * (size_t)q] = obs_uv[2 * (size_t)p];
+    cam_uv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)p + 1];
+    const int prev = q > 0 ? (int)cam_sorted[q - 1] : -1;
+    if (c != prev) fill_ptr(cam_ptr, q, prev, c);
+    if (q == no - 1) fill_ptr(cam_ptr, no, c, nc);
+}
+
+__global__ __launch_bounds__(TPB) void prep_cam_chunk_counts(int nc, const int* __restrict__ cam_ptr, int* __restrict__ nchunk) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c < nc) nchunk[c] = (cam_ptr[c + 1] - cam_ptr[c] + TPB - 1) / TPB;
+}
+__global__ __launch_bounds__(TPB) void prep_cam_chunk_fill(int nc, const int* __restrict__ cam_ptr, const int* __restrict__ cam_chunk_ptr,
+                                                           int2* __restrict__ cam_chunks) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= nc) return;
+    int k = cam_chunk_ptr[c];
+    for (int q = cam_ptr[c]; q < cam_ptr[c + 1]; q += TPB) cam_chunks[k++] = make_int2(q, min(TPB, cam_ptr[c + 1] - q));
+}
+
+// pair-list entries that start at observation a (landmark order): (a, a) and one per later observation b of the landmark,
+// two when a and b sit in the same camera
+__global__ __launch_bounds__(TPB) void prep_pair_counts(int no, const unsigned* __restrict__ obs_cam, const unsigned* __restrict__ obs_lm,
+                                                        const int* __restrict__ lm_ptr, long long* __restrict__ cnt) {
+    const int a = blockIdx.x * TPB + threadIdx.x;
+    if (a >= no) return;
+    const int a1 = lm_ptr[obs_lm[a] + 1];
+    const unsigned ca = obs_cam[a];
+    int c = 1;
+    for (int b = a + 1; b < a1; ++b) c += 1 + (obs_cam[b] == ca ? 1 : 0);
+    cnt[a] = c;
+}
+
+// the entries in (landmark, a, b) order = the order of the host loops; key = camera block, value = the two Et positions
+__global__ __launch_bounds__(TPB) void prep_expand(int no, int nc, const unsigned* __restrict__ obs_cam, const unsigned* __restrict__ obs_lm,
+                                                   const int* __restrict__ lm_ptr, const int* __restrict__ obs_pos,
+                                                   const long long* __restrict__ off, uint32_t* __restrict__ keys,
+                                                   int2* __restrict__ vals, int* __restrict__ bcount) {
+    const int a = blockIdx.x * TPB + threadIdx.x;
+    if (a >= no) return;
+    const int a1 = lm_ptr[obs_lm[a] + 1];
+    const int ca = (int)obs_cam[a], pa = obs_pos[a];
+    long long e = off[a];
+    const int diag = block_row_start(ca, nc);  // block (ca, ca); block (c, c2 >= c) = row_start(c) + c2 - c
+    int same = 1;
+    keys[e] = (uint32_t)diag;
+    vals[e++] = make_int2(pa, pa);
+    for (int b = a + 1; b < a1; ++b) {
+        const int cb = (int)obs_cam[b], pb = obs_pos[b];
+        if (ca < cb) {
+            const int k = diag + (cb - ca);
+            keys[e] = (uint32_t)k;
+            vals[e++] = make_int2(pa, pb);
+            atomicAdd(&bcount[k], 1);
+        } else if (ca > cb) {
+            const int k = block_row_start(cb, nc) + (ca - cb);
+            keys[e] = (uint32_t)k;
+            vals[e++] = make_int2(pb, pa);
+            atomicAdd(&bcount[k], 1);
+        } else {
+            keys[e] = (uint32_t)diag;
+            vals[e++] = make_int2(pa, pb);
+            keys[e] = (uint32_t)diag;
+            vals[e++] = make_int2(pb, pa);
+            same += 2;
+        }
+    }
+    atomicAdd(&bcount[diag], same);
+}
+
+// per block of the upper triangle: {entries, present, chunks}; absent off-diagonal blocks stay out of the tables
+__global__ __launch_bounds__(TPB) void prep_block_counts(int nc, int nblk, const int* __restrict__ bcount, prim::I3* __restrict__ t) {
+    const int b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= nblk) return;
+    int lo = 0, hi = nc - 1;  // largest c with row_start(c) <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_row_start(mid, nc) <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const int cnt = bcount[b];
+    const bool present = cnt > 0 || b == block_row_start(lo, nc);
+    t[b] = prim::I3{cnt, present ? 1 : 0, present ? (cnt + PAIR_CHUNK - 1) / PAIR_CHUNK : 0};
+}
+__global__ __launch_bounds__(TPB) void prep_block_fill(int nc, int nblk, const int* __restrict__ bcount, const prim::I3* __restrict__ s,
+                                                       int4* __restrict__ blocks, int4* __restrict__ chunks) {
+    const int b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= nblk) return;
+    int lo = 0, hi = nc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_row_start(mid, nc) <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const int c = lo, c2 = c + (b - block_row_start(c, nc));
+    const int cnt = bcount[b];
+    if (cnt == 0 && c != c2) return;
+    const prim::I3 at = s[b];  // {first entry, block index, first chunk}
+    const int k = (cnt + PAIR_CHUNK - 1) / PAIR_CHUNK;
+    blocks[at.b] = make_int4(c, c2, at.c, k);
+    for (int i = 0; i < k; ++i) chunks[at.c + i] = make_int4(at.b, at.a + PAIR_CHUNK * i, min(PAIR_CHUNK, cnt - PAIR_CHUNK * i), i);
+}
+
+struct Bump {  // carves 256-byte aligned arrays out of a scratch buffer (base == nullptr: sizes only)
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    template <class T>
+    T* take(size_t n) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+static int ba_scratch(eacham_ctx* ctx, int which, size_t bytes, void** out) {
+    BaScratch& sc = ctx->ba_scratch[which];
+    if (bytes > sc.bytes) {
+        if (sc.dev) {
+            EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(sc.dev);
+            sc.dev = nullptr;
+            sc.bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        EACHAM_HIP_TRY(ctx, hipMalloc(&sc.dev, want));
+        sc.bytes = want;
+    }
+    *out = sc.dev;
+    return EACHAM_OK;
+}
+
+static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
+    const int nc = P->n_cams, nl = P->n_points, no = P->n_obs;
+    const long long nblk_all = (long long)nc * (nc + 1) / 2;
+    if (nblk_all > 0x3fffffffLL) return ctx->fail(EACHAM_ERR_UNSUPPORTED, "too many cameras (%d) for the camera-block index", nc);
+    const int nblk = (int)nblk_all;
+    eacham_ba_handle* h = new eacham_ba_handle();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    BaDev& D = h->D;
+    memset(&D, 0, sizeof(D));
+    D.nc = nc; D.nl = nl; D.no = no; D.n = 6 * nc + 5;
+    D.nz = make_noise();
+    D.n_lm_blocks = std::max(1, (nl + TPB - 1) / TPB);
+    D.lpl = ctx->ba_lpl_lin > 0 ? ctx->ba_lpl_lin : (nl <= 8192 ? 8 : 2);
+    D.n_ll_blocks = std::max(1, (int)(((long long)nl * D.lpl + TPB - 1) / TPB));
+    D.lpl_step = ctx->ba_lpl_step > 0 ? ctx->ba_lpl_step : (nl <= 8192 ? 8 : 2);
+    D.n_step_blocks = std::max(1, (int)(((long long)nl * D.lpl_step + TPB - 1) / TPB));
+    hipStream_t st = ctx->stream;
+    int rc = EACHAM_OK;
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        if (h->block >= 0) ctx->ba_pool[h->block].busy = false;
+        if (h->block2 >= 0) ctx->ba_pool[h->block2].busy = false;
+        delete h;
+        return code;
+    };
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    const int max_cam_chunks = no / TPB + nc + 1;
+    // ---- arena A: everything whose size follows from (nc, nl, no) ----
+    int *lm_ptr = nullptr, *cam_ptr = nullptr, *cam_obs = nullptr, *cam_lm = nullptr, *cam_chunk_ptr = nullptr, *obs_pos = nullptr, *pos_cam = nullptr, *fixed = nullptr;
+    int2* cam_chunks = nullptr;
+    double *lmprior = nullptr, *obs_uv = nullptr, *cam_uv = nullptr;
+    unsigned *obs_cam = nullptr, *obs_lm = nullptr;
+    auto layout_a = [&]() -> int {
+        TRY(dev_alloc(ctx, h, &D.pose0, 12 * (size_t)nc));
+        TRY(dev_alloc(ctx, h, &D.pt0, 3 * (size_t)nl));
+        TRY(dev_alloc(ctx, h, &D.K0, 8));
+        TRY(dev_alloc(ctx, h, &lmprior, 2 * (size_t)nl));
+        TRY(dev_alloc(ctx, h, &obs_uv, 2 * (size_t)no));
+        TRY(dev_alloc(ctx, h, &fixed, (size_t)nc));
+        TRY(dev_alloc(ctx, h, &lm_ptr, (size_t)nl + 1));
+        TRY(dev_alloc(ctx, h, &cam_ptr, (size_t)nc + 1));
+        TRY(dev_alloc(ctx, h, &cam_obs, (size_t)no));
+        TRY(dev_alloc(ctx, h, &cam_lm, (size_t)no));
+        TRY(dev_alloc(ctx, h, &cam_chunks, (size_t)max_cam_chunks));
+        TRY(dev_alloc(ctx, h, &cam_chunk_ptr, (size_t)nc + 1));
+        TRY(dev_alloc(ctx, h, &obs_pos, (size_t)no));
+        TRY(dev_alloc(ctx, h, &pos_cam, (size_t)no));
+        TRY(dev_alloc(ctx, h, &cam_uv, 2 * (size_t)no));
+        TRY(dev_alloc(ctx, h, &obs_cam, (size_t)no));
+        TRY(dev_alloc(ctx, h, &obs_lm, (size_t)no));
+        TRY(ba_alloc_work_a(ctx, h));
+        return EACHAM_OK;
+    };
+    h->planning = true;
+    h->arena_off = 0;
+    rc = layout_a();
+    if (!rc) rc = ba_block_acquire(ctx, h->arena_off, &h->block);
+    if (rc) return fail(rc);
+    h->arena = (char*)ctx->ba_pool[h->block].dev;
+    h->planning = false;
+    h->arena_off = 0;
+    rc = layout_a();
+    if (rc) return fail(rc);
+    D.lmprior = lmprior; D.obs_uv = obs_uv; D.fixed = fixed; D.lm_ptr = lm_ptr; D.cam_ptr = cam_ptr; D.cam_obs = cam_obs; D.cam_lm = cam_lm;
+    D.cam_chunks = cam_chunks; D.cam_chunk_ptr = cam_chunk_ptr; D.obs_pos = obs_pos; D.pos_cam = pos_cam; D.cam_uv = cam_uv;
+    D.obs_cam = obs_cam; D.obs_lm = obs_lm;
+    h->pose_init = D.pose0; h->pt_init = D.pt0; h->K_init = D.K0;
+    // ---- scratch 0: the caller's arrays as they are + the temporaries of the observation sorts ----
+    void* s0 = nullptr;
+    uint32_t *raw_cam, *raw_pt, *kA, *kB, *vA, *vB;
+    double *raw_uv, *raw_T;
+    int *raw_obs, *sort_ws, *nchunk, *nchunk_ws;
+    long long *pcnt, *poff, *pws;
+    PrepCounters* cnt;
+    auto carve0 = [&](void* base) {
+        Bump b(base);
+        raw_pt = b.take<uint32_t>(no); raw_cam = b.take<uint32_t>(no); raw_uv = b.take<double>(2 * (size_t)no);
+        raw_T = b.take<double>(16 * (size_t)nc); raw_obs = b.take<int>(nl);
+        kA = b.take<uint32_t>(no); kB = b.take<uint32_t>(no); vA = b.take<uint32_t>(no); vB = b.take<uint32_t>(no);
+        sort_ws = b.take<int>(prim::radix_ws_ints(no));
+        nchunk = b.take<int>(nc); nchunk_ws = b.take<int>(prim::scan_ws_elems(nc));
+        pcnt = b.take<long long>(no); poff = b.take<long long>((size_t)no + 1); pws = b.take<long long>(prim::scan_ws_elems(no));
+        cnt = b.take<PrepCounters>(1);
+        return b.off;
+    };
+    rc = ba_scratch(ctx, 0, carve0(nullptr), &s0);
+    if (rc) return fail(rc);
+    (void)carve0(s0);
+#define HIPQ(x) do { if ((x) != hipSuccess) return fail(ctx->fail(EACHAM_ERR_HIP, "%s failed (%s:%d)", #x, __FILE__, __LINE__)); } while (0)
+    HIPQ(hipMemsetAsync(cnt, 0, sizeof(PrepCounters), st));
+    // the landmark ids first: their sort runs while the host stages the rest
+    HIPQ(hipMemcpyAsync(raw_pt, P->obs_point, sizeof(uint32_t) * (size_t)no, hipMemcpyHostToDevice, st));
+    HIPQ(hipMemcpyAsync(raw_cam, P->obs_cam, sizeof(uint32_t) * (size_t)no, hipMemcpyHostToDevice, st));
+    const unsigned gobs = (unsigned)((no + TPB - 1) / TPB);
+    auto bits_for = [](long long n) { int b = 1; while ((1ll << b) < n) ++b; return b; };
+    if (no > 0) prep_keys_lm<<<gobs, TPB, 0, st>>>(no, nc, nl, raw_cam, raw_pt, kA, vA, cnt);
+    const int w_lm = prim::radix_sort_pairs<uint32_t>(st, kA, vA, kB, vB, no, bits_for(std::max(nl, 2)), sort_ws);
+    HIPQ(hipMemcpyAsync(raw_uv, P->obs_uv, sizeof(double) * 2 * (size_t)no, hipMemcpyHostToDevice, st));
+    HIPQ(hipMemcpyAsync(raw_T, P->cam_T_wc, sizeof(double) * 16 * (size_t)nc, hipMemcpyHostToDevice, st));
+    HIPQ(hipMemcpyAsync(raw_obs, P->point_observers, sizeof(int) * (size_t)nl, hipMemcpyHostToDevice, st));
+    HIPQ(hipMemcpyAsync(D.pt0, P->points, sizeof(double) * 3 * (size_t)nl, hipMemcpyHostToDevice, st));
+    HIPQ(hipMemcpyAsync(fixed, P->cam_fixed, sizeof(int) * (size_t)nc, hipMemcpyHostToDevice, st));
+    prep_values<<<(unsigned)((nc + nl + TPB) / TPB), TPB, 0, st>>>(nc, nl, raw_T, raw_obs, D.pose0, lmprior, D.K0, P->K[0], P->K[1], P->K[2], P->K[3]);
+    uint32_t *lm_sorted = w_lm ? kB : kA, *lm_order = w_lm ? vB : vA, *ck = w_lm ? kA : kB, *cv = w_lm ? vA : vB;  // the other pair of buffers feeds the camera sort
+    if (no > 0) {
+        prep_gather_lm<<<gobs, TPB, 0, st>>>(no, nl, nc, lm_sorted, lm_order, raw_cam, raw_uv, obs_cam, obs_lm, obs_uv, lm_ptr, ck, cv, cnt);
+    } else {
+        HIPQ(hipMemsetAsync(lm_ptr, 0, sizeof(int) * ((size_t)nl + 1), st));
+        HIPQ(hipMemsetAsync(cam_ptr, 0, sizeof(int) * ((size_t)nc + 1), st));
+    }
+    // the camera sort reuses the landmark sort's output buffers as its second pair (their content has been gathered)
+    const int w_cam = prim::radix_sort_pairs<uint32_t>(st, ck, cv, lm_sorted, lm_order, no, bits_for(std::max(nc, 2)), sort_ws);
+    if (no > 0) {
+        const uint32_t *cs = w_cam ? lm_sorted : ck, *co = w_cam ? lm_order : cv;
+        prep_gather_cam<<<gobs, TPB, 0, st>>>(no, nc, cs, co, obs_lm, obs_uv, cam_obs, obs_pos, pos_cam, cam_lm, cam_uv, cam_ptr);
+        prep_pair_counts<<<gobs, TPB, 0, st>>>(no, obs_cam, obs_lm, lm_ptr, pcnt);
+    }
+    prep_cam_chunk_counts<<<(unsigned)((nc + TPB) / TPB), TPB, 0, st>>>(nc, cam_ptr, nchunk);
+    prim::exclusive_scan<int>(st, nchunk, cam_chunk_ptr, nc, nchunk_ws, &cnt->n_cam_chunks);
+    HIPQ(hipMemcpyAsync(cam_chunk_ptr + nc, &cnt->n_cam_chunks, sizeof(int), hipMemcpyDeviceToDevice, st));
+    prep_cam_chunk_fill<<<(unsigned)((nc + TPB) / TPB), TPB, 0, st>>>(nc, cam_ptr, cam_chunk_ptr, cam_chunks);
+    prim::exclusive_scan<long long>(st, pcnt, poff, no, pws, &cnt->n_entries);
+    // ---- read-back 1: the number of pair entries sizes the next stage ----
+    PrepCounters hc;
+    HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIPQ(hipStreamSynchronize(st));
+    if (hc.bad) return fail(ctx->fail(EACHAM_ERR_INVALID, "an observation references a camera/point out of range"));
+    if (hc.n_entries > 0x7fffffffLL) return fail(ctx->fail(EACHAM_ERR_UNSUPPORTED, "Schur pair list too large (%lld entries)", hc.n_entries));
+    const int n_entries = (int)hc.n_entries;
+    h->n_landmarks_used = hc.n_used;
+    D.n_cam_chunks = hc.n_cam_chunks;
+    // ---- scratch 1: expansion, sort by camera block, block / chunk tables ----
+    const int max_blocks = (int)std::min<long long>(nblk, (long long)n_entries + nc);
+    const int max_chunks = n_entries / PAIR_CHUNK + max_blocks + 1;
+    void* s1 = nullptr;
+    uint32_t *ekA, *ekB;
+    int2 *evA, *evB;
+    int *esort_ws, *bcount;
+    prim::I3 *bt, *bs, *bws;
+    int4 *blocks_tmp, *chunks_tmp;
+    auto carve1 = [&](void* base) {
+        Bump b(base);
+        ekA = b.take<uint32_t>(n_entries); ekB = b.take<uint32_t>(n_entries); evA = b.take<int2>(n_entries); evB = b.take<int2>(n_entries);
+        esort_ws = b.take<int>(prim::radix_ws_ints(n_entries));
+        bcount = b.take<int>(nblk); bt = b.take<prim::I3>(nblk); bs = b.take<prim::I3>(nblk); bws = b.take<prim::I3>(prim::scan_ws_elems(nblk));
+        blocks_tmp = b.take<int4>(max_blocks); chunks_tmp = b.take<int4>(max_chunks);
+        return b.off;
+    };
+    rc = ba_scratch(ctx, 1, carve1(nullptr), &s1);
+    if (rc) return fail(rc);
+    (void)carve1(s1);
+    HIPQ(hipMemsetAsync(bcount, 0, sizeof(int) * (size_t)std::max(nblk, 1), st));
+    if (no > 0) prep_expand<<<gobs, TPB, 0, st>>>(no, nc, obs_cam, obs_lm, lm_ptr, obs_pos, poff, ekA, evA, bcount);
+    const int w_e = prim::radix_sort_pairs<int2>(st, ekA, evA, ekB, evB, n_entries, bits_for(std::max(nblk, 2)), esort_ws);
+    const unsigned gblk = (unsigned)((nblk + TPB) / TPB);
+    if (nblk > 0) prep_block_counts<<<gblk, TPB, 0, st>>>(nc, nblk, bcount, bt);
+    prim::exclusive_scan<prim::I3>(st, bt, bs, nblk, bws, &cnt->totals);
+    if (nblk > 0) prep_block_fill<<<gblk, TPB, 0, st>>>(nc, nblk, bcount, bs, blocks_tmp, chunks_tmp);
+    // ---- read-back 2 + 3: the table sizes, then the block table (the camera graph of the plan) ----
+    HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIPQ(hipStreamSynchronize(st));
+    if (hc.totals.a != n_entries) return fail(ctx->fail(EACHAM_ERR_HIP, "BA structure build: %d pair entries counted, %d placed", n_entries, hc.totals.a));
+    D.n_blocks = hc.totals.b;
+    D.n_chunks = hc.totals.c;
+    std::vector<int4> blocks_h((size_t)D.n_blocks);
+    if (D.n_blocks > 0) HIPQ(hipMemcpyAsync(blocks_h.data(), blocks_tmp, sizeof(int4) * (size_t)D.n_blocks, hipMemcpyDeviceToHost, st));
+    HIPQ(hipStreamSynchronize(st));
+    h->prep_us[0] = us_since(t_begin);
+    // ---- the sparse solve: ordering, panels, symbolic factor, level schedule (ba_plan.hpp) ----
+    const auto t_plan = std::chrono::steady_clock::now();
+    {
+        std::vector<std::pair<int, int>> cam_edges;
+        cam_edges.reserve(blocks_h.size());
+        for (const int4& b : blocks_h)
+            if (b.x != b.y) cam_edges.emplace_back(b.x, b.y);
+        int hint = P->ordering;
+        if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
+        if (hint < EACHAM_BA_ORDER_AUTO || hint > EACHAM_BA_ORDER_ND) return fail(ctx->fail(EACHAM_ERR_INVALID, "unknown BA ordering %d", hint));
+        build_ba_plan(nc, cam_edges, hint, h->plan);
+    }
+    h->prep_us[1] = us_since(t_plan);
+    const auto t_upload = std::chrono::steady_clock::now();
+    const BaPlan& plan = h->plan;
+    D.sp_npan = plan.npan; D.sp_ntiles = plan.ntiles; D.sp_posK = plan.posK; D.sp_rhs_row = plan.rhs_row;
+    D.sp_n_pad = (int)plan.pad_cols.size();
+    std::vector<int2> bs_ent(plan.bs_ent.size());
+    for (size_t e = 0; e < bs_ent.size(); ++e) bs_ent[e] = make_int2(plan.bs_ent[e].first, plan.bs_ent[e].second);
+    // ---- arena B: the pair lists, the plan's tables, what is sized by them ----
+    int2* pair_entries = nullptr;
+    int4 *pair_chunks = nullptr, *blocks = nullptr;
+    auto layout_b = [&]() -> int {
+        TRY(dev_alloc(ctx, h, &pair_entries, (size_t)n_entries));
+        TRY(dev_alloc(ctx, h, &pair_chunks, (size_t)D.n_chunks));
+        TRY(dev_alloc(ctx, h, &blocks, (size_t)D.n_blocks));
+        TRY(ba_upload_plan(ctx, h, plan, bs_ent));
+        TRY(ba_alloc_work_b(ctx, h));
+        return EACHAM_OK;
+    };
+    char* arena_a = h->arena;
+    const size_t off_a = h->arena_off;
+    h->planning = true;
+    h->arena = nullptr;
+    h->arena_off = 0;
+    rc = layout_b();
+    if (!rc) rc = ba_block_acquire(ctx, h->arena_off, &h->block2);
+    if (rc) return fail(rc);
+    h->arena = (char*)ctx->ba_pool[h->block2].dev;
+    h->planning = false;
+    h->arena_off = 0;
+    rc = layout_b();
+    if (rc) return fail(rc);
+    (void)arena_a; (void)off_a;
+    if (n_entries > 0) HIPQ(hipMemcpyAsync(pair_entries, w_e ? evB : evA, sizeof(int2) * (size_t)n_entries, hipMemcpyDeviceToDevice, st));
+    if (D.n_chunks > 0) HIPQ(hipMemcpyAsync(pair_chunks, chunks_tmp, sizeof(int4) * (size_t)D.n_chunks, hipMemcpyDeviceToDevice, st));
+    if (D.n_blocks > 0) HIPQ(hipMemcpyAsync(blocks, blocks_tmp, sizeof(int4) * (size_t)D.n_blocks, hipMemcpyDeviceToDevice, st));
+    D.pair_entries = pair_entries; D.pair_chunks = pair_chunks; D.blocks = blocks;
+    HIPQ(hipStreamSynchronize(st));  // the plan's tables were copied out of host vectors
+    h->prep_us[2] = us_since(t_upload);
+#undef HIPQ
+#undef TRY
+    h->bytes_linearize = (size_t)no * (24 + 144) + (size_t)no * 24 + (size_t)nl * (24 + LMLIN * 8) + (size_t)nc * (96 + CAMLIN * 8);
+    h->bytes_try = (size_t)no * (144 * 2 + 144 + 144) + (size_t)n_entries * 8 + (size_t)nl * (LMLIN * 8 * 3 + 48) +
+                   (size_t)no * 24 + (size_t)D.n * D.n * 8;
+    *out = h;
+    return EACHAM_OK;
+}
+
+static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
+    if (!P || P->n_cams < 0 || P->n_points < 0 || P->n_obs < 0) return ctx->fail(EACHAM_ERR_INVALID, "bad BA problem");
+    if (P->n_obs > 0 && (!P->obs_cam || !P->obs_point || !P->obs_uv)) return ctx->fail(EACHAM_ERR_INVALID, "null observation arrays");
+    if ((P->n_cams > 0 && (!P->cam_T_wc || !P->cam_fixed)) || (P->n_points > 0 && (!P->points || !P->point_observers)))
+        return ctx->fail(EACHAM_ERR_INVALID, "null camera/point arrays");
+    // a local window (the reference's per-frame call, ~10 k observations) is cheaper through the host loops: the device
+    // construction is ~45 dependent launches and three read-backs whatever the size
+    const bool device = ctx->ba_prepare_mode == 2 || (ctx->ba_prepare_mode == 0 && P->n_obs >= 65536);
+    return device ? ba_prepare_device(ctx, P, out) : ba_prepare_host(ctx, P, out);
+}
+
 static void ba_release(eacham_ctx* ctx, eacham_ba_handle* h) {
     if (!h) return;
     (void)hipStreamSynchronize(ctx->stream);
     if (h->block >= 0) ctx->ba_pool[h->block].busy = false;  // the arena and its pinned scalars stay with the context
+    if (h->block2 >= 0) ctx->ba_pool[h->block2].busy = false;
     delete h;
 }
 

@@ -237,6 +237,7 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
         const int v = atoi(l);
         if (v == 1 || v == 2 || v == 4 || v == 8) ctx->ba_lpl_lin = v;
     }
+    if (const char* m = getenv("EACHAM_BA_PREPARE")) ctx->ba_prepare_mode = !strcmp(m, "host") ? 1 : !strcmp(m, "device") ? 2 : 0;
     if (const char* o = getenv("EACHAM_BA_ORDERING"))
         ctx->ba_ordering = !strcmp(o, "natural") ? EACHAM_BA_ORDER_NATURAL : !strcmp(o, "rcm") ? EACHAM_BA_ORDER_RCM : !strcmp(o, "nd") ? EACHAM_BA_ORDER_ND : EACHAM_BA_ORDER_AUTO;
     if (hipSetDevice(device_id) != hipSuccess ||
@@ -291,6 +292,8 @@ void eacham_ctx_destroy(eacham_ctx* ctx) {
         if (b.dev) (void)hipFree(b.dev);
         if (b.pinned) (void)hipHostFree(b.pinned);
     }
+    for (auto& sc : ctx->ba_scratch)
+        if (sc.dev) (void)hipFree(sc.dev);
     for (auto& s : ctx->prof)
         for (auto& ev : s.events) {
             (void)hipEventDestroy(ev.first);

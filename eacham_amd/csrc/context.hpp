@@ -59,6 +59,12 @@ struct BaBlock {
     bool busy = false;
 };
 
+// Scratch of the device-side problem construction (temporaries of its sorts and scans): kept with the context, grown on demand.
+struct BaScratch {
+    void* dev = nullptr;
+    size_t bytes = 0;
+};
+
 struct ProfileSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t used = 0;
@@ -96,6 +102,9 @@ struct eacham_ctx {
     size_t io_bytes = 0;
 
     std::vector<eacham::BaBlock> ba_pool;  // arenas of released BA problems, reused by the next eacham_ba_prepare
+    eacham::BaScratch ba_scratch[2];
+    int ba_prepare_mode = 0;  // EACHAM_BA_PREPARE=host|device (diagnostic / tests: force one form of the structure construction;
+                              // default: device for >= 65536 observations), read at create
     int ba_ordering = 0;  // EACHAM_BA_ORDERING=natural|rcm|nd read ONCE at eacham_ctx_create (diagnostic override of
                           // eacham_ba_problem.ordering == AUTO); nothing on the solve path reads the environment
     int ba_lpl_lin = 0;             // EACHAM_BA_LPL_LIN=1|2|4|8 (diagnostic: lanes per landmark of the linearisation), read at create

@@ -204,20 +204,10 @@ __device__ __forceinline__ void lds_read_frag(V& dst, unsigned addr, int offset_
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offset_bytes));
 }
 
-// GATHER (the candidate-only column pass, see match_rows_kernel): the stationary operand is not a frame's row block but the
-// CANDIDATE columns of frame pairs[p].y — row i of the block is stored column rowcand[candlist[i]].x, its fragments gathered
-// in the prologue — and the streamed frame is pairs[p].x: the same sweep then yields, per candidate column, the top-2 over
-// all rows of the query frame ("rowres" of the swapped roles), i.e. exactly what the mutual check asks of that column.
-struct CandView {
-    const uint2* rowcand;
-    const int* candlist;
-    const int4* state;
-};
-template <int KS, int NSUB, bool COL, bool GATHER>
+template <int KS, int NSUB, bool COL>
 __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, int wgs_per_pair, int col_chunks,
-    uint4* __restrict__ rowres, uint2* __restrict__ colpart, int wb_stride, int row_stride, CandView cand) {
-    static_assert(!(COL && GATHER), "the gathered sweep has no column direction");
+    uint4* __restrict__ rowres, uint2* __restrict__ colpart, int wb_stride, int row_stride) {
     constexpr int TILE_V4 = KS * 64;          // int4 per B tile
     constexpr int ROWS_WAVE = 32 * NSUB;      // query rows a wave keeps in registers
     constexpr int ROWS_WG = WAVES * ROWS_WAVE;
@@ -241,17 +231,9 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     const int rb = (blockIdx.x / col_chunks) % wgs_per_pair;
     const int p = blockIdx.x / (col_chunks * wgs_per_pair);
     const int2 pr = pairs[p];
-    const FrameDev A = frames[GATHER ? pr.y : pr.x], B = frames[GATHER ? pr.x : pr.y];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
     const int tbeg = cc * CHUNK_TILES;
-    int A_even, A_tiles, ncand = 0;
-    if constexpr (GATHER) {
-        const int4 st = cand.state[p];
-        ncand = st.x;
-        A_even = 0;
-        A_tiles = st.y ? (ncand + ROWS_WAVE - 1) / ROWS_WAVE * NSUB : 0;  // whole wave-blocks of candidates of a live pair
-    } else {
-        A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];  // tiles of the even class / in use
-    }
+    const int A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];  // tiles of the even class / in use
     const int B_even = ((gint_t)B.meta)[0], B_tiles = ((gint_t)B.meta)[1];
     if (rb * (ROWS_WG / 32) >= A_tiles || tbeg >= B_tiles) return;  // workgroup-uniform
     const int wb = rb * WAVES + wave;                  // wave-block (ROWS_WAVE rows) of frame A
@@ -264,26 +246,14 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
     v16i cinit[NSUB];                 // floor(|a|^2/2) of this lane's 16 rows per sub-tile: the MFMA C-init
     unsigned rm1[NSUB][16], rm2[NSUB][16];
     const int wbc = active ? wb : 0;  // inactive waves load a valid block and never use it
-    // candidate i of the pair -> its stored column in the candidates' frame (slots past the list repeat the first candidate:
-    // their results are never read)
-    auto cand_col = [&](int i) {
-        const uint2* rc = cand.rowcand + (size_t)p * row_stride;
-        return (int)rc[cand.candlist[(size_t)p * row_stride + (i < ncand ? i : 0)]].x;
-    };
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
-        if constexpr (GATHER) {
-            const int c = cand_col(ROWS_WAVE * wbc + 32 * s + cl);  // this lane's operand row: (c >> 5, c & 31) of the frame
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(c >> 5) * KS + ks) * 64 + 32 * h + (c & 31)];
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
-        }
+        for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int lrow = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
-            cinit[s][r] = GATHER ? Aca[cand_col(ROWS_WAVE * wbc + lrow)] : Aca[ROWS_WAVE * wbc + lrow];
+            cinit[s][r] = Aca[ROWS_WAVE * wbc + lrow];
             rm1[s][r] = 0xffffffffu;
             rm2[s][r] = 0xffffffffu;
         }
@@ -670,10 +640,10 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize_kernel(
 // row q that passed the ratio test: with |mutual| > min_mutual >= min_dir - 1 the two direction thresholds are implied
 // (every mutual match is in m12 and in m21), so a pair with no more than min_mutual passing rows is dead, and for the
 // others the column top-2 is needed for the passing rows' best columns only. Three small kernels replace K2:
-//   R  match_rows_kernel       per pair: merge the row results, ratio test, ordered list of the passing rows (candidates)
-//   V  match_tile_kernel<.., GATHER>  the SAME sweep with the roles swapped: the candidate columns of a live pair, gathered
-//                              as the stationary operand, against all rows of the query frame streamed through LDS; its
-//                              row results are the top-2 of every candidate column (dead pairs' workgroups exit at once)
+//   R  match_rows_kernel       per pair: merge the row results, ratio test, ordered list of the passing rows (candidates),
+//                              one work item per 64 candidates of a live pair
+//   V  match_colverify_kernel  per item: d2 of 64 candidate columns against ALL rows of the query frame on the int8 MFMA
+//                              with the operands swapped (candidates = B operand, one per lane), top-2 VALUES per column
 //   F  match_finalize2_kernel  per pair: keep candidate (q, t) iff column t passes the ratio test with minimum d2(q, t);
 //                              ordered compaction in the caller's row order, threshold
 // ------------------------------------------------------------------------------------------------
@@ -697,13 +667,17 @@ __device__ __forceinline__ int block_rank(bool flag, int tid, int* s_wave /* [FI
     return before + in_wave;
 }
 
+constexpr int VER_GROUPS = 2;                 // 32-candidate groups per wave: one fetched A fragment feeds two MFMA chains
+constexpr int VER_CANDS = 32 * VER_GROUPS;    // candidates per work item
+
 // rowcand[p][j] = {stored column of row j's best, d2} if stored row j passes the ratio test, else {~0, 0};
 // candlist[p][i] = stored row of the i-th passing row (ascending j); state[p] = {passing rows, live, 0, 0}
 __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint4* __restrict__ rowres, int col_chunks,
     int row_stride, double ratio, int min_dir, int min_mutual, int mode, uint2* __restrict__ rowcand,
-    int* __restrict__ candlist, int4* __restrict__ state) {
+    int* __restrict__ candlist, int4* __restrict__ state, int2* __restrict__ items, int* __restrict__ n_items) {
     __shared__ int s_wave[FIN_THREADS / 64];
+    __shared__ int s_item0;
     const int tid = threadIdx.x;
     const int p = blockIdx.x;
     const int2 pr = pairs[p];
@@ -743,14 +717,161 @@ __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
     }
     // main.cpp:111,142: an edge needs |m12| >= min_dir and |mutual| > min_mutual, and mutual is a subset of m12
     const bool live = mode == 0 && base >= min_dir && base > min_mutual;
-    if (tid == 0) state[p] = make_int4(base, live ? 1 : 0, 0, 0);
+    const int groups = (base + VER_CANDS - 1) / VER_CANDS;
+    if (tid == 0) {
+        state[p] = make_int4(base, live ? 1 : 0, 0, 0);
+        if (live) s_item0 = atomicAdd(n_items, groups);
+    }
+    if (live) {  // workgroup-uniform
+        __syncthreads();
+        for (int g = tid; g < groups; g += FIN_THREADS) items[s_item0 + g] = make_int2(p, g);
+    }
+}
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imed3(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// sorted pair (s1 <= s2) merged into the running top-2 (m1 <= m2): 3 ops
+__device__ __forceinline__ void top2_merge(int& m1, int& m2, int s1, int s2) {
+    m2 = imin(imin(imax(m1, s1), m2), s2);
+    m1 = imin(m1, s1);
+}
+
+// colres[p][j] = {v1, v2}: the two smallest 2H + pa over ALL stored rows of frame A against column rowcand[p][j].x of
+// frame B (d2 = v + pb - 2), for the candidates of live pairs. Persistent workgroups over the item list.
+//
+// The MFMA of the sweep with its operands swapped: the 64 candidate columns of an item are the B operand (gathered once,
+// two 32-column groups held in registers: a candidate is a LANE), the query frame's tiles stream as the A operand straight
+// from L2, each fetched fragment feeding both groups' chains. Because a lane's 16 accumulators are 16 rows against ITS
+// column, the column's constant hb is added once at the very end and the top-2 runs on the raw accumulators, three at a
+// time: 27 VALU operations per 16 distances (the sweep needs 48) under 8 MFMAs — the kernel is bound by the matrix pipe,
+// which the sweep (bound by the VALU port) leaves idle more than half of the time. Rows of the two parity classes are kept
+// apart (a tile has one parity) and joined when 2H + pa is formed.
+template <int KS>
+__global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint2* __restrict__ rowcand,
+    const int* __restrict__ candlist, const int4* __restrict__ state, const int2* __restrict__ items,
+    const int* __restrict__ n_items, int row_stride, uint2* __restrict__ colres) {
+    __shared__ int4 sM[WAVES][VER_GROUPS][32];  // per wave, group, column: {m1 even, m2 even, m1 odd, m2 odd}
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 31, h = lane >> 5;
+    const int n = *n_items;
+    constexpr int BIG = 0x7fffffff;
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int2 it = items[w];
+        const int p = it.x;
+        const int2 pr = pairs[p];
+        const FrameDev A = frames[pr.x], B = frames[pr.y];
+        const int A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];
+        const int ncand = state[p].x;
+        const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag;
+        const gint_t Aca = (gint_t)A.norm;
+        const int* cand = candlist + (size_t)p * row_stride;
+        const uint2* rc = rowcand + (size_t)p * row_stride;
+        v4i b[VER_GROUPS][KS];
+        int jg[VER_GROUPS];  // stored row of this lane's candidate per group (-1: past the list)
+#pragma unroll
+        for (int g = 0; g < VER_GROUPS; ++g) {
+            const int i = VER_CANDS * it.y + 32 * g + cl;
+            const int j = cand[i < ncand ? i : VER_CANDS * it.y];  // (an item has at least one candidate)
+            jg[g] = i < ncand ? j : -1;
+            const unsigned col = rc[j].x;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bfrag[((size_t)(col >> 5) * KS + ks) * 64 + 32 * h + (col & 31)];
+        }
+        int m1[VER_GROUPS][2], m2[VER_GROUPS][2];  // [group][row parity]
+#pragma unroll
+        for (int g = 0; g < VER_GROUPS; ++g) m1[g][0] = m1[g][1] = m2[g][0] = m2[g][1] = BIG;
+        // this wave's tiles: wave, wave + 4, ...; the next tile's fragments and C-init are in flight under the current chains
+        v4i a_nxt[KS];
+        v4i c_nxt[4];
+        auto fetch = [&](int t) {
+            const int tc = min(t, A_tiles - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a_nxt[ks] = Afrag[((size_t)tc * KS + ks) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c_nxt[q] = *(const v4i __attribute__((address_space(1)))*)(Aca + 32 * tc + 8 * q + 4 * h);  // rows 8q + 4h .. + 3: registers 4q .. 4q + 3
+        };
+        fetch(wave);
+        for (int t = wave; t < A_tiles; t += WAVES) {
+            v4i a[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[ks] = ~a_nxt[ks];
+            v16i c0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0[r] = c_nxt[r >> 2][r & 3];
+            fetch(t + WAVES);
+            v16i acc[VER_GROUPS];
+#pragma unroll
+            for (int g = 0; g < VER_GROUPS; ++g) {
+                acc[g] = c0;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], b[g][ks], acc[g], 0, 0, 0);
+            }
+            const bool odd = t >= A_even;  // wave-uniform
+#pragma unroll
+            for (int g = 0; g < VER_GROUPS; ++g) {
+                int x1 = odd ? m1[g][1] : m1[g][0], x2 = odd ? m2[g][1] : m2[g][0];
+#pragma unroll
+                for (int k = 0; k < 15; k += 3) {  // five triples: {min3, med3} + a sorted-pair merge
+                    const int s1 = imin(imin(acc[g][k], acc[g][k + 1]), acc[g][k + 2]);
+                    const int s2 = imed3(acc[g][k], acc[g][k + 1], acc[g][k + 2]);
+                    top2_merge(x1, x2, s1, s2);
+                }
+                x2 = imed3(x1, x2, acc[g][15]);
+                x1 = imin(x1, acc[g][15]);
+                if (odd) m1[g][1] = x1, m2[g][1] = x2;
+                else m1[g][0] = x1, m2[g][0] = x2;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < VER_GROUPS; ++g) {  // lanes l and l + 32 hold the same column, different rows
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int o1 = __shfl_xor(m1[g][e], 32), o2 = __shfl_xor(m2[g][e], 32);
+                top2_merge(m1[g][e], m2[g][e], o1, o2);
+            }
+            if (h == 0) sM[wave][g][cl] = make_int4(m1[g][0], m2[g][0], m1[g][1], m2[g][1]);
+        }
+        __syncthreads();
+        if (tid < 32 * VER_GROUPS) {
+            const int g = tid >> 5, c = tid & 31;
+            int4 m = sM[0][g][c];
+#pragma unroll
+            for (int k = 1; k < WAVES; ++k) {
+                const int4 e = sM[k][g][c];
+                top2_merge(m.x, m.y, e.x, e.y);
+                top2_merge(m.z, m.w, e.z, e.w);
+            }
+            // H = acc + hb; v = 2 H + pa. A class without rows stays at BIG (never the minimum of a frame with rows)
+            const int i = VER_CANDS * it.y + tid;
+            if (i < ncand) {
+                const int j = cand[i];
+                const long long hb2 = 2ll * ((gint_t)B.normb)[rc[j].x];
+                auto val = [&](int m, int pa) { return m == BIG ? 0xffffffffull : (unsigned long long)(2ll * m + hb2 + pa); };
+                unsigned long long e1 = val(m.x, 0), e2 = val(m.y, 0), o1 = val(m.z, 1), o2 = val(m.w, 1);
+                const unsigned long long v1 = e1 < o1 ? e1 : o1;
+                const unsigned long long hi = e1 < o1 ? o1 : e1, lo2 = e2 < o2 ? e2 : o2;
+                const unsigned long long v2 = hi < lo2 ? hi : lo2;
+                colres[(size_t)p * row_stride + j] = make_uint2((unsigned)v1, (unsigned)v2);
+            }
+        }
+        __syncthreads();
+        (void)jg;
+    }
 }
 
 // out_matches[p][k] = {q, t} sorted by q; counts[p] (mode 0: |mutual| if it exceeds min_mutual, else 0; mode 1: |m12|)
 __global__ __launch_bounds__(FIN_THREADS) void match_finalize2_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint2* __restrict__ rowcand,
-    const int* __restrict__ candlist, const uint4* __restrict__ colres, const int4* __restrict__ state, int col_chunks,
-    int row_stride, double ratio, int min_mutual, int mode, uint2* __restrict__ out_matches, int* __restrict__ counts) {
+    const uint2* __restrict__ colres, const int4* __restrict__ state, int row_stride, double ratio, int min_mutual, int mode,
+    uint2* __restrict__ out_matches, int* __restrict__ counts) {
     extern __shared__ int smem[];
     __shared__ int s_wave[FIN_THREADS / 64];
     const int tid = threadIdx.x;
@@ -766,29 +887,21 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize2_kernel(
     constexpr unsigned PAD_V = 2u * PADH;
     int* keepcol = smem;  // [row_stride] by stored row: stored column of the kept match or -1
     const uint2* rc = rowcand + (size_t)p * row_stride;
-    const int* cl = candlist + (size_t)p * row_stride;
-    for (int j = tid; j < 32 * A_tiles; j += FIN_THREADS) keepcol[j] = -1;
-    __syncthreads();
-    const int nchunks = (A_tiles + CHUNK_TILES - 1) / CHUNK_TILES;  // the gathered sweep streams frame A
-    for (int i = tid; i < st.x; i += FIN_THREADS) {
-        const int j = cl[i];
-        const uint2 c = rc[j];  // {stored column of row j's best, d2}
-        int keep = (int)c.x;
-        if (mode == 0) {
-            // main.cpp:133-140: q is kept iff t's own best match is q, i.e. iff column t passes the ratio test (a unique
-            // minimum for any ratio <= 1) and its minimum is d2(q, t). Candidate slot i of the gathered sweep holds the
-            // top-2 of column c.x over the rows of frame A, per chunk of streamed rows.
-            unsigned v1 = 0xffffffffu, v2 = 0xffffffffu;
-            for (int ch = 0; ch < nchunks; ++ch) {
-                const uint4 e = colres[((size_t)p * col_chunks + ch) * row_stride + i];
-                v2 = umin(umin(umax(v1, e.x), v2), e.z);  // (e.x <= e.z) merged into (v1 <= v2): values only
-                v1 = umin(v1, e.x);
+    const uint2* cr = colres + (size_t)p * row_stride;
+    for (int j = tid; j < 32 * A_tiles; j += FIN_THREADS) {
+        const uint2 c = rc[j];
+        int keep = -1;
+        if (c.x != 0xffffffffu) {
+            if (mode == 1) {
+                keep = (int)c.x;
+            } else {
+                // main.cpp:133-140: q is kept iff t's own best match is q, i.e. iff column t passes the ratio test (a unique
+                // minimum for any ratio <= 1) and its minimum is d2(q, t)
+                const uint2 v = cr[j];
+                const unsigned pb = (c.x >> 5) >= (unsigned)B_even ? 1u : 0u;
+                const int d1 = (int)(v.x + pb) - 2;
+                if (d1 == (int)c.y && v.y < PAD_V && ratio_pass(d1, (int)(v.y + pb) - 2, ratio)) keep = (int)c.x;
             }
-            // v = 2H + pa of the streamed row: d2 = v + pb - 2 with pb the candidate column's parity... the key's parity bit
-            // is the STREAMED row's, so the constant left to add is the stationary (candidate) side's
-            const unsigned pb = (c.x >> 5) >= (unsigned)B_even ? 1u : 0u;
-            const int d1 = (int)(v1 + pb) - 2;
-            if (!(d1 == (int)c.y && v2 < PAD_V && ratio_pass(d1, (int)(v2 + pb) - 2, ratio))) keep = -1;
         }
         keepcol[j] = keep;
     }
@@ -932,8 +1045,8 @@ struct MatchPlan {
     int col_chunks;  // sweeps of <= 4096 train rows per pair
     int slots;       // workspace copies: batch i+1's tile kernel overlaps batch i's finalize
     size_t off_rowres, off_colpart, off_matches, slot_bytes, total;
-    // the candidate-only column pass: rowcand | candlist | colres (the gathered sweep's row results) | state
-    size_t off_rowcand, off_candlist, off_colres, off_state;
+    // the candidate-only column pass: rowcand | candlist | colres | state | items | n_items
+    size_t off_rowcand, off_candlist, off_colres, off_state, off_items, off_nitems;
 };
 
 static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
@@ -947,7 +1060,7 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
     pl.col_chunks = (max_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
     // per pair: row results + match list, and EITHER the column partials of the full sweep OR the arrays of the candidate pass
     const size_t colpart_pp = full_cols ? (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) : 0;
-    const size_t cand_pp = full_cols ? 0 : (size_t)pl.row_stride * (sizeof(uint2) + sizeof(int) + (size_t)pl.col_chunks * sizeof(uint4)) + sizeof(int4);
+    const size_t cand_pp = full_cols ? 0 : (size_t)pl.row_stride * (sizeof(uint2) + sizeof(int) + sizeof(uint2)) + sizeof(int4) + (size_t)max_tiles * sizeof(int2);
     size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.row_stride * sizeof(uint2) + colpart_pp + cand_pp;
     // bound a slot near 1 GiB so the column partials of one batch stay cache-friendly
     size_t budget = (size_t)ctx->match_budget_mb << 20;
@@ -971,31 +1084,24 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
     const size_t cb = full_cols ? 0 : (size_t)pl.batch;  // the candidate arrays exist in the other form only
     pl.off_candlist = align(pl.off_rowcand + cb * pl.row_stride * sizeof(uint2));
     pl.off_colres = align(pl.off_candlist + cb * pl.row_stride * sizeof(int));
-    pl.off_state = align(pl.off_colres + cb * pl.col_chunks * pl.row_stride * sizeof(uint4));
-    pl.slot_bytes = align(pl.off_state + cb * sizeof(int4) + 256);
+    pl.off_state = align(pl.off_colres + cb * pl.row_stride * sizeof(uint2));
+    pl.off_items = align(pl.off_state + cb * sizeof(int4));
+    pl.off_nitems = align(pl.off_items + cb * max_tiles * sizeof(int2));
+    pl.slot_bytes = align(pl.off_nitems + 256);
     pl.total = pl.slot_bytes * pl.slots;
     return pl;
 }
 
 template <int KS>
 static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws, bool col) {
-    const CandView none{nullptr, nullptr, nullptr};
     if (!col)  // the sweep without its column direction: the candidate-only pass follows (or nothing, for directed lists)
-        match_tile_kernel<KS, MATCH_NSUB, false, false><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
+        match_tile_kernel<KS, MATCH_NSUB, false><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
             ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_rowres),
-            (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride, none);
+            (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
     else
-        match_tile_kernel<KS, MATCH_NSUB, true, false><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
+        match_tile_kernel<KS, MATCH_NSUB, true><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, ctx->stream>>>(
             ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_rowres),
-            (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride, none);
-}
-// the gathered sweep of the candidate columns (roles swapped; results in the colres region, laid out like rowres)
-template <int KS>
-static void launch_verify(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws, hipStream_t st) {
-    const CandView cv{(const uint2*)(ws + pl.off_rowcand), (const int*)(ws + pl.off_candlist), (const int4*)(ws + pl.off_state)};
-    match_tile_kernel<KS, MATCH_NSUB, false, true><<<nb * pl.wgs_per_pair * pl.col_chunks, WG_THREADS, 0, st>>>(
-        ctx->frame_table_dev, pairs_dev, pl.wgs_per_pair, pl.col_chunks, (uint4*)(ws + pl.off_colres), nullptr, pl.wb_stride,
-        pl.row_stride, cv);
+            (uint2*)(ws + pl.off_colpart), pl.wb_stride, pl.row_stride);
 }
 
 // Core driver. mode 0 = mutual (CSR out), mode 1 = directed single pair (fixed-stride out in ws).
@@ -1063,20 +1169,25 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
             } else {
                 uint2* rowcand = (uint2*)(ws + pl.off_rowcand);
                 int* candlist = (int*)(ws + pl.off_candlist);
-                uint4* colres = (uint4*)(ws + pl.off_colres);
+                uint2* colres = (uint2*)(ws + pl.off_colres);
                 int4* state = (int4*)(ws + pl.off_state);
+                int2* items = (int2*)(ws + pl.off_items);
+                int* n_items = (int*)(ws + pl.off_nitems);
+                if (mode == 0) EACHAM_HIP_TRY(ctx, hipMemsetAsync(n_items, 0, sizeof(int), st2));
                 match_rows_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.col_chunks,
-                                                               pl.row_stride, ratio, min_dir, min_mutual, mode, rowcand, candlist, state);
+                                                               pl.row_stride, ratio, min_dir, min_mutual, mode, rowcand, candlist, state,
+                                                               items, n_items);
                 if (mode == 0) {
+                    // persistent workgroups over the item list (its length is only known on the device): one round of the chip
+                    const int vgrid = std::min(std::max(nb * pl.wgs_per_pair, 1), 512);
                     switch (ctx->ks_common) {
-                        case 2: launch_verify<2>(ctx, pl, pb, nb, ws, st2); break;
-                        case 4: launch_verify<4>(ctx, pl, pb, nb, ws, st2); break;
-                        default: launch_verify<8>(ctx, pl, pb, nb, ws, st2); break;
+                        case 2: match_colverify_kernel<2><<<vgrid, WG_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, rowcand, candlist, state, items, n_items, pl.row_stride, colres); break;
+                        case 4: match_colverify_kernel<4><<<vgrid, WG_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, rowcand, candlist, state, items, n_items, pl.row_stride, colres); break;
+                        default: match_colverify_kernel<8><<<vgrid, WG_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, rowcand, candlist, state, items, n_items, pl.row_stride, colres); break;
                     }
                 }
-                match_finalize2_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(ctx->frame_table_dev, pb, rowcand, candlist, (const uint4*)colres, state,
-                                                                          pl.col_chunks, pl.row_stride, ratio, min_mutual, mode,
-                                                                          (uint2*)(ws + pl.off_matches), cnt);
+                match_finalize2_kernel<<<nb, FIN_THREADS, fin_smem, st2>>>(ctx->frame_table_dev, pb, rowcand, colres, state, pl.row_stride, ratio,
+                                                                          min_mutual, mode, (uint2*)(ws + pl.off_matches), cnt);
             }
             if (csr) {
                 scan_counts_kernel<<<1, 1024, 0, st2>>>(cnt, nb, offsets_dev, total_dev, first, first + nb == npairs);
