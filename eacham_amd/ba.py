@@ -181,6 +181,24 @@ class PreparedBA:
                 "tile_updates": int(info.tile_updates), "est_us": round(info.est_us, 1),
                 "prepare_us": [round(v, 1) for v in info.prepare_us]}
 
+    STRUCTURE = {"lm_ptr": (0, np.int32), "cam_ptr": (1, np.int32), "cam_obs": (2, np.int32), "obs_pos": (3, np.int32),
+                 "obs_cam": (4, np.uint32), "obs_lm": (5, np.uint32), "obs_uv": (6, np.float64), "cam_uv": (7, np.float64),
+                 "cam_lm": (8, np.int32), "pos_cam": (9, np.int32), "cam_chunks": (10, np.int32), "cam_chunk_ptr": (11, np.int32),
+                 "blocks": (12, np.int32), "pair_chunks": (13, np.int32), "pair_entries": (14, np.int32), "pose0": (15, np.float64),
+                 "pt0": (16, np.float64), "lmprior": (17, np.float64), "K0": (18, np.float64), "fixed": (19, np.int32)}
+
+    def structure(self, name: str) -> np.ndarray:
+        """eacham_ba_debug_structure: one array of the device-side structure (tests)."""
+        which, dtype = self.STRUCTURE[name]
+        n = C.c_int64(0)
+        rc = self._L.eacham_ba_debug_structure(self.ctx.handle, self._h, which, None, 0, C.byref(n))
+        if rc not in (capi.OK, capi.ERR_CAPACITY):
+            self.ctx._check(rc)
+        out = np.zeros(n.value // np.dtype(dtype).itemsize, dtype)
+        if n.value:
+            self.ctx._check(self._L.eacham_ba_debug_structure(self.ctx.handle, self._h, which, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
     def close(self):
         if self._h:
             self._L.eacham_ba_release(self.ctx.handle, self._h)

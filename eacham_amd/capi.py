@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
     L.eacham_ba_release.restype = None
     L.eacham_ba_debug_step.argtypes = [vp, vp, dbl, vp, vp, vp, vp, vp, vp]
     L.eacham_ba_get_plan_info.argtypes = [vp, vp, vp]
+    if hasattr(L, "eacham_ba_debug_structure"):
+        L.eacham_ba_debug_structure.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64)]
     L.eacham_triangulate_tracks.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     L.eacham_two_view_points.argtypes = [vp, i32, vp, vp, vp, i32, vp, C.c_float, C.c_float, i32, vp, vp, vp]
     L.eacham_score_hypotheses.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp]
@@ -97,6 +99,12 @@ def lib() -> C.CDLL:
         L.eacham_comm_upload_descriptors.argtypes = [vp, i32, vp, i32, i32]
         L.eacham_match_all_pairs_sharded.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64)]
         L.eacham_assemble_match_graph.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
+    if hasattr(L, "eacham_comm_match_run"):
+        L.eacham_comm_match_run.argtypes = [vp, vp, i32, dbl, i32, i32, i32, C.POINTER(i64)]
+        L.eacham_comm_match_fetch.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
+        L.eacham_shard_bounds_weighted.argtypes = [i32, i32, vp, vp]
+        L.eacham_assemble_match_graph_bounds.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
+        L.eacham_comm_edge_region.argtypes = [i32, vp, C.POINTER(i64)]
     _lib = L
     return L
 

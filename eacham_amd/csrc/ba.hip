@@ -2910,8 +2910,10 @@ __global__ __launch_bounds__(TPB) void prep_values(int nc, int nl, const double*
         double* x = pose0 + 12 * (size_t)i;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) x[3 * a + b] = T[4 * b + a];
-        for (int a = 0; a < 3; ++a)
-            x[9 + a] = -__dadd_rn(__dadd_rn(__dmul_rn(T[a], T[3]), __dmul_rn(T[4 + a], T[7])), __dmul_rn(T[8 + a], T[11]));
+        {
+#pragma clang fp contract(off)  // (the header-defined __dmul_rn / __dadd_rn are plain operators and would be fused)
+            for (int a = 0; a < 3; ++a) x[9 + a] = -((T[a] * T[3] + T[4 + a] * T[7]) + T[8 + a] * T[11]);
+        }
     } else if (i - nc < nl) {  // BundleAdjuster.cpp:109-113: sigma = 1.0f/obs, k = 3.0f/obs (float)
         const int j = i - nc;
         const float o = (float)(observers[j] > 0 ? observers[j] : 1);
@@ -3796,6 +3798,52 @@ int eacham_ba_get_plan_info(eacham_ctx* ctx, const eacham_ba_handle* handle, eac
     out->prepare_us[0] = handle->prep_us[0];
     out->prepare_us[1] = handle->prep_us[1];
     out->prepare_us[2] = handle->prep_us[2];
+    return EACHAM_OK;
+}
+
+int eacham_ba_debug_structure(eacham_ctx* ctx, const eacham_ba_handle* h, int which, void* out, int64_t cap_bytes, int64_t* out_bytes) {
+    if (!ctx || !h || !out_bytes) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    const BaDev& D = h->D;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = D.lm_ptr; bytes = sizeof(int) * ((size_t)D.nl + 1); break;
+        case 1: src = D.cam_ptr; bytes = sizeof(int) * ((size_t)D.nc + 1); break;
+        case 2: src = D.cam_obs; bytes = sizeof(int) * (size_t)D.no; break;
+        case 3: src = D.obs_pos; bytes = sizeof(int) * (size_t)D.no; break;
+        case 4: src = D.obs_cam; bytes = sizeof(unsigned) * (size_t)D.no; break;
+        case 5: src = D.obs_lm; bytes = sizeof(unsigned) * (size_t)D.no; break;
+        case 6: src = D.obs_uv; bytes = sizeof(double) * 2 * (size_t)D.no; break;
+        case 7: src = D.cam_uv; bytes = sizeof(double) * 2 * (size_t)D.no; break;
+        case 8: src = D.cam_lm; bytes = sizeof(int) * (size_t)D.no; break;
+        case 9: src = D.pos_cam; bytes = sizeof(int) * (size_t)D.no; break;
+        case 10: src = D.cam_chunks; bytes = sizeof(int2) * (size_t)D.n_cam_chunks; break;
+        case 11: src = D.cam_chunk_ptr; bytes = sizeof(int) * ((size_t)D.nc + 1); break;
+        case 12: src = D.blocks; bytes = sizeof(int4) * (size_t)D.n_blocks; break;
+        case 13: src = D.pair_chunks; bytes = sizeof(int4) * (size_t)D.n_chunks; break;
+        case 14: {
+            long long n = 0;  // entries = first entry + count of the last chunk
+            if (D.n_chunks > 0) {
+                int4 last;
+                EACHAM_HIP_TRY(ctx, hipMemcpy(&last, D.pair_chunks + (D.n_chunks - 1), sizeof(int4), hipMemcpyDeviceToHost));
+                n = (long long)last.y + last.z;
+            }
+            src = D.pair_entries; bytes = sizeof(int2) * (size_t)n;
+            break;
+        }
+        case 15: src = D.pose0; bytes = sizeof(double) * 12 * (size_t)D.nc; break;
+        case 16: src = D.pt0; bytes = sizeof(double) * 3 * (size_t)D.nl; break;
+        case 17: src = D.lmprior; bytes = sizeof(double) * 2 * (size_t)D.nl; break;
+        case 18: src = D.K0; bytes = sizeof(double) * 5; break;
+        case 19: src = D.fixed; bytes = sizeof(int) * (size_t)D.nc; break;
+        default: return ctx->fail(EACHAM_ERR_INVALID, "unknown structure array %d", which);
+    }
+    *out_bytes = (int64_t)bytes;
+    if ((int64_t)bytes > cap_bytes) return ctx->fail(EACHAM_ERR_CAPACITY, "structure array %d needs %zu bytes", which, bytes);
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) EACHAM_HIP_TRY(ctx, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
     return EACHAM_OK;
 }
 

@@ -257,6 +257,13 @@ typedef struct eacham_ba_plan_info {
 } eacham_ba_plan_info;
 int eacham_ba_get_plan_info(eacham_ctx* ctx, const eacham_ba_handle* handle, eacham_ba_plan_info* out);
 
+/* Test/diagnostic entry point: one array of a prepared problem's device-side structure, as built by eacham_ba_prepare
+ * (0 lm_ptr, 1 cam_ptr, 2 cam_obs, 3 obs_pos, 4 obs_cam, 5 obs_lm, 6 obs_uv, 7 cam_uv, 8 cam_lm, 9 pos_cam, 10 cam_chunks,
+ * 11 cam_chunk_ptr, 12 blocks, 13 pair_chunks, 14 pair_entries, 15 pose0, 16 pt0, 17 lmprior, 18 K0, 19 fixed): the tests
+ * hold the structure built by device sorts and scans against the one built by host loops, array by array. */
+int eacham_ba_debug_structure(eacham_ctx* ctx, const eacham_ba_handle* handle, int which, void* out, int64_t cap_bytes,
+                              int64_t* out_bytes);
+
 /* Test/diagnostic entry point: linearises at the problem's initial values and returns the reduced
  * camera system of one damped Gauss-Newton step: S (n x n, row-major, n = 6*n_cams + 5, cameras
  * first, then K), its right-hand side g (n), the step delta for cameras+K (n) and for the points

@@ -42,8 +42,21 @@ def _arrays(seed, n_cams, n_lm, k, shuffle=False, **kw):
     return A
 
 
+def _same_structure(ctx_pair, A):
+    host, dev = ctx_pair
+    a, b = ba.PreparedBA(host, A), ba.PreparedBA(dev, A)
+    try:
+        for name in ba.PreparedBA.STRUCTURE:
+            x, y = a.structure(name), b.structure(name)
+            assert x.shape == y.shape and np.array_equal(x, y), f"structure array {name} differs ({x.shape} vs {y.shape})"
+    finally:
+        a.close()
+        b.close()
+
+
 def _same_step(ctx_pair, A, lam=1e-3):
     host, dev = ctx_pair
+    _same_structure(ctx_pair, A)
     a = ba.debug_step(host, A, lam)
     b = ba.debug_step(dev, A, lam)
     for name, x, y in zip(["S", "g", "delta_c", "delta_l", "error", "lin_change"], a, b):
