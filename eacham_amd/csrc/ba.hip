@@ -35,6 +35,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace eacham {
@@ -3013,6 +3014,21 @@ __global__ __launch_bounds__(TPB) void prep_pair_counts(int no, const unsigned* 
     cnt[a] = c;
 }
 
+// camera graph of the reduced system: adj[c][c'] = 1 iff the two cameras share a landmark (benign races: every writer
+// stores 1). The host's ordering + symbolic analysis starts from it while the device is still building the pair lists.
+__global__ __launch_bounds__(TPB) void prep_cam_adjacency(int no, int nc, const unsigned* __restrict__ obs_cam, const unsigned* __restrict__ obs_lm,
+                                                          const int* __restrict__ lm_ptr, unsigned char* __restrict__ adj) {
+    const int a = blockIdx.x * TPB + threadIdx.x;
+    if (a >= no) return;
+    const int a1 = lm_ptr[obs_lm[a] + 1];
+    const int ca = (int)obs_cam[a];
+    for (int b = a + 1; b < a1; ++b) {
+        const int cb = (int)obs_cam[b];
+        if (ca < cb) adj[(size_t)ca * nc + cb] = 1;
+        else if (cb < ca) adj[(size_t)cb * nc + ca] = 1;
+    }
+}
+
 // the entries in (landmark, a, b) order = the order of the host loops; key = camera block, value = the two Et positions
 __global__ __launch_bounds__(TPB) void prep_expand(int no, int nc, const unsigned* __restrict__ obs_cam, const unsigned* __restrict__ obs_lm,
                                                    const int* __restrict__ lm_ptr, const int* __restrict__ obs_pos,
@@ -3131,8 +3147,12 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     D.n_step_blocks = std::max(1, (int)(((long long)nl * D.lpl_step + TPB - 1) / TPB));
     hipStream_t st = ctx->stream;
     int rc = EACHAM_OK;
+    std::thread plan_thread;
+    std::vector<unsigned char> adj_h;
     auto fail = [&](int code) {
+        if (plan_thread.joinable()) plan_thread.join();
         (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(ctx->stream2);
         if (h->block >= 0) ctx->ba_pool[h->block].busy = false;
         if (h->block2 >= 0) ctx->ba_pool[h->block2].busy = false;
         delete h;
@@ -3187,6 +3207,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     int *raw_obs, *sort_ws, *nchunk, *nchunk_ws;
     long long *pcnt, *poff, *pws;
     PrepCounters* cnt;
+    unsigned char* adj_dev;
     auto carve0 = [&](void* base) {
         Bump b(base);
         raw_pt = b.take<uint32_t>(no); raw_cam = b.take<uint32_t>(no); raw_uv = b.take<double>(2 * (size_t)no);
@@ -3196,6 +3217,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         nchunk = b.take<int>(nc); nchunk_ws = b.take<int>(prim::scan_ws_elems(nc));
         pcnt = b.take<long long>(no); poff = b.take<long long>((size_t)no + 1); pws = b.take<long long>(prim::scan_ws_elems(no));
         cnt = b.take<PrepCounters>(1);
+        adj_dev = b.take<unsigned char>((size_t)nc * nc);
         return b.off;
     };
     rc = ba_scratch(ctx, 0, carve0(nullptr), &s0);
@@ -3223,6 +3245,10 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         HIPQ(hipMemsetAsync(lm_ptr, 0, sizeof(int) * ((size_t)nl + 1), st));
         HIPQ(hipMemsetAsync(cam_ptr, 0, sizeof(int) * ((size_t)nc + 1), st));
     }
+    // the camera graph leaves for the host on the second stream as soon as the landmark grouping exists
+    if (nc > 0) HIPQ(hipMemsetAsync(adj_dev, 0, (size_t)nc * nc, st));
+    if (no > 0 && nc > 0) prep_cam_adjacency<<<gobs, TPB, 0, st>>>(no, nc, obs_cam, obs_lm, lm_ptr, adj_dev);
+    HIPQ(hipEventRecord(ctx->ev_join, st));
     // the camera sort reuses the landmark sort's output buffers as its second pair (their content has been gathered)
     const int w_cam = prim::radix_sort_pairs<uint32_t>(st, ck, cv, lm_sorted, lm_order, no, bits_for(std::max(nc, 2)), sort_ws);
     if (no > 0) {
@@ -3235,6 +3261,23 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     HIPQ(hipMemcpyAsync(cam_chunk_ptr + nc, &cnt->n_cam_chunks, sizeof(int), hipMemcpyDeviceToDevice, st));
     prep_cam_chunk_fill<<<(unsigned)((nc + TPB) / TPB), TPB, 0, st>>>(nc, cam_ptr, cam_chunk_ptr, cam_chunks);
     prim::exclusive_scan<long long>(st, pcnt, poff, no, pws, &cnt->n_entries);
+    // ---- the host's share, beside the device's: ordering, panels, symbolic factor, level schedule (ba_plan.hpp) ----
+    int hint = P->ordering;
+    if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
+    if (hint < EACHAM_BA_ORDER_AUTO || hint > EACHAM_BA_ORDER_ND) return fail(ctx->fail(EACHAM_ERR_INVALID, "unknown BA ordering %d", hint));
+    adj_h.resize((size_t)nc * nc + 1);
+    HIPQ(hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));
+    if (nc > 0) HIPQ(hipMemcpyAsync(adj_h.data(), adj_dev, (size_t)nc * nc, hipMemcpyDeviceToHost, ctx->stream2));
+    HIPQ(hipStreamSynchronize(ctx->stream2));
+    plan_thread = std::thread([&, hint]() {   // (no HIP call in here)
+        const auto t_plan = std::chrono::steady_clock::now();
+        std::vector<std::pair<int, int>> cam_edges;
+        for (int c = 0; c < nc; ++c)
+            for (int c2 = c + 1; c2 < nc; ++c2)
+                if (adj_h[(size_t)c * nc + c2]) cam_edges.emplace_back(c, c2);
+        build_ba_plan(nc, cam_edges, hint, h->plan);
+        h->prep_us[1] = us_since(t_plan);
+    });
     // ---- read-back 1: the number of pair entries sizes the next stage ----
     PrepCounters hc;
     HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -3271,29 +3314,14 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     if (nblk > 0) prep_block_counts<<<gblk, TPB, 0, st>>>(nc, nblk, bcount, bt);
     prim::exclusive_scan<prim::I3>(st, bt, bs, nblk, bws, &cnt->totals);
     if (nblk > 0) prep_block_fill<<<gblk, TPB, 0, st>>>(nc, nblk, bcount, bs, blocks_tmp, chunks_tmp);
-    // ---- read-back 2 + 3: the table sizes, then the block table (the camera graph of the plan) ----
+    // ---- read-back 2: the table sizes ----
     HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
     HIPQ(hipStreamSynchronize(st));
     if (hc.totals.a != n_entries) return fail(ctx->fail(EACHAM_ERR_HIP, "BA structure build: %d pair entries counted, %d placed", n_entries, hc.totals.a));
     D.n_blocks = hc.totals.b;
     D.n_chunks = hc.totals.c;
-    std::vector<int4> blocks_h((size_t)D.n_blocks);
-    if (D.n_blocks > 0) HIPQ(hipMemcpyAsync(blocks_h.data(), blocks_tmp, sizeof(int4) * (size_t)D.n_blocks, hipMemcpyDeviceToHost, st));
-    HIPQ(hipStreamSynchronize(st));
     h->prep_us[0] = us_since(t_begin);
-    // ---- the sparse solve: ordering, panels, symbolic factor, level schedule (ba_plan.hpp) ----
-    const auto t_plan = std::chrono::steady_clock::now();
-    {
-        std::vector<std::pair<int, int>> cam_edges;
-        cam_edges.reserve(blocks_h.size());
-        for (const int4& b : blocks_h)
-            if (b.x != b.y) cam_edges.emplace_back(b.x, b.y);
-        int hint = P->ordering;
-        if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
-        if (hint < EACHAM_BA_ORDER_AUTO || hint > EACHAM_BA_ORDER_ND) return fail(ctx->fail(EACHAM_ERR_INVALID, "unknown BA ordering %d", hint));
-        build_ba_plan(nc, cam_edges, hint, h->plan);
-    }
-    h->prep_us[1] = us_since(t_plan);
+    plan_thread.join();  // prep_us[1] = the plan's own time; what of it was not hidden behind the device shows in [2]
     const auto t_upload = std::chrono::steady_clock::now();
     const BaPlan& plan = h->plan;
     D.sp_npan = plan.npan; D.sp_ntiles = plan.ntiles; D.sp_posK = plan.posK; D.sp_rhs_row = plan.rhs_row;

@@ -26,8 +26,10 @@
 #pragma once
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdint>
 #include <functional>
+#include <mutex>
 #include <numeric>
 #include <utility>
 #include <thread>
@@ -120,11 +122,24 @@ inline int pseudo_peripheral(const Adj& adj, const std::vector<int>& mark, int t
     return s;
 }
 
-// Nested dissection by level-structure separators: nodes are appended children first, separator last.
-inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const std::vector<int>& nodes, int leaf,
-                    std::vector<std::vector<int>>& out, std::vector<int>& lev, int variants = 0) {
-    if ((int)nodes.size() <= leaf) {
-        out.push_back(nodes);
+// Nested dissection by level-structure separators. The bisection of a node set does not depend on the leaf size the
+// recursion stops at, so the recursion is recorded ONCE as a tree (down to the smallest leaf size of interest) and the
+// node list of any leaf size is read off it (emit_nodes): the candidates of build_ba_plan share two dissections instead
+// of running eight.
+struct DTree {
+    enum Kind { LEAF, TERMINAL, COMPONENTS, SPLIT };
+    Kind kind = LEAF;
+    std::vector<int> nodes;  // the set as it was handed to this level (a leaf is emitted in this order)
+    std::vector<int> order;  // TERMINAL: no separator exists (a nearly complete graph) — emitted in level-structure order
+    std::vector<int> sep;    // SPLIT: the separator, eliminated after both sides
+    std::vector<DTree> kids;
+};
+
+inline void dissect_tree(const Adj& adj, std::vector<int>& mark, int& next_tag, const std::vector<int>& nodes, int min_leaf,
+                         DTree& T, std::vector<int>& lev, int variants = 0) {
+    T.nodes = nodes;
+    if ((int)nodes.size() <= min_leaf) {
+        T.kind = DTree::LEAF;
         return;
     }
     const int tag = next_tag++;
@@ -142,7 +157,9 @@ inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const
                 for (int u : comp) lev[u] = -1, seen[u] = 1;
                 comps.push_back(std::move(comp));
             }
-            for (auto& c : comps) dissect(adj, mark, next_tag, c, leaf, out, lev, variants);
+            T.kind = DTree::COMPONENTS;
+            T.kids.resize(comps.size());
+            for (size_t k = 0; k < comps.size(); ++k) dissect_tree(adj, mark, next_tag, comps[k], min_leaf, T.kids[k], lev, variants);
             return;
         }
     }
@@ -187,7 +204,8 @@ inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const
         }
     }
     if (best_l < 0) {  // (nearly) complete graph: no separator
-        out.push_back(order);
+        T.kind = DTree::TERMINAL;
+        T.order = order;
         return;
     }
     {   // the levels of the winning structure again
@@ -220,13 +238,44 @@ inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const
     }
     for (int u : order) lev[u] = -1;
     if (left.empty() || right.empty()) {
-        out.push_back(order);
+        T.kind = DTree::TERMINAL;
+        T.order = order;
         return;
     }
-    dissect(adj, mark, next_tag, left, leaf, out, lev, variants);
-    dissect(adj, mark, next_tag, right, leaf, out, lev, variants);
-    if (!sep.empty()) out.push_back(sep);
+    T.kind = DTree::SPLIT;
+    T.sep = sep;
+    T.kids.resize(2);
+    dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants);
+    dissect_tree(adj, mark, next_tag, right, min_leaf, T.kids[1], lev, variants);
 }
+
+// the node list of the dissection stopped at `leaf` (>= the min_leaf the tree was built with): children first, separator last
+inline void emit_nodes(const DTree& T, int leaf, std::vector<std::vector<int>>& out) {
+    if ((int)T.nodes.size() <= leaf) {
+        out.push_back(T.nodes);
+        return;
+    }
+    switch (T.kind) {
+        case DTree::LEAF: out.push_back(T.nodes); break;
+        case DTree::TERMINAL: out.push_back(T.order); break;
+        case DTree::COMPONENTS:
+            for (const DTree& k : T.kids) emit_nodes(k, leaf, out);
+            break;
+        case DTree::SPLIT:
+            emit_nodes(T.kids[0], leaf, out);
+            emit_nodes(T.kids[1], leaf, out);
+            if (!T.sep.empty()) out.push_back(T.sep);
+            break;
+    }
+}
+
+inline void dissect(const Adj& adj, std::vector<int>& mark, int& next_tag, const std::vector<int>& nodes, int leaf,
+                    std::vector<std::vector<int>>& out, std::vector<int>& lev, int variants = 0) {
+    DTree T;
+    dissect_tree(adj, mark, next_tag, nodes, leaf, T, lev, variants);
+    emit_nodes(T, leaf, out);
+}
+
 
 // reverse Cuthill-McKee over all components
 inline std::vector<int> rcm(const Adj& adj) {
@@ -492,10 +541,11 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     std::iota(all.begin(), all.end(), 0);
     const int cams_per_panel = PLAN_PANEL / PLAN_CAM;  // 10
     // The candidates — the natural order (what a window of a sequence already is), reverse Cuthill-McKee, nested dissection
-    // with four leaf sizes and one / several roots per bisection — are independent of each other: on a scene of some size
-    // (more than four panels) each is dissected, laid out and priced on its own host thread (S200: ten candidates of
-    // ~0.17 ms each, 1.7 ms in sequence), and the choice is then made in the fixed candidate order — first strictly
-    // cheaper — exactly as the sequential loop makes it.
+    // with four leaf sizes and one / several roots per bisection — are independent of each other except that the four leaf
+    // sizes of a dissection share its recursion tree (plan_detail::DTree). On a scene of some size (more than four panels)
+    // the work is a small task list run by a few host threads: the two dissections and the two band orderings first, the
+    // four candidates of a dissection as soon as its tree exists (S200: 1.7 ms in sequence in round 3). The choice is
+    // then made in the fixed candidate order — first strictly cheaper — exactly as a sequential loop would make it.
     struct Cand {
         int ordering, leaf, variants;
         bool force;
@@ -505,36 +555,68 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     cands.push_back({BA_ORDER_NATURAL, 0, 0, false, BaPlan()});
     const bool small = nc <= 2 * cams_per_panel;  // two panels: nothing to reorder
     if (hint == BA_ORDER_RCM || (hint == BA_ORDER_AUTO && !small)) cands.push_back({BA_ORDER_RCM, 0, 0, hint == BA_ORDER_RCM, BaPlan()});
-    if (hint == BA_ORDER_ND || (hint == BA_ORDER_AUTO && !small)) {
+    const int leaves[4] = {cams_per_panel, 2 * cams_per_panel + 1, 3 * cams_per_panel + 2, 4 * cams_per_panel + 2};
+    const int variant_list[2] = {0, 3};
+    const bool with_nd = hint == BA_ORDER_ND || (hint == BA_ORDER_AUTO && !small);
+    size_t nd_first = cands.size();
+    if (with_nd) {
         bool first = true;
-        for (int variants : {0, 3})
-            for (int leaf : {cams_per_panel, 2 * cams_per_panel + 1, 3 * cams_per_panel + 2, 4 * cams_per_panel + 2}) {
+        for (int variants : variant_list)
+            for (int leaf : leaves) {
                 cands.push_back({BA_ORDER_ND, leaf, variants, hint == BA_ORDER_ND && first, BaPlan()});
                 first = false;
             }
     }
+    plan_detail::DTree trees[2];
+    auto build_tree = [&](int k) {
+        std::vector<int> mark(nc, 0), lev(nc, -1);
+        int tag = 1;
+        plan_detail::dissect_tree(adj, mark, tag, all, leaves[0], trees[k], lev, variant_list[k]);
+    };
     auto evaluate = [&](Cand& c) {
         std::vector<std::vector<int>> nodes;
-        if (c.ordering == BA_ORDER_NATURAL) {
-            nodes = {all};
-        } else if (c.ordering == BA_ORDER_RCM) {
-            nodes = {plan_detail::rcm(adj)};
-        } else {
-            std::vector<int> mark(nc, 0), lev(nc, -1);
-            int tag = 1;
-            plan_detail::dissect(adj, mark, tag, all, c.leaf, nodes, lev, c.variants);
-        }
+        if (c.ordering == BA_ORDER_NATURAL) nodes = {all};
+        else if (c.ordering == BA_ORDER_RCM) nodes = {plan_detail::rcm(adj)};
+        else plan_detail::emit_nodes(trees[c.variants == variant_list[0] ? 0 : 1], c.leaf, nodes);
         plan_from_nodes(nc, adj, nodes, c.plan, cm);
         c.plan.ordering = c.ordering;
         c.plan.nd_leaf = c.leaf;
     };
-    if (cands.size() > 2 && nc > 4 * cams_per_panel) {
+    // tasks: -1 / -2 = build tree 0 / 1 (each releases its four candidates), k >= 0 = evaluate candidate k
+    std::vector<int> queue;
+    if (with_nd) queue = {-2, -1};  // (the dissection with several roots per bisection is the longest task: first)
+    for (size_t k = 0; k < nd_first; ++k) queue.push_back((int)k);
+    size_t pending = queue.size() + (with_nd ? 8 : 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    auto worker = [&]() {
+        for (;;) {
+            int task;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return !queue.empty() || pending == 0; });
+                if (queue.empty()) return;
+                task = queue.front();
+                queue.erase(queue.begin());
+            }
+            if (task < 0) build_tree(-task - 1);
+            else evaluate(cands[task]);
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                --pending;
+                if (task < 0)
+                    for (int i = 0; i < 4; ++i) queue.push_back((int)nd_first + 4 * (-task - 1) + i);
+            }
+            cv.notify_all();
+        }
+    };
+    if (with_nd && nc > 4 * cams_per_panel) {
         std::vector<std::thread> th;
-        for (size_t k = 1; k < cands.size(); ++k) th.emplace_back([&, k] { evaluate(cands[k]); });
-        evaluate(cands[0]);
+        for (int k = 0; k < 3; ++k) th.emplace_back(worker);
+        worker();
         for (auto& t : th) t.join();
     } else {
-        for (Cand& c : cands) evaluate(c);
+        worker();
     }
     size_t best = 0;
     for (size_t k = 1; k < cands.size(); ++k)
