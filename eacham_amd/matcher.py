@@ -33,9 +33,19 @@ class HipContext:
             raise capi.EachamError(rc, "eacham_ctx_create failed (no HIP device? the hot path has no CPU fallback)")
         self._h = h
 
+    @classmethod
+    def borrowed(cls, handle):
+        """A view of a context that somebody else owns (a device of an eacham_comm): never destroyed from here."""
+        self = cls.__new__(cls)
+        self._L = capi.lib()
+        self._h = handle
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.eacham_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.eacham_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -26,8 +26,35 @@ def shard_bounds(npairs: int, world: int) -> np.ndarray:
     return np.concatenate([[0], np.cumsum(sizes)])
 
 
-def shard_pairs(pairs: np.ndarray, world: int, rank: int) -> np.ndarray:
-    b = shard_bounds(len(pairs), world)
+def pair_weights(pairs: np.ndarray, rows) -> np.ndarray:
+    """Cost of each pair for the matcher: its distance matrix, rows(f1) * rows(f2) (`rows`: frame id -> row count)."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    r = np.asarray([rows[int(f)] for f in range(int(pairs.max()) + 1)] if len(pairs) else [], dtype=np.int64)
+    return r[pairs[:, 0]] * r[pairs[:, 1]] if len(pairs) else np.zeros(0, np.int64)
+
+
+def shard_bounds_weighted(weights, world: int) -> np.ndarray:
+    """world+1 boundaries of a WORK-balanced contiguous cut (mirror of eacham_shard_bounds_weighted): shard r starts at the
+    smallest k whose prefix weight P[k] satisfies P[k] * world >= r * P[n]. Equal pair counts are the wrong cut for ragged
+    frames (a pair costs rows(f1) * rows(f2)); with equal weights this is the count cut up to rounding."""
+    w = np.asarray(weights, dtype=np.int64)
+    n = len(w)
+    if n == 0 or int(w.sum()) == 0:
+        return shard_bounds(n, world)
+    P = np.concatenate([[0], np.cumsum(w)])
+    W = int(P[-1])
+    b = np.empty(world + 1, dtype=np.int64)
+    k = 0
+    for r in range(world):
+        while k < n and int(P[k]) * world < r * W:
+            k += 1
+        b[r] = k
+    b[world] = n
+    return b
+
+
+def shard_pairs(pairs: np.ndarray, world: int, rank: int, bounds=None) -> np.ndarray:
+    b = shard_bounds(len(pairs), world) if bounds is None else bounds
     return np.ascontiguousarray(pairs[b[rank]:b[rank + 1]])
 
 
@@ -54,10 +81,10 @@ def all_gather_match_graph(counts, edges, shard_cap: int, edge_cap: int, world: 
     return g_counts, g_edges
 
 
-def assemble_match_graph(g_counts: np.ndarray, g_edges: np.ndarray, npairs: int, world: int, shard_cap: int, edge_cap: int):
+def assemble_match_graph(g_counts: np.ndarray, g_edges: np.ndarray, npairs: int, world: int, shard_cap: int, edge_cap: int, bounds=None):
     """Host-side view of the gathered buffers as one CSR over the (ordered) pair list:
-    (counts[npairs], offsets[npairs+1], q, t)."""
-    b = shard_bounds(npairs, world)
+    (counts[npairs], offsets[npairs+1], q, t). `bounds`: the shard boundaries used (default: the equal-count cut)."""
+    b = shard_bounds(npairs, world) if bounds is None else bounds
     g_counts = np.asarray(g_counts).reshape(world, shard_cap)
     g_edges = np.asarray(g_edges).reshape(world, edge_cap, 2)
     counts, qs, ts = [], [], []
@@ -111,6 +138,31 @@ class Comm:
         self._check(self._L.eacham_match_all_pairs_sharded(self.handle, pairs.ctypes.data, n, float(ratio), int(min_dir), int(min_mutual),
                                                            counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total)))
         return counts, offsets, q[: total.value].copy(), t[: total.value].copy()
+
+    def match_run(self, pairs: np.ndarray, ratio: float = 0.8, min_dir: int = 30, min_mutual: int = 30, balance: bool = True) -> int:
+        """eacham_comm_match_run: match + all-gather, the graph stays resident on every device; returns its match count."""
+        C = self._C
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        total = C.c_int64(0)
+        self._check(self._L.eacham_comm_match_run(self.handle, pairs.ctypes.data, len(pairs), float(ratio), int(min_dir), int(min_mutual),
+                                                  int(bool(balance)), C.byref(total)))
+        self._last = pairs
+        return int(total.value)
+
+    def match_fetch(self):
+        """eacham_comm_match_fetch: the graph of the last match_run as (counts, offsets, q, t) in the caller's pair order."""
+        C = self._C
+        n = len(self._last)
+        cap = int(sum(self.rows.get(int(f), 0) for f in self._last[:, 0])) + 1
+        counts = np.zeros(n, np.int32); offsets = np.zeros(n + 1, np.int64)
+        q = np.zeros(cap, np.uint32); t = np.zeros(cap, np.uint32)
+        total = C.c_int64(0)
+        self._check(self._L.eacham_comm_match_fetch(self.handle, counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total)))
+        return counts, offsets, q[: total.value].copy(), t[: total.value].copy()
+
+    def ctx_handle(self, rank: int):
+        """The eacham_ctx of device `rank` (owned by the communicator)."""
+        return self._C.c_void_p(self._L.eacham_comm_ctx(self.handle, int(rank)))
 
     def close(self):
         if self.handle:

@@ -119,6 +119,89 @@ def test_c_abi_assembly_of_gathered_shards_agrees_with_the_python_mirror():
             assert rc == capi.ERR_CAPACITY and total.value == tot_cap
 
 
+def test_weighted_cut_balances_ragged_frames_and_agrees_with_the_c_abi():
+    """eacham_shard_bounds_weighted / shard.shard_bounds_weighted: a pair costs rows(f1) * rows(f2) (apps/sfm/main.cpp:98-109
+    hands every pair to whichever thread is free; a static cut has to weigh them). Ragged frames — 333 .. 1500 rows, some
+    empty — in one job: every shard's work within one pair of the mean, where the equal-count cut is off by tens of per cent."""
+    import ctypes as C
+    from eacham_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    rows = rng.integers(333, 1501, size=60)
+    rows[[7, 31]] = 0                                       # empty frames: zero-weight pairs
+    pairs = shard.order_pairs(synth.all_pairs(60))
+    w = shard.pair_weights(pairs, rows)
+    assert w.dtype == np.int64 and len(w) == len(pairs) and (w[(pairs == 7).any(1)] == 0).all()
+    for world in (1, 2, 3, 8):
+        b = shard.shard_bounds_weighted(w, world)
+        got = np.zeros(world + 1, np.int32)
+        assert L.eacham_shard_bounds_weighted(len(pairs), world, w.ctypes.data, got.ctypes.data) == 0
+        assert np.array_equal(got, b)
+        assert b[0] == 0 and b[-1] == len(pairs) and np.all(np.diff(b) >= 0)
+        work = np.array([w[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert np.abs(work - w.sum() / world).max() <= w.max()             # within one pair of the mean
+        if world == 8:
+            bc = shard.shard_bounds(len(pairs), world)
+            count_work = np.array([w[bc[r]:bc[r + 1]].sum() for r in range(world)])
+            assert count_work.max() / (w.sum() / world) > 1.05 > work.max() / (w.sum() / world)   # what the count cut costs here
+    # no weights / all-zero weights: the equal-count cut; bad input refused
+    got = np.zeros(4, np.int32)
+    assert L.eacham_shard_bounds_weighted(10, 3, None, got.ctypes.data) == 0 and np.array_equal(got, shard.shard_bounds(10, 3))
+    z = np.zeros(10, np.int64)
+    assert L.eacham_shard_bounds_weighted(10, 3, z.ctypes.data, got.ctypes.data) == 0 and np.array_equal(got, shard.shard_bounds(10, 3))
+    assert np.array_equal(shard.shard_bounds_weighted(z, 3), shard.shard_bounds(10, 3))
+    neg = np.array([1, -1, 1], np.int64)
+    assert L.eacham_shard_bounds_weighted(3, 2, neg.ctypes.data, got.ctypes.data) == capi.ERR_INVALID
+    assert L.eacham_shard_bounds_weighted(3, 0, None, got.ctypes.data) == capi.ERR_INVALID
+
+
+def test_assembly_with_explicit_bounds_and_uneven_or_empty_shards():
+    """eacham_assemble_match_graph_bounds on the shards a weighted cut produces — uneven, and EMPTY when there are fewer
+    pairs than ranks — and eacham_comm_edge_region, the sizing rule of the all-gather's send buffers: every rank sends
+    the same number of edge slots (the largest exact total), so every rank's region holds the largest shard bound; a region
+    sized by the rank's own bound (8 bytes for an empty shard) was read out of bounds by the collective (round-3 advice)."""
+    import ctypes as C
+    from eacham_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(13)
+    for npairs, world in [(3, 8), (1, 2), (40, 4), (200, 8)]:
+        pairs = rng.integers(0, 12, size=(npairs, 2)).astype(np.int32)
+        order = np.lexsort((pairs[:, 0], pairs[:, 1])).astype(np.int32)
+        w = rng.integers(1, 1000, size=npairs).astype(np.int64) ** 2
+        b = shard.shard_bounds_weighted(w, world).astype(np.int32)
+        assert npairs >= world or (np.diff(b) == 0).any()                                  # empty shards exist when pairs < ranks
+        counts_sorted = rng.integers(0, 6, size=npairs).astype(np.int32)
+        cap = max(1, int(np.diff(b).max()))
+        edge_cap = max(1, max(int(counts_sorted[b[r]:b[r + 1]].sum()) for r in range(world)))
+        g_counts = np.zeros((world, cap), np.int32)
+        g_edges = rng.integers(0, 1 << 20, size=(world, edge_cap, 2)).astype(np.uint32)
+        for r in range(world):
+            g_counts[r, : b[r + 1] - b[r]] = counts_sorted[b[r]:b[r + 1]]
+        want = shard.assemble_match_graph(g_counts, g_edges.astype(np.int64), npairs, world, cap, edge_cap, bounds=b)
+        counts = np.zeros(npairs, np.int32); offsets = np.zeros(npairs + 1, np.int64)
+        tot_cap = int(counts_sorted.sum())
+        q = np.zeros(max(tot_cap, 1), np.uint32); t = np.zeros(max(tot_cap, 1), np.uint32)
+        total = C.c_int64(-1)
+        rc = L.eacham_assemble_match_graph_bounds(g_counts.ctypes.data, g_edges.ctypes.data, npairs, world, cap, edge_cap, b.ctypes.data,
+                                                  order.ctypes.data, counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data,
+                                                  tot_cap, C.byref(total))
+        assert rc == 0 and total.value == tot_cap
+        for k in range(npairs):
+            p = int(order[k])
+            assert counts[p] == want[0][k]
+            assert np.array_equal(q[offsets[p]:offsets[p + 1]], want[2][want[1][k]:want[1][k + 1]])
+        bad = b.copy(); bad[-1] += 1
+        assert L.eacham_assemble_match_graph_bounds(g_counts.ctypes.data, g_edges.ctypes.data, npairs, world, cap, edge_cap, bad.ctypes.data,
+                                                    order.ctypes.data, counts.ctypes.data, offsets.ctypes.data, q.ctypes.data, t.ctypes.data,
+                                                    tot_cap, C.byref(total)) == capi.ERR_INVALID
+        # the send region of EVERY rank = the largest bound (an empty shard's own bound is 1)
+        bound = np.array([1 + int(counts_sorted[b[r]:b[r + 1]].sum()) * 7 for r in range(world)], np.int64)
+        region = C.c_int64(0)
+        assert L.eacham_comm_edge_region(world, bound.ctypes.data, C.byref(region)) == 0
+        assert region.value == bound.max() >= edge_cap
+    assert L.eacham_comm_edge_region(0, None, C.byref(region)) == capi.ERR_INVALID
+
+
 def test_communicator_needs_a_device():
     import torch
     if torch.cuda.is_available():

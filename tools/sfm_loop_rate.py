@@ -23,8 +23,10 @@ def run(F=100, kpts=600, nl=6000, kobs=10, inlier_px=4.0, debug=False, seed=3):
     exe = os.path.join(tmp, "sfm_loop_driver")
     lib = os.path.join(ROOT, "eacham_amd", "lib")
     cpp = os.path.join(ROOT, "tests", "cpp")
+    t_cc = time.perf_counter()
     subprocess.run(["g++", "-std=c++17", "-O2", *(["-DEACHAM_RECON_DEBUG", "-DEACHAM_GLUE_TIMING"] if debug else []), "-I" + os.path.join(ROOT, "include"), "-I" + cpp,
                     os.path.join(cpp, "sfm_loop_driver.cpp"), "-o", exe, "-L" + lib, "-leacham_hip", "-Wl,-rpath," + lib, "-lpthread"], check=True)
+    compile_s = time.perf_counter() - t_cc   # the host compile of the driver: reported apart from the loop
     fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
     deg = 3.141592 / 180.0
     with open(fin, "wb") as f:
@@ -36,7 +38,7 @@ def run(F=100, kpts=600, nl=6000, kobs=10, inlier_px=4.0, debug=False, seed=3):
     t0 = time.perf_counter()
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=1000)
     dt = time.perf_counter() - t0
-    out = {"frames": F, "kpts": kpts, "landmarks": nl, "returncode": r.returncode, "driver": r.stdout.strip()[-700:], "process_wall_s": round(dt, 2)}
+    out = {"frames": F, "kpts": kpts, "landmarks": nl, "returncode": r.returncode, "driver": r.stdout.strip()[-700:], "process_wall_s": round(dt, 2), "driver_compile_s": round(compile_s, 2)}
     if debug:
         out["stderr"] = r.stderr.strip()[:1500]
     if r.returncode != 0:
