@@ -341,6 +341,7 @@ def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=Tru
     from eacham_amd import ba, capi
 
     arrays = ba.BaArrays.from_scene(scene)
+    ba.PreparedBA(ctx, arrays).close()  # the first construction of a size allocates the context's scratch and arenas: not what is reported
     solver = ba.PreparedBA(ctx, arrays)
     plan = solver.plan_info()
     first = solver.run(cfg)  # warm-up (allocations, code objects)

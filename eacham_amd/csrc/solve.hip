@@ -492,6 +492,399 @@ __device__ static int essential5(const double* p1, const double* p2, const doubl
 }
 
 
+
+/* ---- five-point, one WAVE per sample ---------------------------------------------------------------------------------------
+ * The arithmetic of essential5 / oracle_essential5 entry by entry, spread over the lanes wherever entries are independent:
+ *   null space      the Householder reflections of the 9 x 5 system: a lane per column of Q, a lane per row of P
+ *   constraints     the 10 x 20 matrix: an entry per lane (four rounds), each adding ITS monomial's terms in the order of the
+ *                   sequential triple loop (a table lists, per monomial, the (a, b, c) factor choices that produce it)
+ *   Gauss-Jordan    on one shared copy in LDS: pivot search by every lane (same values), row swap / scale by 20 lanes, the
+ *                   180 eliminated entries of a step over the wave
+ *   det B(z)        every lane, in registers (a few hundred operations on identical values)
+ *   roots           Durand-Kerner in its simultaneous form: root k on lane k, the other iterates by lane shuffles
+ *   x, y, polish    a real root per lane: the 3 Gauss-Newton steps read the assembled constraints from LDS
+ * Nothing is indexed at run time outside LDS: no scratch. A wave's LDS operations execute in program order; the fences only
+ * pin the compiler. */
+struct E5Lds {
+    double A[200], A0[200];  // the constraints as eliminated / as assembled
+    double Q[45], P[81];     // Q^T (9 x 5) and the orthogonal factor
+    double lin[36];          // entry e of E as a linear form in (x, y, z, 1)
+    double poly[11], mon[11];
+    unsigned char term[20][8];  // per monomial: the (a, b, c) choices of mul3acc that produce it, packed a | b << 2 | c << 4, in loop order
+    unsigned char nterm[20];
+};
+
+__device__ __forceinline__ double wave_max_lanes(double v) {  // max over the wave (order-independent)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ static int essential5_wave(const double* p1, const double* p2, const double* K, double* __restrict__ Eout /* global: 10 x 9 */, E5Lds& S) {
+    const int lane = threadIdx.x & 63;
+    // ---- the monomial table (lane 0..19: its own monomial) ----
+    if (lane < 20) {
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ex = (a == 0) + (b == 0) + (c == 0), ey = (a == 1) + (b == 1) + (c == 1), ez = (a == 2) + (b == 2) + (c == 2);
+                    if (mono_col(ex, ey, ez) == lane) S.term[lane][n++] = (unsigned char)(a | (b << 2) | (c << 4));
+                }
+        S.nterm[lane] = (unsigned char)n;
+    }
+    // ---- Q^T ----
+    if (lane < 5) {
+        const int i = lane;
+        double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        if (K) {
+            x1 = (x1 - K[2]) / K[0]; y1 = (y1 - K[3]) / K[1];
+            x2 = (x2 - K[2]) / K[0]; y2 = (y2 - K[3]) / K[1];
+        }
+        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S.Q[k * 5 + i] = row[k];
+    }
+    for (int e = lane; e < 81; e += 64) S.P[e] = (e / 9 == e % 9) ? 1.0 : 0.0;
+    wave_sync_lds();
+    // ---- Householder QR of Q^T: lanes 0..4 own a column of Q, lanes 16..24 a row of P ----
+    for (int k = 0; k < 5; ++k) {
+        double norm = 0.0;
+        for (int r = k; r < 9; ++r) norm += S.Q[r * 5 + k] * S.Q[r * 5 + k];
+        norm = sqrt(norm);
+        if (!(norm > 0.0)) return 0;  // (wave-uniform)
+        double v[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) v[r] = r < k ? 0.0 : S.Q[r * 5 + k];
+        {
+            const double add = S.Q[k * 5 + k] >= 0.0 ? norm : -norm;
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                if (r == k) v[r] += add;
+        }
+        double vv = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+            if (r >= k) vv += v[r] * v[r];
+        if (!(vv > 0.0)) return 0;
+        wave_sync_lds();  // every lane has read column k before anybody rewrites it
+        if (lane < 5 && lane >= k) {  /* Q <- (I - 2 v v^T / vv) Q, column `lane` */
+            const int c = lane;
+            double d = 0.0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                if (r >= k) d += v[r] * S.Q[r * 5 + c];
+            d = 2.0 * d / vv;
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                if (r >= k) S.Q[r * 5 + c] -= d * v[r];
+        }
+        if (lane >= 16 && lane < 25) {  /* P <- P (I - 2 v v^T / vv), row `lane - 16` */
+            const int r = lane - 16;
+            double d = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+                if (c >= k) d += S.P[r * 9 + c] * v[c];
+            d = 2.0 * d / vv;
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+                if (c >= k) S.P[r * 9 + c] -= d * v[c];
+        }
+        wave_sync_lds();
+    }
+    if (lane < 36) S.lin[lane] = S.P[(lane >> 2) * 9 + 5 + (lane & 3)];
+    wave_sync_lds();
+    // ---- the ten cubic constraints: entry (row, col) of the 10 x 20 matrix per lane ----
+    for (int e = lane; e < 200; e += 64) {
+        const int row = e / 20, col = e % 20;
+        const int nt = S.nterm[col];
+        double acc = 0.0;
+        auto mul3 = [&](int e1, int e2, int e3, double sgn) {  // acc += the terms of sgn * l(e1) l(e2) l(e3) that fall on monomial `col`
+            for (int t = 0; t < nt; ++t) {
+                const int tc = S.term[col][t];
+                acc += sgn * (S.lin[4 * e1 + (tc & 3)] * S.lin[4 * e2 + ((tc >> 2) & 3)]) * S.lin[4 * e3 + (tc >> 4)];
+            }
+        };
+        if (row == 0) {  /* det E */
+            const int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+#pragma unroll
+            for (int p = 0; p < 6; ++p) mul3(perm[p][0], 3 + perm[p][1], 6 + perm[p][2], p < 3 ? 1.0 : -1.0);
+        } else {         /* 2 E E^T E - tr(E E^T) E */
+            const int i = (row - 1) / 3, j = (row - 1) % 3;
+            for (int k = 0; k < 3; ++k)
+                for (int l = 0; l < 3; ++l) {
+                    mul3(3 * i + l, 3 * k + l, 3 * k + j, 2.0);
+                    mul3(3 * k + l, 3 * k + l, 3 * i + j, -1.0);
+                }
+        }
+        S.A[e] = acc;
+        S.A0[e] = acc;
+    }
+    wave_sync_lds();
+    // ---- Gauss-Jordan, partial pivoting ----
+    for (int col = 0; col < 10; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 10; ++r)
+            if (fabs(S.A[r * 20 + col]) > fabs(S.A[piv * 20 + col])) piv = r;
+        if (!(fabs(S.A[piv * 20 + col]) > 1e-300)) return 0;  // (wave-uniform)
+        wave_sync_lds();
+        if (piv != col && lane < 20) {
+            const double t = S.A[piv * 20 + lane];
+            S.A[piv * 20 + lane] = S.A[col * 20 + lane];
+            S.A[col * 20 + lane] = t;
+        }
+        wave_sync_lds();
+        const double inv = 1.0 / S.A[col * 20 + col];
+        wave_sync_lds();
+        if (lane < 20) S.A[col * 20 + lane] *= inv;
+        wave_sync_lds();
+        double f[3];
+        int at[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {  // the 9 x 20 entries of the other rows, three per lane: factors first, then the update
+            const int e = lane + 64 * t;
+            int r = e / 20;
+            if (r >= col) ++r;
+            at[t] = e < 180 ? r * 20 + e % 20 : -1;
+            f[t] = e < 180 ? S.A[r * 20 + col] : 0.0;
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (at[t] >= 0 && f[t] != 0.0) S.A[at[t]] -= f[t] * S.A[col * 20 + at[t] % 20];
+        wave_sync_lds();
+    }
+    /* B(z): rows k = e - z f, l = g - z h, m = i - z j; entries = polynomials in z (ascending), degrees 3, 3, 4 */
+    double B[3][3][5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double* e = S.A + (4 + 2 * r) * 20 + 10;
+        const double* f = S.A + (5 + 2 * r) * 20 + 10;
+        B[r][0][0] = e[2];  B[r][0][1] = e[1] - f[2];  B[r][0][2] = e[0] - f[1];  B[r][0][3] = -f[0];  B[r][0][4] = 0.0;
+        B[r][1][0] = e[5];  B[r][1][1] = e[4] - f[5];  B[r][1][2] = e[3] - f[4];  B[r][1][3] = -f[3];  B[r][1][4] = 0.0;
+        B[r][2][0] = e[9];  B[r][2][1] = e[8] - f[9];  B[r][2][2] = e[7] - f[8];  B[r][2][3] = e[6] - f[7];  B[r][2][4] = -f[6];
+    }
+    double poly[11];
+#pragma unroll
+    for (int k = 0; k <= 10; ++k) poly[k] = 0.0;
+#pragma unroll
+    for (int c0 = 0; c0 < 3; ++c0) {  /* cofactor expansion along row 0: columns (c1, c2) of rows 1, 2 */
+        constexpr int cyc[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+        const int c1 = cyc[c0][0], c2 = cyc[c0][1];
+        const int d1 = c1 == 2 ? 4 : 3, d2 = c2 == 2 ? 4 : 3, d0 = c0 == 2 ? 4 : 3;
+        double m1[9], m2[9], minor[9], term[13];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m1[k] = 0.0, m2[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i <= 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= 4; ++j) {
+                if (i <= d1 && j <= d2) m1[i + j] += B[1][c1][i] * B[2][c2][j];
+                if (i <= d2 && j <= d1) m2[i + j] += B[1][c2][i] * B[2][c1][j];
+            }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) minor[k] = k <= d1 + d2 ? m1[k] - m2[k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) term[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i <= 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= 8; ++j)
+                if (i <= d0 && j <= d1 + d2) term[i + j] += B[0][c0][i] * minor[j];
+#pragma unroll
+        for (int k = 0; k <= 10; ++k)
+            if (k <= d0 + d1 + d2) poly[k] += term[k];
+    }
+    // ---- the real roots of poly: Durand-Kerner, root k on lane k ----
+    double cmax = 0.0;
+#pragma unroll
+    for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(poly[k]));
+    if (!(cmax > 0.0)) return 0;
+    if (lane <= 10) {
+#pragma unroll
+        for (int k = 0; k <= 10; ++k)
+            if (k == lane) S.poly[k] = poly[k];
+    }
+    wave_sync_lds();
+    int deg = 10;
+    while (deg > 0 && fabs(S.poly[deg]) <= 1e-14 * cmax) --deg;
+    if (deg == 0) return 0;
+    const double lead = S.poly[deg];
+    if (lane <= deg) S.mon[lane] = S.poly[lane] / lead;  /* monic */
+    wave_sync_lds();
+    double bound = 0.0;
+    for (int k = 0; k < deg; ++k) bound = fmax(bound, fabs(S.mon[k]));
+    bound += 1.0;
+    double zr = 0.0, zi = 0.0;
+    {
+        double r0 = 1.0;
+        const double a0 = fabs(S.mon[0]);
+        if (a0 > 0.0) {
+            double y = a0 > 1.0 ? a0 : 1.0;
+            for (int it = 0; it < 80; ++it) {
+                double yp = 1.0;
+                for (int j = 0; j < deg - 1; ++j) yp *= y;
+                y = ((deg - 1) * y + a0 / yp) / deg;
+            }
+            r0 = y;
+        }
+        r0 = fmin(fmax(r0, 0.5), bound);
+        double cr = 1.0, ci = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            if (k == lane) zr = r0 * cr, zi = r0 * ci;
+            const double tr = cr * 0.4 - ci * 0.9, ti = cr * 0.9 + ci * 0.4;
+            cr = tr, ci = ti;
+        }
+    }
+    const bool mine = lane < deg;
+    for (int it = 0; it < 600; ++it) {
+        double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
+        for (int j = deg - 1; j >= 0; --j) {
+            const double mj = S.mon[j];
+            const double tr = pr * zr - pi * zi + mj, ti = pr * zi + pi * zr;
+            pr = tr, pi = ti;
+        }
+        double dr = 1.0, di = 0.0;
+        for (int j = 0; j < deg; ++j) {
+            const double zrj = __shfl(zr, j), zij = __shfl(zi, j);
+            if (j != lane) {
+                const double ar = zr - zrj, ai = zi - zij;
+                const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+                dr = tr, di = ti;
+            }
+        }
+        const double den = dr * dr + di * di;
+        double ch = 0.0;
+        if (mine && den > 0.0) {
+            const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
+            zr -= qr;
+            zi -= qi;
+            ch = fabs(qr) + fabs(qi);
+        }
+        if (wave_max_lanes(ch) <= 1e-15 * bound) break;
+    }
+    bool real = mine && !(fabs(zi) > 1e-7 * (1.0 + fabs(zr)));
+    double z = zr;
+    if (real)
+        for (int it = 0; it < 4; ++it) {  /* Newton polish on the real polynomial */
+            double p = S.poly[deg], d = 0.0;
+            for (int j = deg - 1; j >= 0; --j) {
+                d = d * z + p;
+                p = p * z + S.poly[j];
+            }
+            if (!(fabs(d) > 0.0)) break;
+            z -= p / d;
+        }
+    // position of this root in the ascending list (the sequential insertion sort is stable)
+    int rank = 0;
+    for (int j = 0; j < deg; ++j) {
+        const double zj = __shfl(z, j);
+        const int rj = __shfl((int)real, j);
+        if (rj && (zj < z || (zj == z && j < lane))) ++rank;
+    }
+    // ---- x, y and the polish, a real root per lane ----
+    bool ok = false;
+    double Ev[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Ev[e] = 0.0;
+    if (real) {
+        double b[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double v = B[i][j][4];
+#pragma unroll
+                for (int k = 3; k >= 0; --k) v = v * z + B[i][j][k];
+                b[i][j] = v;
+            }
+        /* [x y 1]^T spans the null space of b: two of its rows, the pair with the largest 2 x 2 determinant */
+        const double d01 = b[0][0] * b[1][1] - b[0][1] * b[1][0], d02 = b[0][0] * b[2][1] - b[0][1] * b[2][0], d12 = b[1][0] * b[2][1] - b[1][1] * b[2][0];
+        int bp = 0;
+        double bd = 0.0;
+        if (fabs(d01) > fabs(bd)) bd = d01, bp = 0;
+        if (fabs(d02) > fabs(bd)) bd = d02, bp = 1;
+        if (fabs(d12) > fabs(bd)) bd = d12, bp = 2;
+        if (fabs(bd) > 0.0) {
+            double u0[3], u1[3];  // the two rows chosen
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                u0[c] = bp == 2 ? b[1][c] : b[0][c];
+                u1[c] = bp == 0 ? b[1][c] : b[2][c];
+            }
+            double x = (u0[1] * u1[2] - u0[2] * u1[1]) / bd;
+            double y = (u0[2] * u1[0] - u0[0] * u1[2]) / bd;
+            double zz = z;
+            for (int it = 0; it < 3; ++it) {  /* three Gauss-Newton steps on the ten constraints themselves, in (x, y, z) */
+                const double px[4] = {1.0, x, x * x, x * x * x}, py[4] = {1.0, y, y * y, y * y * y}, pz[4] = {1.0, zz, zz * zz, zz * zz * zz};
+                double JtJ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jtr[3] = {0, 0, 0};
+                for (int row = 0; row < 10; ++row) {
+                    double rv = 0.0, g[3] = {0, 0, 0};
+#pragma unroll
+                    for (int ex = 0; ex <= 3; ++ex)
+#pragma unroll
+                        for (int ey = 0; ey <= 3; ++ey)
+#pragma unroll
+                            for (int ez = 0; ez <= 3; ++ez)
+                                if (ex + ey + ez <= 3) {
+                                    const double cf = S.A0[row * 20 + mono_col(ex, ey, ez)];
+                                    rv += cf * (px[ex] * py[ey]) * pz[ez];
+                                    if (ex) g[0] += cf * (ex * px[ex ? ex - 1 : 0] * py[ey]) * pz[ez];
+                                    if (ey) g[1] += cf * (px[ex] * (ey * py[ey ? ey - 1 : 0])) * pz[ez];
+                                    if (ez) g[2] += cf * (px[ex] * py[ey]) * (ez * pz[ez ? ez - 1 : 0]);
+                                }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        Jtr[u] += g[u] * rv;
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) JtJ[u][v] += g[u] * g[v];
+                    }
+                }
+                /* 3 x 3 solve by cofactors */
+                const double c00 = JtJ[1][1] * JtJ[2][2] - JtJ[1][2] * JtJ[2][1], c01 = JtJ[1][2] * JtJ[2][0] - JtJ[1][0] * JtJ[2][2],
+                             c02 = JtJ[1][0] * JtJ[2][1] - JtJ[1][1] * JtJ[2][0];
+                const double dt = JtJ[0][0] * c00 + JtJ[0][1] * c01 + JtJ[0][2] * c02;
+                if (!(fabs(dt) > 0.0)) break;
+                const double c10 = JtJ[0][2] * JtJ[2][1] - JtJ[0][1] * JtJ[2][2], c11 = JtJ[0][0] * JtJ[2][2] - JtJ[0][2] * JtJ[2][0],
+                             c12 = JtJ[0][1] * JtJ[2][0] - JtJ[0][0] * JtJ[2][1];
+                const double c20 = JtJ[0][1] * JtJ[1][2] - JtJ[0][2] * JtJ[1][1], c21 = JtJ[0][2] * JtJ[1][0] - JtJ[0][0] * JtJ[1][2],
+                             c22 = JtJ[0][0] * JtJ[1][1] - JtJ[0][1] * JtJ[1][0];
+                const double dx = (c00 * Jtr[0] + c10 * Jtr[1] + c20 * Jtr[2]) / dt;
+                const double dy = (c01 * Jtr[0] + c11 * Jtr[1] + c21 * Jtr[2]) / dt;
+                const double dz = (c02 * Jtr[0] + c12 * Jtr[1] + c22 * Jtr[2]) / dt;
+                if (!(fabs(dx) + fabs(dy) + fabs(dz) < 1e300)) break;
+                x -= dx, y -= dy, zz -= dz;
+            }
+            double nrm = 0.0;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                Ev[e] = S.lin[4 * e] * x + S.lin[4 * e + 1] * y + S.lin[4 * e + 2] * zz + S.lin[4 * e + 3];
+                nrm += Ev[e] * Ev[e];
+            }
+            nrm = sqrt(nrm);
+            if (nrm > 0.0 && nrm < 1e300) {
+                ok = true;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) Ev[e] = Ev[e] / nrm;
+            }
+        }
+    }
+    // the models leave in ascending root order, the failed ones squeezed out
+    int slot = 0, n = 0;
+    for (int j = 0; j < deg; ++j) {
+        const int okj = __shfl((int)ok, j), rkj = __shfl(rank, j);
+        n += okj;
+        if (okj && rkj < rank) ++slot;
+    }
+    if (ok)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Eout[9 * slot + e] = Ev[e];
+    return n;
+}
+
 /* least squares min |A x - b| for an r x c system (r <= 6, c <= 5), Householder QR on a copy; returns 0 if a column collapses */
 __device__ static int lsq_small(int r, int c, const double* A, const double* b, double* x) {
     double Q[6 * 6];  /* the r x (c + 1) working array [A | b] */

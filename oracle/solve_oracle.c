@@ -185,8 +185,12 @@ static int real_roots10(const double* c, double* roots) {
             cr = tr, ci = ti;
         }
     }
+    /* The simultaneous (Weierstrass) form: every iterate of a sweep is corrected from the iterates the sweep STARTED with, so
+     * the ten corrections are independent of each other — the device solver computes them on ten lanes of a wave
+     * (eacham_amd/csrc/solve.hip) and this restatement defines the same arithmetic. (Until round 4 both used the
+     * Gauss-Seidel form, a correction seeing the corrections before it: one more dependency per root, no better a result.) */
     for (int it = 0; it < 600; ++it) {
-        double change = 0.0;
+        double change = 0.0, nzr[10], nzi[10];
         for (int k = 0; k < deg; ++k) {
             double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
             for (int j = deg - 1; j >= 0; --j) {
@@ -201,12 +205,14 @@ static int real_roots10(const double* c, double* roots) {
                     dr = tr, di = ti;
                 }
             const double den = dr * dr + di * di;
+            nzr[k] = zr[k], nzi[k] = zi[k];
             if (!(den > 0.0)) continue;
             const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
-            zr[k] -= qr;
-            zi[k] -= qi;
+            nzr[k] = zr[k] - qr;
+            nzi[k] = zi[k] - qi;
             change = fmax(change, fabs(qr) + fabs(qi));
         }
+        for (int k = 0; k < deg; ++k) zr[k] = nzr[k], zi[k] = nzi[k];
         if (change <= 1e-15 * bound) break;
     }
     int n = 0;
