@@ -26,22 +26,11 @@
 namespace eacham {
 namespace {
 
-// A thread's large work arrays live in LDS, element e of thread t at arena[e * NT + t] (conflict-free when the lanes of a
-// wave use the same e, which they do outside data-dependent branches): as private arrays they are indexed at run time, i.e.
-// they sit in scratch memory, and a solve is then a chain of ~10^5 dependent scratch round trips (14.7 ms for a five-point
-// sample, 4.2 ms for EPnP, measured) — the arithmetic itself is a few hundred microseconds.
 __device__ __forceinline__ void wave_sync_lds() {  // a wave's own LDS traffic: order its writes before its reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-template <int NT>
-struct PV {
-    double* p;
-    __device__ __forceinline__ double& operator[](int i) const { return p[i * NT]; }
-    __device__ __forceinline__ PV sub(int off) const { return PV{p + off * NT}; }
-};
 
 /* cyclic Jacobi on a symmetric N x N matrix (N <= 12): A is destroyed, V's COLUMNS are the eigenvectors, w the eigenvalues.
  * Small N (3, 4) unrolls completely and stays in registers. */
@@ -100,56 +89,6 @@ __device__ __forceinline__ void jacobi_eig(MA A, MV V, double* w) {
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
 }
 
-/* a: 4 x 2 source points, b: 4 x 2 destination points; H: 9 doubles. Returns 1, or 0 for a degenerate sample. */
-template <class MA>
-__device__ static int homography4(const double* a, const double* b, double* H, MA LtL, MA V) {
-    const int count = 4;
-    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
-    for (int i = 0; i < count; ++i) {
-        cM[0] += a[2 * i]; cM[1] += a[2 * i + 1];
-        cm[0] += b[2 * i]; cm[1] += b[2 * i + 1];
-    }
-    for (int k = 0; k < 2; ++k) cM[k] /= count, cm[k] /= count;
-    for (int i = 0; i < count; ++i)
-        for (int k = 0; k < 2; ++k) {
-            sM[k] += fabs(a[2 * i + k] - cM[k]);
-            sm[k] += fabs(b[2 * i + k] - cm[k]);
-        }
-    for (int k = 0; k < 2; ++k)
-        if (fabs(sM[k]) < 2.220446049250313e-16 || fabs(sm[k]) < 2.220446049250313e-16) return 0;
-    for (int k = 0; k < 2; ++k) sM[k] = count / sM[k], sm[k] = count / sm[k];
-    for (int k = 0; k < 81; ++k) LtL[k] = 0.0;
-    for (int i = 0; i < count; ++i) {
-        const double x = (b[2 * i] - cm[0]) * sm[0], y = (b[2 * i + 1] - cm[1]) * sm[1];
-        const double X = (a[2 * i] - cM[0]) * sM[0], Y = (a[2 * i + 1] - cM[1]) * sM[1];
-        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-        for (int j = 0; j < 9; ++j)
-            for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
-    }
-    for (int j = 0; j < 9; ++j)
-        for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
-    double w[9];
-    jacobi_eig<9>(LtL, V, w);
-    int best = 0;
-    for (int i = 1; i < 9; ++i)
-        if (w[i] < w[best]) best = i;
-    double H0[9];
-    for (int k = 0; k < 9; ++k) H0[k] = V[k * 9 + best];
-    /* H = invHnorm * H0 * Hnorm2, invHnorm = [1/sm.x 0 cm.x; 0 1/sm.y cm.y; 0 0 1], Hnorm2 = [sM.x 0 -cM.x sM.x; 0 sM.y -cM.y sM.y; 0 0 1] */
-    const double inv[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
-    const double n2[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
-    double T[9];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) T[3 * r + c] = inv[3 * r] * H0[c] + inv[3 * r + 1] * H0[3 + c] + inv[3 * r + 2] * H0[6 + c];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) H[3 * r + c] = T[3 * r] * n2[c] + T[3 * r + 1] * n2[3 + c] + T[3 * r + 2] * n2[6 + c];
-    if (!(fabs(H[8]) > 0.0)) return 0;
-    const double s = 1.0 / H[8];
-    for (int k = 0; k < 9; ++k) H[k] *= s;
-    return 1;
-}
-
 /* ---- five-point ---------------------------------------------------------------------------------------------- */
 /* column of the monomial x^ex y^ey z^ez (total degree <= 3) in Nister's elimination order */
 __device__ static int mono_col(int ex, int ey, int ez) {
@@ -159,339 +98,6 @@ __device__ static int mono_col(int ex, int ey, int ez) {
         if (order[k][0] == ex && order[k][1] == ey && order[k][2] == ez) return k;
     return -1;
 }
-/* row += s * l1 l2 l3, each l a linear form {x, y, z, 1} */
-/* (unrolled: the monomial column of every term is then a compile-time constant and `row` can be a register array) */
-__device__ __forceinline__ void mul3acc(const double* l1, const double* l2, const double* l3, double s, double* row) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ex = (a == 0) + (b == 0) + (c == 0), ey = (a == 1) + (b == 1) + (c == 1), ez = (a == 2) + (b == 2) + (c == 2);
-                row[mono_col(ex, ey, ez)] += s * (l1[a] * l2[b]) * l3[c];
-            }
-}
-__device__ static void poly_mul(const double* p, int dp, const double* q, int dq, double* out /* dp + dq + 1 */) {
-    for (int k = 0; k <= dp + dq; ++k) out[k] = 0.0;
-    for (int i = 0; i <= dp; ++i)
-        for (int j = 0; j <= dq; ++j) out[i + j] += p[i] * q[j];
-}
-
-/* real roots of c[0] + c[1] z + ... + c[10] z^10 (ascending), sorted ascending; returns their number */
-__device__ static int real_roots10(const double* c, double* roots) {
-    int deg = 10;
-    double cmax = 0.0;
-    for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(c[k]));
-    if (!(cmax > 0.0)) return 0;
-    while (deg > 0 && fabs(c[deg]) <= 1e-14 * cmax) --deg;
-    if (deg == 0) return 0;
-    double m[11];  /* monic */
-    for (int k = 0; k <= deg; ++k) m[k] = c[k] / c[deg];
-    double bound = 0.0;
-    for (int k = 0; k < deg; ++k) bound = fmax(bound, fabs(m[k]));
-    bound += 1.0;
-    /* Durand-Kerner from the powers of 0.4 + 0.9 i scaled to the geometric mean of the root magnitudes |m0|^(1/deg)
-     * (Newton's iteration for the deg-th root: only + - * /, so that every build computes the same bits) */
-    double zr[10], zi[10];
-    {
-        double r0 = 1.0;
-        const double a0 = fabs(m[0]);
-        if (a0 > 0.0) {
-            double y = a0 > 1.0 ? a0 : 1.0;
-            for (int it = 0; it < 80; ++it) {
-                double yp = 1.0;
-                for (int j = 0; j < deg - 1; ++j) yp *= y;
-                y = ((deg - 1) * y + a0 / yp) / deg;
-            }
-            r0 = y;
-        }
-        r0 = fmin(fmax(r0, 0.5), bound);
-        double cr = 1.0, ci = 0.0;
-        for (int k = 0; k < deg; ++k) {
-            zr[k] = r0 * cr;
-            zi[k] = r0 * ci;
-            const double tr = cr * 0.4 - ci * 0.9, ti = cr * 0.9 + ci * 0.4;
-            cr = tr, ci = ti;
-        }
-    }
-    if (deg == 10) {
-        // the usual case, with every index a compile-time constant: the ten iterates and the coefficients stay in registers
-        // (with run-time indices they are scratch arrays and one sweep is ~200 dependent scratch round trips)
-        double xr[10], xi[10], mm[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) xr[k] = zr[k], xi[k] = zi[k], mm[k] = m[k];
-        for (int it = 0; it < 600; ++it) {
-            double change = 0.0;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                double pr = 1.0, pi = 0.0;
-#pragma unroll
-                for (int j = 9; j >= 0; --j) {
-                    const double tr = pr * xr[k] - pi * xi[k] + mm[j], ti = pr * xi[k] + pi * xr[k];
-                    pr = tr, pi = ti;
-                }
-                double dr = 1.0, di = 0.0;
-#pragma unroll
-                for (int j = 0; j < 10; ++j)
-                    if (j != k) {
-                        const double ar = xr[k] - xr[j], ai = xi[k] - xi[j];
-                        const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
-                        dr = tr, di = ti;
-                    }
-                const double den = dr * dr + di * di;
-                if (den > 0.0) {
-                    const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
-                    xr[k] -= qr;
-                    xi[k] -= qi;
-                    change = fmax(change, fabs(qr) + fabs(qi));
-                }
-            }
-            if (change <= 1e-15 * bound) break;
-        }
-#pragma unroll
-        for (int k = 0; k < 10; ++k) zr[k] = xr[k], zi[k] = xi[k];
-    } else
-    for (int it = 0; it < 600; ++it) {
-        double change = 0.0;
-        for (int k = 0; k < deg; ++k) {
-            double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
-            for (int j = deg - 1; j >= 0; --j) {
-                const double tr = pr * zr[k] - pi * zi[k] + m[j], ti = pr * zi[k] + pi * zr[k];
-                pr = tr, pi = ti;
-            }
-            double dr = 1.0, di = 0.0;
-            for (int j = 0; j < deg; ++j)
-                if (j != k) {
-                    const double ar = zr[k] - zr[j], ai = zi[k] - zi[j];
-                    const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
-                    dr = tr, di = ti;
-                }
-            const double den = dr * dr + di * di;
-            if (!(den > 0.0)) continue;
-            const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
-            zr[k] -= qr;
-            zi[k] -= qi;
-            change = fmax(change, fabs(qr) + fabs(qi));
-        }
-        if (change <= 1e-15 * bound) break;
-    }
-    int n = 0;
-    for (int k = 0; k < deg; ++k) {
-        if (fabs(zi[k]) > 1e-7 * (1.0 + fabs(zr[k]))) continue;
-        double z = zr[k];
-        for (int it = 0; it < 4; ++it) {  /* Newton polish on the real polynomial */
-            double p = c[deg], d = 0.0;
-            for (int j = deg - 1; j >= 0; --j) {
-                d = d * z + p;
-                p = p * z + c[j];
-            }
-            if (!(fabs(d) > 0.0)) break;
-            z -= p / d;
-        }
-        roots[n++] = z;
-    }
-    for (int i = 1; i < n; ++i) {  /* insertion sort */
-        const double v = roots[i];
-        int j = i - 1;
-        while (j >= 0 && roots[j] > v) roots[j + 1] = roots[j], --j;
-        roots[j + 1] = v;
-    }
-    return n;
-}
-
-/* p1, p2: 5 x 2 pixels of view 1 / view 2; K = fx fy cx cy (NULL: already normalised). E: 10 x 9. Returns the number of models. */
-template <class MA>
-__device__ static int essential5(const double* p1, const double* p2, const double* K, double* E, MA A, MA A0) {
-    double Q[9][5];  /* Q^T: column i = the constraint row of correspondence i */
-    for (int i = 0; i < 5; ++i) {
-        double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
-        if (K) {
-            x1 = (x1 - K[2]) / K[0]; y1 = (y1 - K[3]) / K[1];
-            x2 = (x2 - K[2]) / K[0]; y2 = (y2 - K[3]) / K[1];
-        }
-        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
-        for (int k = 0; k < 9; ++k) Q[k][i] = row[k];
-    }
-    /* Householder QR of Q^T (9 x 5): the last four columns of the orthogonal factor span the null space of Q */
-    double P[9][9];
-    for (int r = 0; r < 9; ++r)
-        for (int c = 0; c < 9; ++c) P[r][c] = r == c ? 1.0 : 0.0;
-    for (int k = 0; k < 5; ++k) {
-        double norm = 0.0;
-        for (int r = k; r < 9; ++r) norm += Q[r][k] * Q[r][k];
-        norm = sqrt(norm);
-        if (!(norm > 0.0)) return 0;
-        double v[9];
-        for (int r = 0; r < 9; ++r) v[r] = r < k ? 0.0 : Q[r][k];
-        v[k] += Q[k][k] >= 0.0 ? norm : -norm;
-        double vv = 0.0;
-        for (int r = k; r < 9; ++r) vv += v[r] * v[r];
-        if (!(vv > 0.0)) return 0;
-        for (int c = k; c < 5; ++c) {  /* Q <- (I - 2 v v^T / vv) Q */
-            double d = 0.0;
-            for (int r = k; r < 9; ++r) d += v[r] * Q[r][c];
-            d = 2.0 * d / vv;
-            for (int r = k; r < 9; ++r) Q[r][c] -= d * v[r];
-        }
-        for (int r = 0; r < 9; ++r) {  /* P <- P (I - 2 v v^T / vv) */
-            double d = 0.0;
-            for (int c = k; c < 9; ++c) d += P[r][c] * v[c];
-            d = 2.0 * d / vv;
-            for (int c = k; c < 9; ++c) P[r][c] -= d * v[c];
-        }
-    }
-    double lin[9][4];  /* entry e of E as a linear form in (x, y, z, 1) */
-    for (int e = 0; e < 9; ++e)
-        for (int b = 0; b < 4; ++b) lin[e][b] = P[e][5 + b];
-    {   /* det E */
-        constexpr int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
-        double row[20];
-#pragma unroll
-        for (int c = 0; c < 20; ++c) row[c] = 0.0;
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-            mul3acc(lin[perm[p][0]], lin[3 + perm[p][1]], lin[6 + perm[p][2]], p < 3 ? 1.0 : -1.0, row);
-#pragma unroll
-        for (int c = 0; c < 20; ++c) A[c] = row[c];
-    }
-    for (int i = 0; i < 3; ++i)      /* 2 E E^T E - tr(E E^T) E: a row is accumulated in registers and stored once */
-        for (int j = 0; j < 3; ++j) {
-            double row[20];
-#pragma unroll
-            for (int c = 0; c < 20; ++c) row[c] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int l = 0; l < 3; ++l) {
-                    mul3acc(lin[3 * i + l], lin[3 * k + l], lin[3 * k + j], 2.0, row);
-                    mul3acc(lin[3 * k + l], lin[3 * k + l], lin[3 * i + j], -1.0, row);
-                }
-#pragma unroll
-            for (int c = 0; c < 20; ++c) A[(1 + 3 * i + j) * 20 + c] = row[c];
-        }
-    for (int r = 0; r < 10; ++r)  /* A0: the constraints as assembled, the polish below evaluates them */
-        for (int c = 0; c < 20; ++c) A0[r * 20 + c] = A[r * 20 + c];
-    for (int col = 0; col < 10; ++col) {  /* Gauss-Jordan, partial pivoting */
-        int piv = col;
-        for (int r = col + 1; r < 10; ++r)
-            if (fabs(A[(r) * 20 + col]) > fabs(A[(piv) * 20 + col])) piv = r;
-        if (!(fabs(A[(piv) * 20 + col]) > 1e-300)) return 0;
-        if (piv != col)
-            for (int c = 0; c < 20; ++c) {
-                const double t = A[(piv) * 20 + c];
-                A[(piv) * 20 + c] = A[(col) * 20 + c];
-                A[(col) * 20 + c] = t;
-            }
-        const double inv = 1.0 / A[(col) * 20 + col];
-        for (int c = 0; c < 20; ++c) A[(col) * 20 + c] *= inv;
-        for (int r = 0; r < 10; ++r)
-            if (r != col) {
-                const double f = A[(r) * 20 + col];
-                if (f != 0.0)
-                    for (int c = 0; c < 20; ++c) A[(r) * 20 + c] -= f * A[(col) * 20 + c];
-            }
-    }
-    /* B(z): rows k = e - z f, l = g - z h, m = i - z j; entries = polynomials in z (ascending), degrees 3, 3, 4 */
-    double B[3][3][5];
-    for (int r = 0; r < 3; ++r) {
-        const MA e = A.sub((4 + 2 * r) * 20 + 10);
-        const MA f = A.sub((5 + 2 * r) * 20 + 10);
-        B[r][0][0] = e[2];  B[r][0][1] = e[1] - f[2];  B[r][0][2] = e[0] - f[1];  B[r][0][3] = -f[0];  B[r][0][4] = 0.0;
-        B[r][1][0] = e[5];  B[r][1][1] = e[4] - f[5];  B[r][1][2] = e[3] - f[4];  B[r][1][3] = -f[3];  B[r][1][4] = 0.0;
-        B[r][2][0] = e[9];  B[r][2][1] = e[8] - f[9];  B[r][2][2] = e[7] - f[8];  B[r][2][3] = e[6] - f[7];  B[r][2][4] = -f[6];
-    }
-    double poly[11];
-    for (int k = 0; k <= 10; ++k) poly[k] = 0.0;
-    {
-        constexpr int cyc[3][2] = {{1, 2}, {2, 0}, {0, 1}};  /* cofactor expansion along row 0: columns (c1, c2) of rows 1, 2 */
-        for (int c0 = 0; c0 < 3; ++c0) {
-            const int c1 = cyc[c0][0], c2 = cyc[c0][1];
-            const int d1 = c1 == 2 ? 4 : 3, d2 = c2 == 2 ? 4 : 3, d0 = c0 == 2 ? 4 : 3;
-            double m1[9], m2[9], minor[9], term[13];
-            poly_mul(B[1][c1], d1, B[2][c2], d2, m1);
-            poly_mul(B[1][c2], d2, B[2][c1], d1, m2);
-            for (int k = 0; k <= d1 + d2; ++k) minor[k] = m1[k] - m2[k];
-            poly_mul(B[0][c0], d0, minor, d1 + d2, term);
-            for (int k = 0; k <= d0 + d1 + d2 && k <= 10; ++k) poly[k] += term[k];
-        }
-    }
-    double roots[10];
-    const int nr = real_roots10(poly, roots);
-    int n = 0;
-    for (int r = 0; r < nr; ++r) {
-        const double z = roots[r];
-        double b[3][3];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double v = B[i][j][4];
-                for (int k = 3; k >= 0; --k) v = v * z + B[i][j][k];
-                b[i][j] = v;
-            }
-        /* [x y 1]^T spans the null space of b: two of its rows, the pair with the largest 2 x 2 determinant */
-        constexpr int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-        int bp = 0;
-        double bd = 0.0;
-        for (int p = 0; p < 3; ++p) {
-            const double d = b[pr[p][0]][0] * b[pr[p][1]][1] - b[pr[p][0]][1] * b[pr[p][1]][0];
-            if (fabs(d) > fabs(bd)) bd = d, bp = p;
-        }
-        if (!(fabs(bd) > 0.0)) continue;
-        const int r0 = pr[bp][0], r1 = pr[bp][1];
-        double x = (b[r0][1] * b[r1][2] - b[r0][2] * b[r1][1]) / bd;
-        double y = (b[r0][2] * b[r1][0] - b[r0][0] * b[r1][2]) / bd;
-        double zz = z;
-        /* The root of a degree-10 polynomial carries the conditioning of the whole elimination (1e-4 seen on samples of a
-         * short baseline): three Gauss-Newton steps on the ten constraints themselves, in (x, y, z), bring the solution
-         * back to the accuracy of the input. (five-point.cpp returns the unpolished root.) */
-        for (int it = 0; it < 3; ++it) {
-            const double px[4] = {1.0, x, x * x, x * x * x}, py[4] = {1.0, y, y * y, y * y * y}, pz[4] = {1.0, zz, zz * zz, zz * zz * zz};
-            double JtJ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jtr[3] = {0, 0, 0};
-            for (int row = 0; row < 10; ++row) {
-                double rv = 0.0, g[3] = {0, 0, 0};
-                for (int ex = 0; ex <= 3; ++ex)
-                    for (int ey = 0; ex + ey <= 3; ++ey)
-                        for (int ez = 0; ex + ey + ez <= 3; ++ez) {
-                            const double cf = A0[(row) * 20 + mono_col(ex, ey, ez)];
-                            rv += cf * (px[ex] * py[ey]) * pz[ez];
-                            if (ex) g[0] += cf * (ex * px[ex - 1] * py[ey]) * pz[ez];
-                            if (ey) g[1] += cf * (px[ex] * (ey * py[ey - 1])) * pz[ez];
-                            if (ez) g[2] += cf * (px[ex] * py[ey]) * (ez * pz[ez - 1]);
-                        }
-                for (int u = 0; u < 3; ++u) {
-                    Jtr[u] += g[u] * rv;
-                    for (int v = 0; v < 3; ++v) JtJ[u][v] += g[u] * g[v];
-                }
-            }
-            /* 3 x 3 solve by cofactors */
-            const double c00 = JtJ[1][1] * JtJ[2][2] - JtJ[1][2] * JtJ[2][1], c01 = JtJ[1][2] * JtJ[2][0] - JtJ[1][0] * JtJ[2][2],
-                         c02 = JtJ[1][0] * JtJ[2][1] - JtJ[1][1] * JtJ[2][0];
-            const double dt = JtJ[0][0] * c00 + JtJ[0][1] * c01 + JtJ[0][2] * c02;
-            if (!(fabs(dt) > 0.0)) break;
-            const double c10 = JtJ[0][2] * JtJ[2][1] - JtJ[0][1] * JtJ[2][2], c11 = JtJ[0][0] * JtJ[2][2] - JtJ[0][2] * JtJ[2][0],
-                         c12 = JtJ[0][1] * JtJ[2][0] - JtJ[0][0] * JtJ[2][1];
-            const double c20 = JtJ[0][1] * JtJ[1][2] - JtJ[0][2] * JtJ[1][1], c21 = JtJ[0][2] * JtJ[1][0] - JtJ[0][0] * JtJ[1][2],
-                         c22 = JtJ[0][0] * JtJ[1][1] - JtJ[0][1] * JtJ[1][0];
-            const double dx = (c00 * Jtr[0] + c10 * Jtr[1] + c20 * Jtr[2]) / dt;
-            const double dy = (c01 * Jtr[0] + c11 * Jtr[1] + c21 * Jtr[2]) / dt;
-            const double dz = (c02 * Jtr[0] + c12 * Jtr[1] + c22 * Jtr[2]) / dt;
-            if (!(fabs(dx) + fabs(dy) + fabs(dz) < 1e300)) break;
-            x -= dx, y -= dy, zz -= dz;
-        }
-        double Ev[9], nrm = 0.0;
-        for (int e = 0; e < 9; ++e) {
-            Ev[e] = lin[e][0] * x + lin[e][1] * y + lin[e][2] * zz + lin[e][3];
-            nrm += Ev[e] * Ev[e];
-        }
-        nrm = sqrt(nrm);
-        if (!(nrm > 0.0) || !(nrm < 1e300)) continue;
-        for (int e = 0; e < 9; ++e) E[9 * n + e] = Ev[e] / nrm;
-        ++n;
-    }
-    return n;
-}
-
-
 
 /* ---- five-point, one WAVE per sample ---------------------------------------------------------------------------------------
  * The arithmetic of essential5 / oracle_essential5 entry by entry, spread over the lanes wherever entries are independent:
@@ -510,6 +116,8 @@ struct E5Lds {
     double Q[45], P[81];     // Q^T (9 x 5) and the orthogonal factor
     double lin[36];          // entry e of E as a linear form in (x, y, z, 1)
     double poly[11], mon[11];
+    double B[45];            // B(z): [row][column][power of z]
+    unsigned char mcol[64];     // column of the monomial x^ex y^ey z^ez at [16 ex + 4 ey + ez]
     unsigned char term[20][8];  // per monomial: the (a, b, c) choices of mul3acc that produce it, packed a | b << 2 | c << 4, in loop order
     unsigned char nterm[20];
 };
@@ -520,7 +128,8 @@ __device__ __forceinline__ double wave_max_lanes(double v) {  // max over the wa
     return v;
 }
 
-__device__ static int essential5_wave(const double* p1, const double* p2, const double* K, double* __restrict__ Eout /* global: 10 x 9 */, E5Lds& S) {
+__device__ static int essential5_wave(const double* p1, const double* p2, bool has_K, double fx, double fy, double cx, double cy,
+                                      double* __restrict__ Eout /* global: 10 x 9 */, E5Lds& S) {
     const int lane = threadIdx.x & 63;
     // ---- the monomial table (lane 0..19: its own monomial) ----
     if (lane < 20) {
@@ -536,13 +145,17 @@ __device__ static int essential5_wave(const double* p1, const double* p2, const 
                 }
         S.nterm[lane] = (unsigned char)n;
     }
+    {
+        const int ex = lane >> 4, ey = (lane >> 2) & 3, ez = lane & 3;
+        S.mcol[lane] = ex + ey + ez <= 3 ? (unsigned char)mono_col(ex, ey, ez) : (unsigned char)0;
+    }
     // ---- Q^T ----
     if (lane < 5) {
         const int i = lane;
         double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
-        if (K) {
-            x1 = (x1 - K[2]) / K[0]; y1 = (y1 - K[3]) / K[1];
-            x2 = (x2 - K[2]) / K[0]; y2 = (y2 - K[3]) / K[1];
+        if (has_K) {
+            x1 = (x1 - cx) / fx; y1 = (y1 - cy) / fy;
+            x2 = (x2 - cx) / fx; y2 = (y2 - cy) / fy;
         }
         const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
 #pragma unroll
@@ -657,58 +270,54 @@ __device__ static int essential5_wave(const double* p1, const double* p2, const 
             if (at[t] >= 0 && f[t] != 0.0) S.A[at[t]] -= f[t] * S.A[col * 20 + at[t] % 20];
         wave_sync_lds();
     }
-    /* B(z): rows k = e - z f, l = g - z h, m = i - z j; entries = polynomials in z (ascending), degrees 3, 3, 4 */
-    double B[3][3][5];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    /* B(z): rows k = e - z f, l = g - z h, m = i - z j; entries = polynomials in z (ascending), degrees 3, 3, 4. An entry per lane:
+     * column j of row r reads e[top_j - k] and f[top_j - k + 1] with top = 2, 5, 9 and 3, 3, 4 coefficients of e */
+    if (lane < 45) {
+        const int r = lane / 15, j = (lane % 15) / 5, k = lane % 5;
         const double* e = S.A + (4 + 2 * r) * 20 + 10;
         const double* f = S.A + (5 + 2 * r) * 20 + 10;
-        B[r][0][0] = e[2];  B[r][0][1] = e[1] - f[2];  B[r][0][2] = e[0] - f[1];  B[r][0][3] = -f[0];  B[r][0][4] = 0.0;
-        B[r][1][0] = e[5];  B[r][1][1] = e[4] - f[5];  B[r][1][2] = e[3] - f[4];  B[r][1][3] = -f[3];  B[r][1][4] = 0.0;
-        B[r][2][0] = e[9];  B[r][2][1] = e[8] - f[9];  B[r][2][2] = e[7] - f[8];  B[r][2][3] = e[6] - f[7];  B[r][2][4] = -f[6];
-    }
-    double poly[11];
-#pragma unroll
-    for (int k = 0; k <= 10; ++k) poly[k] = 0.0;
-#pragma unroll
-    for (int c0 = 0; c0 < 3; ++c0) {  /* cofactor expansion along row 0: columns (c1, c2) of rows 1, 2 */
-        constexpr int cyc[3][2] = {{1, 2}, {2, 0}, {0, 1}};
-        const int c1 = cyc[c0][0], c2 = cyc[c0][1];
-        const int d1 = c1 == 2 ? 4 : 3, d2 = c2 == 2 ? 4 : 3, d0 = c0 == 2 ? 4 : 3;
-        double m1[9], m2[9], minor[9], term[13];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) m1[k] = 0.0, m2[k] = 0.0;
-#pragma unroll
-        for (int i = 0; i <= 4; ++i)
-#pragma unroll
-            for (int j = 0; j <= 4; ++j) {
-                if (i <= d1 && j <= d2) m1[i + j] += B[1][c1][i] * B[2][c2][j];
-                if (i <= d2 && j <= d1) m2[i + j] += B[1][c2][i] * B[2][c1][j];
-            }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) minor[k] = k <= d1 + d2 ? m1[k] - m2[k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 13; ++k) term[k] = 0.0;
-#pragma unroll
-        for (int i = 0; i <= 4; ++i)
-#pragma unroll
-            for (int j = 0; j <= 8; ++j)
-                if (i <= d0 && j <= d1 + d2) term[i + j] += B[0][c0][i] * minor[j];
-#pragma unroll
-        for (int k = 0; k <= 10; ++k)
-            if (k <= d0 + d1 + d2) poly[k] += term[k];
-    }
-    // ---- the real roots of poly: Durand-Kerner, root k on lane k ----
-    double cmax = 0.0;
-#pragma unroll
-    for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(poly[k]));
-    if (!(cmax > 0.0)) return 0;
-    if (lane <= 10) {
-#pragma unroll
-        for (int k = 0; k <= 10; ++k)
-            if (k == lane) S.poly[k] = poly[k];
+        const int top = j == 0 ? 2 : (j == 1 ? 5 : 9), ne = j == 2 ? 4 : 3;
+        double v;
+        if (k == 0) v = e[top];
+        else if (k < ne) v = e[top - k] - f[top - k + 1];
+        else if (k == ne) v = -f[top - k + 1];
+        else v = 0.0;
+        S.B[lane] = v;
     }
     wave_sync_lds();
+    /* det B(z) by cofactor expansion along row 0, coefficient k on lane k: for every coefficient the products enter in the order the
+     * sequential polynomial multiplications add them (first factor's power ascending) */
+    if (lane <= 10) {
+        const int k = lane;
+        double pk = 0.0;
+        for (int c0 = 0; c0 < 3; ++c0) {
+            const int c1 = c0 == 0 ? 1 : (c0 == 1 ? 2 : 0), c2 = c0 == 0 ? 2 : (c0 == 1 ? 0 : 1);
+            const int d1 = c1 == 2 ? 4 : 3, d2 = c2 == 2 ? 4 : 3, d0 = c0 == 2 ? 4 : 3;
+            if (k > d0 + d1 + d2) continue;
+            double tk = 0.0;  /* term[k] = sum_i B[0][c0][i] * minor[k - i] */
+            for (int i = 0; i <= d0; ++i) {
+                const int j = k - i;
+                if (j < 0 || j > d1 + d2) continue;
+                double m1 = 0.0, m2 = 0.0;  /* minor[j] = (B[1][c1] B[2][c2] - B[1][c2] B[2][c1])[j] */
+                for (int a = 0; a <= d1; ++a) {
+                    const int b = j - a;
+                    if (b >= 0 && b <= d2) m1 += S.B[15 + 5 * c1 + a] * S.B[30 + 5 * c2 + b];
+                }
+                for (int a = 0; a <= d2; ++a) {
+                    const int b = j - a;
+                    if (b >= 0 && b <= d1) m2 += S.B[15 + 5 * c2 + a] * S.B[30 + 5 * c1 + b];
+                }
+                tk += S.B[5 * c0 + i] * (m1 - m2);
+            }
+            pk += tk;
+        }
+        S.poly[k] = pk;
+    }
+    wave_sync_lds();
+    // ---- the real roots of poly: Durand-Kerner, root k on lane k ----
+    double cmax = 0.0;
+    for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(S.poly[k]));
+    if (!(cmax > 0.0)) return 0;
     int deg = 10;
     while (deg > 0 && fabs(S.poly[deg]) <= 1e-14 * cmax) --deg;
     if (deg == 0) return 0;
@@ -796,9 +405,9 @@ __device__ static int essential5_wave(const double* p1, const double* p2, const 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                double v = B[i][j][4];
+                double v = S.B[15 * i + 5 * j + 4];
 #pragma unroll
-                for (int k = 3; k >= 0; --k) v = v * z + B[i][j][k];
+                for (int k = 3; k >= 0; --k) v = v * z + S.B[15 * i + 5 * j + k];
                 b[i][j] = v;
             }
         /* [x y 1]^T spans the null space of b: two of its rows, the pair with the largest 2 x 2 determinant */
@@ -819,23 +428,28 @@ __device__ static int essential5_wave(const double* p1, const double* p2, const 
             double y = (u0[2] * u1[0] - u0[0] * u1[2]) / bd;
             double zz = z;
             for (int it = 0; it < 3; ++it) {  /* three Gauss-Newton steps on the ten constraints themselves, in (x, y, z) */
-                const double px[4] = {1.0, x, x * x, x * x * x}, py[4] = {1.0, y, y * y, y * y * y}, pz[4] = {1.0, zz, zz * zz, zz * zz * zz};
+                // (rolled loops and powers by selection: unrolled, the 20 monomials and their derivatives are ~100 live registers
+                // per lane and the kernel spills; the monomial's column comes from a 64-byte table)
+                const double x2 = x * x, x3 = x * x * x, y2 = y * y, y3 = y * y * y, z2 = zz * zz, z3 = zz * zz * zz;
+                auto pw = [](double v1, double v2, double v3, int e) { return e == 0 ? 1.0 : (e == 1 ? v1 : (e == 2 ? v2 : v3)); };
                 double JtJ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jtr[3] = {0, 0, 0};
+#pragma clang loop unroll(disable)
                 for (int row = 0; row < 10; ++row) {
-                    double rv = 0.0, g[3] = {0, 0, 0};
-#pragma unroll
+                    double rv = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma clang loop unroll(disable)
                     for (int ex = 0; ex <= 3; ++ex)
-#pragma unroll
-                        for (int ey = 0; ey <= 3; ++ey)
-#pragma unroll
-                            for (int ez = 0; ez <= 3; ++ez)
-                                if (ex + ey + ez <= 3) {
-                                    const double cf = S.A0[row * 20 + mono_col(ex, ey, ez)];
-                                    rv += cf * (px[ex] * py[ey]) * pz[ez];
-                                    if (ex) g[0] += cf * (ex * px[ex ? ex - 1 : 0] * py[ey]) * pz[ez];
-                                    if (ey) g[1] += cf * (px[ex] * (ey * py[ey ? ey - 1 : 0])) * pz[ez];
-                                    if (ez) g[2] += cf * (px[ex] * py[ey]) * (ez * pz[ez ? ez - 1 : 0]);
-                                }
+#pragma clang loop unroll(disable)
+                        for (int ey = 0; ex + ey <= 3; ++ey)
+#pragma clang loop unroll(disable)
+                            for (int ez = 0; ex + ey + ez <= 3; ++ez) {
+                                const double cf = S.A0[row * 20 + S.mcol[16 * ex + 4 * ey + ez]];
+                                const double pxe = pw(x, x2, x3, ex), pye = pw(y, y2, y3, ey), pze = pw(zz, z2, z3, ez);
+                                rv += cf * (pxe * pye) * pze;
+                                if (ex) g0 += cf * (ex * pw(x, x2, x3, ex - 1) * pye) * pze;
+                                if (ey) g1 += cf * (pxe * (ey * pw(y, y2, y3, ey - 1))) * pze;
+                                if (ez) g2 += cf * (pxe * pye) * (ez * pw(zz, z2, z3, ez - 1));
+                            }
+                    const double g[3] = {g0, g1, g2};
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
                         Jtr[u] += g[u] * rv;
@@ -885,46 +499,9 @@ __device__ static int essential5_wave(const double* p1, const double* p2, const 
     return n;
 }
 
-/* least squares min |A x - b| for an r x c system (r <= 6, c <= 5), Householder QR on a copy; returns 0 if a column collapses */
-__device__ static int lsq_small(int r, int c, const double* A, const double* b, double* x) {
-    double Q[6 * 6];  /* the r x (c + 1) working array [A | b] */
-    for (int i = 0; i < r; ++i) {
-        for (int j = 0; j < c; ++j) Q[i * 6 + j] = A[i * c + j];
-        Q[i * 6 + c] = b[i];
-    }
-    for (int j = 0; j < c; ++j) {
-        double nrm = 0.0;
-        for (int i = j; i < r; ++i) nrm += Q[i * 6 + j] * Q[i * 6 + j];
-        nrm = sqrt(nrm);
-        if (!(nrm > 0.0)) return 0;
-        const double alpha = Q[j * 6 + j] > 0.0 ? -nrm : nrm;
-        double v[6];
-        for (int i = j; i < r; ++i) v[i] = Q[i * 6 + j];
-        v[j] -= alpha;
-        double vv = 0.0;
-        for (int i = j; i < r; ++i) vv += v[i] * v[i];
-        if (!(vv > 0.0)) return 0;
-        for (int k = j; k <= c; ++k) {
-            double d = 0.0;
-            for (int i = j; i < r; ++i) d += v[i] * Q[i * 6 + k];
-            d = 2.0 * d / vv;
-            for (int i = j; i < r; ++i) Q[i * 6 + k] -= d * v[i];
-        }
-        Q[j * 6 + j] = alpha;
-    }
-    for (int j = c - 1; j >= 0; --j) {
-        double s = Q[j * 6 + c];
-        for (int k = j + 1; k < c; ++k) s -= Q[j * 6 + k] * x[k];
-        x[j] = s / Q[j * 6 + j];
-    }
-    for (int j = 0; j < c; ++j)
-        if (!(fabs(x[j]) < 1e300)) return 0;
-    return 1;
-}
-
-/* lsq_small for 6 rows and a compile-time number of columns, every loop unrolled: the working array and the callers' matrices stay in
- * registers (as run-time-indexed arrays they are scratch memory, and the eighteen small solves of a sample were most of EPnP's
- * 1.2 ms). Same operations in the same order as lsq_small(6, C, ...). */
+/* least squares min |A x - b| for a 6 x C system (C <= 5), Householder QR on a copy, every loop unrolled: the working array and the
+ * callers' matrices stay in registers (as run-time-indexed arrays they are scratch memory). Returns 0 if a column collapses. Same
+ * operations in the same order as lsq_small(6, C, ...) of oracle/solve_oracle.c. */
 template <int C>
 __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x) {
     constexpr int r = 6, c = C;
@@ -975,28 +552,14 @@ __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x)
     return 1;
 }
 
-/* EPnP (Lepetit, Moreno-Noguer, Fua 2009) on the m >= 4 points idx[0..m) of obj (n x 3) / img (n x 2), K = fx fy cx cy.
- * Rt = R (row-major) | t of x_cam = R X + t. Every pass over the points recomputes the barycentric coordinates, so the
- * working set does not grow with m (the RANSAC kernel calls it with m = 5, the final refit with all inliers).
- * Returns 1, or 0 for a degenerate point set (coplanar / coincident points: the 4-control-point form needs volume). */
-// Sum of one value per lane in LANE ORDER, ((v0 + v1) + v2) + ... + v63, returned to every lane. With at most 64 points (one
-// per lane, the others 0) this is the sequential sum over the points, bit for bit: the one-thread-per-sample form below.
-__device__ __forceinline__ double ordered_wave_sum(double v, double* red) {
-    red[threadIdx.x] = v;
-    wave_sync_lds();
-    double t = red[0];
-    for (int l = 1; l < 64; ++l) t += red[l];
-    wave_sync_lds();
-    return t;
-}
-
-// The 12 x 12 eigenproblem by ONE WAVE on one shared copy of A and V: the three loops of a rotation (columns p, q; rows p, q; V) run
-// over their index k on the lanes 0..11, every lane forms the rotation itself from the same three entries. Element by element the
-// arithmetic is that of jacobi_eig<12> (a rotation's loop iterations are independent), so the result is the same bits; the rotations
+// The N x N eigenproblem (N = 9, 12) by ONE WAVE on one shared copy of A and V: the three loops of a rotation (columns p, q; rows p, q; V)
+// run over their index k on the lanes 0..N-1, every lane forms the rotation itself from the same three entries. Element by element the
+// arithmetic is that of jacobi_eig<N> (a rotation's loop iterations are independent), so the result is the same bits; the rotations
 // stay in their cyclic order. A wave's LDS operations execute in program order: the barriers only pin the compiler.
 // (One thread walking these loops was two thirds of an EPnP solve: 0.73 of 1.1 ms, measured with a one-sweep build.)
-__device__ __forceinline__ void jacobi12_wave(double* A, double* V, double* w) {
-    constexpr int n = 12;
+template <int N>
+__device__ __forceinline__ void jacobi_wave(double* A, double* V, double* w) {
+    constexpr int n = N;
     const int k = threadIdx.x & 63;
     for (int e = k; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     wave_sync_lds();
@@ -1035,107 +598,268 @@ __device__ __forceinline__ void jacobi12_wave(double* A, double* V, double* w) {
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
 }
 
-// WAVE = false: one thread solves the sample (the RANSAC kernel: thousands of 5-point samples). WAVE = true: one wave solves it
-// — lane l accumulates the points l, l + 64, ... of every pass over the points, the 64 partial sums are added in lane order, and
-// every lane then runs the small dense algebra on identical values (the all-inlier refit: one sample of thousands of points,
-// 5.2 ms on one thread). The CPU restatement defines the sums the same way (64 strided partials when m > 64), so both
-// forms agree with it bit for bit.
-template <bool WAVE, class MA>
-__device__ static int epnp_solve(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt, MA MtM, MA V, double* red,
-                                 double* jac /* WAVE: 2 x 144 doubles shared by the wave */) {
-    if (m < 4) return 0;
-    const int kfirst = WAVE ? (int)threadIdx.x : 0, kstep = WAVE ? 64 : 1;
-    auto total = [&](double v) { return WAVE ? ordered_wave_sum(v, red) : v; };
+/* homography4 by one wave: L^T L (shared, an upper-triangle entry per lane, the four points added in order), the 9 x 9 eigenproblem by
+ * jacobi_wave, the rest on identical values in every lane. a, b: this sample's 4 x 2 points. Returns 1 / 0; H (9) valid in every lane. */
+__device__ static int homography4_wave(const double* a, const double* b, double* H, double* LtL /* 81 */, double* V /* 81 */) {
+    const int lane = threadIdx.x & 63;
+    const int count = 4;
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < count; ++i) {
+        cM[0] += a[2 * i]; cM[1] += a[2 * i + 1];
+        cm[0] += b[2 * i]; cm[1] += b[2 * i + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) cM[k] /= count, cm[k] /= count;
+#pragma unroll
+    for (int i = 0; i < count; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            sM[k] += fabs(a[2 * i + k] - cM[k]);
+            sm[k] += fabs(b[2 * i + k] - cm[k]);
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (fabs(sM[k]) < 2.220446049250313e-16 || fabs(sm[k]) < 2.220446049250313e-16) return 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) sM[k] = count / sM[k], sm[k] = count / sm[k];
+    for (int e = lane; e < 81; e += 64) {
+        const int j = e / 9, k = e % 9;
+        if (k < j) continue;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < count; ++i) {
+            const double x = (b[2 * i] - cm[0]) * sm[0], y = (b[2 * i + 1] - cm[1]) * sm[1];
+            const double X = (a[2 * i] - cM[0]) * sM[0], Y = (a[2 * i + 1] - cM[1]) * sM[1];
+            const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+            const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+            double lxj = 0, lxk = 0, lyj = 0, lyk = 0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                if (q == j) lxj = Lx[q], lyj = Ly[q];
+                if (q == k) lxk = Lx[q], lyk = Ly[q];
+            }
+            acc += lxj * lxk + lyj * lyk;
+        }
+        LtL[j * 9 + k] = acc;
+        LtL[k * 9 + j] = acc;
+    }
+    wave_sync_lds();
+    double w[9];
+    jacobi_wave<9>(LtL, V, w);
+    int best = 0;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        double wb = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            if (q == best) wb = w[q];
+        if (w[i] < wb) best = i;
+    }
+    double H0[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H0[k] = V[k * 9 + best];
+    const double inv[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double n2[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double T[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[3 * r + c] = inv[3 * r] * H0[c] + inv[3 * r + 1] * H0[3 + c] + inv[3 * r + 2] * H0[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) H[3 * r + c] = T[3 * r] * n2[c] + T[3 * r + 1] * n2[3 + c] + T[3 * r + 2] * n2[6 + c];
+    if (!(fabs(H[8]) > 0.0)) return 0;
+    const double s = 1.0 / H[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H[k] *= s;
+    return 1;
+}
+
+// EPnP by one wave. Lane l accumulates the points l, l + 64, ... of every pass over the points; the partial sums are added in
+// lane order — for at most 64 points that is the sequential sum over the points, bit for bit, and the CPU restatement defines the
+// sums of more than 64 points the same way (64 strided partials) — and the small dense algebra then runs on identical values in
+// every lane, with everything that is indexed at run time (M^T M, its eigenvectors, the 6 x 10 distance system) in one SHARED
+// copy in LDS. BIG = false: samples of at most 64 points (the RANSAC loop's 5-point samples: a point per lane, its two rows
+// of the projection system parked in LDS, an entry of M^T M per lane) — 16 KB of LDS per wave, ten waves per CU; BIG = true: the
+// all-inlier refit, any number of points, a private partial M^T M per lane (40 KB).
+struct PnpLds {
+    double red[64];
+    double A[144], V[144];   // M^T M and its eigenvectors
+    double ev[48], L[60];    // the four null vectors, the distance system
+};
+
+// sum of one value per lane in LANE ORDER over the first `terms` lanes, ((v0 + v1) + v2) + ..., returned to every lane
+__device__ __forceinline__ double ordered_wave_sum(double v, double* red, int terms) {
+    red[threadIdx.x & 63] = v;
+    wave_sync_lds();
+    double t = red[0];
+    for (int l = 1; l < terms; ++l) t += red[l];
+    wave_sync_lds();
+    return t;
+}
+
+template <bool BIG>
+__device__ static int epnp_wave(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt, PnpLds& S,
+                                double* rows /* !BIG: 64 x 24 */, double* part /* BIG: 78 x 64 */) {
+    if (m < 4 || (!BIG && m > 64)) return 0;
+    const int lane = threadIdx.x & 63;
+    const int terms = m < 64 ? m : 64;  // lanes that hold a partial sum
+    auto total = [&](double v) { return ordered_wave_sum(v, S.red, terms); };
     const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
     /* control points: centroid + principal axes scaled by the spread along them */
     double c0[3] = {0, 0, 0};
-    for (int k = kfirst; k < m; k += kstep)
+    for (int k = lane; k < m; k += 64)
+#pragma unroll
         for (int e = 0; e < 3; ++e) c0[e] += obj[3 * (size_t)idx[k] + e];
+#pragma unroll
     for (int e = 0; e < 3; ++e) c0[e] = total(c0[e]) / (double)m;
     double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9], w3[3];
-    for (int k = kfirst; k < m; k += kstep) {
+    for (int k = lane; k < m; k += 64) {
         double d[3];
+#pragma unroll
         for (int e = 0; e < 3; ++e) d[e] = obj[3 * (size_t)idx[k] + e] - c0[e];
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j) C[3 * i + j] += d[i] * d[j];
     }
+#pragma unroll
     for (int i = 0; i < 9; ++i) C[i] = total(C[i]);
     jacobi_eig<3>(C, V3, w3);
     double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
     wmax = wmax > w3[2] ? wmax : w3[2];
     double ax[3][3], sc[3];  /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (!(w3[k] > 1e-12 * wmax) || !(wmax > 0.0)) return 0;
         sc[k] = sqrt(w3[k] / (double)m);
+#pragma unroll
         for (int e = 0; e < 3; ++e) ax[k][e] = V3[3 * e + k];
     }
 #define EPNP_ALPHAS(i, al)                                                                        \
     {                                                                                             \
         double d_[3];                                                                             \
-        for (int e_ = 0; e_ < 3; ++e_) d_[e_] = obj[3 * (size_t)(i) + e_] - c0[e_];               \
-        for (int k_ = 0; k_ < 3; ++k_) (al)[k_ + 1] = (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
+        _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) d_[e_] = obj[3 * (size_t)(i) + e_] - c0[e_];               \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) (al)[k_ + 1] = (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
         (al)[0] = 1.0 - (al)[1] - (al)[2] - (al)[3];                                              \
     }
     /* M^T M of the 2m x 12 projection system  sum_j alpha_j (fu Xc_j + (uc - u) Zc_j) = 0, same with v */
-    double w[12];
-    for (int i = 0; i < 144; ++i) MtM[i] = 0.0;
-    for (int k = kfirst; k < m; k += kstep) {
-        double al[4], r1[12], r2[12];
-        EPNP_ALPHAS(idx[k], al);
-        const double du = uc - img[2 * (size_t)idx[k]], dv = vc - img[2 * (size_t)idx[k] + 1];
-        for (int j = 0; j < 4; ++j) {
-            r1[3 * j] = al[j] * fu, r1[3 * j + 1] = 0.0, r1[3 * j + 2] = al[j] * du;
-            r2[3 * j] = 0.0, r2[3 * j + 1] = al[j] * fv, r2[3 * j + 2] = al[j] * dv;
+    if constexpr (!BIG) {
+        if (lane < m) {  // this lane's point: its two rows
+            double al[4];
+            EPNP_ALPHAS(idx[lane], al);
+            const double du = uc - img[2 * (size_t)idx[lane]], dv = vc - img[2 * (size_t)idx[lane] + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rows[24 * lane + 3 * j] = al[j] * fu, rows[24 * lane + 3 * j + 1] = 0.0, rows[24 * lane + 3 * j + 2] = al[j] * du;
+                rows[24 * lane + 12 + 3 * j] = 0.0, rows[24 * lane + 12 + 3 * j + 1] = al[j] * fv, rows[24 * lane + 12 + 3 * j + 2] = al[j] * dv;
+            }
         }
-        for (int i = 0; i < 12; ++i)
-            for (int j = i; j < 12; ++j) MtM[12 * i + j] += r1[i] * r1[j] + r2[i] * r2[j];
-    }
-    if (WAVE)
-        for (int i = 0; i < 12; ++i)
-            for (int j = i; j < 12; ++j) MtM[12 * i + j] = total(MtM[12 * i + j]);
-    for (int i = 0; i < 12; ++i)
-        for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
-    if (WAVE) {   // every lane holds the same M^T M: one shared copy, the eigenproblem by the whole wave, V back into the lane's array
-        for (int e = (int)threadIdx.x; e < 144; e += 64) jac[e] = MtM[e];
         wave_sync_lds();
-        jacobi12_wave(jac, jac + 144, w);
-        for (int e = 0; e < 144; ++e) V[e] = jac[144 + e];
+        for (int e = lane; e < 144; e += 64) {  // an entry per lane: the points in order, as the sequential loop adds them
+            const int i = e / 12, j = e % 12;
+            if (j < i) continue;
+            double acc = 0.0;
+            for (int k = 0; k < m; ++k) acc += rows[24 * k + i] * rows[24 * k + j] + rows[24 * k + 12 + i] * rows[24 * k + 12 + j];
+            S.A[12 * i + j] = acc;
+            S.A[12 * j + i] = acc;
+        }
+        wave_sync_lds();
     } else {
-        jacobi_eig<12>(MtM, V, w);
+        for (int e = 0; e < 78; ++e) part[64 * e + lane] = 0.0;
+        for (int k = lane; k < m; k += 64) {
+            double al[4], r1[12], r2[12];
+            EPNP_ALPHAS(idx[k], al);
+            const double du = uc - img[2 * (size_t)idx[k]], dv = vc - img[2 * (size_t)idx[k] + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r1[3 * j] = al[j] * fu, r1[3 * j + 1] = 0.0, r1[3 * j + 2] = al[j] * du;
+                r2[3 * j] = 0.0, r2[3 * j + 1] = al[j] * fv, r2[3 * j + 2] = al[j] * dv;
+            }
+            int e = 0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+#pragma unroll
+                for (int j = i; j < 12; ++j, ++e) part[64 * e + lane] += r1[i] * r1[j] + r2[i] * r2[j];
+        }
+        wave_sync_lds();
+        for (int e = lane; e < 78; e += 64) {  // entry e of the upper triangle: the 64 partials in lane order
+            double t = part[64 * e];
+            for (int l = 1; l < 64; ++l) t += part[64 * e + l];
+            int i = 0, rem = e;
+            while (rem >= 12 - i) rem -= 12 - i, ++i;
+            const int j = i + rem;
+            S.A[12 * i + j] = t;
+            S.A[12 * j + i] = t;
+        }
+        wave_sync_lds();
     }
+    double w[12];
+    jacobi_wave<12>(S.A, S.V, w);
     int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         int best = -1;
+        double wbest = 0.0;
+#pragma unroll
         for (int i = 0; i < 12; ++i) {
-            int used = 0;
-            for (int q = 0; q < k; ++q) used |= ord[q] == i;
-            if (!used && (best < 0 || w[i] < w[best])) best = i;
+            bool used = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < k) used |= ord[q] == i;
+            if (!used && (best < 0 || w[i] < wbest)) best = i, wbest = w[i];
         }
         ord[k] = best;
     }
-    double ev[4][12];
-    for (int k = 0; k < 4; ++k)
-        for (int i = 0; i < 12; ++i) ev[k][i] = V[12 * i + ord[k]];
+    // ev[k][i] = V[12 i + ord[k]]: the shared copy, an element per lane
+    if (lane < 48) {
+        const int k = lane / 12, i = lane % 12;
+        int o = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q == k) o = ord[q];
+        S.ev[12 * k + i] = S.V[12 * i + o];
+    }
+    wave_sync_lds();
     /* the six control-point distance constraints, quadratic in beta: L (6 x 10) over [b00 b01 b11 b02 b12 b22 b03 b13 b23 b33] */
-    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
     double cw[4][3];
+#pragma unroll
     for (int e = 0; e < 3; ++e) {
         cw[0][e] = c0[e];
+#pragma unroll
         for (int k = 0; k < 3; ++k) cw[k + 1][e] = c0[e] + sc[k] * ax[k][e];
     }
-    double L[6][10], rho[6];
-    for (int p = 0; p < 6; ++p) {
-        double dv[4][3];
-        for (int k = 0; k < 4; ++k)
-            for (int e = 0; e < 3; ++e) dv[k][e] = ev[k][3 * pa[p] + e] - ev[k][3 * pb[p] + e];
-        int col = 0;
-        for (int j = 0; j < 4; ++j)
-            for (int i = 0; i <= j; ++i) {
-                const double d = dv[i][0] * dv[j][0] + dv[i][1] * dv[j][1] + dv[i][2] * dv[j][2];
-                L[p][col++] = i == j ? d : 2.0 * d;
+    double rho[6];
+    {
+        constexpr int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+        if (lane < 60) {  // entry (p, col) of L per lane
+            const int p = lane / 10, col = lane % 10;
+            int i = 0, j = 0, cc = 0;
+            for (int jj = 0; jj < 4; ++jj)
+                for (int ii = 0; ii <= jj; ++ii, ++cc)
+                    if (cc == col) i = ii, j = jj;
+            int a_ = 0, b_ = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (q == p) a_ = pa[q], b_ = pb[q];
+            double di[3], dj[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                di[e] = S.ev[12 * i + 3 * a_ + e] - S.ev[12 * i + 3 * b_ + e];
+                dj[e] = S.ev[12 * j + 3 * a_ + e] - S.ev[12 * j + 3 * b_ + e];
             }
-        rho[p] = 0.0;
-        for (int e = 0; e < 3; ++e) rho[p] += (cw[pa[p]][e] - cw[pb[p]][e]) * (cw[pa[p]][e] - cw[pb[p]][e]);
+            const double d = di[0] * dj[0] + di[1] * dj[1] + di[2] * dj[2];
+            S.L[10 * p + col] = i == j ? d : 2.0 * d;
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            rho[p] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) rho[p] += (cw[pa[p]][e] - cw[pb[p]][e]) * (cw[pa[p]][e] - cw[pb[p]][e]);
+        }
+        wave_sync_lds();
     }
     double best_err = -1.0;
 #pragma unroll
@@ -1148,13 +872,14 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         for (int p = 0; p < 6; ++p)
 #pragma unroll
             for (int j = 0; j < 5; ++j)
-                if (j < ncol[variant]) A[p * ncol[variant] + j] = L[p][cols[variant][j]];
+                if (j < ncol[variant]) A[p * ncol[variant] + j] = S.L[10 * p + cols[variant][j]];
         const int solved = variant == 0 ? lsq6<4>(A, rho, x) : (variant == 1 ? lsq6<3>(A, rho, x) : lsq6<5>(A, rho, x));
         if (!solved) continue;
         if (variant == 0) {  /* x = b00 b01 b02 b03 */
             const double s = x[0] < 0.0 ? -1.0 : 1.0;
             beta[0] = sqrt(s * x[0]);
             if (!(beta[0] > 0.0)) continue;
+#pragma unroll
             for (int k = 1; k < 4; ++k) beta[k] = s * x[k] / beta[0];
         } else {             /* x = b00 b01 b11 (b02 b12) */
             const double s = x[0] < 0.0 ? -1.0 : 1.0;
@@ -1168,7 +893,9 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
             double J[24], r[6], dx[4];
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
-                const double* l = L[p];
+                double l[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) l[q] = S.L[10 * p + q];
                 J[4 * p + 0] = 2.0 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
                 J[4 * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1] + l[4] * beta[2] + l[7] * beta[3];
                 J[4 * p + 2] = l[3] * beta[0] + l[4] * beta[1] + 2.0 * l[5] * beta[2] + l[8] * beta[3];
@@ -1178,54 +905,66 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
                                  l[8] * beta[2] * beta[3] + l[9] * beta[3] * beta[3]);
             }
             if (!lsq6<4>(J, r, dx)) break;
+#pragma unroll
             for (int k = 0; k < 4; ++k) beta[k] += dx[k];
         }
         /* control points in the camera frame, sign from the first point's depth */
         double cc[4][3];
+#pragma unroll
         for (int j = 0; j < 4; ++j)
-            for (int e = 0; e < 3; ++e) cc[j][e] = beta[0] * ev[0][3 * j + e] + beta[1] * ev[1][3 * j + e] + beta[2] * ev[2][3 * j + e] + beta[3] * ev[3][3 * j + e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                cc[j][e] = beta[0] * S.ev[3 * j + e] + beta[1] * S.ev[12 + 3 * j + e] + beta[2] * S.ev[24 + 3 * j + e] + beta[3] * S.ev[36 + 3 * j + e];
         {
             double al[4];
             EPNP_ALPHAS(idx[0], al);
             const double z0 = al[0] * cc[0][2] + al[1] * cc[1][2] + al[2] * cc[2][2] + al[3] * cc[3][2];
             if (z0 < 0.0)
+#pragma unroll
                 for (int j = 0; j < 4; ++j)
+#pragma unroll
                     for (int e = 0; e < 3; ++e) cc[j][e] = -cc[j][e];
         }
         /* absolute orientation world -> camera (Horn's quaternion form): S = sum pc (pw - c0)^T */
-        double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pcm[3] = {0, 0, 0};
-        for (int k = kfirst; k < m; k += kstep) {
+        double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pcm[3] = {0, 0, 0};
+        for (int k = lane; k < m; k += 64) {
             double al[4], pc[3];
             EPNP_ALPHAS(idx[k], al);
+#pragma unroll
             for (int e = 0; e < 3; ++e) {
                 pc[e] = al[0] * cc[0][e] + al[1] * cc[1][e] + al[2] * cc[2][e] + al[3] * cc[3][e];
                 pcm[e] += pc[e];
             }
+#pragma unroll
             for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) S[3 * i + j] += pc[i] * (obj[3 * (size_t)idx[k] + j] - c0[j]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Sm[3 * i + j] += pc[i] * (obj[3 * (size_t)idx[k] + j] - c0[j]);
         }
-        for (int i = 0; i < 9; ++i) S[i] = total(S[i]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Sm[i] = total(Sm[i]);
+#pragma unroll
         for (int e = 0; e < 3; ++e) pcm[e] = total(pcm[e]) / (double)m;
-        /* S[i][j] = sum camera_i world_j; the rotation maximising tr(R^T S) is the top eigenvector of Horn's 4 x 4 matrix
+        /* Sm[i][j] = sum camera_i world_j; the rotation maximising tr(R^T S) is the top eigenvector of Horn's 4 x 4 matrix
          * written for the map world -> camera (its "left" set is the world points: Sxy = sum world_x camera_y = S[y][x]) */
-        const double Sxx = S[0], Sxy = S[3], Sxz = S[6], Syx = S[1], Syy = S[4], Syz = S[7], Szx = S[2], Szy = S[5], Szz = S[8];
+        const double Sxx = Sm[0], Sxy = Sm[3], Sxz = Sm[6], Syx = Sm[1], Syy = Sm[4], Syz = Sm[7], Szx = Sm[2], Szy = Sm[5], Szz = Sm[8];
         double N[16] = {Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx,
                         Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz,
                         Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy,
                         Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz};
         double V4[16], w4[4];
         jacobi_eig<4>(N, V4, w4);
-        int top = 0;
+        double q0 = V4[0], qx = V4[4], qy = V4[8], qz = V4[12], wtop = w4[0];
+#pragma unroll
         for (int k = 1; k < 4; ++k)
-            if (w4[k] > w4[top]) top = k;
-        const double q0 = V4[top], qx = V4[4 + top], qy = V4[8 + top], qz = V4[12 + top];
+            if (w4[k] > wtop) wtop = w4[k], q0 = V4[k], qx = V4[4 + k], qy = V4[8 + k], qz = V4[12 + k];
         double cand[12];
         cand[0] = q0 * q0 + qx * qx - qy * qy - qz * qz, cand[1] = 2.0 * (qx * qy - q0 * qz), cand[2] = 2.0 * (qx * qz + q0 * qy);
         cand[3] = 2.0 * (qy * qx + q0 * qz), cand[4] = q0 * q0 - qx * qx + qy * qy - qz * qz, cand[5] = 2.0 * (qy * qz - q0 * qx);
         cand[6] = 2.0 * (qz * qx - q0 * qy), cand[7] = 2.0 * (qz * qy + q0 * qx), cand[8] = q0 * q0 - qx * qx - qy * qy + qz * qz;
+#pragma unroll
         for (int i = 0; i < 3; ++i) cand[9 + i] = pcm[i] - (cand[3 * i] * c0[0] + cand[3 * i + 1] * c0[1] + cand[3 * i + 2] * c0[2]);
         double err = 0.0;
-        for (int k = kfirst; k < m; k += kstep) {
+        for (int k = lane; k < m; k += 64) {
             const double* X = obj + 3 * (size_t)idx[k];
             const double xc = cand[0] * X[0] + cand[1] * X[1] + cand[2] * X[2] + cand[9];
             const double yc = cand[3] * X[0] + cand[4] * X[1] + cand[5] * X[2] + cand[10];
@@ -1237,6 +976,7 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
         if (!(err < 1e300)) continue;
         if (best_err < 0.0 || err < best_err) {
             best_err = err;
+#pragma unroll
             for (int i = 0; i < 12; ++i) Rt[i] = cand[i];
         }
     }
@@ -1244,83 +984,94 @@ __device__ static int epnp_solve(int m, const int* idx, const double* obj, const
     return best_err >= 0.0 ? 1 : 0;
 }
 
-constexpr int PNP_NT = 64, H4_NT = 64, E5_NT = 32;   // threads per workgroup = samples per workgroup
+constexpr int SOLVE_WAVES = 4;   // samples (waves) per workgroup of the minimal-sample kernels
 
-__global__ __launch_bounds__(PNP_NT) void solve_pnp_kernel(const double* __restrict__ obj, const double* __restrict__ img,
-                                                           const double* __restrict__ K, int sample_size, int n_samples,
-                                                           const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
-    __shared__ double arena[2 * 144 * PNP_NT];   // M^T M and its eigenvectors per thread: 144 KiB
-    const int s = blockIdx.x * PNP_NT + threadIdx.x;
+// one WAVE per sample, SOLVE_WAVES samples per workgroup (no workgroup barrier anywhere: waves return on their own)
+__global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_pnp_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                                    const double* __restrict__ K, int sample_size, int n_samples,
+                                                                    const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
+    __shared__ PnpLds lds[SOLVE_WAVES];
+    __shared__ double rows[SOLVE_WAVES][64 * 24];
+    const int wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * SOLVE_WAVES + wave;
     if (s >= n_samples) return;
-    const PV<PNP_NT> MtM{arena + threadIdx.x}, V = MtM.sub(144);
     double K4[4], out[12];
+#pragma unroll
     for (int k = 0; k < 4; ++k) K4[k] = K[k];
+#pragma unroll
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_solve<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, nullptr, nullptr);
-    for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
-    n_models[s] = n;
-}
-
-// one WAVE per sample
-__global__ __launch_bounds__(PNP_NT) void solve_pnp_wave_kernel(const double* __restrict__ obj, const double* __restrict__ img,
-                                                                const double* __restrict__ K, int sample_size, const int* __restrict__ idx,
-                                                                double* __restrict__ models, int* __restrict__ n_models) {
-    static_assert(PNP_NT == 64, "one wave");
-    __shared__ double arena[2 * 144 * PNP_NT];
-    __shared__ double red[64];
-    __shared__ double jac[2 * 144];
-    const int s = blockIdx.x;
-    const PV<PNP_NT> MtM{arena + threadIdx.x}, V = MtM.sub(144);
-    double K4[4], out[12];
-    for (int k = 0; k < 4; ++k) K4[k] = K[k];
-    for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_solve<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, MtM, V, red, jac);
-    if (threadIdx.x == 0) {
+    const int n = epnp_wave<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, lds[wave], rows[wave], nullptr);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
         for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
         n_models[s] = n;
     }
 }
 
-__global__ __launch_bounds__(H4_NT) void solve_h4_kernel(const double* __restrict__ a, const double* __restrict__ b, int n_samples,
-                                                         const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
-    __shared__ double arena[2 * 81 * H4_NT];     // L^T L and its eigenvectors per thread: 81 KiB
-    const int s = blockIdx.x * H4_NT + threadIdx.x;
+// samples of more than 64 points (the all-inlier refit): one wave per workgroup, a partial M^T M per lane
+__global__ __launch_bounds__(64) void solve_pnp_big_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                           const double* __restrict__ K, int sample_size, const int* __restrict__ idx,
+                                                           double* __restrict__ models, int* __restrict__ n_models) {
+    __shared__ PnpLds lds;
+    __shared__ double part[78 * 64];
+    const int s = blockIdx.x;
+    double K4[4], out[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) K4[k] = K[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) out[k] = 0.0;
+    const int n = epnp_wave<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, lds, nullptr, part);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
+        n_models[s] = n;
+    }
+}
+
+__global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_h4_kernel(const double* __restrict__ a, const double* __restrict__ b, int n_samples,
+                                                                   const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
+    __shared__ double LtL[SOLVE_WAVES][81], V[SOLVE_WAVES][81];
+    const int wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * SOLVE_WAVES + wave;
     if (s >= n_samples) return;
-    const PV<H4_NT> LtL{arena + threadIdx.x}, V = LtL.sub(81);
     double pa[8], pb[8], out[9];
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = idx[s * 4 + k];
         pa[2 * k] = a[2 * (size_t)i]; pa[2 * k + 1] = a[2 * (size_t)i + 1];
         pb[2 * k] = b[2 * (size_t)i]; pb[2 * k + 1] = b[2 * (size_t)i + 1];
     }
+#pragma unroll
     for (int k = 0; k < 9; ++k) out[k] = 0.0;
-    const int n = homography4(pa, pb, out, LtL, V);
-    for (int k = 0; k < 9; ++k) models[9 * (size_t)s + k] = out[k];
-    n_models[s] = n;
+    const int n = homography4_wave(pa, pb, out, LtL[wave], V[wave]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) models[9 * (size_t)s + k] = out[k];
+        n_models[s] = n;
+    }
 }
 
-__global__ __launch_bounds__(E5_NT) void solve_e5_kernel(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ K,
-                                                         int has_K, int n_samples, const int* __restrict__ idx, double* __restrict__ models,
-                                                         int* __restrict__ n_models) {
-    __shared__ double arena[2 * 200 * E5_NT];    // the 10 x 20 constraint matrix, as assembled and as eliminated, per thread: 100 KiB
-    const int s = blockIdx.x * E5_NT + threadIdx.x;
+__global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_e5_kernel(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ K,
+                                                                   int has_K, int n_samples, const int* __restrict__ idx, double* __restrict__ models,
+                                                                   int* __restrict__ n_models) {
+    __shared__ E5Lds lds[SOLVE_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * SOLVE_WAVES + wave;
     if (s >= n_samples) return;
-    const PV<E5_NT> A{arena + threadIdx.x}, A0 = A.sub(200);
     double pa[10], pb[10];
+#pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int i = idx[s * 5 + k];
         pa[2 * k] = a[2 * (size_t)i]; pa[2 * k + 1] = a[2 * (size_t)i + 1];
         pb[2 * k] = b[2 * (size_t)i]; pb[2 * k + 1] = b[2 * (size_t)i + 1];
     }
-    double out[90];
-    for (int k = 0; k < 90; ++k) out[k] = 0.0;
-    double K4[4] = {1, 1, 0, 0};
-    if (has_K)
-        for (int k = 0; k < 4; ++k) K4[k] = K[k];
-    const int n = essential5(pa, pb, has_K ? K4 : nullptr, out, A, A0);
+    double fx = 1, fy = 1, cx = 0, cy = 0;
+    if (has_K) fx = K[0], fy = K[1], cx = K[2], cy = K[3];
     double* dst = models + (size_t)s * 90;
-    for (int k = 0; k < 90; ++k) dst[k] = out[k];
-    n_models[s] = n;
+    for (int k = lane; k < 90; k += 64) dst[k] = 0.0;  // (this wave's own stores below follow in program order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int n = essential5_wave(pa, pb, has_K != 0, fx, fy, cx, cy, dst, lds[wave]);
+    if (lane == 0) n_models[s] = n;
 }
 
 }  // namespace
@@ -1356,13 +1107,13 @@ extern "C" int eacham_solve_minimal(eacham_ctx* ctx, int kind, int n_points, con
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)n_samples * m, hipMemcpyHostToDevice, st));
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
+        const unsigned grid = (unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES);
         if (kind == EACHAM_SOLVE_HOMOGRAPHY4)
-            solve_h4_kernel<<<(unsigned)((n_samples + H4_NT - 1) / H4_NT), H4_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), n_samples,
-                                                                                       (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+            solve_h4_kernel<<<grid, 64 * SOLVE_WAVES, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), n_samples,
+                                                               (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
         else
-            solve_e5_kernel<<<(unsigned)((n_samples + E5_NT - 1) / E5_NT), E5_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b),
-                                                                                       (const double*)(base + o_K), K ? 1 : 0, n_samples,
-                                                                                       (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+            solve_e5_kernel<<<grid, 64 * SOLVE_WAVES, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
+                                                               K ? 1 : 0, n_samples, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(models, base + o_m, sizeof(double) * 9 * (size_t)maxm * n_samples, hipMemcpyDeviceToHost, st));
@@ -1398,17 +1149,15 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
-        // One wave per sample (0.45 ms whatever the sample size: the eigenproblem runs on twelve lanes) holds 144 KiB of LDS, i.e. one
-        // sample per CU at a time: it serves the all-inlier refit and batches of up to two rounds of the chip (the 256-sample chunks of the
-        // RANSAC loop); larger batches of minimal samples take the one-thread-per-sample kernel (1.1 ms, 64 samples per workgroup). Both
-        // produce the bits of the CPU restatement.
-        if (sample_size > 64 || n_samples <= 512)
-            solve_pnp_wave_kernel<<<(unsigned)n_samples, PNP_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
-                                                                          sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+        // One wave per sample either way (bit-identical with the CPU restatement): samples of at most 64 points — the RANSAC loop's — four
+        // to a workgroup with 16 KB of LDS each; larger ones — the all-inlier refit — with a partial M^T M per lane.
+        if (sample_size <= 64)
+            solve_pnp_kernel<<<(unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES), 64 * SOLVE_WAVES, 0, st>>>(
+                (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
+                (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
         else
-            solve_pnp_kernel<<<(unsigned)((n_samples + PNP_NT - 1) / PNP_NT), PNP_NT, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b),
-                                                                          (const double*)(base + o_K), sample_size, n_samples,
-                                                                          (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+            solve_pnp_big_kernel<<<(unsigned)n_samples, 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
+                                                                     sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(models, base + o_m, sizeof(double) * 12 * (size_t)n_samples, hipMemcpyDeviceToHost, st));
