@@ -21,6 +21,7 @@
 // 1000 / 100 iterations the reference asks for are one launch.
 #include "context.hpp"
 
+#include <algorithm>
 #include <cstdint>
 
 namespace eacham {
@@ -122,6 +123,11 @@ struct E5Lds {
     unsigned char nterm[20];
 };
 
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {  // the value of lane `lane_uniform` (a wave-uniform index)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane_uniform), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_max_lanes(double v) {  // max over the wave (order-independent)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
@@ -349,22 +355,14 @@ __device__ static int essential5_wave(const double* p1, const double* p2, bool h
         }
     }
     const bool mine = lane < deg;
-    for (int it = 0; it < 600; ++it) {
-        double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
-        for (int j = deg - 1; j >= 0; --j) {
-            const double mj = S.mon[j];
-            const double tr = pr * zr - pi * zi + mj, ti = pr * zi + pi * zr;
-            pr = tr, pi = ti;
-        }
-        double dr = 1.0, di = 0.0;
-        for (int j = 0; j < deg; ++j) {
-            const double zrj = __shfl(zr, j), zij = __shfl(zi, j);
-            if (j != lane) {
-                const double ar = zr - zrj, ai = zi - zij;
-                const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
-                dr = tr, di = ti;
-            }
-        }
+#ifndef E5_EXP_DK_SWEEPS
+#define E5_EXP_DK_SWEEPS 200
+#endif
+    // one sweep: this lane's correction from the iterates the sweep starts with. `change <= 1e-11 bound` of the restatement = no
+    // lane's correction above it (a NaN correction is ignored by fmax there and by the comparison here); tolerance and sweep
+    // limit: see oracle/solve_oracle.c
+    const double stop = 1e-11 * bound;
+    auto correct = [&](double pr, double pi, double dr, double di) {
         const double den = dr * dr + di * di;
         double ch = 0.0;
         if (mine && den > 0.0) {
@@ -373,7 +371,50 @@ __device__ static int essential5_wave(const double* p1, const double* p2, bool h
             zi -= qi;
             ch = fabs(qr) + fabs(qi);
         }
-        if (wave_max_lanes(ch) <= 1e-15 * bound) break;
+        return __ballot(ch > stop) == 0ull;
+    };
+    if (deg == 10) {  // the usual case: coefficients in registers, the other iterates by v_readlane with constant lanes
+        double mm[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) mm[j] = S.mon[j];
+        for (int it = 0; it < E5_EXP_DK_SWEEPS; ++it) {
+            double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
+#pragma unroll
+            for (int j = 9; j >= 0; --j) {
+                const double tr = pr * zr - pi * zi + mm[j], ti = pr * zi + pi * zr;
+                pr = tr, pi = ti;
+            }
+            double dr = 1.0, di = 0.0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const double zrj = readlane_f64(zr, j), zij = readlane_f64(zi, j);
+                if (j != lane) {
+                    const double ar = zr - zrj, ai = zi - zij;
+                    const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+                    dr = tr, di = ti;
+                }
+            }
+            if (correct(pr, pi, dr, di)) break;
+        }
+    } else {
+        for (int it = 0; it < E5_EXP_DK_SWEEPS; ++it) {
+            double pr = 1.0, pi = 0.0;
+            for (int j = deg - 1; j >= 0; --j) {
+                const double mj = S.mon[j];
+                const double tr = pr * zr - pi * zi + mj, ti = pr * zi + pi * zr;
+                pr = tr, pi = ti;
+            }
+            double dr = 1.0, di = 0.0;
+            for (int j = 0; j < deg; ++j) {
+                const double zrj = readlane_f64(zr, j), zij = readlane_f64(zi, j);  // (j is wave-uniform: two v_readlane, no LDS permute)
+                if (j != lane) {
+                    const double ar = zr - zrj, ai = zi - zij;
+                    const double tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+                    dr = tr, di = ti;
+                }
+            }
+            if (correct(pr, pi, dr, di)) break;
+        }
     }
     bool real = mine && !(fabs(zi) > 1e-7 * (1.0 + fabs(zr)));
     double z = zr;
@@ -427,7 +468,10 @@ __device__ static int essential5_wave(const double* p1, const double* p2, bool h
             double x = (u0[1] * u1[2] - u0[2] * u1[1]) / bd;
             double y = (u0[2] * u1[0] - u0[0] * u1[2]) / bd;
             double zz = z;
-            for (int it = 0; it < 3; ++it) {  /* three Gauss-Newton steps on the ten constraints themselves, in (x, y, z) */
+#ifndef E5_EXP_POLISH
+#define E5_EXP_POLISH 3
+#endif
+            for (int it = 0; it < E5_EXP_POLISH; ++it) {  /* three Gauss-Newton steps on the ten constraints themselves, in (x, y, z) */
                 // (rolled loops and powers by selection: unrolled, the 20 monomials and their derivatives are ~100 live registers
                 // per lane and the kernel spills; the monomial's column comes from a 64-byte table)
                 const double x2 = x * x, x3 = x * x * x, y2 = y * y, y3 = y * y * y, z2 = zz * zz, z3 = zz * zz * zz;
@@ -552,39 +596,70 @@ __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x)
     return 1;
 }
 
-// The N x N eigenproblem (N = 9, 12) by ONE WAVE on one shared copy of A and V: the three loops of a rotation (columns p, q; rows p, q; V)
-// run over their index k on the lanes 0..N-1, every lane forms the rotation itself from the same three entries. Element by element the
-// arithmetic is that of jacobi_eig<N> (a rotation's loop iterations are independent), so the result is the same bits; the rotations
-// stay in their cyclic order. A wave's LDS operations execute in program order: the barriers only pin the compiler.
-// (One thread walking these loops was two thirds of an EPnP solve: 0.73 of 1.1 ms, measured with a one-sweep build.)
+// The N x N eigenproblem (N = 9, 12) by ONE WAVE on one shared copy of A and V, in the ROUND-ROBIN ordering of
+// oracle/solve_oracle.c's jacobi_eig_rr: a sweep is N' - 1 rounds of N' / 2 disjoint rotations (N' = N rounded up to even; position 0
+// holds index 0, position j >= 1 holds 1 + ((j - 1 - round) mod (N' - 1)), pair i = positions i and N' - 1 - i, index N is a bye).
+// Lane i forms rotation i of the round from the matrix the round starts with; then the three stages — columns, rows, eigenvector
+// columns of every pair — run with one (pair, k) per lane: no element is written twice inside a stage, and element by element the
+// arithmetic is the restatement's, so the result is the same bits. A wave's LDS operations execute in program order: the barriers
+// only pin the compiler. 11 rounds of three stages per sweep of a 12 x 12 system, where the cyclic order is 66 dependent rotations
+// (1.9 of the 3.9 ms of a 10 000-sample EPnP batch, measured with a one-sweep build).
+struct JacRound {
+    double c[8], s[8];
+    int p[8], q[8], on[8];
+};
 template <int N>
-__device__ __forceinline__ void jacobi_wave(double* A, double* V, double* w) {
-    constexpr int n = N;
-    const int k = threadIdx.x & 63;
-    for (int e = k; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+__device__ __forceinline__ void jacobi_wave(double* A, double* V, double* w, JacRound& R) {
+    constexpr int n = N, np = N + (N & 1), half = np / 2;
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     wave_sync_lds();
-    for (int sweep = 0; sweep < 60; ++sweep) {
+#ifndef JAC_EXP_SWEEPS
+#define JAC_EXP_SWEEPS 60
+#endif
+    for (int sweep = 0; sweep < JAC_EXP_SWEEPS; ++sweep) {
         double off = 0.0, diag = 0.0;
         for (int p = 0; p < n; ++p) {
             diag += A[p * n + p] * A[p * n + p];
             for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
         }
         if (off <= 1e-60 || off <= 1e-32 * diag) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;  // (wave-uniform)
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                wave_sync_lds();
-                if (k < n) {  /* columns p, q */
+        for (int round = 0; round < np - 1; ++round) {
+            if (lane < half) {
+                const int i = lane, j1 = i, j2 = np - 1 - i;
+                const int a = j1 == 0 ? 0 : 1 + ((j1 - 1 - round) % (np - 1) + (np - 1)) % (np - 1);
+                const int b = 1 + ((j2 - 1 - round) % (np - 1) + (np - 1)) % (np - 1);
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                int on = 0;
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double apq = A[p * n + q];
+                    if (apq != 0.0) {
+                        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                        on = 1;
+                    }
+                }
+                R.p[i] = p, R.q[i] = q, R.on[i] = on, R.c[i] = c, R.s[i] = s;
+            }
+            wave_sync_lds();
+            for (int e = lane; e < half * n; e += 64) {  /* columns p, q of every pair */
+                const int i = e / n, k = e % n;
+                if (R.on[i]) {
+                    const int p = R.p[i], q = R.q[i];
+                    const double c = R.c[i], s = R.s[i];
                     const double akp = A[k * n + p], akq = A[k * n + q];
                     A[k * n + p] = c * akp - s * akq;
                     A[k * n + q] = s * akp + c * akq;
                 }
-                wave_sync_lds();
-                if (k < n) {  /* rows p, q; V */
+            }
+            wave_sync_lds();
+            for (int e = lane; e < half * n; e += 64) {  /* rows p, q of every pair; the eigenvector columns */
+                const int i = e / n, k = e % n;
+                if (R.on[i]) {
+                    const int p = R.p[i], q = R.q[i];
+                    const double c = R.c[i], s = R.s[i];
                     const double apk = A[p * n + k], aqk = A[q * n + k];
                     A[p * n + k] = c * apk - s * aqk;
                     A[q * n + k] = s * apk + c * aqk;
@@ -592,15 +667,16 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* V, double* w) {
                     V[k * n + p] = c * vkp - s * vkq;
                     V[k * n + q] = s * vkp + c * vkq;
                 }
-                wave_sync_lds();
             }
+            wave_sync_lds();
+        }
     }
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
 }
 
 /* homography4 by one wave: L^T L (shared, an upper-triangle entry per lane, the four points added in order), the 9 x 9 eigenproblem by
  * jacobi_wave, the rest on identical values in every lane. a, b: this sample's 4 x 2 points. Returns 1 / 0; H (9) valid in every lane. */
-__device__ static int homography4_wave(const double* a, const double* b, double* H, double* LtL /* 81 */, double* V /* 81 */) {
+__device__ static int homography4_wave(const double* a, const double* b, double* H, double* LtL /* 81 */, double* V /* 81 */, JacRound& R) {
     const int lane = threadIdx.x & 63;
     const int count = 4;
     double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
@@ -646,7 +722,7 @@ __device__ static int homography4_wave(const double* a, const double* b, double*
     }
     wave_sync_lds();
     double w[9];
-    jacobi_wave<9>(LtL, V, w);
+    jacobi_wave<9>(LtL, V, w, R);
     int best = 0;
 #pragma unroll
     for (int i = 1; i < 9; ++i) {
@@ -688,6 +764,7 @@ struct PnpLds {
     double red[64];
     double A[144], V[144];   // M^T M and its eigenvectors
     double ev[48], L[60];    // the four null vectors, the distance system
+    JacRound R;
 };
 
 // sum of one value per lane in LANE ORDER over the first `terms` lanes, ((v0 + v1) + v2) + ..., returned to every lane
@@ -797,7 +874,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
         wave_sync_lds();
     }
     double w[12];
-    jacobi_wave<12>(S.A, S.V, w);
+    jacobi_wave<12>(S.A, S.V, w, S.R);
     int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -991,16 +1068,17 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_pnp_kernel(const doubl
                                                                     const double* __restrict__ K, int sample_size, int n_samples,
                                                                     const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
     __shared__ PnpLds lds[SOLVE_WAVES];
-    __shared__ double rows[SOLVE_WAVES][64 * 24];
+    extern __shared__ double rows_dyn[];   // SOLVE_WAVES x min(sample_size, 64) x 24: the two rows of every point of a wave's sample
     const int wave = threadIdx.x >> 6;
     const int s = blockIdx.x * SOLVE_WAVES + wave;
     if (s >= n_samples) return;
+    double* rows = rows_dyn + (size_t)wave * 24 * (sample_size < 64 ? sample_size : 64);
     double K4[4], out[12];
 #pragma unroll
     for (int k = 0; k < 4; ++k) K4[k] = K[k];
 #pragma unroll
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_wave<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, lds[wave], rows[wave], nullptr);
+    const int n = epnp_wave<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, lds[wave], rows, nullptr);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
@@ -1031,6 +1109,7 @@ __global__ __launch_bounds__(64) void solve_pnp_big_kernel(const double* __restr
 __global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_h4_kernel(const double* __restrict__ a, const double* __restrict__ b, int n_samples,
                                                                    const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
     __shared__ double LtL[SOLVE_WAVES][81], V[SOLVE_WAVES][81];
+    __shared__ JacRound R[SOLVE_WAVES];
     const int wave = threadIdx.x >> 6;
     const int s = blockIdx.x * SOLVE_WAVES + wave;
     if (s >= n_samples) return;
@@ -1043,7 +1122,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_h4_kernel(const double
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) out[k] = 0.0;
-    const int n = homography4_wave(pa, pb, out, LtL[wave], V[wave]);
+    const int n = homography4_wave(pa, pb, out, LtL[wave], V[wave], R[wave]);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) models[9 * (size_t)s + k] = out[k];
@@ -1152,7 +1231,8 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
         // One wave per sample either way (bit-identical with the CPU restatement): samples of at most 64 points — the RANSAC loop's — four
         // to a workgroup with 16 KB of LDS each; larger ones — the all-inlier refit — with a partial M^T M per lane.
         if (sample_size <= 64)
-            solve_pnp_kernel<<<(unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES), 64 * SOLVE_WAVES, 0, st>>>(
+            solve_pnp_kernel<<<(unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES), 64 * SOLVE_WAVES,
+                               sizeof(double) * SOLVE_WAVES * 24 * (size_t)std::min(sample_size, 64), st>>>(
                 (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
                 (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
         else

@@ -74,6 +74,71 @@ static void jacobi_eig(int n, double* A, double* V, double* w) {
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
 }
 
+/* The same eigenproblem in the ROUND-ROBIN (tournament) ordering, for the 9 x 9 and 12 x 12 systems: a sweep is n' - 1 rounds
+ * (n' = n rounded up to even), a round rotates n' / 2 DISJOINT index pairs — position 0 holds index 0, position j >= 1 holds
+ * 1 + ((j - 1 - round) mod (n' - 1)), pair i = the indices at positions i and n' - 1 - i, an index n of an odd system is a bye.
+ * The rotations of a round do not touch each other's pivots, so all of them are formed from the matrix the round starts
+ * with, then applied in three stages — every pair's column rotation, every pair's row rotation, every pair's eigenvector
+ * columns — inside which no element is written twice: the device solver runs a stage on the lanes of a wave
+ * (eacham_amd/csrc/solve.hip, jacobi_wave) and this restatement defines the same arithmetic, element by element. The cyclic
+ * order above needs 66 dependent rotations per sweep of a 12 x 12 system, this one 11 rounds. */
+static void jacobi_eig_rr(int n, double* A, double* V, double* w) {
+    const int np = n + (n & 1), half = np / 2;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < n; ++p) {
+            diag += A[p * n + p] * A[p * n + p];
+            for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int round = 0; round < np - 1; ++round) {
+            int P[8], Q[8], on[8];
+            double C[8], S[8];
+            for (int i = 0; i < half; ++i) {
+                const int j1 = i, j2 = np - 1 - i;
+                const int a = j1 == 0 ? 0 : 1 + ((j1 - 1 - round) % (np - 1) + (np - 1)) % (np - 1);
+                const int b = 1 + ((j2 - 1 - round) % (np - 1) + (np - 1)) % (np - 1);
+                P[i] = a < b ? a : b, Q[i] = a < b ? b : a;
+                on[i] = 0;
+                if (Q[i] >= n) continue;  /* the bye of an odd system */
+                const double apq = A[P[i] * n + Q[i]];
+                if (apq == 0.0) continue;
+                const double theta = (A[Q[i] * n + Q[i]] - A[P[i] * n + P[i]]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                C[i] = 1.0 / sqrt(t * t + 1.0), S[i] = t * C[i];
+                on[i] = 1;
+            }
+            for (int i = 0; i < half; ++i) {  /* columns p, q of every pair */
+                if (!on[i]) continue;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k * n + P[i]], akq = A[k * n + Q[i]];
+                    A[k * n + P[i]] = C[i] * akp - S[i] * akq;
+                    A[k * n + Q[i]] = S[i] * akp + C[i] * akq;
+                }
+            }
+            for (int i = 0; i < half; ++i) {  /* rows p, q of every pair */
+                if (!on[i]) continue;
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[P[i] * n + k], aqk = A[Q[i] * n + k];
+                    A[P[i] * n + k] = C[i] * apk - S[i] * aqk;
+                    A[Q[i] * n + k] = S[i] * apk + C[i] * aqk;
+                }
+            }
+            for (int i = 0; i < half; ++i) {  /* the eigenvector columns */
+                if (!on[i]) continue;
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + P[i]], vkq = V[k * n + Q[i]];
+                    V[k * n + P[i]] = C[i] * vkp - S[i] * vkq;
+                    V[k * n + Q[i]] = S[i] * vkp + C[i] * vkq;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
 /* a: 4 x 2 source points, b: 4 x 2 destination points; H: 9 doubles. Returns 1, or 0 for a degenerate sample. */
 int oracle_homography4(const double* a, const double* b, double* H) {
     const int count = 4;
@@ -104,7 +169,7 @@ int oracle_homography4(const double* a, const double* b, double* H) {
     for (int j = 0; j < 9; ++j)
         for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
     double V[81], w[9];
-    jacobi_eig(9, LtL, V, w);
+    jacobi_eig_rr(9, LtL, V, w);
     int best = 0;
     for (int i = 1; i < 9; ++i)
         if (w[i] < w[best]) best = i;
@@ -188,8 +253,12 @@ static int real_roots10(const double* c, double* roots) {
     /* The simultaneous (Weierstrass) form: every iterate of a sweep is corrected from the iterates the sweep STARTED with, so
      * the ten corrections are independent of each other — the device solver computes them on ten lanes of a wave
      * (eacham_amd/csrc/solve.hip) and this restatement defines the same arithmetic. (Until round 4 both used the
-     * Gauss-Seidel form, a correction seeing the corrections before it: one more dependency per root, no better a result.) */
-    for (int it = 0; it < 600; ++it) {
+     * Gauss-Seidel form, a correction seeing the corrections before it: one more dependency per root, no better a result.)
+     * The sweeps stop at a correction of 1e-11 of the root bound, at most 200 of them: the real roots are polished by Newton's
+     * iteration on the real polynomial right below (quadratic: one step from 1e-11 is machine precision), and clustered roots,
+     * which converge linearly and never reach 1e-15 — 3.6 % of the samples of a two-view scene ran the old limit of 600 sweeps
+     * to its end — are not solutions anybody wants to wait for. */
+    for (int it = 0; it < 200; ++it) {
         double change = 0.0, nzr[10], nzi[10];
         for (int k = 0; k < deg; ++k) {
             double pr = 1.0, pi = 0.0;  /* Horner on the monic polynomial */
@@ -213,7 +282,7 @@ static int real_roots10(const double* c, double* roots) {
             change = fmax(change, fabs(qr) + fabs(qi));
         }
         for (int k = 0; k < deg; ++k) zr[k] = nzr[k], zi[k] = nzi[k];
-        if (change <= 1e-15 * bound) break;
+        if (change <= 1e-11 * bound) break;
     }
     int n = 0;
     for (int k = 0; k < deg; ++k) {
@@ -525,7 +594,7 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
     }
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
-    jacobi_eig(12, MtM, V, w);
+    jacobi_eig_rr(12, MtM, V, w);
     int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
     for (int k = 0; k < 4; ++k) {
         int best = -1;
