@@ -11,6 +11,9 @@
 // the lexicographic maximum of (count, node, neighbour) — an order-free reduction.
 #include "context.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace eacham {
 
 namespace {
@@ -103,6 +106,149 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace eacham
 
 using namespace eacham;
+
+// ---- the resident form: the CSR match graph is validated and uploaded ONCE, the per-frame state (Node::IsValid, the keypoints that
+// carry a not-two-view 3-D point) is updated frame by frame as the incremental loop changes it, a query is two small kernels.
+// (The one-shot entry point below re-validates and re-uploads the whole graph per call: 3.9 ms per query on a 500-frame sequence,
+// more than PnP + triangulation + bundle adjustment of the frame the query is for.)
+struct eacham_graph {
+    eacham_ctx* ctx = nullptr;
+    int n_frames = 0, n_edges = 0;       // edges = pairs with matches
+    long long n_matches = 0, n_kp = 0;
+    char* dev = nullptr;
+    int2* pairs = nullptr;
+    int* counts = nullptr;
+    long long* offsets = nullptr;
+    unsigned *q = nullptr, *t = nullptr, *edge_counts = nullptr, *best = nullptr;
+    unsigned char *valid = nullptr, *excluded = nullptr, *has3d = nullptr;
+    long long* kp_offsets = nullptr;
+    std::vector<long long> kp_offsets_h;
+};
+
+extern "C" int eacham_graph_create(eacham_ctx* ctx, int n_frames, const int32_t* pairs, int npairs, const int32_t* counts,
+                                   const int64_t* offsets, const uint32_t* q, const uint32_t* t, const int64_t* kp_offsets,
+                                   eacham_graph** out) {
+    if (!ctx || !out) return EACHAM_ERR_INVALID;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_frames <= 0 || npairs < 0 || !kp_offsets || (npairs > 0 && (!pairs || !counts || !offsets)))
+        return ctx->fail(EACHAM_ERR_INVALID, "graph_create: null argument or negative size");
+    if (n_frames >= (1 << 21)) return ctx->fail(EACHAM_ERR_CAPACITY, "graph_create: at most 2^21 frames");
+    for (int f = 0; f < n_frames; ++f)
+        if (kp_offsets[f + 1] < kp_offsets[f] || kp_offsets[f] < 0) return ctx->fail(EACHAM_ERR_INVALID, "graph_create: kp_offsets not monotone");
+    // the edges (pairs with matches), compacted, their match lists packed in pair order
+    std::vector<int> e_pairs, e_counts;
+    std::vector<long long> e_off;
+    std::vector<unsigned> e_q, e_t;
+    for (int p = 0; p < npairs; ++p) {
+        const int f1 = pairs[2 * p], f2 = pairs[2 * p + 1];
+        if (f1 < 0 || f2 < 0 || f1 >= n_frames || f2 >= n_frames)
+            return ctx->fail(EACHAM_ERR_INVALID, "graph_create: pair %d names frame %d/%d of %d", p, f1, f2, n_frames);
+        if (counts[p] < 0 || offsets[p] < 0) return ctx->fail(EACHAM_ERR_INVALID, "graph_create: negative count/offset at pair %d", p);
+        if (counts[p] >= (1 << 21)) return ctx->fail(EACHAM_ERR_CAPACITY, "graph_create: more than 2^21 matches in pair %d", p);
+        if (counts[p] == 0) continue;
+        if (!q || !t) return ctx->fail(EACHAM_ERR_INVALID, "graph_create: null edge arrays");
+        const long long n1 = kp_offsets[f1 + 1] - kp_offsets[f1], n2 = kp_offsets[f2 + 1] - kp_offsets[f2];
+        e_pairs.push_back(f1);
+        e_pairs.push_back(f2);
+        e_counts.push_back(counts[p]);
+        e_off.push_back((long long)e_q.size());
+        for (long long k = offsets[p]; k < offsets[p] + counts[p]; ++k) {
+            if (q[k] >= n1 || t[k] >= n2) return ctx->fail(EACHAM_ERR_INVALID, "graph_create: match %lld of pair %d is out of range", k, p);
+            e_q.push_back(q[k]);
+            e_t.push_back(t[k]);
+        }
+    }
+    eacham_graph* g = new eacham_graph();
+    g->ctx = ctx;
+    g->n_frames = n_frames;
+    g->n_edges = (int)e_counts.size();
+    g->n_matches = (long long)e_q.size();
+    g->n_kp = kp_offsets[n_frames];
+    g->kp_offsets_h.assign(kp_offsets, kp_offsets + n_frames + 1);
+    (void)hipSetDevice(ctx->device);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align256(off + std::max<size_t>(bytes, 8)); return o; };
+    const size_t o_pairs = take(sizeof(int) * 2 * (size_t)g->n_edges), o_cnt = take(sizeof(int) * (size_t)g->n_edges);
+    const size_t o_off = take(sizeof(long long) * (size_t)g->n_edges), o_q = take(sizeof(unsigned) * (size_t)g->n_matches);
+    const size_t o_t = take(sizeof(unsigned) * (size_t)g->n_matches), o_valid = take((size_t)n_frames), o_excl = take((size_t)n_frames);
+    const size_t o_kpo = take(sizeof(long long) * ((size_t)n_frames + 1)), o_h3 = take((size_t)g->n_kp);
+    const size_t o_ec = take(sizeof(unsigned) * 2 * (size_t)g->n_edges), o_best = take(sizeof(unsigned) * 4);
+    if (hipMalloc((void**)&g->dev, off) != hipSuccess) {
+        delete g;
+        return ctx->fail(EACHAM_ERR_HIP, "graph_create: allocating %zu bytes failed", off);
+    }
+    char* base = g->dev;
+    g->pairs = (int2*)(base + o_pairs); g->counts = (int*)(base + o_cnt); g->offsets = (long long*)(base + o_off);
+    g->q = (unsigned*)(base + o_q); g->t = (unsigned*)(base + o_t); g->valid = (unsigned char*)(base + o_valid);
+    g->excluded = (unsigned char*)(base + o_excl); g->kp_offsets = (long long*)(base + o_kpo); g->has3d = (unsigned char*)(base + o_h3);
+    g->edge_counts = (unsigned*)(base + o_ec); g->best = (unsigned*)(base + o_best);
+    hipStream_t st = ctx->stream;
+    bool ok = hipMemsetAsync(base, 0, off, st) == hipSuccess;
+    auto up = [&](void* dst, const void* src, size_t bytes) { return !bytes || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess; };
+    ok = ok && up(g->pairs, e_pairs.data(), sizeof(int) * e_pairs.size()) && up(g->counts, e_counts.data(), sizeof(int) * e_counts.size()) &&
+         up(g->offsets, e_off.data(), sizeof(long long) * e_off.size()) && up(g->q, e_q.data(), sizeof(unsigned) * e_q.size()) &&
+         up(g->t, e_t.data(), sizeof(unsigned) * e_t.size()) && up(g->kp_offsets, kp_offsets, sizeof(long long) * ((size_t)n_frames + 1));
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;   // (the host vectors die here)
+    if (!ok) {
+        (void)hipFree(g->dev);
+        delete g;
+        return ctx->fail(EACHAM_ERR_HIP, "graph_create: upload failed");
+    }
+    *out = g;
+    return EACHAM_OK;
+}
+
+extern "C" void eacham_graph_destroy(eacham_graph* g) {
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lock(g->ctx->mu);
+        (void)hipSetDevice(g->ctx->device);
+        (void)hipStreamSynchronize(g->ctx->stream);
+        if (g->dev) (void)hipFree(g->dev);
+    }
+    delete g;
+}
+
+// Node::IsValid() of a frame and, per keypoint, HasPoint3d(k) && !IsPoint3dTwoView(k) (has3d == NULL: the flags stay as they are)
+extern "C" int eacham_graph_set_frame(eacham_graph* g, int frame, int valid, const uint8_t* has3d, int n_keypoints) {
+    if (!g) return EACHAM_ERR_INVALID;
+    eacham_ctx* ctx = g->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (frame < 0 || frame >= g->n_frames) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frame: frame %d of %d", frame, g->n_frames);
+    const long long nk = g->kp_offsets_h[frame + 1] - g->kp_offsets_h[frame];
+    if (has3d && n_keypoints != nk) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frame: frame %d has %lld keypoints, got %d flags", frame, nk, n_keypoints);
+    (void)hipSetDevice(ctx->device);
+    // (small pageable copies: staged by the runtime before the call returns, so the caller's buffer may die)
+    const unsigned char v = valid ? 1 : 0;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(g->valid + frame, &v, 1, hipMemcpyHostToDevice, ctx->stream));
+    if (has3d && nk > 0) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(g->has3d + g->kp_offsets_h[frame], has3d, (size_t)nk, hipMemcpyHostToDevice, ctx->stream));
+    return EACHAM_OK;
+}
+
+// Graph::GetBestPairForValid(excluded) on the resident state
+extern "C" int eacham_graph_query(eacham_graph* g, const int32_t* excluded_frames, int n_excluded, uint32_t* best) {
+    if (!g || !best || n_excluded < 0 || (n_excluded > 0 && !excluded_frames)) return EACHAM_ERR_INVALID;
+    eacham_ctx* ctx = g->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    best[0] = best[1] = 0xffffffffu;
+    best[2] = 0;
+    if (g->n_edges == 0) return EACHAM_OK;
+    std::vector<unsigned char> ex((size_t)g->n_frames, 0);
+    for (int k = 0; k < n_excluded; ++k) {
+        if (excluded_frames[k] < 0 || excluded_frames[k] >= g->n_frames) return ctx->fail(EACHAM_ERR_INVALID, "graph_query: excluded frame %d", excluded_frames[k]);
+        ex[excluded_frames[k]] = 1;
+    }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(g->excluded, ex.data(), ex.size(), hipMemcpyHostToDevice, st));
+    graph_edge_counts_kernel<<<g->n_edges, GT, 0, st>>>(g->pairs, g->counts, g->offsets, g->q, g->t, g->kp_offsets, g->has3d, g->edge_counts);
+    graph_best_pair_kernel<<<1, 1024, 0, st>>>(g->pairs, g->n_edges, g->counts, g->edge_counts, g->valid, g->excluded, g->best);
+    EACHAM_HIP_TRY(ctx, hipGetLastError());
+    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(best, g->best, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, st));
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return EACHAM_OK;
+}
 
 extern "C" int eacham_graph_best_pair(eacham_ctx* ctx, int n_frames, const int32_t* pairs, int npairs, const int32_t* counts,
                                       const int64_t* offsets, const uint32_t* q, const uint32_t* t, const uint8_t* valid,

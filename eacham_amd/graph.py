@@ -45,3 +45,39 @@ def best_pair_for_valid(ctx: HipContext, n_frames: int, pairs, counts, offsets, 
         flat.ctypes.data, ec.ctypes.data, best.ctypes.data))
     out = (int(best[0]), int(best[1]), int(best[2]))
     return (out, ec) if want_edge_counts else out
+
+
+class ResidentGraph:
+    """eacham_graph_create / _set_frame / _query: the match graph uploaded once, the per-frame state set frame by frame,
+    the query two small kernels — what the incremental loop of apps/sfm/main.cpp:188-214 uses after every frame it adds."""
+
+    def __init__(self, ctx: HipContext, n_frames: int, pairs, counts, offsets, q, t, keypoints_per_frame):
+        import ctypes as C
+        self._C, self.ctx, self.n_frames = C, ctx, n_frames
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        q = np.ascontiguousarray(q, dtype=np.uint32)
+        t = np.ascontiguousarray(t, dtype=np.uint32)
+        kpo = np.zeros(n_frames + 1, dtype=np.int64)
+        kpo[1:] = np.cumsum(np.asarray(keypoints_per_frame, dtype=np.int64))
+        h = C.c_void_p()
+        ctx._check(ctx._L.eacham_graph_create(ctx.handle, n_frames, pairs.ctypes.data, pairs.shape[0], counts.ctypes.data, offsets.ctypes.data,
+                                              q.ctypes.data, t.ctypes.data, kpo.ctypes.data, C.byref(h)))
+        self._h = h
+
+    def set_frame(self, frame: int, valid: bool, has3d=None):
+        f = None if has3d is None else np.ascontiguousarray(has3d, dtype=np.uint8)
+        self.ctx._check(self.ctx._L.eacham_graph_set_frame(self._h, int(frame), int(bool(valid)), None if f is None else f.ctypes.data,
+                                                           0 if f is None else f.size))
+
+    def query(self, excluded_frames=()):
+        ex = np.ascontiguousarray(list(excluded_frames), dtype=np.int32)
+        best = np.zeros(3, dtype=np.uint32)
+        self.ctx._check(self.ctx._L.eacham_graph_query(self._h, ex.ctypes.data if ex.size else None, int(ex.size), best.ctypes.data))
+        return int(best[0]), int(best[1]), int(best[2])
+
+    def close(self):
+        if self._h:
+            self.ctx._L.eacham_graph_destroy(self._h)
+            self._h = None

@@ -442,5 +442,40 @@ inline BestPair GetBestPairForValid(Context& ctx, const std::vector<std::pair<un
     return r;
 }
 
+// The resident form for the incremental loop (apps/sfm/main.cpp:188-214 asks after every frame it adds): the graph is uploaded once,
+// SetFrame refreshes the frames the loop has just changed — the one it posed and triangulated and that frame's factor neighbours —
+// and Query costs two small kernels (eacham_graph_create / _set_frame / _query).
+class ResidentMatchGraph {
+public:
+    ResidentMatchGraph(Context& ctx, const std::vector<std::pair<unsigned, unsigned>>& pairs, const MatchGraph& g,
+                       const std::vector<size_t>& keypointsPerFrame)
+        : ctx_(ctx) {
+        std::vector<int32_t> flat(2 * pairs.size());
+        for (size_t p = 0; p < pairs.size(); ++p) flat[2 * p] = (int32_t)pairs[p].first, flat[2 * p + 1] = (int32_t)pairs[p].second;
+        std::vector<int64_t> kpo(keypointsPerFrame.size() + 1, 0);
+        for (size_t f = 0; f < keypointsPerFrame.size(); ++f) kpo[f + 1] = kpo[f] + (int64_t)keypointsPerFrame[f];
+        ctx.check(eacham_graph_create(ctx.get(), (int)keypointsPerFrame.size(), flat.data(), (int)pairs.size(), g.counts.data(), g.offsets.data(),
+                                      g.q.data(), g.t.data(), kpo.data(), &h_));
+    }
+    ~ResidentMatchGraph() { eacham_graph_destroy(h_); }
+    ResidentMatchGraph(const ResidentMatchGraph&) = delete;
+    ResidentMatchGraph& operator=(const ResidentMatchGraph&) = delete;
+    void SetFrame(unsigned frame, bool valid, const std::vector<uint8_t>& has3d) {
+        ctx_.check(eacham_graph_set_frame(h_, (int)frame, valid ? 1 : 0, has3d.data(), (int)has3d.size()));
+    }
+    template <class Set>
+    BestPair Query(const Set& excluded) {
+        std::vector<int32_t> ex(excluded.begin(), excluded.end());
+        uint32_t best[3] = {0, 0, 0};
+        ctx_.check(eacham_graph_query(h_, ex.data(), (int)ex.size(), best));
+        BestPair r;
+        r.id = best[0], r.id2 = best[1], r.points3dCount = best[2];
+        return r;
+    }
+private:
+    Context& ctx_;
+    eacham_graph* h_ = nullptr;
+};
+
 }  // namespace hip
 }  // namespace eacham

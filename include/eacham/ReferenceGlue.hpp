@@ -20,6 +20,8 @@
 // not in the image), driven by tests/cpp/adapter_driver.cpp / tri_driver.cpp with -DEACHAM_TEST_GLUE.
 #pragma once
 
+#include <algorithm>
+#include <map>
 #include <memory>
 #ifdef EACHAM_GLUE_TIMING
 #include <chrono>
@@ -29,6 +31,9 @@
 #include <stdexcept>
 #include <type_traits>
 #include <utility>
+#include <vector>
+#include <unordered_map>
+#include <string>
 
 #include "BundleAdjusterHip.hpp"
 #include "TriangulatorHip.hpp"
@@ -61,216 +66,291 @@ inline void matrix_to_rows(const Mat4& M, double* out) {
         for (int c = 0; c < 4; ++c) out[4 * r + c] = M(r, c);
 }
 
-// RefineBA with the reference's argument list (BundleAdjuster.cpp:40-250).
+// RefineBA with the reference's argument list (BundleAdjuster.cpp:40-250), directly on the reference's objects: the graph walk
+// of :57-162 — the window (the current frame and its valid factor neighbours, or every valid node for currentFrameId = -1), the
+// landmark filter `status && observers >= 2` (:84), first-seen landmark registration (:100-117) — fills the plain arrays of
+// eacham_ba_problem straight from Graph / Node / Map (no intermediate views, no copies to diff against), eacham_ba_solve runs,
+// and :221-249 is replayed: K, UpdatePoint + UpdateStatus(true) of every landmark of the problem, SetTransform of every camera.
+// A node's keypoint -> landmark map is walked in ascending keypoint order and the window's neighbours in ascending id (the
+// reference iterates unordered_maps there: no order to keep; a fixed one makes the call reproducible).
 template <class GraphT, class MapT, class MatT, class ConfigT>
 inline RefineBAReport RefineBA(const int currentFrameId, const std::shared_ptr<GraphT>& graph, const std::shared_ptr<MapT>& map,
                                MatT& K, const ConfigT& config) {
-    GraphView gv;
-    MapView mv;
-    // Only what the adapter reads is converted: the local window is the current frame and its factor neighbours
-    // (BundleAdjuster.cpp:123-145), the global problem (currentFrameId = -1) every node. Converting the whole graph and map per
-    // call made the incremental loop quadratic in the sequence length (7.9 ms per TriangulateFrame at 100 frames).
-    std::set<unsigned> needed;
-    if (currentFrameId > -1) {
+    std::vector<unsigned> frameIds;
+    std::vector<double> camT, points, uv;
+    std::vector<int32_t> camFixed, pointObservers;
+    std::vector<uint32_t> obsCam, obsPoint;
+    std::vector<unsigned> mapIds;                      // dense point index -> landmark id
+    std::unordered_map<unsigned, uint32_t> mapIndex;   // landmark id -> dense point index
+    const auto& all = map->GetAll();                   // (Map::Get / GetStatus / GetObservers of the reference each take a lock and the last one copies the map)
+    std::vector<std::pair<unsigned, unsigned>> items;
+    auto frameAdder = [&](unsigned id, auto* node) {   // BundleAdjuster.cpp:57-121
+        const uint32_t cam = (uint32_t)frameIds.size();
+        frameIds.push_back(id);
+        double T[16];
+        matrix_to_rows(node->GetTransform(), T);
+        camT.insert(camT.end(), T, T + 16);
+        camFixed.push_back(graph->IsFixed(id) ? 1 : 0);
+        const auto& kps = node->GetFeatures();
+        items.assign(node->GetPoints3d().begin(), node->GetPoints3d().end());
+        std::sort(items.begin(), items.end());
+        for (const auto& kv : items) {
+            const unsigned id2d = kv.first, id3d = kv.second;
+            const auto it = all.find(id3d);
+            if (it == all.end()) throw std::runtime_error("Map: point is not found");
+            if (!it->second.isValid || it->second.observers.size() < 2) continue;   // :84
+            if ((size_t)id2d >= kps.size()) throw std::runtime_error("RefineBA: keypoint out of range");
+            auto ins = mapIndex.insert({id3d, (uint32_t)mapIds.size()});
+            if (ins.second) {                                                        // :100-117
+                mapIds.push_back(id3d);
+                points.push_back(it->second.point3d(0));
+                points.push_back(it->second.point3d(1));
+                points.push_back(it->second.point3d(2));
+                pointObservers.push_back((int32_t)it->second.observers.size());
+            }
+            obsCam.push_back(cam);
+            obsPoint.push_back(ins.first->second);
+            uv.push_back((double)kps[id2d].x);
+            uv.push_back((double)kps[id2d].y);
+        }
+    };
+    if (currentFrameId > -1) {                          // local window (:123-145)
         auto* start = graph->Get((unsigned)currentFrameId);
         if (!start) throw std::runtime_error("Node is null");
-        needed.insert((unsigned)currentFrameId);
-        for (const auto& f : start->GetFactors()) needed.insert(f.first);
+        frameAdder((unsigned)currentFrameId, start);
+        std::vector<unsigned> nb;
+        for (const auto& f : start->GetFactors()) nb.push_back(f.first);
+        std::sort(nb.begin(), nb.end());
+        for (unsigned id : nb) {
+            auto* node = graph->Get(id);
+            if (!node) throw std::runtime_error("Node is null");
+            if (node->IsValid()) frameAdder(id, node);
+        }
+    } else {                                            // global (:146-162)
+        for (const auto& entry : graph->GetNodes())
+            if (entry.second->IsValid()) frameAdder(entry.first, entry.second);
     }
-    for (const auto& entry : graph->GetNodes()) {
-        const unsigned id = entry.first;
-        if (currentFrameId > -1 && !needed.count(id)) continue;
-        auto* node = entry.second;
-        NodeView nv;
-        nv.id = id;
-        nv.valid = node->IsValid();
-        nv.fixed = graph->IsFixed(id);
-        matrix_to_rows(node->GetTransform(), nv.transform);
-        nv.keypoints.reserve(2 * node->GetFeatures().size());
-        for (const auto& kp : node->GetFeatures()) {   // Node::GetKeyPoint(id2d) of every keypoint (cv::Point2f)
-            nv.keypoints.push_back(kp.x);
-            nv.keypoints.push_back(kp.y);
-        }
-        {
-            std::vector<FlatMap::value_type> items;
-            items.reserve(node->GetPoints3d().size());
-            for (const auto& p : node->GetPoints3d()) items.emplace_back(p.first, p.second);
-            nv.points3d.assign_unsorted(std::move(items));
-        }
-        const auto& all = map->GetAll();
-        for (const auto& p : nv.points3d) {
-            if (mv.points.find(p.second) == mv.points.end()) {
-                const auto it = all.find(p.second);   // (Map::Get / GetStatus / GetObservers of the reference each take a lock and the last one copies the map)
-                if (it == all.end()) throw std::runtime_error("Map: point is not found");
-                MapPointView mp;
-                mp.point3d[0] = it->second.point3d(0), mp.point3d[1] = it->second.point3d(1), mp.point3d[2] = it->second.point3d(2);
-                mp.status = it->second.isValid;
-                mp.observers = (unsigned)it->second.observers.size();
-                mv.points[p.second] = mp;
-            }
-        }
-        for (const auto& f : node->GetFactors()) nv.neighbours.push_back(f.first);
-        gv.nodes[id] = std::move(nv);
-    }
-    double K9[9] = {K.template at<double>(0, 0), 0.0, K.template at<double>(0, 2), 0.0, K.template at<double>(1, 1),
-                    K.template at<double>(1, 2), 0.0, 0.0, 1.0};
-    OptimizerConfig c;
-    c.method = config.method;
-    c.maxIter = config.maxIter;
-    c.maxTolerance = config.maxTolerance;
-    c.delta = config.delta;
-    c.usePreconditioner = config.usePreconditioner;
-    // what the adapter is about to overwrite: only poses / points that moved are written back
-    GraphView before_g = gv;
-    MapView before_m = mv;
-    const RefineBAReport rep = eacham::hip::RefineBA(shared_context().get(), currentFrameId, gv, mv, K9, c);
+    RefineBAReport rep;
+    rep.frames = frameIds.size();
+    rep.landmarks = mapIds.size();
+    rep.observations = obsCam.size();
+    eacham_ba_problem prob{};
+    prob.n_cams = (int32_t)frameIds.size();
+    prob.n_points = (int32_t)mapIds.size();
+    prob.n_obs = (int32_t)obsCam.size();
+    prob.cam_T_wc = camT.data();
+    prob.cam_fixed = camFixed.data();
+    prob.points = points.data();
+    prob.point_observers = pointObservers.data();
+    prob.obs_cam = obsCam.data();
+    prob.obs_point = obsPoint.data();
+    prob.obs_uv = uv.data();
+    prob.K[0] = K.template at<double>(0, 0); prob.K[1] = K.template at<double>(1, 1);       // :47-49
+    prob.K[2] = K.template at<double>(0, 2); prob.K[3] = K.template at<double>(1, 2);
+    eacham_ba_options opt{};
+    const std::string method = config.method;
+    if (method == "LM") opt.method = EACHAM_BA_LM;
+    else if (method == "DogLeg") opt.method = EACHAM_BA_DOGLEG;
+    else throw std::runtime_error("RefineBA: unknown method " + method);                   // the reference would dereference a null optimizer
+    opt.max_iter = config.maxIter;
+    opt.max_tolerance = config.maxTolerance;
+    opt.delta = config.delta;
+    opt.use_preconditioner = config.usePreconditioner ? 1 : 0;
+    opt.min_landmarks = 50;                                                                 // :166
+    std::vector<double> outT(camT.size() + 1), outP(points.size() + 1);
+    eacham_ba_result res{};
+    res.cam_T_wc = outT.data();
+    res.points = outP.data();
+    eacham_ctx* ctx = shared_context().get();
+    const int rc = eacham_ba_solve(ctx, &prob, &opt, &res);
+    if (rc != EACHAM_OK) throw std::runtime_error(std::string("eacham_hip: ") + eacham_last_error(ctx));
+    rep.skipped = res.status == EACHAM_BA_SKIPPED;
     if (rep.skipped) return rep;  // fewer than 50 landmarks: the reference returns without touching anything (:166-169)
-    K.template at<double>(0, 0) = K9[0];   // :224-227
-    K.template at<double>(1, 1) = K9[4];
-    K.template at<double>(0, 2) = K9[2];
-    K.template at<double>(1, 2) = K9[5];
+    rep.initial_error = res.initial_error;
+    rep.final_error = res.final_error;
+    rep.outer_iterations = res.outer_iterations;
+    rep.inner_iterations = res.inner_iterations;
+    K.template at<double>(0, 0) = res.K[0];   // :224-227
+    K.template at<double>(1, 1) = res.K[1];
+    K.template at<double>(0, 2) = res.K[2];
+    K.template at<double>(1, 2) = res.K[3];
     using Vec3 = std::decay_t<decltype(map->Get(0u))>;
-    for (const auto& kv : mv.points) {     // :229-241 (every landmark of the problem: UpdatePoint + UpdateStatus(true))
-        const MapPointView& was = before_m.points[kv.first];
-        const MapPointView& now = kv.second;
-        if (now.point3d[0] != was.point3d[0] || now.point3d[1] != was.point3d[1] || now.point3d[2] != was.point3d[2] ||
-            now.status != was.status) {
-            Vec3 X;
-            X(0) = now.point3d[0], X(1) = now.point3d[1], X(2) = now.point3d[2];
-            map->UpdatePoint(kv.first, X);
-            map->UpdateStatus(kv.first, now.status);
-        }
+    for (size_t j = 0; j < mapIds.size(); ++j) {   // :229-241
+        Vec3 X;
+        X(0) = outP[3 * j], X(1) = outP[3 * j + 1], X(2) = outP[3 * j + 2];
+        map->UpdatePoint(mapIds[j], X);
+        map->UpdateStatus(mapIds[j], true);
     }
-    for (const auto& kv : gv.nodes) {      // :243-248
-        const NodeView& was = before_g.nodes[kv.first];
-        bool moved = false;
-        for (int k = 0; k < 16; ++k) moved = moved || kv.second.transform[k] != was.transform[k];
-        if (!moved) continue;
-        auto* node = graph->Get(kv.first);
+    for (size_t i = 0; i < frameIds.size(); ++i) {  // :243-248
+        auto* node = graph->Get(frameIds[i]);
         using Mat4 = std::decay_t<decltype(node->GetTransform())>;
         Mat4 M;
         for (int r = 0; r < 4; ++r)
-            for (int col = 0; col < 4; ++col) M(r, col) = kv.second.transform[4 * r + col];
+            for (int col = 0; col < 4; ++col) M(r, col) = outT[16 * i + 4 * r + col];
         node->SetTransform(M);
     }
     return rep;
 }
 
-// TriangulateFrame with the reference's argument list (Triangulator.cpp:188-300). `color`: the reference draws one per
-// call from cv::RNG (:192-199, display only); the caller's colour type is default-constructed here.
+// TriangulateFrame with the reference's argument list (Triangulator.cpp:188-300), DIRECTLY on the reference's objects: the walk
+// of :204-296 is restated on the live Graph / Node / Map — same reads, same mutations in the same order (SetPoint3d /
+// AddObserver in the re-observation gate, Map::Add / RemoveObserver / UpdateStatus / SetPoint3d / AddObserver per accepted
+// track) — and only the arithmetic leaves for the device, in two batches: every candidate's reprojection error before the
+// gate is walked (CalcReprojectionError does not depend on what the gate mutates), every candidate track before the
+// bookkeeping. Until round 4 this function converted the frame, its ~20 factor neighbours and every map point they reference
+// into views (one small vector per map point), ran the view-based adapter of TriangulatorHip.hpp and diffed the views back:
+// 2 ms per call around tens of microseconds of kernels, 4.0 of the 7.4 ms the incremental loop spent per frame.
+// Neighbours are visited in ascending id and matches in ascending (m1, m2), as the adapter does (the reference iterates
+// unordered_maps: no order to keep). `color`: the reference draws one per call from cv::RNG (:192-199, display only).
 template <class GraphT, class MapT, class MatT>
 inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std::shared_ptr<GraphT>& graph,
                                                const std::shared_ptr<MapT>& map, const MatT& K, const unsigned minObservers,
                                                const float maxReprError, const float minTriAngle) {
 #ifdef EACHAM_GLUE_TIMING
-    struct Tm { double conv = 0, call = 0, back = 0; long n = 0; ~Tm() { std::fprintf(stderr, "TriangulateFrame glue: %ld calls, convert %.3f ms, adapter %.3f ms, write-back %.3f ms per call\n", n, conv / n, call / n, back / n); } };
+    struct Tm { double conv = 0, call = 0, back = 0; long n = 0; ~Tm() { std::fprintf(stderr, "TriangulateFrame glue: %ld calls, gate %.3f ms, tracks %.3f ms, bookkeeping %.3f ms per call\n", n, conv / n, call / n, back / n); } };
     static Tm tm;
     const auto t_a = std::chrono::steady_clock::now();
 #endif
-    TriGraphView gv;
-    TriMapView mv;
-    // the walk reads the frame, the nodes it has factors to, and the map points those nodes reference (Triangulator.cpp:204-296)
-    std::set<unsigned> needed{frameId};
-    {
-        auto* start = graph->Get(frameId);
-        if (!start) throw std::runtime_error("Node is null");
-        for (const auto& f : start->GetFactors()) needed.insert(f.first);
+    Context& ctx = shared_context();
+    auto* current = graph->Get(frameId);
+    if (!current) throw std::runtime_error("Node is null");
+    using NodeT = std::remove_pointer_t<decltype(current)>;
+    const double K4[4] = {K.template at<double>(0, 0), K.template at<double>(1, 1), K.template at<double>(0, 2), K.template at<double>(1, 2)};
+    TriangulateFrameReport rep;
+    auto keypoint = [](NodeT* n, unsigned k, double* out) {
+        const auto& f = n->GetFeatures();
+        if ((size_t)k >= f.size()) throw std::runtime_error("TriangulateFrame: keypoint out of range");
+        out[0] = f[k].x;
+        out[1] = f[k].y;
+    };
+    struct Nb {
+        unsigned id;
+        NodeT* node;
+        std::vector<std::pair<unsigned, unsigned>> matches;
+    };
+    std::vector<Nb> nbs;
+    for (const auto& f : current->GetFactors()) {
+        auto* other = graph->Get(f.first);
+        if (!other) throw std::runtime_error("Node is null");
+        if (!other->IsValid()) continue;                 // :208-211
+        Nb nb{f.first, other, {}};
+        nb.matches.reserve(f.second.matches.size());
+        for (const auto& mm : f.second.matches) nb.matches.emplace_back(mm.first, mm.second);
+        std::sort(nb.matches.begin(), nb.matches.end());
+        nbs.push_back(std::move(nb));
     }
-    for (const auto& entry : graph->GetNodes()) {
-        if (!needed.count(entry.first)) continue;
-        auto* node = entry.second;
-        TriNodeView nv;
-        nv.valid = node->IsValid();
-        matrix_to_rows(node->GetTransform(), nv.transform);
-        nv.keypoints.reserve(2 * node->GetFeatures().size());
-        for (const auto& kp : node->GetFeatures()) {
-            nv.keypoints.push_back(kp.x);
-            nv.keypoints.push_back(kp.y);
-        }
-        {
-            std::vector<FlatMap::value_type> items;
-            items.reserve(node->GetPoints3d().size());
-            for (const auto& p : node->GetPoints3d()) items.emplace_back(p.first, p.second);
-            nv.points3d.assign_unsorted(std::move(items));
-        }
-        if (entry.first == frameId)   // the walk only reads the factors of the frame being inserted (:204)
-            for (const auto& f : node->GetFactors()) {
-                auto& dst = nv.factors[f.first];
-                for (const auto& mm : f.second.matches) dst.emplace_back(mm.first, mm.second);
-                std::sort(dst.begin(), dst.end());  // (match_t is an unordered_map: no order to keep)
-            }
-        gv.nodes[entry.first] = std::move(nv);
-    }
+    std::sort(nbs.begin(), nbs.end(), [](const Nb& a, const Nb& b) { return a.id < b.id; });
+    // ---- the re-observation gate (:213-240): errors of all candidates in one call, then the walk ----
     const auto& all = map->GetAll();
-    for (const auto& kv : all)
-        if (kv.first > mv.mapPointId) mv.mapPointId = kv.first;  // Map never removes a point: its counter is the largest id
-    for (const auto& nk : gv.nodes)
-        for (const auto& p : nk.second.points3d) {
-            if (mv.points.count(p.second)) continue;
-            const auto it = all.find(p.second);
-            if (it == all.end()) throw std::runtime_error("Map: point is not found");
-            TriMapPoint mp;
-            mp.point3d[0] = it->second.point3d(0), mp.point3d[1] = it->second.point3d(1), mp.point3d[2] = it->second.point3d(2);
-            mp.isValid = it->second.isValid;
-            {
-                std::vector<FlatMap::value_type> items;
-                items.reserve(it->second.observers.size());
-                for (const auto& ob : it->second.observers) items.emplace_back(ob.first, ob.second);
-                mp.observers.assign_unsorted(std::move(items));
-            }
-            mv.points[p.second] = std::move(mp);
+    std::vector<unsigned> cand3d;     // the partner's map point per candidate, walk order
+    std::vector<uint32_t> cframe;
+    std::vector<double> cpts, cuv;
+    for (const Nb& nb : nbs) {
+        const auto& p3 = nb.node->GetPoints3d();
+        for (const auto& mm : nb.matches) {
+            const auto has = p3.find(mm.second);
+            if (has == p3.end()) continue;
+            const auto mp = all.find(has->second);
+            if (mp == all.end()) throw std::runtime_error("Map: point is not found");
+            cand3d.push_back(has->second);
+            cframe.push_back(0);
+            cpts.push_back(mp->second.point3d(0));
+            cpts.push_back(mp->second.point3d(1));
+            cpts.push_back(mp->second.point3d(2));
+            double uv[2];
+            keypoint(current, mm.first, uv);
+            cuv.push_back(uv[0]);
+            cuv.push_back(uv[1]);
         }
-    const unsigned lastId = mv.mapPointId;   // ids above it after the call are new map points
-    const double K9[9] = {K.template at<double>(0, 0), 0.0, K.template at<double>(0, 2), 0.0, K.template at<double>(1, 1),
-                          K.template at<double>(1, 2), 0.0, 0.0, 1.0};
+    }
+    std::vector<float> cerr(cand3d.size() + 1);
+    double Tcur[16];
+    matrix_to_rows(current->GetTransform(), Tcur);
+    ctx.check(eacham_reprojection_errors(ctx.get(), Tcur, 1, (int)cand3d.size(), cframe.data(), cpts.data(), cuv.data(), K4, cerr.data()));
+    std::map<unsigned, FlatMap> observersFull;
+    {
+        size_t ci = 0;
+        for (const Nb& nb : nbs) {
+            const auto& p3 = nb.node->GetPoints3d();   // (the gate only writes the CURRENT frame's points3d: a neighbour's is what pass one saw)
+            for (const auto& mm : nb.matches) {
+                if (p3.find(mm.second) != p3.end()) {
+                    const unsigned id3d = cand3d[ci];
+                    const float err = cerr[ci++];
+                    if (all.find(id3d)->second.observers.size() > 2 && err < maxReprError) {  // the LIVE observer count, in walk order (:218)
+                        current->SetPoint3d(mm.first, id3d, false);
+                        map->AddObserver(frameId, mm.first, id3d);
+                        ++rep.reobserved;
+                        continue;
+                    }
+                }
+                observersFull[mm.first][frameId] = mm.first;
+                observersFull[mm.first][nb.id] = mm.second;
+            }
+        }
+    }
 #ifdef EACHAM_GLUE_TIMING
     const auto t_b = std::chrono::steady_clock::now();
 #endif
-    const TriangulateFrameReport rep =
-        eacham::hip::TriangulateFrame(shared_context(), frameId, gv, mv, K9, minObservers, maxReprError, minTriAngle);
+    // ---- candidate tracks (:248-262): one call ----
+    std::map<unsigned, uint32_t> frameRow;   // node id -> row of the transform table
+    std::map<unsigned, NodeT*> nodeOf;
+    std::vector<double> transforms, uv;
+    std::vector<int32_t> trackPtr{0};
+    std::vector<uint32_t> obsFrame;
+    std::vector<const FlatMap*> trackObs;
+    for (const auto& kv : observersFull) {
+        if (kv.second.size() < minObservers) continue;
+        for (const auto& ob : kv.second) {
+            auto ins = frameRow.insert({ob.first, (uint32_t)frameRow.size()});
+            if (ins.second) {
+                auto* n = graph->Get(ob.first);
+                if (!n) throw std::runtime_error("Node is null");
+                nodeOf[ob.first] = n;
+                double T[16];
+                matrix_to_rows(n->GetTransform(), T);
+                transforms.insert(transforms.end(), T, T + 16);
+            }
+            obsFrame.push_back(ins.first->second);
+            double p[2];
+            keypoint(nodeOf[ob.first], ob.second, p);
+            uv.push_back(p[0]);
+            uv.push_back(p[1]);
+        }
+        trackPtr.push_back((int32_t)obsFrame.size());
+        trackObs.push_back(&kv.second);
+    }
+    const int nTracks = (int)trackObs.size();
+    std::vector<double> pts((size_t)nTracks * 3 + 3);
+    std::vector<int32_t> status(nTracks + 1);
+    std::vector<uint8_t> masks(obsFrame.size() + 1);
+    ctx.check(eacham_triangulate_tracks(ctx.get(), transforms.data(), (int)frameRow.size(), nTracks, trackPtr.data(), obsFrame.data(),
+                                        uv.data(), K4, maxReprError, minTriAngle, pts.data(), status.data(), masks.data()));
 #ifdef EACHAM_GLUE_TIMING
     const auto t_c = std::chrono::steady_clock::now();
 #endif
-    // ---- write-back, in the order the reference mutates its objects; the views are compared with the LIVE objects (which the
-    //      adapter never touched) instead of with copies taken before the call ----
+    // ---- map bookkeeping for accepted tracks (:270-296), on the live objects ----
     using Vec3 = std::decay_t<decltype(map->Get(0u))>;
-    for (auto& kv : mv.points) {           // new map points: Map::Add hands out the ids the view counted up
-        if (kv.first <= lastId) continue;
-        Vec3 X;
-        X(0) = kv.second.point3d[0], X(1) = kv.second.point3d[1], X(2) = kv.second.point3d[2];
-        const unsigned id = map->Add(X);
-        if (id != kv.first) throw std::runtime_error("TriangulateFrame glue: Map::Add returned an unexpected id");
-    }
-    for (const auto& kv : mv.points) {     // observers and validity
-        const bool isNew = kv.first > lastId;
-        std::vector<std::pair<unsigned, unsigned>> gone, come;
-        bool wasValid = false;
-        {
-            const auto live = map->GetAll().find(kv.first);
-            if (live == map->GetAll().end()) throw std::runtime_error("Map: point is not found");
-            wasValid = live->second.isValid;
-            for (const auto& ob : live->second.observers)
-                if (kv.second.observers.find(ob.first) == kv.second.observers.end()) gone.emplace_back(ob.first, ob.second);
-            for (const auto& ob : kv.second.observers) {
-                const auto had = live->second.observers.find(ob.first);
-                if (had == live->second.observers.end() || had->second != ob.second) come.emplace_back(ob.first, ob.second);
+    for (int t = 0; t < nTracks; ++t) {
+        if (status[t] == 3) {
+            Vec3 X;
+            X(0) = pts[(size_t)t * 3], X(1) = pts[(size_t)t * 3 + 1], X(2) = pts[(size_t)t * 3 + 2];
+            const unsigned mapPointId = map->Add(X);
+            for (const auto& ob : *trackObs[t]) {
+                NodeT* n = nodeOf[ob.first];
+                const auto& p3 = n->GetPoints3d();
+                const auto old = p3.find(ob.second);
+                if (old != p3.end()) {
+                    const unsigned oldId = old->second;
+                    map->RemoveObserver(ob.first, ob.second, oldId);
+                    map->UpdateStatus(oldId, false);
+                }
+                n->SetPoint3d(ob.second, mapPointId, false);
+                map->AddObserver(ob.first, ob.second, mapPointId);
             }
+            map->UpdateStatus(mapPointId, true);
+            ++rep.added;
         }
-        for (const auto& ob : gone) map->RemoveObserver(ob.first, ob.second, kv.first);
-        for (const auto& ob : come) map->AddObserver(ob.first, ob.second, kv.first);
-        if (kv.second.isValid != wasValid || isNew) map->UpdateStatus(kv.first, kv.second.isValid);
-    }
-    for (const auto& kv : gv.nodes) {      // Node::SetPoint3d(id2d, id3d, false) for every keypoint that changed its point
-        auto* node = graph->Get(kv.first);
-        std::vector<std::pair<unsigned, unsigned>> changed;
-        {
-            const auto& live = node->GetPoints3d();
-            for (const auto& p : kv.second.points3d) {
-                const auto had = live.find(p.first);
-                if (had == live.end() || had->second != p.second) changed.push_back(p);
-            }
-        }
-        for (const auto& p : changed) node->SetPoint3d(p.first, p.second, false);
+        ++rep.total;
     }
 #ifdef EACHAM_GLUE_TIMING
     {

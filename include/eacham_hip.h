@@ -382,6 +382,20 @@ int eacham_graph_best_pair(eacham_ctx* ctx, int n_frames, const int32_t* pairs, 
                            const uint8_t* excluded, const int64_t* kp_offsets, const uint8_t* kp_has3d,
                            uint32_t* edge_counts, uint32_t* best);
 
+/* The resident form of the same query, for the incremental loop of apps/sfm/main.cpp:188-214, which asks it after every frame
+ * it adds: the CSR match graph is validated and uploaded once (eacham_graph_create: same arguments as above minus the per-frame
+ * state; kp_offsets gives every frame's keypoint count), the per-frame state — Node::IsValid() and, per keypoint,
+ * HasPoint3d(k) && !IsPoint3dTwoView(k) — is set frame by frame as the loop changes it (eacham_graph_set_frame: the frame it
+ * just posed and triangulated and that frame's factor neighbours are the only ones that change between two queries), and
+ * eacham_graph_query(excluded set) is two small kernels. Same result as eacham_graph_best_pair on the same state. The graph
+ * belongs to its context (calls are serialised with the context's others); destroy it before the context. */
+typedef struct eacham_graph eacham_graph;
+int eacham_graph_create(eacham_ctx* ctx, int n_frames, const int32_t* pairs, int npairs, const int32_t* counts, const int64_t* offsets,
+                        const uint32_t* q, const uint32_t* t, const int64_t* kp_offsets, eacham_graph** out_graph);
+void eacham_graph_destroy(eacham_graph* graph);
+int eacham_graph_set_frame(eacham_graph* graph, int frame, int valid, const uint8_t* has3d, int n_keypoints);
+int eacham_graph_query(eacham_graph* graph, const int32_t* excluded_frames, int n_excluded, uint32_t* best);
+
 /* ---- kernel timing (HIP events on the context stream; used for roofline reporting) ---------- */
 
 #define EACHAM_KERNEL_MATCH_TILE 0     /* all-pairs int8 MFMA distance + fused row/col top-2      */

@@ -91,18 +91,19 @@ int main(int argc, char** argv) {
         return 3;
     }
     // ---- the incremental loop (:178-214)
-    auto best_pair = [&](const std::set<unsigned>& excluded) {
-        std::vector<uint8_t> valid(F), ex(F, 0);
-        std::vector<std::vector<uint8_t>> has3d(F);
-        for (int f = 0; f < F; ++f) {
-            auto* n = graph->Get((unsigned)f);
-            valid[f] = n->IsValid();
-            has3d[f].resize(n->GetFeatures().size());
-            for (size_t k = 0; k < has3d[f].size(); ++k) has3d[f][k] = n->HasPoint3d((unsigned)k) && !n->IsPoint3dTwoView((unsigned)k);
-        }
-        for (unsigned e : excluded) ex[e] = 1;
-        return GetBestPairForValid(ctx, pairs, g, valid, has3d, ex);
+    // The view-graph query on the RESIDENT match graph: uploaded once, then only the frames the loop has just changed are refreshed —
+    // the one it posed and triangulated and that frame's factor neighbours (TriangulateFrame's SetPoint3d reaches no further).
+    std::vector<size_t> kpCount(F);
+    for (int f = 0; f < F; ++f) kpCount[f] = graph->Get((unsigned)f)->GetFeatures().size();
+    ResidentMatchGraph rg(ctx, pairs, g, kpCount);
+    auto refresh = [&](unsigned f) {
+        auto* n = graph->Get(f);
+        std::vector<uint8_t> has3d(n->GetFeatures().size(), 0);
+        for (const auto& kv : n->GetPoints3d()) has3d[kv.first] = !n->IsPoint3dTwoView(kv.first);
+        rg.SetFrame(f, n->IsValid(), has3d);
     };
+    for (int f = 0; f < F; ++f) refresh((unsigned)f);
+    auto best_pair = [&](const std::set<unsigned>& excluded) { return rg.Query(excluded); };
     std::set<unsigned> excluded{prevId, currentId};
     BestPair bp = best_pair(excluded);
     int pnp_ok = 0, pnp_failed = 0;
@@ -128,6 +129,8 @@ int main(int argc, char** argv) {
             ++pnp_failed;
         }
         ta = std::chrono::steady_clock::now();
+        refresh(bp.id2);
+        for (const auto& f : graph->Get(bp.id2)->GetFactors()) refresh(f.first);
         bp = best_pair(excluded);
         ms_query += since(ta);
         if (bp.id > graph->Size() || bp.id2 > graph->Size()) break;

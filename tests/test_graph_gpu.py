@@ -25,6 +25,39 @@ def test_matches_oracle(ctx, n_frames, seed):
         assert got == want and np.array_equal(ec, wec)
 
 
+@pytest.mark.parametrize("n_frames,seed", [(9, 1), (40, 3), (64, 4)])
+def test_resident_graph_follows_the_state_frame_by_frame(ctx, n_frames, seed):
+    """eacham_graph_create / _set_frame / _query: the graph uploaded once, the loop's state changes applied frame by frame —
+    after every change the query must answer what the one-shot entry point (and the oracle) answer on the full state."""
+    pairs, counts, offsets, q, t, valid, has3d, excluded = scenario(n_frames, seed)
+    rng = np.random.default_rng(seed)
+    rg = G.ResidentGraph(ctx, n_frames, pairs, counts, offsets, q, t, [len(a) for a in has3d])
+    try:
+        state_valid = np.zeros(n_frames, np.uint8)
+        state_h = [np.zeros(len(a), np.uint8) for a in has3d]
+        assert rg.query() == (G.NONE, G.NONE, 0)                       # nothing valid yet
+        for f in rng.permutation(n_frames):                            # the frames arrive one by one
+            state_valid[f] = valid[f]
+            state_h[f] = np.asarray(has3d[f], np.uint8)
+            rg.set_frame(int(f), bool(valid[f]), state_h[f])
+            ex = [int(e) for e in np.flatnonzero(excluded)] if f % 2 else []
+            exm = np.zeros(n_frames, np.uint8); exm[ex] = 1
+            want, _ = O.graph_best_pair(n_frames, pairs, counts, offsets, q, t, state_valid, state_h, exm)
+            assert rg.query(ex) == want == G.best_pair_for_valid(ctx, n_frames, pairs, counts, offsets, q, t, state_valid, state_h, exm)
+        rg.set_frame(0, True)                                           # validity alone (flags untouched)
+        state_valid[0] = 1
+        want, _ = O.graph_best_pair(n_frames, pairs, counts, offsets, q, t, state_valid, state_h, None)
+        assert rg.query() == want
+        with pytest.raises(capi.EachamError):
+            rg.set_frame(n_frames, True)
+        with pytest.raises(capi.EachamError):
+            rg.set_frame(0, True, np.zeros(len(has3d[0]) + 1, np.uint8))
+        with pytest.raises(capi.EachamError):
+            rg.query([n_frames])
+    finally:
+        rg.close()
+
+
 def test_on_a_real_match_graph(ctx):
     """The matcher's own CSR output feeds the query without any re-packing."""
     sc = synth.make_scene(8, 2500, 4, seed=3)
