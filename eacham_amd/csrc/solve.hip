@@ -360,7 +360,7 @@ __device__ static int essential5_wave(const double* p1, const double* p2, bool h
 #endif
     // one sweep: this lane's correction from the iterates the sweep starts with. `change <= 1e-11 bound` of the restatement = no
     // lane's correction above it (a NaN correction is ignored by fmax there and by the comparison here); tolerance and sweep
-    // limit: see oracle/solve_oracle.c
+    // limit: see the CPU restatement (solve_oracle.c)
     const double stop = 1e-11 * bound;
     auto correct = [&](double pr, double pi, double dr, double di) {
         const double den = dr * dr + di * di;
@@ -545,7 +545,7 @@ __device__ static int essential5_wave(const double* p1, const double* p2, bool h
 
 /* least squares min |A x - b| for a 6 x C system (C <= 5), Householder QR on a copy, every loop unrolled: the working array and the
  * callers' matrices stay in registers (as run-time-indexed arrays they are scratch memory). Returns 0 if a column collapses. Same
- * operations in the same order as lsq_small(6, C, ...) of oracle/solve_oracle.c. */
+ * operations in the same order as lsq_small(6, C, ...) of the CPU restatement (solve_oracle.c). */
 template <int C>
 __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x) {
     constexpr int r = 6, c = C;
@@ -597,7 +597,7 @@ __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x)
 }
 
 // The N x N eigenproblem (N = 9, 12) by ONE WAVE on one shared copy of A and V, in the ROUND-ROBIN ordering of
-// oracle/solve_oracle.c's jacobi_eig_rr: a sweep is N' - 1 rounds of N' / 2 disjoint rotations (N' = N rounded up to even; position 0
+// the CPU restatement (solve_oracle.c)'s jacobi_eig_rr: a sweep is N' - 1 rounds of N' / 2 disjoint rotations (N' = N rounded up to even; position 0
 // holds index 0, position j >= 1 holds 1 + ((j - 1 - round) mod (N' - 1)), pair i = positions i and N' - 1 - i, index N is a bye).
 // Lane i forms rotation i of the round from the matrix the round starts with; then the three stages — columns, rows, eigenvector
 // columns of every pair — run with one (pair, k) per lane: no element is written twice inside a stage, and element by element the
