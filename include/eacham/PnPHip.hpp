@@ -10,9 +10,10 @@
 // rows, one eacham_score_hypotheses(kind PNP) call for its models against every point — and the sequential rule is replayed
 // over the chunk's inlier counts in sample order, so the loop ends at exactly the sample OpenCV's would (`iterations`) and
 // the winner is the best model among the samples before it; with 70 % inliers that is one chunk instead of the 10 000
-// samples asked for. The last launch is EPnP on the one row of the winner's inliers. The samples come from a counter-based
-// generator seeded by the caller — OpenCV's own RNG stream is not reproduced (parity unpinned; tests hold the result
-// against the ground truth).
+// samples asked for. The last launch is EPnP on the one row of the winner's inliers. The samples are OpenCV's own stream by
+// default (Sampling::OpenCV, CvSampling.hpp: cv::RNG seeded (uint64)-1, getSubset; from memory of the 4.5.5 sources, unverified:
+// parity unpinned) or the counter-based generator seeded by the caller (Sampling::Counter); tests hold the result against the
+// ground truth under both.
 #pragma once
 
 #include <algorithm>
@@ -54,7 +55,8 @@ inline Vec3 RodriguesFromMatrix(const Mat3& R) {   // rotation matrix -> axis * 
 
 // object: n x 3, image: n x 2 (pixels), K9: row-major 3 x 3 (no distortion — the reference passes zeros).
 inline PnPResult SolvePnPRansac(Context& ctx, const std::vector<double>& object, const std::vector<double>& image, const double* K9,
-                                int iterations = 10000, float reprojectionError = 4.0f, double confidence = 0.999, uint64_t seed = 1) {
+                                int iterations = 10000, float reprojectionError = 4.0f, double confidence = 0.999, uint64_t seed = 1,
+                                Sampling sampling = Sampling::OpenCV) {
     PnPResult out;
     const int n = (int)(image.size() / 2), m = 5;
     if (n < m || object.size() != (size_t)3 * n || iterations <= 0) return out;
@@ -64,10 +66,19 @@ inline PnPResult SolvePnPRansac(Context& ctx, const std::vector<double>& object,
     std::vector<double> models((size_t)chunk * 12), best_model(12, 0.0);
     std::vector<int32_t> okv(chunk), inl(chunk);
     int best_inl = -1, budget = iterations, done = 0;
+    CvRNG rng(0xffffffffffffffffull);   // RANSACPointSetRegistrator::run: RNG rng((uint64)-1), one stream for the whole call
     for (int first = 0; first < budget; first += chunk) {
         const int cnt = std::min(chunk, iterations - first);
-        // sample s of the whole run is row (s - first) of this chunk: the generator is indexed by the global sample number
-        const std::vector<int32_t> idx = twoview_detail::draw_samples(n, m, cnt, seed, first);
+        // sample s of the whole run is row (s - first) of this chunk: OpenCV's stream is drawn in sample order (a chunk draws ahead
+        // of the budget, which only shrinks: the samples the sequential rule consumes are the stream's prefix); the counter-based
+        // generator is indexed by the global sample number
+        std::vector<int32_t> idx;
+        if (sampling == Sampling::OpenCV) {
+            idx.resize((size_t)cnt * m);
+            for (int k = 0; k < cnt; ++k) (void)cv_get_subset(rng, n, m, &idx[(size_t)k * m], 10000, [](const int32_t*) { return true; });
+        } else {
+            idx = twoview_detail::draw_samples(n, m, cnt, seed, first);
+        }
         ctx.check(eacham_solve_pnp(ctx.get(), n, object.data(), image.data(), K4, m, cnt, idx.data(), models.data(), okv.data()));
         ctx.check(eacham_score_hypotheses(ctx.get(), EACHAM_SCORE_PNP, n, object.data(), image.data(), cnt, models.data(), K4, thr, nullptr,
                                           inl.data(), nullptr));

@@ -12,7 +12,8 @@
 // repository's tests, against tests/cpp/ref_standins.hpp (tests/cpp/sfm_loop_driver.cpp runs the whole loop of
 // apps/sfm/main.cpp:150-240 on them).
 // Differences a maintainer should know: the matches of a factor are visited in ascending keypoint id (the reference iterates
-// an unordered_map: no order to keep); the estimators draw their samples from a seeded counter-based generator, not cv::RNG.
+// an unordered_map: no order to keep); the estimators draw their samples from OpenCV's own stream by default (CvSampling.hpp:
+// cv::RNG seeded (uint64)-1 per call + getSubset, restated from memory) or, with Sampling::Counter, from the seeded counter-based generator.
 #pragma once
 
 #include <algorithm>
@@ -47,9 +48,9 @@ public:
     // inlierThresholdPx > 0 counts the inliers of the two winning models at that pixel threshold instead (what the `4.0`
     // the reference passes to both estimators would mean under RANSAC; LMEDS ignores it): an option, not the reference's behaviour.
     ReconstructionManagerHip(Context& ctx, std::shared_ptr<GraphT> graph, std::shared_ptr<MapT> map, float maxReprError, float minTriAngle,
-                             int minPnpInliers, uint64_t seed = 12345, float inlierThresholdPx = 0.0f)
+                             int minPnpInliers, uint64_t seed = 12345, float inlierThresholdPx = 0.0f, Sampling sampling = Sampling::OpenCV)
         : ctx_(ctx), graph_(std::move(graph)), map_(std::move(map)), maxReprError_(maxReprError), minTriAngle_(minTriAngle),
-          minPnpInliers_(minPnpInliers), seed_(seed), inlierThresholdPx_(inlierThresholdPx) {}
+          minPnpInliers_(minPnpInliers), seed_(seed), inlierThresholdPx_(inlierThresholdPx), sampling_(sampling) {}
 
     // ReconstructionManager.cpp:47-183
     template <class MatT>
@@ -71,9 +72,9 @@ public:
         // :57-61 findEssentialMat(pts1, pts2, focal = K(0,0), pp, LMEDS, 0.99, 4.0, 1000, mask)
         const double K4[4] = {K9[0], K9[0], K9[2], K9[5]};
         const uint64_t s = seed_ + 0x9E3779B97F4A7C15ull * ((uint64_t)id1 * 65536 + id2);
-        const RobustModel E = FindEssentialMat(ctx_, pts1, pts2, K4, 1000, s, 0.99);
+        const RobustModel E = FindEssentialMat(ctx_, pts1, pts2, K4, 1000, s, 0.99, sampling_);
         // :75 findHomography(pts1, pts2, LMEDS, 4.0, mask2, 100, 0.999)
-        const RobustModel H = FindHomography(ctx_, pts1, pts2, 100, s + 1, 0.999);
+        const RobustModel H = FindHomography(ctx_, pts1, pts2, 100, s + 1, 0.999, sampling_);
         if (!E.ok) return result;
         int eInliers = E.inliers, hInliers = H.ok ? H.inliers : 0;
         if (inlierThresholdPx_ > 0.0f) {
@@ -138,7 +139,7 @@ public:
         if ((int)(pts2d.size() / 2) < minPnpInliers_) return false;                               // :214-217
         const double K9[9] = {K.template at<double>(0, 0), 0, K.template at<double>(0, 2), 0, K.template at<double>(1, 1),
                               K.template at<double>(1, 2), 0, 0, 1};
-        const PnPResult r = SolvePnPRansac(ctx_, pts3d, pts2d, K9, 10000, 4.0f, 0.999, seed_ + 0xD1B54A32D192ED03ull * ((uint64_t)id1 * 65536 + id2));
+        const PnPResult r = SolvePnPRansac(ctx_, pts3d, pts2d, K9, 10000, 4.0f, 0.999, seed_ + 0xD1B54A32D192ED03ull * ((uint64_t)id1 * 65536 + id2), sampling_);
         if (!r.ok || (int)r.inliers.size() < minPnpInliers_) return false;                         // :229-234
         using Mat4 = std::decay_t<decltype(node2->GetTransform())>;
         Mat4 M;
@@ -163,6 +164,7 @@ private:
     float maxReprError_, minTriAngle_;
     int minPnpInliers_;
     uint64_t seed_;
+    Sampling sampling_;   // OpenCV's own sample stream (default) or the counter-based generator seeded with seed_
     float inlierThresholdPx_;
 };
 

@@ -9,11 +9,11 @@
 // The robust estimators are the pair (eacham_solve_minimal: every minimal sample -> its models, one launch) +
 // (eacham_score_hypotheses: every model against every correspondence, one launch) with the LMedS rule of
 // LMeDSPointSetRegistrator::run in between: smallest median wins, sigma = 2.5 * 1.4826 * (1 + 5 / (n - m)) * sqrt(median),
-// inliers = err <= sigma^2 (ptsetreg.cpp). WHAT CANNOT BE REPRODUCED is OpenCV's sampling: getSubset draws from the
-// estimator's own cv::RNG stream; here the samples come from a counter-based generator seeded by the caller, so the
-// models offered to the median test differ from OpenCV's and only the STATISTICS of the result can agree (parity
-// unpinned; the tests hold the result against ground truth). Neither estimator is followed by OpenCV's final
-// Levenberg-Marquardt polish on the inliers (findHomography does one; findEssentialMat does not).
+// inliers = err <= sigma^2 (ptsetreg.cpp). The SAMPLES: by default OpenCV's own stream (Sampling::OpenCV, CvSampling.hpp: cv::RNG
+// seeded (uint64)-1 per call, getSubset, the homography's checkSubset — restated from memory of the 4.5.5 sources, unverified
+// here like the rest: parity unpinned); Sampling::Counter is the library's counter-based generator seeded by the caller (the
+// rounds 1-3 form). The tests hold the result against ground truth under both. Neither estimator is followed by OpenCV's final
+// Levenberg-Marquardt polish on the inliers except findHomography's (RefitHomography below; findEssentialMat has none).
 // DecomposeHomographyMat returns the four {R, t, n} of the Faugeras decomposition — the solution set of
 // cv::decomposeHomographyMat (OpenCV computes it with the Malis-Vargas closed form and in another order: the reference
 // keeps "the first solution with the strictly largest number of good points", so the order only matters on ties).
@@ -28,6 +28,7 @@
 #include <limits>
 #include <vector>
 
+#include "CvSampling.hpp"
 #include "TriangulatorHip.hpp"
 
 namespace eacham {
@@ -144,14 +145,43 @@ inline int ransac_update_num_iters(double p, double ep, int m, int maxIters) {
 // LMeDSPointSetRegistrator::run fixes its iteration count up front from the confidence at an assumed outlier ratio of 0.45
 // (at least 3, at most maxIters): 1000 asked for with confidence 0.99 and 5-point samples are 89 iterations, 100 asked for
 // with 0.999 and 4-point samples are 72.
+// The minimal samples of one LMeDSPointSetRegistrator::run: `iterations` subsets of m out of n. Sampling::OpenCV replays the
+// registrator's own stream — RNG rng((uint64)-1), getSubset with at most 1000 attempts per subset, the homography's
+// checkSubset (CvSampling.hpp) — and may return fewer subsets when getSubset gives up (run() then stops iterating);
+// Sampling::Counter is the library's counter-based generator seeded by the caller.
+inline std::vector<int32_t> lmeds_samples(int n, int m, int iterations, bool homography, const std::vector<double>& uv1,
+                                          const std::vector<double>& uv2, uint64_t seed, Sampling sampling) {
+    if (sampling == Sampling::Counter) return draw_samples(n, m, iterations, seed);
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)iterations * m);
+    CvRNG rng(0xffffffffffffffffull);
+    std::vector<int32_t> sub(m);
+    for (int it = 0; it < iterations; ++it) {
+        const bool found = cv_get_subset(rng, n, m, sub.data(), 1000, [&](const int32_t* s) {
+            if (!homography) return true;
+            float a[8], b[8];
+            for (int k = 0; k < 4; ++k) {
+                a[2 * k] = (float)uv1[2 * (size_t)s[k]], a[2 * k + 1] = (float)uv1[2 * (size_t)s[k] + 1];
+                b[2 * k] = (float)uv2[2 * (size_t)s[k]], b[2 * k + 1] = (float)uv2[2 * (size_t)s[k] + 1];
+            }
+            return cv_check_subset_homography(a, b, 4);
+        });
+        if (!found) break;
+        idx.insert(idx.end(), sub.begin(), sub.end());
+    }
+    return idx;
+}
+
 inline RobustModel lmeds(Context& ctx, int solve_kind, int score_kind, int m, const std::vector<double>& uv1, const std::vector<double>& uv2,
-                         const double* K4, int maxIters, double confidence, uint64_t seed) {
+                         const double* K4, int maxIters, double confidence, uint64_t seed, Sampling sampling) {
     RobustModel out;
     const int n = (int)(uv1.size() / 2), maxm = solve_kind == EACHAM_SOLVE_ESSENTIAL5 ? 10 : 1;
     if (n < m || uv2.size() != uv1.size() || maxIters <= 0) return out;
-    const int iterations = std::min(maxIters, std::max(ransac_update_num_iters(confidence, 0.45, m, maxIters), 3));
+    int iterations = std::min(maxIters, std::max(ransac_update_num_iters(confidence, 0.45, m, maxIters), 3));
+    const std::vector<int32_t> idx = lmeds_samples(n, m, iterations, solve_kind == EACHAM_SOLVE_HOMOGRAPHY4, uv1, uv2, seed, sampling);
+    iterations = (int)(idx.size() / m);
     out.iterations = iterations;
-    const std::vector<int32_t> idx = draw_samples(n, m, iterations, seed);
+    if (iterations == 0) return out;
     std::vector<double> models((size_t)iterations * maxm * 9);
     std::vector<int32_t> counts(iterations);
     ctx.check(eacham_solve_minimal(ctx.get(), solve_kind, n, uv1.data(), uv2.data(), K4, iterations, idx.data(), models.data(), counts.data()));
@@ -192,8 +222,8 @@ using twoview_detail::RobustModel;
 // cv::findEssentialMat(pts1, pts2, focal, pp, LMEDS, prob, threshold, maxIters, mask): pixels in, K4 = fx fy cx cy
 // (the reference passes focal = K(0,0) and pp = (K(0,2), K(1,2)): fx = fy = focal). The model is a unit-norm E.
 inline RobustModel FindEssentialMat(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2, const double* K4,
-                                    int maxIters = 1000, uint64_t seed = 12345, double prob = 0.99) {
-    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_ESSENTIAL5, EACHAM_SCORE_ESSENTIAL, 5, uv1, uv2, K4, maxIters, prob, seed);
+                                    int maxIters = 1000, uint64_t seed = 12345, double prob = 0.99, Sampling sampling = Sampling::OpenCV) {
+    return twoview_detail::lmeds(ctx, EACHAM_SOLVE_ESSENTIAL5, EACHAM_SCORE_ESSENTIAL, 5, uv1, uv2, K4, maxIters, prob, seed, sampling);
 }
 // What cv::findHomography does with the inliers of the robust stage (fundam.cpp, "if (result && npoints > 4 ...)"): the
 // normalised DLT over ALL inliers (HomographyEstimatorCallback::runKernel with count = inliers), then at most 10
@@ -314,8 +344,8 @@ inline bool RefitHomography(const std::vector<double>& uv1, const std::vector<do
 // cv::findHomography(pts1, pts2, LMEDS, ransacReprojThreshold, mask, maxIters, confidence). The model has H[8] = 1:
 // the LMedS winner refitted on its inliers as above (the mask stays the winner's).
 inline RobustModel FindHomography(Context& ctx, const std::vector<double>& uv1, const std::vector<double>& uv2, int maxIters = 100,
-                                  uint64_t seed = 12345, double confidence = 0.999) {
-    RobustModel r = twoview_detail::lmeds(ctx, EACHAM_SOLVE_HOMOGRAPHY4, EACHAM_SCORE_HOMOGRAPHY, 4, uv1, uv2, nullptr, maxIters, confidence, seed);
+                                  uint64_t seed = 12345, double confidence = 0.999, Sampling sampling = Sampling::OpenCV) {
+    RobustModel r = twoview_detail::lmeds(ctx, EACHAM_SOLVE_HOMOGRAPHY4, EACHAM_SCORE_HOMOGRAPHY, 4, uv1, uv2, nullptr, maxIters, confidence, seed, sampling);
     if (r.ok && uv1.size() / 2 > 4) {
         Mat3 H;
         if (RefitHomography(uv1, uv2, r.mask, H)) r.model = H;

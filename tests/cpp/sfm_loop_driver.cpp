@@ -9,6 +9,7 @@
 //      [+ an eighth: pixel threshold for the H / E inlier counts of RecoverPoseTwoView, 0 = the reference's LMedS masks]
 // out: per frame valid flag + 16 doubles (world -> camera); map: n points x (id, x, y, z, valid, observers); log counters
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <fstream>
 #include <set>
@@ -82,7 +83,9 @@ int main(int argc, char** argv) {
         ++edges;
     }
     // ---- two view (:157-176)
-    glue::ReconstructionManagerHip<graph_t, Map> reconstructor(ctx, graph, globalMap, initialMaxReprError, initialMinTriAngle, minPnpInliers, 12345, inlierPx);
+    const Sampling sampling = (argc > 3 && !std::strcmp(argv[3], "counter")) ? Sampling::Counter : Sampling::OpenCV;
+    glue::ReconstructionManagerHip<graph_t, Map> reconstructor(ctx, graph, globalMap, initialMaxReprError, initialMinTriAngle, minPnpInliers, 12345, inlierPx,
+                                                                sampling);
     auto [prevId, currentId] = glue::FindBestPair(graph, globalMap, reconstructor, K, initialMinInliers);
     std::vector<double> log{(double)edges, (double)prevId, (double)currentId, (double)globalMap->GetAll().size()};
     if (prevId > graph->Size() || currentId > graph->Size()) {
@@ -163,6 +166,8 @@ int main(int argc, char** argv) {
         pts.push_back((double)kv.second.observers.size());
     }
     wr(out, pts);
+    if (inlierPx > 0.0f) std::printf("H/E rule: inliers at %.1f px (not the reference's); sampling: %s\n", inlierPx, sampling == Sampling::OpenCV ? "opencv" : "counter");
+    else std::printf("H/E rule: LMedS masks (the reference's); sampling: %s\n", sampling == Sampling::OpenCV ? "opencv" : "counter");
     std::printf("sfm loop ok: %zu edges, initial pair %u-%u, %d frames added, %d PnP failures, %zu map points; [Match] %.1f ms (upload + %zu pairs), [SfM] %.1f ms = PnP %.1f + TriangulateFrame %.1f + RefineBA %.1f + GetBestPairForValid %.1f + global BA %.1f + two-view\n",
                 edges, prevId, currentId, pnp_ok, pnp_failed, globalMap->GetAll().size(), match_ms, pairs.size(), sfm_ms, ms_pnp, ms_tri, ms_ba, ms_query, ms_global);
     return 0;

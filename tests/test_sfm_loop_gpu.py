@@ -36,11 +36,13 @@ def umeyama(src, dst):
     return s, R, md - s * R @ ms
 
 
+@pytest.mark.parametrize("sampling", ["opencv", "counter"])   # the estimators' sample stream: cv::RNG + getSubset restated (default) / counter-based
 @pytest.mark.parametrize("n_frames,kpts,n_lm,k_obs,inlier_px,tol", [
-    (12, 700, 2200, 6, 0.0, 0.05),      # the reference's own rule for the H / E branch (LMedS masks)
-    (60, 600, 3600, 10, 4.0, 0.05),     # a longer sequence with narrow baselines: H / E inliers counted at 4 px (ReconstructionHip.hpp)
+    (12, 700, 2200, 6, 0.0, 0.05),      # H / E branch by the REFERENCE's rule: the LMedS masks of findEssentialMat / findHomography (:63-90)
+    (60, 600, 3600, 10, 4.0, 0.05),     # a longer sequence with narrow baselines: H / E branch by inliers counted at 4 px — NOT the
+                                        # reference's rule (ReconstructionHip.hpp inlierThresholdPx; the driver's output names the rule it ran)
 ])
-def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path, n_frames, kpts, n_lm, k_obs, inlier_px, tol):
+def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path, n_frames, kpts, n_lm, k_obs, inlier_px, tol, sampling):
     dim = 128
     sc = synth.make_scene(n_frames, n_lm, k_obs, seed=21, pixel_noise=0.5)
     descs, ids = synth.make_frame_descriptors(sc, kpts, dim, seed=21)
@@ -62,9 +64,10 @@ def test_incremental_reconstruction_from_keypoints_and_descriptors(tmp_path, n_f
         # inliers_ratio, initial max reprojection error / min angle, processing max reprojection error / min angle, min_pnp_inliers
         # (config/SfmConfigNerf.json), initial min_inliers scaled to this scene's ~300 shared keypoints per pair (350 there)
         f.write(np.array([0.8, 3.5, 3.0 * deg, 8.0, 3.0 * deg, 15, 100, inlier_px], dtype=np.float32).tobytes())
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, fin, fout, sampling], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     print(r.stdout.strip())
+    assert ("H/E rule: " + ("LMedS masks (the reference's)" if inlier_px == 0.0 else "inliers at")) in r.stdout and ("sampling: " + sampling) in r.stdout
     with open(fout, "rb") as f:
         log, poses, pts = _vec(f), _vec(f).reshape(n_frames, 17), _vec(f).reshape(-1, 6)
     valid = poses[:, 0] == 1
