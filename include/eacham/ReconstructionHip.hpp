@@ -164,8 +164,8 @@ private:
     float maxReprError_, minTriAngle_;
     int minPnpInliers_;
     uint64_t seed_;
-    Sampling sampling_;   // OpenCV's own sample stream (default) or the counter-based generator seeded with seed_
     float inlierThresholdPx_;
+    Sampling sampling_;   // OpenCV's own sample stream (default) or the counter-based generator seeded with seed_
 };
 
 // utils::FindBestPair (Utils.h:24-70): the first pair of connected nodes whose two-view reconstruction passes in BOTH directions;

@@ -123,6 +123,46 @@ int eacham_graph_best_pair(eacham_ctx*, int, const int32_t* pairs, int npairs, c
     return EACHAM_OK;
 }
 
+// the resident form of the query: the stub keeps the arrays and answers with the same fake rule
+struct eacham_graph {
+    eacham_ctx* ctx;
+    int n_frames;
+    std::vector<int32_t> pairs, counts;
+    std::vector<int64_t> kpo;
+    std::vector<uint8_t> valid;
+};
+int eacham_graph_create(eacham_ctx* c, int n_frames, const int32_t* pairs, int npairs, const int32_t* counts, const int64_t* offsets,
+                        const uint32_t* q, const uint32_t* t, const int64_t* kp_offsets, eacham_graph** out) {
+    if (!out || n_frames <= 0 || !kp_offsets) return fail(c, EACHAM_ERR_INVALID, "null");
+    long long acc = 0;
+    for (int p = 0; p < npairs; ++p)
+        for (int64_t k = offsets[p]; k < offsets[p] + counts[p]; ++k) acc += q[k] + t[k];   // every match is read
+    (void)acc;
+    eacham_graph* g = new eacham_graph{c, n_frames, {pairs, pairs + 2 * (size_t)npairs}, {counts, counts + npairs},
+                                       {kp_offsets, kp_offsets + n_frames + 1}, std::vector<uint8_t>(n_frames, 0)};
+    *out = g;
+    return EACHAM_OK;
+}
+void eacham_graph_destroy(eacham_graph* g) { delete g; }
+int eacham_graph_set_frame(eacham_graph* g, int frame, int valid, const uint8_t* has3d, int n_keypoints) {
+    if (!g || frame < 0 || frame >= g->n_frames) return EACHAM_ERR_INVALID;
+    if (has3d) {
+        if (n_keypoints != g->kpo[frame + 1] - g->kpo[frame]) return fail(g->ctx, EACHAM_ERR_INVALID, "keypoint count");
+        int acc = 0;
+        for (int k = 0; k < n_keypoints; ++k) acc += has3d[k];
+        (void)acc;
+    }
+    g->valid[frame] = valid != 0;
+    return EACHAM_OK;
+}
+int eacham_graph_query(eacham_graph* g, const int32_t* excluded_frames, int n_excluded, uint32_t* best) {
+    if (!g || !best) return EACHAM_ERR_INVALID;
+    std::vector<uint8_t> ex(g->n_frames, 0);
+    for (int k = 0; k < n_excluded; ++k) ex[excluded_frames[k]] = 1;
+    return eacham_graph_best_pair(g->ctx, g->n_frames, g->pairs.data(), (int)g->counts.size(), g->counts.data(), nullptr, nullptr, nullptr,
+                                  g->valid.data(), ex.data(), nullptr, nullptr, nullptr, best);
+}
+
 // bundle adjustment: every array is read completely (ASAN sees a short buffer), values pass through, K moves by +1
 int eacham_ba_solve(eacham_ctx* c, const eacham_ba_problem* P, const eacham_ba_options* O, eacham_ba_result* R) {
     if (!P || !O || !R) return fail(c, EACHAM_ERR_INVALID, "null");

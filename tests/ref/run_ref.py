@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Drives the gated reference harness (tests/ref/ref_cpu_opencv_gtsam.cpp: OpenCV's matcher + GTSAM's optimisers) on the
+committed golden fixtures and holds its output against what the fixtures record from the CPU oracle:
+
+    cmake -S tests/ref -B build/ref && cmake --build build/ref
+    python3 tests/ref/run_ref.py build/ref/ref_cpu_opencv_gtsam
+
+Needs OpenCV 4.5.5 and GTSAM 4.1.1 (conanfile.txt:2-3 of the reference) — neither is in this project's image, so NOTHING here has
+run yet; the repository's oracles stay "parity unpinned" until somebody runs this and the comparison below is green
+(DESIGN.md section 2). What it checks:
+  match bf     cv::BFMatcher(NORM_L2) 2-NN + ratio + mutual check + thresholds  ==  the oracle's CSR, index for index
+  match flann  what the reference actually runs (approximate, randomised): reported as an agreement rate, not asserted
+  ba           GTSAM LM on the golden BA problems: iterations, initial / final error and poses / points / K within 1e-5 relative
+               of both recorded LM growth-factor readings (`trace` = RESET, `double_*` = DOUBLE: the run tells which one GTSAM's is)
+Writes tests/ref/ref_outputs.npz (the harness's numbers in the golden files' schema) and prints timings."""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def wr(f, a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype).ravel()
+    f.write(struct.pack("<q", a.size))
+    f.write(a.tobytes())
+
+
+def rd(f, dtype):
+    n = struct.unpack("<q", f.read(8))[0]
+    return np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype).copy()
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def run_match(exe, tmp, out):
+    g = np.load(os.path.join(GOLD, "match_golden.npz"))
+    for tag, (md, mm) in {"ref": (30, 30), "low": (5, 5)}.items():
+        fin, fout = os.path.join(tmp, f"m_{tag}.bin"), os.path.join(tmp, f"m_{tag}.out")
+        with open(fin, "wb") as f:
+            wr(f, [4, int(g["dim"]), md, mm], np.int32)
+            wr(f, [float(g["ratio"])], np.float64)
+            for k in range(4):
+                wr(f, g[f"desc{k}"].astype(np.float32), np.float32)
+            wr(f, g["pairs"], np.int32)
+        for kind in ("bf", "flann"):
+            subprocess.run([exe, "match", fin, fout, kind], check=True)
+            with open(fout, "rb") as f:
+                counts, q, t, stats, ms = rd(f, np.int32), rd(f, np.uint32), rd(f, np.uint32), rd(f, np.int32).reshape(-1, 4), rd(f, np.float64)
+            want = (g[f"counts_{tag}"], g[f"q_{tag}"][: int(g[f"counts_{tag}"].sum())], g[f"t_{tag}"][: int(g[f"counts_{tag}"].sum())], g[f"stats_{tag}"])
+            same = all(np.array_equal(a, b) for a, b in zip((counts, q, t, stats), want))
+            print(f"match[{tag}, {kind}]: {'IDENTICAL to the oracle' if same else 'differs from the oracle'} ({ms[0]:.1f} ms)")
+            if kind == "bf":
+                assert same, "cv::BFMatcher + ratio + mutual check disagrees with the oracle's exact 2-NN: the oracle is wrong (or this harness is)"
+            out[f"match_{tag}_{kind}_counts"], out[f"match_{tag}_{kind}_q"], out[f"match_{tag}_{kind}_t"] = counts, q, t
+
+
+def run_ba(exe, tmp, out):
+    for name in ("ba_golden.npz", "ba_golden_hard.npz", "ba_golden_policy.npz"):
+        g = np.load(os.path.join(GOLD, name))
+        fin, fout = os.path.join(tmp, name + ".bin"), os.path.join(tmp, name + ".out")
+        with open(fin, "wb") as f:
+            wr(f, g["cam_T_wc"], np.float64); wr(f, g["cam_fixed"], np.int32); wr(f, g["points"], np.float64)
+            wr(f, g["point_observers"], np.int32); wr(f, g["obs_cam"], np.uint32); wr(f, g["obs_point"], np.uint32)
+            wr(f, g["obs_uv"], np.float64); wr(f, g["K"], np.float64)
+            wr(f, [0.0, float(g["max_iter"]), float(g["max_toler"]), 10.0, 0.0], np.float64)
+        subprocess.run([exe, "ba", fin, fout], check=True)
+        with open(fout, "rb") as f:
+            meta, T, P, K = rd(f, np.float64), rd(f, np.float64).reshape(-1, 4, 4), rd(f, np.float64).reshape(-1, 3), rd(f, np.float64)
+        verdicts = {}
+        for pre, label in (("", "RESET"), ("double_", "DOUBLE")):
+            ok = (int(meta[1]) == int(g[pre + "outer_iterations"]) and rel(meta[3], g[pre + "final_error"]) < 1e-6 and
+                  rel(T, g[pre + "out_T_wc"]) < 1e-5 and rel(P, g[pre + "out_points"]) < 1e-5 and rel(K, g[pre + "out_K"]) < 1e-5)
+            verdicts[label] = ok
+        print(f"ba[{name}]: {int(meta[1])} iterations, error {meta[2]:.6g} -> {meta[3]:.6g}, lambda {meta[4]:.3g}, {meta[5]:.1f} ms; "
+              f"agrees with the oracle under factor policy: {[k for k, v in verdicts.items() if v] or 'NEITHER'}")
+        assert rel(meta[2], g["initial_error"]) < 1e-9, "graph.error(initial) differs: factors / noise models are not the reference's"
+        assert any(verdicts.values()), "GTSAM's optimum differs from both recorded LM trajectories"
+        out[name + "_meta"], out[name + "_T"], out[name + "_points"], out[name + "_K"] = meta, T, P, K
+
+
+def main():
+    if len(sys.argv) < 2:
+        raise SystemExit(__doc__)
+    exe = os.path.abspath(sys.argv[1])
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        run_match(exe, tmp, out)
+        run_ba(exe, tmp, out)
+    np.savez(os.path.join(ROOT, "tests", "ref", "ref_outputs.npz"), **out)
+    print("reference harness agrees with the oracle: parity is pinned for these fixtures (commit tests/ref/ref_outputs.npz)")
+
+
+if __name__ == "__main__":
+    main()
