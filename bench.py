@@ -75,8 +75,9 @@ def parse():
 
 
 SOURCE_GROUPS = {"match": ("matcher.hip", "matcher_f32.hip", "context.hip", "context.hpp"),
-                 "ba": ("ba.hip", "ba_plan.hpp", "context.hpp")}
-PROFILE_ROUND = "r03"  # profiles/<round>_pmc_*.json read for roofline.traffic
+                 "ba": ("ba.hip", "ba_plan.hpp", "devprim.hpp", "context.hpp"),
+                 "solve": ("solve.hip", "score.hip", "context.hpp")}
+PROFILE_ROUND = "r04"  # profiles/<round>_pmc_*.json read for roofline.traffic
 
 
 def kernel_source_sha(group: str | None = None) -> str:
@@ -617,9 +618,9 @@ def main():
     head, r = matching_line(D, descs, "i8", args.dim, args.steps, args.warmup,
                             f"S200 matching: {args.frames} frames x {args.kpts} kpts x {args.dim}-D, "
                             f"{len(synth.all_pairs(args.frames))} unordered pairs (both directions + mutual check)",
-                            "match_tile_kernel<8, 2>" if args.dim > 128 else "match_tile_kernel<4, 2>")
+                            "match_tile_kernel<8, 2, false>" if args.dim > 128 else "match_tile_kernel<4, 2, false>")
     if args.kpts == 2000 and args.dim == 256:
-        head["roofline"]["traffic"], head["roofline"]["traffic_source"] = measured_traffic("eacham::match_tile_kernel<8, 2>")
+        head["roofline"]["traffic"], head["roofline"]["traffic_source"] = measured_traffic("eacham::match_tile_kernel<8, 2, false>")
     else:
         head["roofline"]["traffic_source"] = "not the profiled workload"
 
@@ -649,7 +650,7 @@ def main():
     leg("s200_d128_i8", lambda: matching_line(
         D, synth.make_frame_descriptors(scene, args.kpts, 128)[0], "i8", 128, sub_steps, 1,
         f"S200 matching with SIFT-shaped descriptors: {args.frames} frames x {args.kpts} kpts x 128-D integers "
-        "(FeatureExtractorSift.cpp:8)", "match_tile_kernel<4, 2>")[0])
+        "(FeatureExtractorSift.cpp:8)", "match_tile_kernel<4, 2, false>")[0])
 
     def f32_line():
         base = synth.unit_float_descriptors(args.kpts, 256, 1, 99)
@@ -661,7 +662,7 @@ def main():
     leg("c2", lambda: matching_line(
         D, descs[:100] if args.frames >= 100 else descs, "i8", args.dim, sub_steps, 1,
         "BASELINE configs[1]: brute-force 256-D descriptor match, 2k kpts x 100 synthetic frames (4950 pairs)",
-        "match_tile_kernel<8, 2>")[0])
+        "match_tile_kernel<8, 2, false>")[0])
 
     def tum_line():
         # config/ConfigTUM.json:3,28: <= 500 frames x 600 features (it asks for ORB/Hamming; the path stays L2 on
@@ -670,7 +671,7 @@ def main():
         td, _ = synth.make_frame_descriptors(tum, 600, 128, seed=3)
         out, _r = matching_line(D, td, "i8", 128, sub_steps, 1,
                                 "BASELINE configs[2] stand-in (TUM fr1/desk sizes): 500 frames x 600 kpts x 128-D, 124750 pairs",
-                                "match_tile_kernel<4, 2>")
+                                "match_tile_kernel<4, 2, false>")
         out["ba"] = bench_local_windows(D, ctx, tum, range(100, 140), ba.OptimizerConfig.refine_ba())
         return out
 
@@ -703,7 +704,7 @@ def main():
         out, _r = matching_line(D, kd, "i8", 128, sub_steps, 1,
                                 f"BASELINE configs[4] stand-in (KITTI seq-00 sizes): 100 frames x 1500 kpts x 128-D, 4950 pairs sharded "
                                 f"over {D.world} GPU(s) + all-gather of the match graph ({D.collective_name})",
-                                "match_tile_kernel<4, 2>", gather_at_one=True)
+                                "match_tile_kernel<4, 2, false>", gather_at_one=True)
         if D.group_note:
             out["all_gather_note"] = D.group_note
         out["scaling"] = "strong"
@@ -716,7 +717,7 @@ def main():
         kd, _ = synth.make_frame_descriptors(kit, 1500, 128, seed=6)
         out, _r = matching_line(D, kd, "i8", 128, 1, 1,
                                 f"KITTI-like long sequence: 1000 frames x 1500 kpts x 128-D, 499500 pairs sharded over {D.world} GPU(s)"
-                                + (f" + all-gather of the match graph ({D.collective_name})" if D.world > 1 else ""), "match_tile_kernel<4, 2>")
+                                + (f" + all-gather of the match graph ({D.collective_name})" if D.world > 1 else ""), "match_tile_kernel<4, 2, false>")
         out["scaling"] = "strong"
         return out
     leg("c5_kitti_long", kitti_long_line)

@@ -675,7 +675,7 @@ constexpr int VER_CANDS = 32 * VER_GROUPS;    // candidates per work item
 __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint4* __restrict__ rowres, int col_chunks,
     int row_stride, double ratio, int min_dir, int min_mutual, int mode, uint2* __restrict__ rowcand,
-    int* __restrict__ candlist, int4* __restrict__ state, int2* __restrict__ items, int* __restrict__ n_items) {
+    int* __restrict__ candlist, int4* __restrict__ state, int2* __restrict__ items, int* __restrict__ n_items, int exp_all) {
     __shared__ int s_wave[FIN_THREADS / 64];
     __shared__ int s_item0;
     const int tid = threadIdx.x;
@@ -708,6 +708,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
             const unsigned pa = (j >> 5) >= A_even ? 1u : 0u;
             d2 = (int)(v1 + pa) - 2;
             ok = v2 < PAD_V && ratio_pass(d2, (int)(v2 + pa) - 2, ratio);  // pad second => < 2 train rows
+            if (exp_all) ok = true;  // (diagnostic: every row a candidate — the candidate pass then sweeps the whole pair)
         }
         if (j < 32 * A_tiles) rc[j] = ok ? make_uint2(col, (unsigned)d2) : make_uint2(0xffffffffu, 0u);
         int total;
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
         base += total;
     }
     // main.cpp:111,142: an edge needs |m12| >= min_dir and |mutual| > min_mutual, and mutual is a subset of m12
-    const bool live = mode == 0 && base >= min_dir && base > min_mutual;
+    const bool live = (mode == 0 && base >= min_dir && base > min_mutual) || exp_all;
     const int groups = (base + VER_CANDS - 1) / VER_CANDS;
     if (tid == 0) {
         state[p] = make_int4(base, live ? 1 : 0, 0, 0);
@@ -1184,7 +1185,7 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
                 if (mode == 0) EACHAM_HIP_TRY(ctx, hipMemsetAsync(n_items, 0, sizeof(int), st2));
                 match_rows_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.col_chunks,
                                                                pl.row_stride, ratio, min_dir, min_mutual, mode, rowcand, candlist, state,
-                                                               items, n_items);
+                                                               items, n_items, ctx->exp_all_candidates ? 1 : 0);
                 if (mode == 0) {
                     // persistent workgroups over the item list (its length is only known on the device): one round of the chip
                     const int vgrid = std::min(std::max(nb * pl.wgs_per_pair, 1), 512);

@@ -99,6 +99,11 @@ def main():
             out[name] = {"kernels_ms": round(ms / (reps + 1), 4), "end_to_end_ms": round(dt * 1e3, 3), "cpu_ms": round(dc * 1e3, 2),
                          "iterations_per_s_end_to_end": round(iters / dt), "cpu_iterations_per_s": round(iters / dc),
                          "models_bit_identical": same}
+    try:   # which kernel sources these numbers belong to (bench.py's sha over solve.hip / score.hip)
+        import bench
+        out["__meta__"] = {"kernel_source_sha_solve": bench.kernel_source_sha("solve")}
+    except Exception:  # noqa: BLE001
+        pass
     print(json.dumps(out))
 
 
