@@ -226,6 +226,7 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     ctx->exp_no_coltop2 = getenv("EACHAM_EXP_NO_COLTOP2") != nullptr;
     ctx->match_full_columns = getenv("EACHAM_MATCH_FULL_COLUMNS") != nullptr;
     ctx->exp_all_candidates = getenv("EACHAM_EXP_ALL_CANDIDATES") != nullptr;
+    ctx->match_tile_sweep = getenv("EACHAM_MATCH_TILE_SWEEP") != nullptr;
     if (const char* b = getenv("EACHAM_MATCH_BUDGET_MB")) {
         const int v = atoi(b);
         if (v >= 16 && v <= 65536) ctx->match_budget_mb = v;

@@ -517,6 +517,222 @@ __global__ __launch_bounds__(WG_THREADS, (NSUB <= 2 ? 2 : 1)) void match_tile_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1r: the ROW sweep with the MFMA operands swapped (round 4) — the sweep of the candidate-only pipeline.
+//
+// match_tile_kernel keeps its query rows as the A operand: a lane then holds one train COLUMN of the tile, its 16 accumulators are 16
+// different query rows, and every distance needs a key of its own — one VALU op to add the column's constant and tag the tile, two
+// for the running top-2 of its row: 3 ops per distance on a kernel bound by the VALU issue port. Swapped — the train tile as the A
+// operand, the wave's 64 query rows as the B operand — a lane IS a query row, its 16 accumulators are 16 train rows against it, and
+// the per-train-row constant hb is the accumulator's C-init (read from LDS next to the tile: no VALU op), the per-query constant
+// is added once after the sweep. The row's top-2 VALUES then run on the raw accumulators three at a time — {min3, med3} of a
+// triple, a sorted-pair merge: 27 ops per 16 distances — and what a key used to carry is recovered elsewhere:
+//   * the parity of the train row's norm: frames are stored parity-sorted, so the sweep passes all even tiles, then all odd ones;
+//     the running state is set aside ONCE at the boundary and the two classes are joined when 2H + pb is formed;
+//   * the column of the minimum: only the TILE of the first strict improvement is tracked (a compare + select per 16 distances);
+//     the row inside it is found afterwards for the rows that pass the ratio test only (match_argmin_kernel: one 32 x 32 MFMA
+//     group per (train tile, <= 32 passing rows)), lowest train index on ties as the reference's scan.
+// 31 VALU ops per 16 distances instead of 48, and no 7-bit tile field: frames of any size in one sweep (no column chunks).
+// Pipeline, LDS-DMA ring, just-in-time fragment ring and the three-tiles-per-trip loop are match_tile_kernel's.
+// out   rowres[p][j] = {v1, tile1, v2, 0}: v = 2H + pb = d2 - pa_j + 2 of stored query row j, tile1 = first tile holding the minimum
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imed3(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// sorted pair (s1 <= s2) merged into the running top-2 (m1 <= m2): 3 ops
+__device__ __forceinline__ void top2_merge(int& m1, int& m2, int s1, int s2) {
+    m2 = imin(imin(imax(m1, s1), m2), s2);
+    m1 = imin(m1, s1);
+}
+
+template <int KS>
+__global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
+                                                                   int wgs_per_pair, uint4* __restrict__ rowres, int row_stride) {
+    constexpr int NSUB = 2;
+    constexpr int TILE_V4 = KS * 64;
+    constexpr int ROWS_WAVE = 32 * NSUB, ROWS_WG = WAVES * ROWS_WAVE;
+    constexpr int BIG = 0x7fffffff;
+    __shared__ v4i sB[3][TILE_V4];
+    __shared__ __attribute__((aligned(16))) int sHb[3][32];  // hb of the tile in the same ring slot: the C-init of its MFMA chains
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 31, h = lane >> 5;
+    const int rb = blockIdx.x % wgs_per_pair;
+    const int p = blockIdx.x / wgs_per_pair;
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    const int A_tiles = ((gint_t)A.meta)[1];
+    const int B_even = ((gint_t)B.meta)[0], T = ((gint_t)B.meta)[1];
+    if (rb * (ROWS_WG / 32) >= A_tiles) return;  // workgroup-uniform
+    const int wb = rb * WAVES + wave;
+    const bool active = NSUB * wb < A_tiles;
+    const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag;
+    const gint_t Aca = (gint_t)A.norm, Bhb = (gint_t)B.normb;
+    const int wbc = active ? wb : 0;
+
+    v4i a[NSUB][KS];   // this wave's 64 query rows, complemented: the B operand (a lane = a query row of the sub-tile)
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
+    // running top-2 values and the tile of the minimum, per sub-tile; the even class is set aside at the parity boundary
+    int x1[NSUB], x2[NSUB], xt[NSUB], e1[NSUB], e2[NSUB], et[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) x1[s] = x2[s] = e1[s] = e2[s] = BIG, xt[s] = et[s] = 0;
+
+    static_assert(TILE_V4 % 64 == 0, "a tile is a whole number of 1 KiB pieces");
+    constexpr int PIECES = TILE_V4 / 64;
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;
+    auto stage_tile = [&](int tile, int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + i * WAVES;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(Bfrag + (size_t)tile * TILE_V4 + piece * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(&sB[slot][piece * 64]), 16, 0, 0);
+        }
+    };
+    if (T > 0) {
+        stage_tile(0, 0);
+        stage_tile(min(1, T - 1), 1);
+        if (tid < 32) sHb[0][tid] = Bhb[tid];
+        else if (tid < 64) sHb[1][tid - 32] = Bhb[32 * min(1, T - 1) + tid - 32];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    // C-init of a chain on the tile in ring slot `slot`: accumulator r is train row (r & 3) + 8 (r >> 2) + 4 h
+    auto cinit_of = [&](int slot) {
+        v16i c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4i q = *reinterpret_cast<const v4i*>(&sHb[slot][8 * g + 4 * h]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[4 * g + k] = q[k];
+        }
+        return c;
+    };
+    v16i acc[NSUB], cnext;  // cnext: the C-init of the chain the NEXT phase issues, read from LDS a phase ahead
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) acc[s] = zero16;
+    cnext = zero16;
+    v4i bq[3];
+    if (T > 0 && active) {
+        v4i b0[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b0[ks] = sB[0][ks * 64 + lane];
+        const v16i c0 = cinit_of(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0[ks], a[0][ks], ks ? acc[0] : c0, 0, 0, 0);
+        bq[0] = sB[0][lane];
+        bq[1] = sB[0][64 + lane];
+        cnext = c0;  // phase 0 of tile 0 issues chain (0, 1): the same tile
+    }
+    constexpr int EPK = 16 / KS;
+    constexpr int NSTEP = NSUB * KS;
+    auto tile = [&](auto PHc, auto SLc, const int t) {
+        constexpr int PH = decltype(PHc)::value, SL = decltype(SLc)::value;
+        constexpr int slot_cur = SL, slot_nxt = (SL + 1) % 3, slot_new = (SL + 2) % 3;
+        const int t2 = min(t + 2, T - 1);
+        const int hb_new = (tid < 32) ? Bhb[32 * t2 + tid] : 0;   // lands during this tile; stored to the ring before the barrier
+        stage_tile(t2, slot_new);
+        if (t == B_even) {  // (workgroup-uniform, once per sweep) the even tiles are done: set their state aside, start the odd class
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) e1[s] = x1[s], e2[s] = x2[s], et[s] = xt[s], x1[s] = x2[s] = BIG;
+        }
+        if (active) {
+            const unsigned curB = lds_addr(&sB[slot_cur][lane]);
+            const unsigned nxtB = lds_addr(&sB[slot_nxt][lane]);
+            int pend[3] = {0, 0, 0}, before = 0;
+#pragma unroll
+            for (int i = 0; i < NSTEP; ++i) {
+                const int ph = i / KS, ks = i % KS;  // phase ph: epilogue of acc[ph] (tile t), MFMAs of the next chain
+                const int j = i + 2;
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[(i + PH) % 3]));
+                lds_read_frag(bq[(j + PH) % 3], (j / KS < NSUB - 1) ? curB : nxtB, (j % KS) * 1024);
+                const int q = (ph + 1) % NSUB;   // accumulator of the chain being issued: (t, 1) in phase 0, (t + 1, 0) in phase 1
+                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[(i + PH) % 3], a[q][ks], ks ? acc[q] : cnext, 0, 0, 0);
+                // phase 1 issues chain (t + 1, 0) and the next tile's phase 0 chain (t + 1, 1): both start from tile t + 1's constants,
+                // read from the ring right after phase 0 has handed its own (tile t's) to the matrix pipe
+                if (i == 0) cnext = cinit_of(slot_nxt);
+#pragma unroll
+                for (int e = 0; e < EPK; ++e) {
+                    const int eg = ks * EPK + e;  // 0..15 within the sub-tile
+                    const int key = acc[ph][eg];
+                    if (eg == 0) before = x1[ph];  // the class minimum this sub-tile meets
+                    pend[eg % 3] = key;
+                    if (eg % 3 == 2) {
+                        const int s1 = imin(imin(pend[0], pend[1]), pend[2]);
+                        const int s2 = imed3(pend[0], pend[1], pend[2]);
+                        top2_merge(x1[ph], x2[ph], s1, s2);
+                    } else if (eg == 15) {
+                        x2[ph] = imed3(x1[ph], x2[ph], key);
+                        x1[ph] = imin(x1[ph], key);
+                        xt[ph] = x1[ph] < before ? t : xt[ph];  // a strict improvement somewhere in this tile: it is the minimum's tile now
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));
+        }
+        if (tid < 32) sHb[slot_new][tid] = hb_new;
+        __syncthreads();
+    };
+    {
+        constexpr int ADV = NSTEP % 3;
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, ADV % 3>;
+        using P2 = std::integral_constant<int, (2 * ADV) % 3>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        int t = 0;
+        for (; t + 3 <= T; t += 3) {
+            tile(P0{}, P0{}, t);
+            tile(P1{}, S1{}, t + 1);
+            tile(P2{}, S2{}, t + 2);
+        }
+        if (t < T) {
+            tile(P0{}, P0{}, t);
+            if (t + 1 < T) tile(P1{}, S1{}, t + 1);
+        }
+    }
+    if (!active) return;
+    if (B_even >= T) {  // a frame without odd rows never met the boundary: what ran is the even class
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) e1[s] = x1[s], e2[s] = x2[s], et[s] = xt[s], x1[s] = x2[s] = BIG;
+    }
+    uint4* rr = rowres + (size_t)p * row_stride + ROWS_WAVE * wb;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        // lanes l and l + 32 hold the same query row against complementary train rows of every tile: join them (equal minima:
+        // the earlier tile), then the two parity classes as v = 2 (m + ca) + pb (never equal across classes)
+        const int ca = Aca[ROWS_WAVE * wb + 32 * s + cl];
+        int cls1[2] = {e1[s], x1[s]}, cls2[2] = {e2[s], x2[s]}, clst[2] = {et[s], xt[s]};
+        unsigned v1 = 0xffffffffu, v2 = 0xffffffffu, t1 = 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int o1 = __shfl_xor(cls1[c], 32), o2 = __shfl_xor(cls2[c], 32), ot = __shfl_xor(clst[c], 32);
+            const int tt = o1 < cls1[c] ? ot : (o1 == cls1[c] ? imin(ot, clst[c]) : clst[c]);
+            int m1 = cls1[c], m2 = cls2[c];
+            top2_merge(m1, m2, o1, o2);
+            const unsigned w1 = m1 == BIG ? 0xffffffffu : (unsigned)(2 * (m1 + ca) + c);
+            const unsigned w2 = m2 == BIG ? 0xffffffffu : (unsigned)(2 * (m2 + ca) + c);
+            // (w1 <= w2) into (v1 <= v2)
+            t1 = w1 < v1 ? (unsigned)tt : t1;
+            v2 = umin(umin(umax(v1, w1), v2), w2);
+            v1 = umin(v1, w1);
+        }
+        if (h == 0) rr[32 * s + cl] = make_uint4(v1, t1, v2, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: merge column partials, ratio test, mutual check, thresholds, ordered compaction
 // ------------------------------------------------------------------------------------------------
 
@@ -729,17 +945,139 @@ __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
     }
 }
 
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int imed3(int a, int b, int c) {
-    int d;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
+// The rows kernel of the operand-swapped sweep (match_sweep_kernel): rowres carries the TILE of a row's minimum, not its column.
+// Besides what match_rows_kernel does, the passing rows of a pair that goes on are grouped by that tile (bytile[p][..], a counting
+// sort in LDS) and one argmin item is appended per (tile, <= 32 rows) — match_argmin_kernel turns the tile into the column.
+constexpr int MAX_TILES = MAX_ROWS / 32;
+__global__ __launch_bounds__(FIN_THREADS) void match_rows2_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint4* __restrict__ rowres, int row_stride, double ratio,
+    int min_dir, int min_mutual, int mode, uint2* __restrict__ rowcand, int* __restrict__ candlist, int* __restrict__ bytile,
+    int4* __restrict__ state, int2* __restrict__ vitems, int* __restrict__ n_vitems, int4* __restrict__ aitems, int* __restrict__ n_aitems,
+    int exp_all) {
+    __shared__ int s_wave[FIN_THREADS / 64];
+    __shared__ int s_cnt[MAX_TILES], s_pos[MAX_TILES], s_grp[MAX_TILES];
+    __shared__ int s_scan[FIN_THREADS], s_scan2[FIN_THREADS];
+    __shared__ int s_item0, s_aitem0;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x], B = frames[pr.y];
+    const int A_even = A.meta[0], A_tiles = A.meta[1], B_tiles = B.meta[1];
+    constexpr unsigned PAD_V = 2u * PADH;
+    uint2* rc = rowcand + (size_t)p * row_stride;
+    int* cl = candlist + (size_t)p * row_stride;
+    for (int t = tid; t < MAX_TILES; t += FIN_THREADS) s_cnt[t] = 0;
+    __syncthreads();
+    int base = 0;
+    for (int j0 = 0; j0 < 32 * A_tiles; j0 += FIN_THREADS) {
+        const int j = j0 + tid;
+        bool ok = false;
+        unsigned tile = 0;
+        int d2 = 0;
+        if (j < 32 * A_tiles && A.orig[j] >= 0) {
+            const uint4 e = rowres[(size_t)p * row_stride + j];
+            const unsigned pa = (j >> 5) >= A_even ? 1u : 0u;
+            tile = e.y;
+            d2 = (int)(e.x + pa) - 2;
+            ok = e.z < PAD_V && ratio_pass(d2, (int)(e.z + pa) - 2, ratio);  // pad second => < 2 train rows
+            if (exp_all) ok = e.x < PAD_V;
+        }
+        if (j < 32 * A_tiles) rc[j] = ok ? make_uint2(tile, (unsigned)d2) : make_uint2(0xffffffffu, 0u);
+        if (ok) atomicAdd(&s_cnt[tile], 1);
+        int total;
+        const int rank = block_rank(ok, tid, s_wave, total);
+        if (ok) cl[base + rank] = j;
+        base += total;
+    }
+    // main.cpp:111,142: an edge needs |m12| >= min_dir and |mutual| > min_mutual, and mutual is a subset of m12
+    const bool live = (mode == 0 && base >= min_dir && base > min_mutual) || (exp_all && base > 0);
+    const bool want_col = live || (mode == 1 && base > 0);   // directed lists need the column of every passing row
+    const int groups = (base + VER_CANDS - 1) / VER_CANDS;
+    __syncthreads();
+    if (want_col) {  // workgroup-uniform
+        // exclusive prefix of the per-tile counts (positions in bytile) and of the per-tile item counts, two tiles per thread
+        static_assert(MAX_TILES == 2 * FIN_THREADS, "two tiles per thread");
+        const int c0 = 2 * tid < B_tiles ? s_cnt[2 * tid] : 0, c1 = 2 * tid + 1 < B_tiles ? s_cnt[2 * tid + 1] : 0;
+        const int g0 = (c0 + 31) / 32, g1 = (c1 + 31) / 32;
+        s_scan[tid] = c0 + c1;
+        s_scan2[tid] = g0 + g1;
+        __syncthreads();
+        for (int off = 1; off < FIN_THREADS; off <<= 1) {
+            const int u = tid >= off ? s_scan[tid - off] : 0, v = tid >= off ? s_scan2[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += u;
+            s_scan2[tid] += v;
+            __syncthreads();
+        }
+        const int pos0 = s_scan[tid] - (c0 + c1), grp0 = s_scan2[tid] - (g0 + g1), n_groups = s_scan2[FIN_THREADS - 1];
+        s_pos[2 * tid] = pos0;
+        s_pos[2 * tid + 1] = pos0 + c0;
+        s_grp[2 * tid] = grp0;
+        s_grp[2 * tid + 1] = grp0 + g0;
+        if (tid == 0) s_aitem0 = atomicAdd(n_aitems, n_groups);
+        __syncthreads();
+        for (int t = tid; t < B_tiles; t += FIN_THREADS) {  // the items of tile t: rows [pos, pos + cnt) of bytile in groups of 32
+            const int cnt = s_cnt[t], pos = s_pos[t];
+            for (int g = 0; g < (cnt + 31) / 32; ++g) aitems[s_aitem0 + s_grp[t] + g] = make_int4(p, t, pos + 32 * g, min(32, cnt - 32 * g));
+        }
+        __syncthreads();
+        int* bt = bytile + (size_t)p * row_stride;
+        for (int i = tid; i < base; i += FIN_THREADS) {
+            const int j = cl[i];
+            bt[atomicAdd(&s_pos[rc[j].x], 1)] = j;   // (any order inside a tile: every row is resolved on its own)
+        }
+    }
+    if (tid == 0) {
+        state[p] = make_int4(base, live ? 1 : 0, 0, 0);
+        if (live) s_item0 = atomicAdd(n_vitems, groups);
+    }
+    if (live) {  // workgroup-uniform
+        __syncthreads();
+        for (int g = tid; g < groups; g += FIN_THREADS) vitems[s_item0 + g] = make_int2(p, g);
+    }
 }
-// sorted pair (s1 <= s2) merged into the running top-2 (m1 <= m2): 3 ops
-__device__ __forceinline__ void top2_merge(int& m1, int& m2, int s1, int s2) {
-    m2 = imin(imin(imax(m1, s1), m2), s2);
-    m1 = imin(m1, s1);
+
+// rowcand[p][j].x: the tile of row j's minimum -> its column. One wave per item (train tile T of the pair, <= 32 passing rows whose
+// minimum lies in T): the 32 x 32 distance block on the MFMA with the operands of match_sweep_kernel (the tile as A, the gathered
+// query rows as B, hb as C-init), then every lane scans its 16 train rows in ascending order with a strict '<', the two halves
+// of a query row are joined lower-index-first: the lowest train row of the minimum, the reference's tie rule.
+template <int KS>
+__global__ __launch_bounds__(64) void match_argmin_kernel(const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
+                                                          uint2* __restrict__ rowcand, const int* __restrict__ bytile,
+                                                          const int4* __restrict__ aitems, const int* __restrict__ n_aitems, int row_stride) {
+    const int lane = threadIdx.x & 63, cl = lane & 31, h = lane >> 5;
+    const int n = *n_aitems;
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int4 it = aitems[w];
+        const int p = it.x, tile = it.y;
+        const int2 pr = pairs[p];
+        const FrameDev A = frames[pr.x], B = frames[pr.y];
+        const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag;
+        const gint_t Bhb = (gint_t)B.normb;
+        const int j = bytile[(size_t)p * row_stride + it.z + (cl < it.w ? cl : 0)];
+        v16i acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4i q = *(const v4i __attribute__((address_space(1)))*)(Bhb + 32 * tile + 8 * g + 4 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * g + k] = q[k];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4i t = Bfrag[((size_t)tile * KS + ks) * 64 + lane];
+            const v4i q = ~Afrag[((size_t)(j >> 5) * KS + ks) * 64 + 32 * h + (j & 31)];
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, q, acc, 0, 0, 0);
+        }
+        int best = 0x7fffffff, bi = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // ascending in r
+            if (acc[r] < best) best = acc[r], bi = row;
+        }
+        const int o = __shfl_xor(best, 32), oi = __shfl_xor(bi, 32);
+        if (o < best || (o == best && oi < bi)) bi = oi;
+        if (h == 0 && cl < it.w) rowcand[(size_t)p * row_stride + j].x = (unsigned)(32 * tile + bi);
+    }
 }
 
 // colres[p][j] = {v1, v2}: the two smallest 2H + pa over ALL stored rows of frame A against column rowcand[p][j].x of
@@ -1048,7 +1386,7 @@ struct MatchPlan {
     int slots;       // workspace copies: batch i+1's tile kernel overlaps batch i's finalize
     size_t off_rowres, off_colpart, off_matches, slot_bytes, total;
     // the candidate-only column pass: rowcand | candlist | colres | state | items | n_items
-    size_t off_rowcand, off_candlist, off_colres, off_state, off_items, off_nitems;
+    size_t off_rowcand, off_candlist, off_colres, off_state, off_items, off_nitems, off_bytile, off_aitems;
 };
 
 static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
@@ -1062,7 +1400,8 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
     pl.col_chunks = (max_tiles + CHUNK_TILES - 1) / CHUNK_TILES;
     // per pair: row results + match list, and EITHER the column partials of the full sweep OR the arrays of the candidate pass
     const size_t colpart_pp = full_cols ? (size_t)pl.wb_stride * pl.row_stride * sizeof(int2) : 0;
-    const size_t cand_pp = full_cols ? 0 : (size_t)pl.row_stride * (sizeof(uint2) + sizeof(int) + sizeof(uint2)) + sizeof(int4) + (size_t)max_tiles * sizeof(int2);
+    const size_t cand_pp = full_cols ? 0 : (size_t)pl.row_stride * (sizeof(uint2) + 2 * sizeof(int) + sizeof(uint2)) + sizeof(int4) +
+                                               (size_t)max_tiles * (sizeof(int2) + 2 * sizeof(int4));
     size_t per_pair = (size_t)pl.col_chunks * pl.row_stride * sizeof(int4) + (size_t)pl.row_stride * sizeof(uint2) + colpart_pp + cand_pp;
     // bound a slot near 1 GiB so the column partials of one batch stay cache-friendly
     size_t budget = (size_t)ctx->match_budget_mb << 20;
@@ -1090,7 +1429,9 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
     pl.off_state = align(pl.off_colres + cb * pl.row_stride * sizeof(uint2));
     pl.off_items = align(pl.off_state + cb * sizeof(int4));
     pl.off_nitems = align(pl.off_items + cb * max_tiles * sizeof(int2));
-    pl.slot_bytes = align(pl.off_nitems + 256);
+    pl.off_bytile = align(pl.off_nitems + 256);
+    pl.off_aitems = align(pl.off_bytile + cb * pl.row_stride * sizeof(int));
+    pl.slot_bytes = align(pl.off_aitems + cb * 2 * max_tiles * sizeof(int4));
     pl.total = pl.slot_bytes * pl.slots;
     return pl;
 }
@@ -1154,13 +1495,22 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
         char* ws = (char*)ctx->ws + (size_t)slot * pl.slot_bytes;
         const int2* pb = pairs_dev + first;
         if (b >= pl.slots) EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st1, ctx->ev_fin[slot], 0));  // slot free again
+        const bool row_sweep = !full_cols && !ctx->match_tile_sweep;   // the operand-swapped row sweep (match_sweep_kernel): the default of the lean form
         {
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_TILE, st1);
             const bool col = full_cols && !ctx->exp_no_coltop2;
-            switch (ctx->ks_common) {
-                case 2: launch_tile<2>(ctx, pl, pb, nb, ws, col); break;
-                case 4: launch_tile<4>(ctx, pl, pb, nb, ws, col); break;
-                default: launch_tile<8>(ctx, pl, pb, nb, ws, col); break;
+            if (row_sweep) {
+                switch (ctx->ks_common) {
+                    case 2: match_sweep_kernel<2><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride); break;
+                    case 4: match_sweep_kernel<4><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride); break;
+                    default: match_sweep_kernel<8><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride); break;
+                }
+            } else {
+                switch (ctx->ks_common) {
+                    case 2: launch_tile<2>(ctx, pl, pb, nb, ws, col); break;
+                    case 4: launch_tile<4>(ctx, pl, pb, nb, ws, col); break;
+                    default: launch_tile<8>(ctx, pl, pb, nb, ws, col); break;
+                }
             }
         }
         EACHAM_HIP_TRY(ctx, hipEventRecord(ctx->ev_tile[slot], st1));
@@ -1182,10 +1532,25 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
                 int4* state = (int4*)(ws + pl.off_state);
                 int2* items = (int2*)(ws + pl.off_items);
                 int* n_items = (int*)(ws + pl.off_nitems);
-                if (mode == 0) EACHAM_HIP_TRY(ctx, hipMemsetAsync(n_items, 0, sizeof(int), st2));
-                match_rows_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.col_chunks,
-                                                               pl.row_stride, ratio, min_dir, min_mutual, mode, rowcand, candlist, state,
-                                                               items, n_items, ctx->exp_all_candidates ? 1 : 0);
+                int* n_aitems = n_items + 16;
+                EACHAM_HIP_TRY(ctx, hipMemsetAsync(n_items, 0, 32 * sizeof(int), st2));
+                if (row_sweep) {
+                    int* bytile = (int*)(ws + pl.off_bytile);
+                    int4* aitems = (int4*)(ws + pl.off_aitems);
+                    match_rows2_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.row_stride, ratio,
+                                                                    min_dir, min_mutual, mode, rowcand, candlist, bytile, state, items, n_items, aitems,
+                                                                    n_aitems, ctx->exp_all_candidates ? 1 : 0);
+                    const int agrid = std::min(std::max(nb * pl.wgs_per_pair, 1), 4096);   // one wave per item, persistent over the list
+                    switch (ctx->ks_common) {
+                        case 2: match_argmin_kernel<2><<<agrid, 64, 0, st2>>>(ctx->frame_table_dev, pb, rowcand, bytile, aitems, n_aitems, pl.row_stride); break;
+                        case 4: match_argmin_kernel<4><<<agrid, 64, 0, st2>>>(ctx->frame_table_dev, pb, rowcand, bytile, aitems, n_aitems, pl.row_stride); break;
+                        default: match_argmin_kernel<8><<<agrid, 64, 0, st2>>>(ctx->frame_table_dev, pb, rowcand, bytile, aitems, n_aitems, pl.row_stride); break;
+                    }
+                } else {
+                    match_rows_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.col_chunks,
+                                                                   pl.row_stride, ratio, min_dir, min_mutual, mode, rowcand, candlist, state,
+                                                                   items, n_items, ctx->exp_all_candidates ? 1 : 0);
+                }
                 if (mode == 0) {
                     // persistent workgroups over the item list (its length is only known on the device): one round of the chip
                     const int vgrid = std::min(std::max(nb * pl.wgs_per_pair, 1), 512);
