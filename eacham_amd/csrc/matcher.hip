@@ -600,8 +600,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameD
     if (T > 0) {
         stage_tile(0, 0);
         stage_tile(min(1, T - 1), 1);
-        if (tid < 32) sHb[0][tid] = Bhb[tid];
-        else if (tid < 64) sHb[1][tid - 32] = Bhb[32 * min(1, T - 1) + tid - 32];
+        stage_tile(min(2, T - 1), 2);
+        if (tid < 96) sHb[tid >> 5][tid & 31] = Bhb[32 * min(tid >> 5, T - 1) + (tid & 31)];
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -617,54 +617,70 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameD
         }
         return c;
     };
-    v16i acc[NSUB], cnext;  // cnext: the C-init of the chain the NEXT phase issues, read from LDS a phase ahead
+    // Software pipeline: the MFMAs of tile t + 1 (both sub-tiles: every fragment is read from LDS ONCE and feeds two independent
+    // chains) are issued interleaved with the epilogue of tile t, so the accumulators are double-buffered (tile parity). With one
+    // LDS read per fragment and accumulator — the first form of this kernel, and match_tile_kernel's — the CU's LDS port is as busy as
+    // its matrix pipes (16 KiB per wave-tile at 128 B / cycle = the 1024 cycles the MFMAs of two resident waves take) and the 256-D
+    // sweep stayed where the VALU-bound kernel was; read once, the port is at half of that.
+    // The chains' C-init (hb of the tile) is read from LDS straight into the accumulators that will take the chain: the ones whose
+    // epilogue has just finished (a separate register set for it cost 16 VGPRs and, by the allocator's choice, a copy of a live chain).
+    static_assert(KS >= 2, "the epilogue of a tile is spread over the first KS - 1 steps of the next tile's MFMAs");
+    v16i accA[NSUB], accB[NSUB];
     const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) acc[s] = zero16;
-    cnext = zero16;
-    v4i bq[3];
+    for (int s = 0; s < NSUB; ++s) accA[s] = zero16, accB[s] = zero16;
+    v4i bq[3];  // fragment ring: step i of the ks sequence lives in bq[i % 3]
+    constexpr int DIST = KS >= 2 ? 2 : 1;   // fragments are read DIST steps ahead of their MFMAs (a 32-D tile is a single step)
     if (T > 0 && active) {
-        v4i b0[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b0[ks] = sB[0][ks * 64 + lane];
         const v16i c0 = cinit_of(0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0[ks], a[0][ks], ks ? acc[0] : c0, 0, 0, 0);
-        bq[0] = sB[0][lane];
-        bq[1] = sB[0][64 + lane];
-        cnext = c0;  // phase 0 of tile 0 issues chain (0, 1): the same tile
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4i b0 = sB[0][ks * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) accA[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, a[s][ks], ks ? accA[s] : c0, 0, 0, 0);
+        }
+        bq[0] = sB[1][lane];   // the first fragments of tile 1 (the ring holds tile T - 1 again past the end: recomputed, never read)
+        if constexpr (DIST == 2) bq[1] = sB[1][64 + lane];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) accB[s] = cinit_of(1);
     }
-    constexpr int EPK = 16 / KS;
-    constexpr int NSTEP = NSUB * KS;
-    auto tile = [&](auto PHc, auto SLc, const int t) {
-        constexpr int PH = decltype(PHc)::value, SL = decltype(SLc)::value;
-        constexpr int slot_cur = SL, slot_nxt = (SL + 1) % 3, slot_new = (SL + 2) % 3;
-        const int t2 = min(t + 2, T - 1);
-        const int hb_new = (tid < 32) ? Bhb[32 * t2 + tid] : 0;   // lands during this tile; stored to the ring before the barrier
-        stage_tile(t2, slot_new);
+    __syncthreads();   // slot 0 is staged into again by the first call below
+    // keys of tile t handled by step ks of tile t + 1's MFMAs: all 32 within the first KS - 1 steps, so that the accumulators are
+    // free for tile t + 2's constants a step before the call's drain
+    auto key_lo = [](int ks) constexpr { return ks >= KS - 1 ? 32 : (32 * ks + KS - 2) / (KS - 1); };
+    // One call: epilogue of tile t (held in `cur`), MFMAs of tile t + 1 into `nxt`, tile t + 3 staged into tile t's ring slot (its
+    // fragments were consumed a call ago), the first fragments and the constants of tile t + 2 fetched at the end (published by the
+    // previous call's barrier) and drained before this call's: nothing is in flight across a call. The LDS slot ring (period 3), the
+    // fragment register ring (advance KS % 3 per call) and the accumulator parity (period 2) are compile-time: six instantiations.
+    auto tile = [&](auto PHc, auto SLc, auto PARc, const int t) {
+        constexpr int PH = decltype(PHc)::value, SL = decltype(SLc)::value, PAR = decltype(PARc)::value;
+        constexpr int slot_nxt = (SL + 1) % 3, slot_nn = (SL + 2) % 3;
+        v16i(&cur)[NSUB] = PAR ? accB : accA;
+        v16i(&nxt)[NSUB] = PAR ? accA : accB;
+        const int t3 = min(t + 3, T - 1);
+        const int hb_new = (tid < 32) ? Bhb[32 * t3 + tid] : 0;   // lands during this call; stored to the ring before the barrier
+        stage_tile(t3, SL);
         if (t == B_even) {  // (workgroup-uniform, once per sweep) the even tiles are done: set their state aside, start the odd class
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) e1[s] = x1[s], e2[s] = x2[s], et[s] = xt[s], x1[s] = x2[s] = BIG;
         }
         if (active) {
-            const unsigned curB = lds_addr(&sB[slot_cur][lane]);
             const unsigned nxtB = lds_addr(&sB[slot_nxt][lane]);
+            const unsigned nnB = lds_addr(&sB[slot_nn][lane]);
             int pend[3] = {0, 0, 0}, before = 0;
 #pragma unroll
-            for (int i = 0; i < NSTEP; ++i) {
-                const int ph = i / KS, ks = i % KS;  // phase ph: epilogue of acc[ph] (tile t), MFMAs of the next chain
-                const int j = i + 2;
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[(i + PH) % 3]));
-                lds_read_frag(bq[(j + PH) % 3], (j / KS < NSUB - 1) ? curB : nxtB, (j % KS) * 1024);
-                const int q = (ph + 1) % NSUB;   // accumulator of the chain being issued: (t, 1) in phase 0, (t + 1, 0) in phase 1
-                acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[(i + PH) % 3], a[q][ks], ks ? acc[q] : cnext, 0, 0, 0);
-                // phase 1 issues chain (t + 1, 0) and the next tile's phase 0 chain (t + 1, 1): both start from tile t + 1's constants,
-                // read from the ring right after phase 0 has handed its own (tile t's) to the matrix pipe
-                if (i == 0) cnext = cinit_of(slot_nxt);
+            for (int ks = 0; ks < KS; ++ks) {
+                if constexpr (DIST == 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[(ks + PH) % 3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[(ks + PH) % 3]));
+                const int j = ks + DIST;
+                lds_read_frag(bq[(j + PH) % 3], j < KS ? nxtB : nnB, (j % KS) * 1024);
 #pragma unroll
-                for (int e = 0; e < EPK; ++e) {
-                    const int eg = ks * EPK + e;  // 0..15 within the sub-tile
-                    const int key = acc[ph][eg];
+                for (int s = 0; s < NSUB; ++s)
+                    nxt[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[(ks + PH) % 3], a[s][ks], nxt[s], 0, 0, 0);
+#pragma unroll
+                for (int idx = key_lo(ks); idx < key_lo(ks + 1); ++idx) {
+                    const int ph = idx / 16, eg = idx % 16;  // key eg of sub-tile ph of tile t
+                    const int key = cur[ph][eg];
                     if (eg == 0) before = x1[ph];  // the class minimum this sub-tile meets
                     pend[eg % 3] = key;
                     if (eg % 3 == 2) {
@@ -675,32 +691,38 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameD
                         x2[ph] = imed3(x1[ph], x2[ph], key);
                         x1[ph] = imin(x1[ph], key);
                         xt[ph] = x1[ph] < before ? t : xt[ph];  // a strict improvement somewhere in this tile: it is the minimum's tile now
+                        cur[ph] = cinit_of(slot_nn);   // done with these accumulators: tile t + 2's constants, for the next call's chains
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));
         }
-        if (tid < 32) sHb[slot_new][tid] = hb_new;
+        if (tid < 32) sHb[SL][tid] = hb_new;
         __syncthreads();
     };
     {
-        constexpr int ADV = NSTEP % 3;
-        using P0 = std::integral_constant<int, 0>;
-        using P1 = std::integral_constant<int, ADV % 3>;
-        using P2 = std::integral_constant<int, (2 * ADV) % 3>;
-        using S1 = std::integral_constant<int, 1>;
-        using S2 = std::integral_constant<int, 2>;
+        // tile(t) consumes tile t's accumulators and issues tile t + 1's: the last call (t = T - 1) issues a recomputation of a
+        // clamped tile that nobody reads
+        constexpr int ADV = KS % 3;
         int t = 0;
-        for (; t + 3 <= T; t += 3) {
-            tile(P0{}, P0{}, t);
-            tile(P1{}, S1{}, t + 1);
-            tile(P2{}, S2{}, t + 2);
+        auto run = [&](auto K6c, int tt) {
+            constexpr int K6 = decltype(K6c)::value;
+            tile(std::integral_constant<int, (K6 * ADV) % 3>{}, std::integral_constant<int, K6 % 3>{}, std::integral_constant<int, K6 % 2>{}, tt);
+        };
+        for (; t + 6 <= T; t += 6) {
+            run(std::integral_constant<int, 0>{}, t);
+            run(std::integral_constant<int, 1>{}, t + 1);
+            run(std::integral_constant<int, 2>{}, t + 2);
+            run(std::integral_constant<int, 3>{}, t + 3);
+            run(std::integral_constant<int, 4>{}, t + 4);
+            run(std::integral_constant<int, 5>{}, t + 5);
         }
-        if (t < T) {
-            tile(P0{}, P0{}, t);
-            if (t + 1 < T) tile(P1{}, S1{}, t + 1);
-        }
+        if (t < T) run(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) run(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < T) run(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < T) run(std::integral_constant<int, 3>{}, t + 3);
+        if (t + 4 < T) run(std::integral_constant<int, 4>{}, t + 4);
     }
     if (!active) return;
     if (B_even >= T) {  // a frame without odd rows never met the boundary: what ran is the even class
