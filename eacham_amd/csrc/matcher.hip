@@ -549,7 +549,7 @@ __device__ __forceinline__ void top2_merge(int& m1, int& m2, int s1, int s2) {
 }
 
 template <int KS>
-__global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
+__global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kernel(const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
                                                                    int wgs_per_pair, uint4* __restrict__ rowres, int row_stride) {
     constexpr int NSUB = 2;
     constexpr int TILE_V4 = KS * 64;
@@ -580,21 +580,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameD
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
     // running top-2 values and the tile of the minimum, per sub-tile; the even class is set aside at the parity boundary
-    int x1[NSUB], x2[NSUB], xt[NSUB], e1[NSUB], e2[NSUB], et[NSUB];
+    // (set aside in LDS, each lane its own words: six registers less through the sweep)
+    __shared__ int sEven[3 * NSUB][WG_THREADS];
+    int x1[NSUB], x2[NSUB], xt[NSUB];
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) x1[s] = x2[s] = e1[s] = e2[s] = BIG, xt[s] = et[s] = 0;
+    for (int s = 0; s < NSUB; ++s) x1[s] = x2[s] = BIG, xt[s] = 0;
 
     static_assert(TILE_V4 % 64 == 0, "a tile is a whole number of 1 KiB pieces");
     constexpr int PIECES = TILE_V4 / 64;
     constexpr int PPW = (PIECES + WAVES - 1) / WAVES;
+    // (a wave stages PPW consecutive 1 KiB pieces: a scalar base, ONE 32-bit lane offset and immediate offsets — no 64-bit
+    // per-lane addresses held through the sweep)
+    const unsigned stage_off = (unsigned)(wave * PPW * 64 + lane) * 16u;
     auto stage_tile = [&](int tile, int slot) {
+        const __attribute__((address_space(1))) char* base = (const __attribute__((address_space(1))) char*)(Bfrag + (size_t)tile * TILE_V4);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int piece = wave + i * WAVES;
+            const int piece = wave * PPW + i;
             if (piece < PIECES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(Bfrag + (size_t)tile * TILE_V4 + piece * 64 + lane),
-                    (__attribute__((address_space(3))) void*)(&sB[slot][piece * 64]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + stage_off + i * 1024),
+                                                 (__attribute__((address_space(3))) void*)(&sB[slot][piece * 64]), 16, 0, 0);
         }
     };
     if (T > 0) {
@@ -658,11 +663,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameD
         v16i(&cur)[NSUB] = PAR ? accB : accA;
         v16i(&nxt)[NSUB] = PAR ? accA : accB;
         const int t3 = min(t + 3, T - 1);
-        const int hb_new = (tid < 32) ? Bhb[32 * t3 + tid] : 0;   // lands during this call; stored to the ring before the barrier
+        const int hb_new = (tid < 32) ? *reinterpret_cast<const __attribute__((address_space(1))) int*>(reinterpret_cast<const __attribute__((address_space(1))) char*>(Bhb + 32 * t3) + (unsigned)tid * 4u) : 0;   // lands during this call; stored to the ring before the barrier
         stage_tile(t3, SL);
         if (t == B_even) {  // (workgroup-uniform, once per sweep) the even tiles are done: set their state aside, start the odd class
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) e1[s] = x1[s], e2[s] = x2[s], et[s] = xt[s], x1[s] = x2[s] = BIG;
+            for (int s = 0; s < NSUB; ++s) {
+                sEven[3 * s][tid] = x1[s], sEven[3 * s + 1][tid] = x2[s], sEven[3 * s + 2][tid] = xt[s];
+                x1[s] = x2[s] = BIG;
+            }
         }
         if (active) {
             const unsigned nxtB = lds_addr(&sB[slot_nxt][lane]);
@@ -725,9 +733,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void match_sweep_kernel(const FrameD
         if (t + 4 < T) run(std::integral_constant<int, 4>{}, t + 4);
     }
     if (!active) return;
-    if (B_even >= T) {  // a frame without odd rows never met the boundary: what ran is the even class
+    int e1[NSUB], e2[NSUB], et[NSUB];
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) e1[s] = x1[s], e2[s] = x2[s], et[s] = xt[s], x1[s] = x2[s] = BIG;
+    for (int s = 0; s < NSUB; ++s) {
+        if (B_even >= T) {  // a frame without odd rows never met the boundary: what ran is the even class
+            e1[s] = x1[s], e2[s] = x2[s], et[s] = xt[s], x1[s] = x2[s] = BIG;
+        } else {
+            e1[s] = sEven[3 * s][tid], e2[s] = sEven[3 * s + 1][tid], et[s] = sEven[3 * s + 2][tid];
+        }
     }
     uint4* rr = rowres + (size_t)p * row_stride + ROWS_WAVE * wb;
 #pragma unroll
