@@ -308,6 +308,14 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int, gather_at_o
     return out
 
 
+def sweep_kernel(dim: int) -> str:
+    """The distance sweep run_match launches for `dim`-D integer descriptors without per-pair statistics (matcher.hip: run_match)."""
+    ks = 2 if dim <= 64 else 4 if dim <= 128 else 8
+    if os.environ.get("EACHAM_MATCH_TILE_SWEEP", "0") not in ("", "0"):
+        return f"match_tile_kernel<{ks}, 2, false>"
+    return f"match_sweep_kernel<{ks}>"
+
+
 def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str, gather_at_one: bool = False):
     """One matching sub-line: value + roofline against the MFMA peak of the arithmetic used."""
     r = run_matching(D, descs, kind, steps, warmup, gather_at_one)
@@ -618,9 +626,9 @@ def main():
     head, r = matching_line(D, descs, "i8", args.dim, args.steps, args.warmup,
                             f"S200 matching: {args.frames} frames x {args.kpts} kpts x {args.dim}-D, "
                             f"{len(synth.all_pairs(args.frames))} unordered pairs (both directions + mutual check)",
-                            "match_tile_kernel<8, 2, false>" if args.dim > 128 else "match_tile_kernel<4, 2, false>")
+                            sweep_kernel(args.dim))
     if args.kpts == 2000 and args.dim == 256:
-        head["roofline"]["traffic"], head["roofline"]["traffic_source"] = measured_traffic("eacham::match_tile_kernel<8, 2, false>")
+        head["roofline"]["traffic"], head["roofline"]["traffic_source"] = measured_traffic("eacham::" + sweep_kernel(256))
     else:
         head["roofline"]["traffic_source"] = "not the profiled workload"
 
@@ -650,7 +658,7 @@ def main():
     leg("s200_d128_i8", lambda: matching_line(
         D, synth.make_frame_descriptors(scene, args.kpts, 128)[0], "i8", 128, sub_steps, 1,
         f"S200 matching with SIFT-shaped descriptors: {args.frames} frames x {args.kpts} kpts x 128-D integers "
-        "(FeatureExtractorSift.cpp:8)", "match_tile_kernel<4, 2, false>")[0])
+        "(FeatureExtractorSift.cpp:8)", sweep_kernel(128))[0])
 
     def f32_line():
         base = synth.unit_float_descriptors(args.kpts, 256, 1, 99)
@@ -662,7 +670,7 @@ def main():
     leg("c2", lambda: matching_line(
         D, descs[:100] if args.frames >= 100 else descs, "i8", args.dim, sub_steps, 1,
         "BASELINE configs[1]: brute-force 256-D descriptor match, 2k kpts x 100 synthetic frames (4950 pairs)",
-        "match_tile_kernel<8, 2, false>")[0])
+        sweep_kernel(args.dim))[0])
 
     def tum_line():
         # config/ConfigTUM.json:3,28: <= 500 frames x 600 features (it asks for ORB/Hamming; the path stays L2 on
@@ -671,7 +679,7 @@ def main():
         td, _ = synth.make_frame_descriptors(tum, 600, 128, seed=3)
         out, _r = matching_line(D, td, "i8", 128, sub_steps, 1,
                                 "BASELINE configs[2] stand-in (TUM fr1/desk sizes): 500 frames x 600 kpts x 128-D, 124750 pairs",
-                                "match_tile_kernel<4, 2, false>")
+                                sweep_kernel(128))
         out["ba"] = bench_local_windows(D, ctx, tum, range(100, 140), ba.OptimizerConfig.refine_ba())
         return out
 
@@ -704,7 +712,7 @@ def main():
         out, _r = matching_line(D, kd, "i8", 128, sub_steps, 1,
                                 f"BASELINE configs[4] stand-in (KITTI seq-00 sizes): 100 frames x 1500 kpts x 128-D, 4950 pairs sharded "
                                 f"over {D.world} GPU(s) + all-gather of the match graph ({D.collective_name})",
-                                "match_tile_kernel<4, 2, false>", gather_at_one=True)
+                                sweep_kernel(128), gather_at_one=True)
         if D.group_note:
             out["all_gather_note"] = D.group_note
         out["scaling"] = "strong"
@@ -717,7 +725,7 @@ def main():
         kd, _ = synth.make_frame_descriptors(kit, 1500, 128, seed=6)
         out, _r = matching_line(D, kd, "i8", 128, 1, 1,
                                 f"KITTI-like long sequence: 1000 frames x 1500 kpts x 128-D, 499500 pairs sharded over {D.world} GPU(s)"
-                                + (f" + all-gather of the match graph ({D.collective_name})" if D.world > 1 else ""), "match_tile_kernel<4, 2, false>")
+                                + (f" + all-gather of the match graph ({D.collective_name})" if D.world > 1 else ""), sweep_kernel(128))
         out["scaling"] = "strong"
         return out
     leg("c5_kitti_long", kitti_long_line)

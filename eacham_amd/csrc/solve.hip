@@ -777,16 +777,27 @@ __device__ __forceinline__ double ordered_wave_sum(double v, double* red, int te
     return t;
 }
 
+// What the front half leaves in registers (identical in every lane) for the back half: the control-point frame and the six squared
+// control-point distances; the four null vectors (S.ev) and the distance system (S.L) stay in LDS.
+struct PnpFrame {
+    double c0[3], ax[3][3], sc[3], rho[6];
+};
+
+// Front half, ONE WAVE per sample: control points, M^T M (shared), its eigenvectors by jacobi_wave, the distance system.
 template <bool BIG>
-__device__ static int epnp_wave(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt, PnpLds& S,
-                                double* rows /* !BIG: 64 x 24 */, double* part /* BIG: 78 x 64 */) {
+__device__ static int epnp_front(int m, const int* idx, const double* obj, const double* img, const double* K, PnpFrame& F, PnpLds& S,
+                                 double* rows /* !BIG: 64 x 24 */, double* part /* BIG: 78 x 64 */) {
     if (m < 4 || (!BIG && m > 64)) return 0;
     const int lane = threadIdx.x & 63;
     const int terms = m < 64 ? m : 64;  // lanes that hold a partial sum
     auto total = [&](double v) { return ordered_wave_sum(v, S.red, terms); };
-    const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
+    const double fu = K[0], uc = K[2], fv = K[1], vc = K[3];
+    double (&c0)[3] = F.c0;
+    double (&ax)[3][3] = F.ax;
+    double (&sc)[3] = F.sc;
+    double (&rho)[6] = F.rho;
     /* control points: centroid + principal axes scaled by the spread along them */
-    double c0[3] = {0, 0, 0};
+    c0[0] = c0[1] = c0[2] = 0.0;
     for (int k = lane; k < m; k += 64)
 #pragma unroll
         for (int e = 0; e < 3; ++e) c0[e] += obj[3 * (size_t)idx[k] + e];
@@ -807,7 +818,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
     jacobi_eig<3>(C, V3, w3);
     double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
     wmax = wmax > w3[2] ? wmax : w3[2];
-    double ax[3][3], sc[3];  /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
+    /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (!(w3[k] > 1e-12 * wmax) || !(wmax > 0.0)) return 0;
@@ -908,7 +919,6 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
 #pragma unroll
         for (int k = 0; k < 3; ++k) cw[k + 1][e] = c0[e] + sc[k] * ax[k][e];
     }
-    double rho[6];
     {
         constexpr int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
         if (lane < 60) {  // entry (p, col) of L per lane
@@ -938,6 +948,21 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
         }
         wave_sync_lds();
     }
+    return 1;
+}
+
+template <bool LANE>
+__device__ static int epnp_back(int m, const int* idx, const double* obj, const double* img, const double* K, const PnpFrame& F,
+                                const double* ev, const double* L, size_t es, double* red, double* Rt) {
+    const int lane = LANE ? 0 : (int)(threadIdx.x & 63);
+    const int kstep = LANE ? 1 : 64;
+    const int terms = m < 64 ? m : 64;
+    auto total = [&](double v) { return LANE ? v : ordered_wave_sum(v, red, terms); };
+    const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
+    const double (&c0)[3] = F.c0;
+    const double (&ax)[3][3] = F.ax;
+    const double (&sc)[3] = F.sc;
+    const double (&rho)[6] = F.rho;
     double best_err = -1.0;
 #pragma unroll
     for (int variant = 0; variant < 3; ++variant) {
@@ -949,7 +974,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
         for (int p = 0; p < 6; ++p)
 #pragma unroll
             for (int j = 0; j < 5; ++j)
-                if (j < ncol[variant]) A[p * ncol[variant] + j] = S.L[10 * p + cols[variant][j]];
+                if (j < ncol[variant]) A[p * ncol[variant] + j] = L[(size_t)(10 * p + cols[variant][j]) * es];
         const int solved = variant == 0 ? lsq6<4>(A, rho, x) : (variant == 1 ? lsq6<3>(A, rho, x) : lsq6<5>(A, rho, x));
         if (!solved) continue;
         if (variant == 0) {  /* x = b00 b01 b02 b03 */
@@ -972,7 +997,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
             for (int p = 0; p < 6; ++p) {
                 double l[10];
 #pragma unroll
-                for (int q = 0; q < 10; ++q) l[q] = S.L[10 * p + q];
+                for (int q = 0; q < 10; ++q) l[q] = L[(size_t)(10 * p + q) * es];
                 J[4 * p + 0] = 2.0 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
                 J[4 * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1] + l[4] * beta[2] + l[7] * beta[3];
                 J[4 * p + 2] = l[3] * beta[0] + l[4] * beta[1] + 2.0 * l[5] * beta[2] + l[8] * beta[3];
@@ -991,7 +1016,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 3; ++e)
-                cc[j][e] = beta[0] * S.ev[3 * j + e] + beta[1] * S.ev[12 + 3 * j + e] + beta[2] * S.ev[24 + 3 * j + e] + beta[3] * S.ev[36 + 3 * j + e];
+                cc[j][e] = beta[0] * ev[(size_t)(3 * j + e) * es] + beta[1] * ev[(size_t)(12 + 3 * j + e) * es] + beta[2] * ev[(size_t)(24 + 3 * j + e) * es] + beta[3] * ev[(size_t)(36 + 3 * j + e) * es];
         {
             double al[4];
             EPNP_ALPHAS(idx[0], al);
@@ -1004,7 +1029,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
         }
         /* absolute orientation world -> camera (Horn's quaternion form): S = sum pc (pw - c0)^T */
         double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pcm[3] = {0, 0, 0};
-        for (int k = lane; k < m; k += 64) {
+        for (int k = lane; k < m; k += kstep) {
             double al[4], pc[3];
             EPNP_ALPHAS(idx[k], al);
 #pragma unroll
@@ -1041,7 +1066,7 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
 #pragma unroll
         for (int i = 0; i < 3; ++i) cand[9 + i] = pcm[i] - (cand[3 * i] * c0[0] + cand[3 * i + 1] * c0[1] + cand[3 * i + 2] * c0[2]);
         double err = 0.0;
-        for (int k = lane; k < m; k += 64) {
+        for (int k = lane; k < m; k += kstep) {
             const double* X = obj + 3 * (size_t)idx[k];
             const double xc = cand[0] * X[0] + cand[1] * X[1] + cand[2] * X[2] + cand[9];
             const double yc = cand[3] * X[0] + cand[4] * X[1] + cand[5] * X[2] + cand[10];
@@ -1063,27 +1088,76 @@ __device__ static int epnp_wave(int m, const int* idx, const double* obj, const 
 
 constexpr int SOLVE_WAVES = 4;   // samples (waves) per workgroup of the minimal-sample kernels
 
-// one WAVE per sample, SOLVE_WAVES samples per workgroup (no workgroup barrier anywhere: waves return on their own)
-__global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_pnp_kernel(const double* __restrict__ obj, const double* __restrict__ img,
-                                                                    const double* __restrict__ K, int sample_size, int n_samples,
-                                                                    const int* __restrict__ idx, double* __restrict__ models, int* __restrict__ n_models) {
+// Samples of at most 64 points (the RANSAC loop's five-point samples) in two launches. Front: ONE WAVE per sample, SOLVE_WAVES samples
+// per workgroup (no workgroup barrier anywhere: waves return on their own), leaving the sample's frame — 130 doubles: c0 3, axes 9,
+// lengths 3, rho 6, null vectors 48, distance system 60, valid 1 — in the batch's arrays, field-major (element e of sample s at
+// frame[e * n_samples + s]: the back half's lanes read neighbouring words). Back: ONE LANE per sample. The back half is scalar work
+// with ~380 live registers: run by a whole wave per sample it held the kernel at one wave per SIMD and 64 lanes repeated every
+// operation (2.0 ms for 10 000 samples); by lanes, 10 000 samples are 157 waves.
+constexpr int PNP_FRAME = 130, PNP_F_EV = 21, PNP_F_L = 69, PNP_F_VALID = 129;
+
+__global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_pnp_front_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                                          const double* __restrict__ K, int sample_size, int n_samples,
+                                                                          const int* __restrict__ idx, double* __restrict__ frame) {
     __shared__ PnpLds lds[SOLVE_WAVES];
     extern __shared__ double rows_dyn[];   // SOLVE_WAVES x min(sample_size, 64) x 24: the two rows of every point of a wave's sample
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * SOLVE_WAVES + wave;
     if (s >= n_samples) return;
     double* rows = rows_dyn + (size_t)wave * 24 * (sample_size < 64 ? sample_size : 64);
-    double K4[4], out[12];
+    const double K4[4] = {K[0], K[1], K[2], K[3]};
+    PnpFrame F;
+    PnpLds& S = lds[wave];
+    const int ok = epnp_front<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, F, S, rows, nullptr);
+    const size_t ns = (size_t)n_samples;
+    double* dst = frame + s;
+    if (lane == 0) {
+        dst[PNP_F_VALID * ns] = ok ? 1.0 : 0.0;
+        if (ok) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) K4[k] = K[k];
+            for (int e = 0; e < 3; ++e) dst[e * ns] = F.c0[e], dst[(12 + e) * ns] = F.sc[e];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) dst[(3 + 3 * k + e) * ns] = F.ax[k][e];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dst[(15 + q) * ns] = F.rho[q];
+        }
+    }
+    if (ok) {
+        if (lane < 48) dst[(PNP_F_EV + lane) * ns] = S.ev[lane];
+        if (lane < 60) dst[(PNP_F_L + lane) * ns] = S.L[lane];
+    }
+}
+
+__global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                            const double* __restrict__ K, int sample_size, int n_samples,
+                                                            const int* __restrict__ idx, const double* __restrict__ frame,
+                                                            double* __restrict__ models, int* __restrict__ n_models) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_samples) return;
+    const size_t ns = (size_t)n_samples;
+    const double* src = frame + s;
+    const double K4[4] = {K[0], K[1], K[2], K[3]};
+    double out[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_wave<false>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, lds[wave], rows, nullptr);
-    if ((threadIdx.x & 63) == 0) {
+    int n = 0;
+    if (src[PNP_F_VALID * ns] != 0.0) {
+        PnpFrame F;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
-        n_models[s] = n;
+        for (int e = 0; e < 3; ++e) F.c0[e] = src[e * ns], F.sc[e] = src[(12 + e) * ns];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) F.ax[k][e] = src[(3 + 3 * k + e) * ns];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) F.rho[q] = src[(15 + q) * ns];
+        n = epnp_back<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, F, src + PNP_F_EV * ns, src + PNP_F_L * ns, ns, nullptr, out);
     }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
+    n_models[s] = n;
 }
 
 // samples of more than 64 points (the all-inlier refit): one wave per workgroup, a partial M^T M per lane
@@ -1093,12 +1167,14 @@ __global__ __launch_bounds__(64) void solve_pnp_big_kernel(const double* __restr
     __shared__ PnpLds lds;
     __shared__ double part[78 * 64];
     const int s = blockIdx.x;
-    double K4[4], out[12];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) K4[k] = K[k];
+    const double K4[4] = {K[0], K[1], K[2], K[3]};
+    double out[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    const int n = epnp_wave<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, out, lds, nullptr, part);
+    PnpFrame F;
+    const int* rows_idx = idx + (size_t)s * sample_size;
+    int n = epnp_front<true>(sample_size, rows_idx, obj, img, K4, F, lds, nullptr, part);
+    if (n) n = epnp_back<false>(sample_size, rows_idx, obj, img, K4, F, lds.ev, lds.L, 1, lds.red, out);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
@@ -1219,6 +1295,7 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     const size_t o_a = take(sizeof(double) * 3 * (size_t)n_points), o_b = take(sizeof(double) * 2 * (size_t)n_points), o_K = take(sizeof(double) * 4);
     const size_t o_i = take(sizeof(int) * (size_t)total), o_m = take(sizeof(double) * 12 * (size_t)n_samples), o_n = take(sizeof(int) * (size_t)n_samples);
+    const size_t o_f = take(sample_size <= 64 ? sizeof(double) * PNP_FRAME * (size_t)n_samples : 0);   // the samples' frames between the two launches
     if (int rc = ensure_io(ctx, off)) return rc;
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
@@ -1228,13 +1305,17 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
-        // One wave per sample either way (bit-identical with the CPU restatement): samples of at most 64 points — the RANSAC loop's — four
-        // to a workgroup with 16 KB of LDS each; larger ones — the all-inlier refit — with a partial M^T M per lane.
-        if (sample_size <= 64)
-            solve_pnp_kernel<<<(unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES), 64 * SOLVE_WAVES,
-                               sizeof(double) * SOLVE_WAVES * 24 * (size_t)std::min(sample_size, 64), st>>>(
+        // Bit-identical with the CPU restatement either way: samples of at most 64 points — the RANSAC loop's — a wave per sample for the
+        // shared front half, a lane per sample for the scalar back half; larger ones — the all-inlier refit — one wave for both.
+        if (sample_size <= 64) {
+            solve_pnp_front_kernel<<<(unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES), 64 * SOLVE_WAVES,
+                                     sizeof(double) * SOLVE_WAVES * 24 * (size_t)std::min(sample_size, 64), st>>>(
                 (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
-                (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
+                (const int*)(base + o_i), (double*)(base + o_f));
+            solve_pnp_back_kernel<<<(unsigned)((n_samples + 63) / 64), 64, 0, st>>>(
+                (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
+                (const int*)(base + o_i), (const double*)(base + o_f), (double*)(base + o_m), (int*)(base + o_n));
+        }
         else
             solve_pnp_big_kernel<<<(unsigned)n_samples, 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
                                                                      sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
