@@ -657,6 +657,30 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
     // fragments were consumed a call ago), the first fragments and the constants of tile t + 2 fetched at the end (published by the
     // previous call's barrier) and drained before this call's: nothing is in flight across a call. The LDS slot ring (period 3), the
     // fragment register ring (advance KS % 3 per call) and the accumulator parity (period 2) are compile-time: six instantiations.
+    // key idx (sub-tile idx / 16, accumulator idx % 16) of tile t into the running state: triples through {min3, med3} + a sorted-pair
+    // merge, the sixteenth key alone; the tile is recorded when the sub-tile has improved the class minimum strictly
+    auto consume = [&](const v16i(&cur)[NSUB], const int idx, const int t, int(&pend)[3], int& before) {
+        const int ph = idx / 16, eg = idx % 16;
+        const int key = cur[ph][eg];
+        if (eg == 0) before = x1[ph];  // the class minimum this sub-tile meets
+        pend[eg % 3] = key;
+        if (eg % 3 == 2) {
+            const int s1 = imin(imin(pend[0], pend[1]), pend[2]);
+            const int s2 = imed3(pend[0], pend[1], pend[2]);
+            top2_merge(x1[ph], x2[ph], s1, s2);
+        } else if (eg == 15) {
+            x2[ph] = imed3(x1[ph], x2[ph], key);
+            x1[ph] = imin(x1[ph], key);
+            xt[ph] = x1[ph] < before ? t : xt[ph];  // a strict improvement somewhere in this tile: it is the minimum's tile now
+        }
+    };
+    auto set_aside_even = [&]() {
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            sEven[3 * s][tid] = x1[s], sEven[3 * s + 1][tid] = x2[s], sEven[3 * s + 2][tid] = xt[s];
+            x1[s] = x2[s] = BIG;
+        }
+    };
     auto tile = [&](auto PHc, auto SLc, auto PARc, const int t) {
         constexpr int PH = decltype(PHc)::value, SL = decltype(SLc)::value, PAR = decltype(PARc)::value;
         constexpr int slot_nxt = (SL + 1) % 3, slot_nn = (SL + 2) % 3;
@@ -665,13 +689,7 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
         const int t3 = min(t + 3, T - 1);
         const int hb_new = (tid < 32) ? *reinterpret_cast<const __attribute__((address_space(1))) int*>(reinterpret_cast<const __attribute__((address_space(1))) char*>(Bhb + 32 * t3) + (unsigned)tid * 4u) : 0;   // lands during this call; stored to the ring before the barrier
         stage_tile(t3, SL);
-        if (t == B_even) {  // (workgroup-uniform, once per sweep) the even tiles are done: set their state aside, start the odd class
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                sEven[3 * s][tid] = x1[s], sEven[3 * s + 1][tid] = x2[s], sEven[3 * s + 2][tid] = xt[s];
-                x1[s] = x2[s] = BIG;
-            }
-        }
+        if (t == B_even) set_aside_even();  // (workgroup-uniform, once per sweep) the even tiles are done: start the odd class
         if (active) {
             const unsigned nxtB = lds_addr(&sB[slot_nxt][lane]);
             const unsigned nnB = lds_addr(&sB[slot_nn][lane]);
@@ -687,20 +705,8 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
                     nxt[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[(ks + PH) % 3], a[s][ks], nxt[s], 0, 0, 0);
 #pragma unroll
                 for (int idx = key_lo(ks); idx < key_lo(ks + 1); ++idx) {
-                    const int ph = idx / 16, eg = idx % 16;  // key eg of sub-tile ph of tile t
-                    const int key = cur[ph][eg];
-                    if (eg == 0) before = x1[ph];  // the class minimum this sub-tile meets
-                    pend[eg % 3] = key;
-                    if (eg % 3 == 2) {
-                        const int s1 = imin(imin(pend[0], pend[1]), pend[2]);
-                        const int s2 = imed3(pend[0], pend[1], pend[2]);
-                        top2_merge(x1[ph], x2[ph], s1, s2);
-                    } else if (eg == 15) {
-                        x2[ph] = imed3(x1[ph], x2[ph], key);
-                        x1[ph] = imin(x1[ph], key);
-                        xt[ph] = x1[ph] < before ? t : xt[ph];  // a strict improvement somewhere in this tile: it is the minimum's tile now
-                        cur[ph] = cinit_of(slot_nn);   // done with these accumulators: tile t + 2's constants, for the next call's chains
-                    }
+                    consume(cur, idx, t, pend, before);
+                    if (idx % 16 == 15) cur[idx / 16] = cinit_of(slot_nn);   // done with these accumulators: tile t + 2's constants, for the next call's chains
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -709,16 +715,27 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
         if (tid < 32) sHb[SL][tid] = hb_new;
         __syncthreads();
     };
-    {
-        // tile(t) consumes tile t's accumulators and issues tile t + 1's: the last call (t = T - 1) issues a recomputation of a
-        // clamped tile that nobody reads
+    // the last tile has nothing to issue and nothing to stage: its epilogue alone (which accumulators hold it is its parity)
+    auto last = [&](auto PARc, const int t) {
+        constexpr int PAR = decltype(PARc)::value;
+        v16i(&cur)[NSUB] = PAR ? accB : accA;
+        if (t == B_even) set_aside_even();
+        if (active) {
+            int pend[3] = {0, 0, 0}, before = 0;
+#pragma unroll
+            for (int idx = 0; idx < 32; ++idx) consume(cur, idx, t, pend, before);
+        }
+    };
+    if (T > 0) {
+        // tile(t) consumes tile t's accumulators and issues tile t + 1's, for t < T - 1
         constexpr int ADV = KS % 3;
+        const int TM = T - 1;
         int t = 0;
         auto run = [&](auto K6c, int tt) {
             constexpr int K6 = decltype(K6c)::value;
             tile(std::integral_constant<int, (K6 * ADV) % 3>{}, std::integral_constant<int, K6 % 3>{}, std::integral_constant<int, K6 % 2>{}, tt);
         };
-        for (; t + 6 <= T; t += 6) {
+        for (; t + 6 <= TM; t += 6) {
             run(std::integral_constant<int, 0>{}, t);
             run(std::integral_constant<int, 1>{}, t + 1);
             run(std::integral_constant<int, 2>{}, t + 2);
@@ -726,11 +743,13 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
             run(std::integral_constant<int, 4>{}, t + 4);
             run(std::integral_constant<int, 5>{}, t + 5);
         }
-        if (t < T) run(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < T) run(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < T) run(std::integral_constant<int, 2>{}, t + 2);
-        if (t + 3 < T) run(std::integral_constant<int, 3>{}, t + 3);
-        if (t + 4 < T) run(std::integral_constant<int, 4>{}, t + 4);
+        if (t < TM) run(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < TM) run(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < TM) run(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < TM) run(std::integral_constant<int, 3>{}, t + 3);
+        if (t + 4 < TM) run(std::integral_constant<int, 4>{}, t + 4);
+        if (TM & 1) last(std::integral_constant<int, 1>{}, TM);
+        else last(std::integral_constant<int, 0>{}, TM);
     }
     if (!active) return;
     int e1[NSUB], e2[NSUB], et[NSUB];
