@@ -135,8 +135,11 @@ struct DTree {
     std::vector<DTree> kids;
 };
 
+// `par` > 0: the two sides of a split of some size are dissected by two threads, `par` levels deep. The sides are not adjacent
+// (that is what the separator is for) and a recursion reads mark / lev of its own nodes and their neighbours only, so the two
+// threads touch disjoint elements; the second side draws its tags from a range of its own.
 inline void dissect_tree(const Adj& adj, std::vector<int>& mark, int& next_tag, const std::vector<int>& nodes, int min_leaf,
-                         DTree& T, std::vector<int>& lev, int variants = 0) {
+                         DTree& T, std::vector<int>& lev, int variants = 0, int par = 0) {
     T.nodes = nodes;
     if ((int)nodes.size() <= min_leaf) {
         T.kind = DTree::LEAF;
@@ -159,7 +162,7 @@ inline void dissect_tree(const Adj& adj, std::vector<int>& mark, int& next_tag, 
             }
             T.kind = DTree::COMPONENTS;
             T.kids.resize(comps.size());
-            for (size_t k = 0; k < comps.size(); ++k) dissect_tree(adj, mark, next_tag, comps[k], min_leaf, T.kids[k], lev, variants);
+            for (size_t k = 0; k < comps.size(); ++k) dissect_tree(adj, mark, next_tag, comps[k], min_leaf, T.kids[k], lev, variants, 0);
             return;
         }
     }
@@ -245,8 +248,15 @@ inline void dissect_tree(const Adj& adj, std::vector<int>& mark, int& next_tag, 
     T.kind = DTree::SPLIT;
     T.sep = sep;
     T.kids.resize(2);
-    dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants);
-    dissect_tree(adj, mark, next_tag, right, min_leaf, T.kids[1], lev, variants);
+    if (par > 0 && (int)left.size() > 4 * min_leaf && (int)right.size() > 4 * min_leaf) {
+        int tag_r = next_tag + (1 << (18 + par));
+        std::thread other([&] { dissect_tree(adj, mark, tag_r, right, min_leaf, T.kids[1], lev, variants, par - 1); });
+        dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants, par - 1);
+        other.join();
+    } else {
+        dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants, 0);
+        dissect_tree(adj, mark, next_tag, right, min_leaf, T.kids[1], lev, variants, 0);
+    }
 }
 
 // the node list of the dissection stopped at `leaf` (>= the min_leaf the tree was built with): children first, separator last
@@ -571,7 +581,8 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     auto build_tree = [&](int k) {
         std::vector<int> mark(nc, 0), lev(nc, -1);
         int tag = 1;
-        plan_detail::dissect_tree(adj, mark, tag, all, leaves[0], trees[k], lev, variant_list[k]);
+        // (the dissection with several roots per bisection is the critical path of the whole plan: its top two splits fan out)
+        plan_detail::dissect_tree(adj, mark, tag, all, leaves[0], trees[k], lev, variant_list[k], nc > 8 * cams_per_panel ? (k == 1 ? 2 : 1) : 0);
     };
     auto evaluate = [&](Cand& c) {
         std::vector<std::vector<int>> nodes;
