@@ -36,6 +36,13 @@ int ensure_io(eacham_ctx* ctx, size_t bytes) {
     return EACHAM_OK;
 }
 
+// the two kernels of the second-stream probe of eacham_ctx_create
+__global__ void stream_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void stream_probe_kernel() {}
+
 __global__ void sanitize_pairs_kernel(const int2* __restrict__ in, int npairs, const FrameDev* __restrict__ frames, int n_frames,
                                       int2* __restrict__ out, int* __restrict__ flag) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,9 +249,57 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     if (const char* m = getenv("EACHAM_BA_PREPARE")) ctx->ba_prepare_mode = !strcmp(m, "host") ? 1 : !strcmp(m, "device") ? 2 : 0;
     if (const char* o = getenv("EACHAM_BA_ORDERING"))
         ctx->ba_ordering = !strcmp(o, "natural") ? EACHAM_BA_ORDER_NATURAL : !strcmp(o, "rcm") ? EACHAM_BA_ORDER_RCM : !strcmp(o, "nd") ? EACHAM_BA_ORDER_ND : EACHAM_BA_ORDER_AUTO;
-    if (hipSetDevice(device_id) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+    // The second stream carries the work behind a batch's distance sweep, which is meant to run BESIDE the next batch's sweep. The
+    // runtime deals its few hardware queues out to all streams of the process in creation order, so two streams may share one and
+    // then run strictly one behind the other (the kernel traces of rounds 3 and 4 show exactly that for the first context of
+    // bench.py: every kernel of the second stream behind the sweep). Priorities are no way out: a high-priority stream that lands
+    // on a queue in use is slower than no second stream (measured, tools/experiments/c5_probe2.py). So the context TRIES: a 40 us
+    // spin on the first stream, an empty kernel on the candidate; a candidate whose kernel does not finish well before the spin
+    // shares the queue and is set aside (destroyed after the search, so that the next candidate gets the next queue).
+    int stream2_mode = 0;   // 0 = probe for a stream on a queue of its own (default); 1 / -1 = high / low priority, no probe (A/B: EACHAM_STREAM2_PRIORITY)
+    if (const char* sp = getenv("EACHAM_STREAM2_PRIORITY")) stream2_mode = !strcmp(sp, "high") ? 1 : !strcmp(sp, "low") ? -1 : !strcmp(sp, "noprobe") ? 2 : 0;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return EACHAM_ERR_HIP;
+    }
+    if (stream2_mode == 1 || stream2_mode == -1) {
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, stream2_mode > 0 ? prio_greatest : prio_least) != hipSuccess) {
+            delete ctx;
+            return EACHAM_ERR_HIP;
+        }
+    } else {
+        hipStream_t rejected[4];
+        int n_rejected = 0;
+        hipEvent_t e_spin = nullptr, e_probe = nullptr;
+        bool ok = hipEventCreate(&e_spin) == hipSuccess && hipEventCreate(&e_probe) == hipSuccess;
+        for (int attempt = 0; ok && attempt < 5; ++attempt) {
+            hipStream_t cand = nullptr;
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
+            bool beside = stream2_mode == 2 || attempt == 4;   // (the last candidate is kept whatever it does)
+            if (!beside) {
+                stream_spin_kernel<<<1, 64, 0, ctx->stream>>>(4000);   // 40 us of the 100 MHz wall clock
+                ok = ok && hipEventRecord(e_spin, ctx->stream) == hipSuccess;
+                stream_probe_kernel<<<1, 64, 0, cand>>>();
+                ok = ok && hipEventRecord(e_probe, cand) == hipSuccess;
+                ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
+                float ms = 0.f;   // from the probe's end to the spin's end
+                ok = ok && hipEventElapsedTime(&ms, e_probe, e_spin) == hipSuccess;
+                beside = ok && ms > 0.010f;
+            }
+            if (beside) { ctx->stream2 = cand; break; }
+            rejected[n_rejected++] = cand;
+        }
+        for (int k = 0; k < n_rejected; ++k) (void)hipStreamDestroy(rejected[k]);
+        if (e_spin) (void)hipEventDestroy(e_spin);
+        if (e_probe) (void)hipEventDestroy(e_probe);
+        if (!ok || !ctx->stream2) {
+            delete ctx;
+            return EACHAM_ERR_HIP;
+        }
+    }
+    if (
         hipEventCreateWithFlags(&ctx->ev_tile[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_tile[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fin[0], hipEventDisableTiming) != hipSuccess ||
