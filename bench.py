@@ -334,7 +334,10 @@ def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, 
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "kernel": kernel, "launches": r["launches"],
                          "avg_launch_ms": r["tile_ms"] / max(r["launches"], 1),
-                         "finalize_ms_per_step": r["fin_ms"] / steps}}, r
+                         "finalize_ms_per_step": r["fin_ms"] / steps,
+                         # the same work over the WHOLE step (sweeps + what runs beside and behind them): the launch time above
+                         # includes the candidate-pass kernels that share the chip with a sweep on the second stream
+                         "frac_of_step": (ops / r["elapsed"] / 1e12 / peak) if r["elapsed"] > 0 else 0.0}}, r
 
 
 def ba_bytes_flops(nc, nl, no):
@@ -731,7 +734,7 @@ def main():
     leg("c5_kitti_long", kitti_long_line)
 
     if D.rank == 0:
-        def compact_roofline(rf, keys=("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")):
+        def compact_roofline(rf, keys=("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "frac_of_step")):
             return {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rf.items() if k in keys}
 
         out = {
