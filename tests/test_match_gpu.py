@@ -198,6 +198,33 @@ def test_parity_sorted_layout_edges(hip_ctx, n1, n2, mode):
     hip_ctx.clear_descriptors()
 
 
+@pytest.mark.parametrize("dim", [64, 128, 256])
+def test_row_sweep_every_tile_count_and_parity_boundary(hip_ctx, dim):
+    """The row sweep (match_sweep_kernel) is a software pipeline unrolled six tiles deep with a separate last
+    call and a once-per-sweep parity boundary: train frames of 1 .. 15 tiles (every residue of the unrolling, one tile short
+    and one over a tile edge), with the even / odd boundary at the first tile, at the last, in the middle and absent, all
+    frames against all frames in ONE call (ragged sizes in one batch), both forms of the column direction (conftest)."""
+    sizes = [1, 31, 32, 33, 64, 95, 97, 128, 160, 190, 224, 257, 288, 320, 350, 384, 417, 448, 480]
+    rng_rows = synth.random_u8_descriptors(max(sizes), dim, 123, 0)
+    descs = []
+    for k, n in enumerate(sizes):
+        D = np.clip(rng_rows[:n] + np.rint(6 * synth.rng_normal(123, 10 + k, (n, dim))), 0, 255).astype(np.float32)
+        mode = k % 4   # 0: parities as they fall, 1: all even (no boundary), 2: all odd (boundary at tile 0), 3: one odd row (boundary at the last tile)
+        par = [None] * n if mode == 0 else [0] * n if mode == 1 else [1] * n if mode == 2 else [0] * (n - 1) + [1]
+        D = _with_norm_parity(D, par)
+        if n > 40:
+            D[n - 3] = D[5]   # a duplicate far apart (same parity: identical rows): the lower index must win
+        descs.append(D)
+    _upload(hip_ctx, descs)
+    pairs = np.array([[a, b] for a in range(len(sizes)) for b in range(len(sizes)) if a != b], dtype=np.int32)
+    for md, mm in ((1, 0), (3, 2), (30, 30)):
+        got = hip_ctx.match_all_pairs(pairs, min_dir=md, min_mutual=mm)
+        want = O.match_all_pairs(descs, pairs, min_dir=md, min_mutual=mm)
+        _assert_csr_equal(got, want)
+    assert got[0].sum() > 0
+    hip_ctx.clear_descriptors()
+
+
 def test_ratio_range(hip_ctx):
     """The mutual entry points take 0 < ratio <= 1; the directed one takes any ratio
     and must agree with the oracle also when ties pass (ratio > 1: the lower index wins)."""
