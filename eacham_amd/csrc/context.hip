@@ -36,6 +36,22 @@ int ensure_io(eacham_ctx* ctx, size_t bytes) {
     return EACHAM_OK;
 }
 
+// pinned mirror of the first `bytes` of the staging buffer (grown, never shrunk; capped: large arrays are copied directly)
+int ensure_io_host(eacham_ctx* ctx, size_t bytes) {
+    bytes = std::min<size_t>(bytes, 4u << 20);
+    if (bytes <= ctx->io_host_bytes) return EACHAM_OK;
+    if (ctx->io_host) {
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        EACHAM_HIP_TRY(ctx, hipHostFree(ctx->io_host));
+        ctx->io_host = nullptr;
+        ctx->io_host_bytes = 0;
+    }
+    const size_t want = std::max<size_t>(bytes, 256 * 1024);
+    EACHAM_HIP_TRY(ctx, hipHostMalloc(&ctx->io_host, want, hipHostMallocDefault));
+    ctx->io_host_bytes = want;
+    return EACHAM_OK;
+}
+
 // the two kernels of the second-stream probe of eacham_ctx_create
 __global__ void stream_spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();
@@ -345,6 +361,7 @@ void eacham_ctx_destroy(eacham_ctx* ctx) {
     if (ctx->pairs_safe) (void)hipFree(ctx->pairs_safe);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->io) (void)hipFree(ctx->io);
+    if (ctx->io_host) (void)hipHostFree(ctx->io_host);
     for (auto& b : ctx->ba_pool) {
         if (b.dev) (void)hipFree(b.dev);
         if (b.pinned) (void)hipHostFree(b.pinned);

@@ -6,7 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
+#include <cstring>
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
@@ -100,6 +102,8 @@ struct eacham_ctx {
     int pairs_safe_cap = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
+    void* io_host = nullptr;  // pinned mirror of the head of `io`: the small arrays of a call travel as ONE copy each way (IoPack)
+    size_t io_host_bytes = 0;
 
     std::vector<eacham::BaBlock> ba_pool;  // arenas of released BA problems, reused by the next eacham_ba_prepare
     eacham::BaScratch ba_scratch[2];
@@ -143,6 +147,59 @@ namespace eacham {
 
 int ensure_workspace(eacham_ctx* ctx, size_t bytes);
 int ensure_io(eacham_ctx* ctx, size_t bytes);
+int ensure_io_host(eacham_ctx* ctx, size_t bytes);
+
+// The host-pointer entry points of the estimators, the triangulation and the graph query are called once or more per frame of
+// the incremental loop with a handful of small arrays each way (points, a few models, counts): as separate copies from pageable
+// memory every one of them is a submission and a wait of ~10 us (25 copies per solvePnPRansac of the loop). IoPack lays the
+// arrays that are small into a pinned mirror of the device staging buffer at the SAME offsets and moves each direction in one
+// copy (the bytes between two packed arrays travel along); arrays above PACK_MAX keep their own direct copy.
+struct IoPack {
+    static constexpr size_t PACK_MAX = 256 * 1024;
+    eacham_ctx* ctx;
+    char* dev;
+    hipStream_t st;
+    size_t in_lo = ~(size_t)0, in_hi = 0, out_lo = ~(size_t)0, out_hi = 0;
+    struct Out { void* dst; size_t off, bytes; };
+    Out outs[8];
+    int n_outs = 0;
+    IoPack(eacham_ctx* c, hipStream_t s) : ctx(c), dev((char*)c->io), st(s) {}
+    // host -> device: packed (memcpy now, one copy at flush_in) or direct
+    int in(size_t off, const void* src, size_t bytes) {
+        if (bytes == 0) return EACHAM_OK;
+        if (bytes <= PACK_MAX && off + bytes <= ctx->io_host_bytes) {
+            memcpy((char*)ctx->io_host + off, src, bytes);
+            in_lo = std::min(in_lo, off), in_hi = std::max(in_hi, off + bytes);
+            return EACHAM_OK;
+        }
+        // (a packed span never straddles a directly copied array: what has been packed so far goes first)
+        if (int rc = flush_in()) return rc;
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dev + off, src, bytes, hipMemcpyHostToDevice, st));
+        return EACHAM_OK;
+    }
+    int flush_in() {
+        if (in_hi > in_lo) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dev + in_lo, (char*)ctx->io_host + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
+        in_lo = ~(size_t)0, in_hi = 0;
+        return EACHAM_OK;
+    }
+    // device -> host: registered now, moved by finish()
+    int out(void* dst, size_t off, size_t bytes) {
+        if (bytes == 0 || !dst) return EACHAM_OK;
+        if (bytes <= PACK_MAX && off + bytes <= ctx->io_host_bytes && n_outs < 8) {
+            outs[n_outs++] = Out{dst, off, bytes};
+            out_lo = std::min(out_lo, off), out_hi = std::max(out_hi, off + bytes);
+            return EACHAM_OK;
+        }
+        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dst, dev + off, bytes, hipMemcpyDeviceToHost, st));
+        return EACHAM_OK;
+    }
+    int finish() {   // one copy back, the stream's synchronisation, the hand-over to the caller's arrays
+        if (out_hi > out_lo) EACHAM_HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->io_host + out_lo, dev + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, st));
+        EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+        for (int k = 0; k < n_outs; ++k) memcpy(outs[k].dst, (char*)ctx->io_host + outs[k].off, outs[k].bytes);
+        return EACHAM_OK;
+    }
+};
 int sync_frame_table(eacham_ctx* ctx);
 // copies `pairs` into the workspace tail with every pair that names a missing frame redirected to the empty
 // stand-in entry frames[n_frames] (and flags it); returns the sanitised device pointer in *out

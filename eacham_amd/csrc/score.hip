@@ -194,14 +194,18 @@ extern "C" int eacham_score_hypotheses(eacham_ctx* ctx, int kind, int n_points, 
     const size_t o_c = take(sizeof(int) * (size_t)n_models), o_med = take(sizeof(float) * (size_t)n_models);
     const size_t o_e = take(need_err ? sizeof(float) * (size_t)total : 0);
     if (int rc = ensure_io(ctx, off)) return rc;
+    if (int rc = ensure_io_host(ctx, o_e)) return rc;   // everything but the error matrix
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
+    IoPack io(ctx, st);
     if (n_points > 0) {
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_a, a, sizeof(double) * ma * (size_t)n_points, hipMemcpyHostToDevice, st));
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_b, b, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, st));
+        if (int rc = io.in(o_a, a, sizeof(double) * ma * (size_t)n_points)) return rc;
+        if (int rc = io.in(o_b, b, sizeof(double) * 2 * (size_t)n_points)) return rc;
     }
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_m, models, sizeof(double) * mm * (size_t)n_models, hipMemcpyHostToDevice, st));
-    if (K) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4, hipMemcpyHostToDevice, st));
+    if (int rc = io.in(o_m, models, sizeof(double) * mm * (size_t)n_models)) return rc;
+    if (K)
+        if (int rc = io.in(o_K, K, sizeof(double) * 4)) return rc;
+    if (int rc = io.flush_in()) return rc;
     const size_t smem = keys_in_lds && medians ? sizeof(unsigned) * (size_t)(n_points > 0 ? n_points : 1) : 0;
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
@@ -221,9 +225,10 @@ extern "C" int eacham_score_hypotheses(eacham_ctx* ctx, int kind, int n_points, 
 #undef EACHAM_SCORE_LAUNCH
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
-    if (inlier_counts) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(inlier_counts, base + o_c, sizeof(int) * (size_t)n_models, hipMemcpyDeviceToHost, st));
-    if (medians) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(medians, base + o_med, sizeof(float) * (size_t)n_models, hipMemcpyDeviceToHost, st));
-    if (errors && total > 0) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(errors, base + o_e, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (int rc = io.out(inlier_counts, o_c, sizeof(int) * (size_t)n_models)) return rc;
+    if (int rc = io.out(medians, o_med, sizeof(float) * (size_t)n_models)) return rc;
+    if (total > 0)
+        if (int rc = io.out(errors, o_e, sizeof(float) * (size_t)total)) return rc;
+    if (int rc = io.finish()) return rc;
     return EACHAM_OK;
 }

@@ -1254,12 +1254,16 @@ extern "C" int eacham_solve_minimal(eacham_ctx* ctx, int kind, int n_points, con
     const size_t o_i = take(sizeof(int) * (size_t)n_samples * m), o_m = take(sizeof(double) * 9 * (size_t)maxm * n_samples);
     const size_t o_n = take(sizeof(int) * (size_t)n_samples);
     if (int rc = ensure_io(ctx, off)) return rc;
+    if (int rc = ensure_io_host(ctx, off)) return rc;
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_a, a, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_b, b, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, st));
-    if (K) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)n_samples * m, hipMemcpyHostToDevice, st));
+    IoPack io(ctx, st);
+    if (int rc = io.in(o_a, a, sizeof(double) * 2 * (size_t)n_points)) return rc;
+    if (int rc = io.in(o_b, b, sizeof(double) * 2 * (size_t)n_points)) return rc;
+    if (K)
+        if (int rc = io.in(o_K, K, sizeof(double) * 4)) return rc;
+    if (int rc = io.in(o_i, sample_idx, sizeof(int) * (size_t)n_samples * m)) return rc;
+    if (int rc = io.flush_in()) return rc;
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
         const unsigned grid = (unsigned)((n_samples + SOLVE_WAVES - 1) / SOLVE_WAVES);
@@ -1271,9 +1275,9 @@ extern "C" int eacham_solve_minimal(eacham_ctx* ctx, int kind, int n_points, con
                                                                K ? 1 : 0, n_samples, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(models, base + o_m, sizeof(double) * 9 * (size_t)maxm * n_samples, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(n_models, base + o_n, sizeof(int) * (size_t)n_samples, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (int rc = io.out(models, o_m, sizeof(double) * 9 * (size_t)maxm * n_samples)) return rc;
+    if (int rc = io.out(n_models, o_n, sizeof(int) * (size_t)n_samples)) return rc;
+    if (int rc = io.finish()) return rc;
     return EACHAM_OK;
 }
 
@@ -1297,12 +1301,15 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     const size_t o_i = take(sizeof(int) * (size_t)total), o_m = take(sizeof(double) * 12 * (size_t)n_samples), o_n = take(sizeof(int) * (size_t)n_samples);
     const size_t o_f = take(sample_size <= 64 ? sizeof(double) * PNP_FRAME * (size_t)n_samples : 0);   // the samples' frames between the two launches
     if (int rc = ensure_io(ctx, off)) return rc;
+    if (int rc = ensure_io_host(ctx, o_f)) return rc;   // everything but the samples' frames, which never leave the device
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_a, object_points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_b, image_points, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_i, sample_idx, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
+    IoPack io(ctx, st);
+    if (int rc = io.in(o_a, object_points, sizeof(double) * 3 * (size_t)n_points)) return rc;
+    if (int rc = io.in(o_b, image_points, sizeof(double) * 2 * (size_t)n_points)) return rc;
+    if (int rc = io.in(o_K, K, sizeof(double) * 4)) return rc;
+    if (int rc = io.in(o_i, sample_idx, sizeof(int) * (size_t)total)) return rc;
+    if (int rc = io.flush_in()) return rc;
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_SCORE);
         // Bit-identical with the CPU restatement either way: samples of at most 64 points — the RANSAC loop's — a wave per sample for the
@@ -1321,8 +1328,8 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
                                                                      sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(models, base + o_m, sizeof(double) * 12 * (size_t)n_samples, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(n_models, base + o_n, sizeof(int) * (size_t)n_samples, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (int rc = io.out(models, o_m, sizeof(double) * 12 * (size_t)n_samples)) return rc;
+    if (int rc = io.out(n_models, o_n, sizeof(int) * (size_t)n_samples)) return rc;
+    if (int rc = io.finish()) return rc;
     return EACHAM_OK;
 }

@@ -318,16 +318,20 @@ extern "C" int eacham_triangulate_tracks(eacham_ctx* ctx, const double* transfor
     const size_t o_pt = take(sizeof(double) * 3 * (size_t)n_tracks), o_ac = take(sizeof(int) * (size_t)n_tracks);
     const size_t o_mk = take((size_t)n_obs), o_pi = take(sizeof(int) * (size_t)n_pairs);
     if (int rc = ensure_io(ctx, off)) return rc;
+    if (int rc = ensure_io_host(ctx, o_pi)) return rc;   // everything but the per-pair scratch
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_tp, track_ptr, sizeof(int) * ((size_t)n_tracks + 1), hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_pp, pair_ptr.data(), sizeof(long long) * ((size_t)n_tracks + 1), hipMemcpyHostToDevice, st));
+    IoPack io(ctx, st);
+    if (n_obs > 0)
+        if (int rc = io.in(o_T, transforms, sizeof(double) * 16 * (size_t)n_frames)) return rc;
+    if (int rc = io.in(o_K, K, sizeof(double) * 4)) return rc;
+    if (int rc = io.in(o_tp, track_ptr, sizeof(int) * ((size_t)n_tracks + 1))) return rc;
+    if (int rc = io.in(o_pp, pair_ptr.data(), sizeof(long long) * ((size_t)n_tracks + 1))) return rc;
     if (n_obs > 0) {
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_T, transforms, sizeof(double) * 16 * (size_t)n_frames, hipMemcpyHostToDevice, st));
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_of, obs_frame, sizeof(unsigned) * (size_t)n_obs, hipMemcpyHostToDevice, st));
-        EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_uv, obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, st));
+        if (int rc = io.in(o_of, obs_frame, sizeof(unsigned) * (size_t)n_obs)) return rc;
+        if (int rc = io.in(o_uv, obs_uv, sizeof(double) * 2 * (size_t)n_obs)) return rc;
     }
+    if (int rc = io.flush_in()) return rc;
     {
         ProfileScope scope(ctx, EACHAM_KERNEL_TRIANGULATE);
         if (n_pairs > 0)
@@ -341,10 +345,11 @@ extern "C" int eacham_triangulate_tracks(eacham_ctx* ctx, const double* transfor
             min_tri_angle, (const int*)(base + o_pi), (double*)(base + o_pt), (int*)(base + o_ac), (unsigned char*)(base + o_mk));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(points, base + o_pt, sizeof(double) * 3 * (size_t)n_tracks, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(status, base + o_ac, sizeof(int) * (size_t)n_tracks, hipMemcpyDeviceToHost, st));
-    if (n_obs > 0) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(masks, base + o_mk, (size_t)n_obs, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (int rc = io.out(points, o_pt, sizeof(double) * 3 * (size_t)n_tracks)) return rc;
+    if (int rc = io.out(status, o_ac, sizeof(int) * (size_t)n_tracks)) return rc;
+    if (n_obs > 0)
+        if (int rc = io.out(masks, o_mk, (size_t)n_obs)) return rc;
+    if (int rc = io.finish()) return rc;
     return EACHAM_OK;
 }
 
@@ -366,19 +371,22 @@ extern "C" int eacham_reprojection_errors(eacham_ctx* ctx, const double* transfo
     const size_t o_f = take(sizeof(unsigned) * (size_t)n), o_p = take(sizeof(double) * 3 * (size_t)n);
     const size_t o_uv = take(sizeof(double) * 2 * (size_t)n), o_e = take(sizeof(float) * (size_t)n);
     if (int rc = ensure_io(ctx, off)) return rc;
+    if (int rc = ensure_io_host(ctx, off)) return rc;
     char* base = (char*)ctx->io;
     hipStream_t st = ctx->stream;
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_T, transforms, sizeof(double) * 16 * (size_t)n_frames, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_f, frame, sizeof(unsigned) * (size_t)n, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_p, points, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(base + o_uv, uv, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
+    IoPack io(ctx, st);
+    if (int rc = io.in(o_T, transforms, sizeof(double) * 16 * (size_t)n_frames)) return rc;
+    if (int rc = io.in(o_K, K, sizeof(double) * 4)) return rc;
+    if (int rc = io.in(o_f, frame, sizeof(unsigned) * (size_t)n)) return rc;
+    if (int rc = io.in(o_p, points, sizeof(double) * 3 * (size_t)n)) return rc;
+    if (int rc = io.in(o_uv, uv, sizeof(double) * 2 * (size_t)n)) return rc;
+    if (int rc = io.flush_in()) return rc;
     reproject_kernel<<<(unsigned)((n + TRI_BLOCK - 1) / TRI_BLOCK), TRI_BLOCK, 0, st>>>(
         (const double*)(base + o_T), n, (const unsigned*)(base + o_f), (const double*)(base + o_p),
         (const double2*)(base + o_uv), (const double*)(base + o_K), (float*)(base + o_e));
     EACHAM_HIP_TRY(ctx, hipGetLastError());
-    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(err, base + o_e, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (int rc = io.out(err, o_e, sizeof(float) * (size_t)n)) return rc;
+    if (int rc = io.finish()) return rc;
     return EACHAM_OK;
 }
 
