@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
         L.eacham_graph_destroy.argtypes = [vp]
         L.eacham_graph_destroy.restype = None
         L.eacham_graph_set_frame.argtypes = [vp, i32, i32, vp, i32]
+        L.eacham_graph_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
         L.eacham_graph_query.argtypes = [vp, vp, i32, vp]
     L.eacham_reprojection_errors.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.eacham_profile_enable.argtypes = [vp, i32]

@@ -226,6 +226,59 @@ extern "C" int eacham_graph_set_frame(eacham_graph* g, int frame, int valid, con
     return EACHAM_OK;
 }
 
+// the flags of several frames, staged one behind the other, to their places (block = frame of the batch)
+__global__ __launch_bounds__(256) void graph_scatter_frames_kernel(int n, const int* __restrict__ frames, const long long* __restrict__ src_off,
+                                                                     const unsigned char* __restrict__ valid_in, const unsigned char* __restrict__ flags,
+                                                                     const long long* __restrict__ kp_offsets, unsigned char* __restrict__ valid,
+                                                                     unsigned char* __restrict__ has3d) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int f = frames[i];
+    const long long s0 = src_off[i], cnt = src_off[i + 1] - s0, d0 = kp_offsets[f];
+    for (long long k = threadIdx.x; k < cnt; k += 256) has3d[d0 + k] = flags[s0 + k];
+    if (threadIdx.x == 0) valid[f] = valid_in[i];
+}
+
+extern "C" int eacham_graph_set_frames(eacham_graph* g, int n, const int32_t* frames, const uint8_t* valid, const uint8_t* has3d,
+                                       const int64_t* has3d_offsets) {
+    if (!g) return EACHAM_ERR_INVALID;
+    eacham_ctx* ctx = g->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n < 0 || (n > 0 && (!frames || !valid || !has3d_offsets))) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frames: null argument or negative size");
+    if (n == 0) return EACHAM_OK;
+    if (has3d_offsets[0] != 0) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frames: has3d_offsets[0] must be 0");
+    for (int i = 0; i < n; ++i) {
+        if (frames[i] < 0 || frames[i] >= g->n_frames) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frames: frame %d of %d", frames[i], g->n_frames);
+        const long long nk = g->kp_offsets_h[frames[i] + 1] - g->kp_offsets_h[frames[i]];
+        if (has3d_offsets[i + 1] - has3d_offsets[i] != nk)
+            return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frames: frame %d has %lld keypoints, got %lld flags", frames[i], nk,
+                             (long long)(has3d_offsets[i + 1] - has3d_offsets[i]));
+    }
+    const long long total = has3d_offsets[n];
+    if (total > 0 && !has3d) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frames: null flags");
+    EACHAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_fr = 0, o_off = align(sizeof(int) * (size_t)n), o_v = o_off + align(sizeof(long long) * ((size_t)n + 1));
+    const size_t o_fl = o_v + align((size_t)n), bytes = o_fl + align((size_t)std::max<long long>(total, 1));
+    if (int rc = ensure_io(ctx, bytes)) return rc;
+    if (int rc = ensure_io_host(ctx, bytes)) return rc;
+    IoPack io(ctx, ctx->stream);
+    if (int rc = io.in(o_fr, frames, sizeof(int) * (size_t)n)) return rc;
+    if (int rc = io.in(o_off, has3d_offsets, sizeof(long long) * ((size_t)n + 1))) return rc;
+    if (int rc = io.in(o_v, valid, (size_t)n)) return rc;
+    if (total > 0)
+        if (int rc = io.in(o_fl, has3d, (size_t)total)) return rc;
+    if (int rc = io.flush_in()) return rc;
+    char* base = (char*)ctx->io;
+    graph_scatter_frames_kernel<<<n, 256, 0, ctx->stream>>>(n, (const int*)(base + o_fr), (const long long*)(base + o_off), (const unsigned char*)(base + o_v),
+                                                            (const unsigned char*)(base + o_fl), g->kp_offsets, g->valid, g->has3d);
+    EACHAM_HIP_TRY(ctx, hipGetLastError());
+    // (the staging buffer is the context's: the next call that uses it is ordered behind this kernel on the same stream, and the
+    // pinned mirror is rewritten only after a call that synchronised — every user of IoPack ends with finish() or is this one)
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EACHAM_OK;
+}
+
 // Graph::GetBestPairForValid(excluded) on the resident state
 extern "C" int eacham_graph_query(eacham_graph* g, const int32_t* excluded_frames, int n_excluded, uint32_t* best) {
     if (!g || !best || n_excluded < 0 || (n_excluded > 0 && !excluded_frames)) return EACHAM_ERR_INVALID;

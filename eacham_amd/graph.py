@@ -71,6 +71,15 @@ class ResidentGraph:
         self.ctx._check(self.ctx._L.eacham_graph_set_frame(self._h, int(frame), int(bool(valid)), None if f is None else f.ctypes.data,
                                                            0 if f is None else f.size))
 
+    def set_frames(self, frames, valid, has3d_per_frame):
+        """eacham_graph_set_frames: several frames in one copy + one kernel (has3d_per_frame[i]: the full flag array of frames[i])."""
+        fr = np.ascontiguousarray(frames, dtype=np.int32)
+        va = np.ascontiguousarray(valid, dtype=np.uint8)
+        off = np.zeros(len(fr) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(a) for a in has3d_per_frame])
+        fl = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.uint8) for a in has3d_per_frame]) if len(fr) else np.zeros(0, np.uint8))
+        self.ctx._check(self.ctx._L.eacham_graph_set_frames(self._h, int(len(fr)), fr.ctypes.data, va.ctypes.data, fl.ctypes.data if fl.size else None, off.ctypes.data))
+
     def query(self, excluded_frames=()):
         ex = np.ascontiguousarray(list(excluded_frames), dtype=np.int32)
         best = np.zeros(3, dtype=np.uint32)

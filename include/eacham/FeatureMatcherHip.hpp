@@ -463,6 +463,20 @@ public:
     void SetFrame(unsigned frame, bool valid, const std::vector<uint8_t>& has3d) {
         ctx_.check(eacham_graph_set_frame(h_, (int)frame, valid ? 1 : 0, has3d.data(), (int)has3d.size()));
     }
+    // several frames at once: {frame, valid, flags} — one copy and one kernel (what the loop calls after every frame it adds)
+    struct FrameState { unsigned frame; bool valid; std::vector<uint8_t> has3d; };
+    void SetFrames(const std::vector<FrameState>& states) {
+        std::vector<int32_t> frames;
+        std::vector<uint8_t> valid, flags;
+        std::vector<int64_t> off{0};
+        for (const auto& st : states) {
+            frames.push_back((int32_t)st.frame);
+            valid.push_back(st.valid ? 1 : 0);
+            flags.insert(flags.end(), st.has3d.begin(), st.has3d.end());
+            off.push_back((int64_t)flags.size());
+        }
+        ctx_.check(eacham_graph_set_frames(h_, (int)frames.size(), frames.data(), valid.data(), flags.data(), off.data()));
+    }
     template <class Set>
     BestPair Query(const Set& excluded) {
         std::vector<int32_t> ex(excluded.begin(), excluded.end());

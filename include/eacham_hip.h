@@ -394,6 +394,12 @@ int eacham_graph_create(eacham_ctx* ctx, int n_frames, const int32_t* pairs, int
                         const uint32_t* q, const uint32_t* t, const int64_t* kp_offsets, eacham_graph** out_graph);
 void eacham_graph_destroy(eacham_graph* graph);
 int eacham_graph_set_frame(eacham_graph* graph, int frame, int valid, const uint8_t* has3d, int n_keypoints);
+/* Several frames in one call — what the loop does after every frame it adds: the frame and its ~20 factor neighbours
+ * (apps/sfm/main.cpp:203-209: TriangulateFrame's SetPoint3d reaches exactly those). frames[i], valid[i], and the frames' flag
+ * arrays one behind the other in has3d (frame i's start at has3d_offsets[i], has3d_offsets[n] = total; every frame's full
+ * keypoint count). One copy and one kernel instead of two small copies per frame. */
+int eacham_graph_set_frames(eacham_graph* graph, int n, const int32_t* frames, const uint8_t* valid, const uint8_t* has3d,
+                            const int64_t* has3d_offsets);
 int eacham_graph_query(eacham_graph* graph, const int32_t* excluded_frames, int n_excluded, uint32_t* best);
 
 /* ---- kernel timing (HIP events on the context stream; used for roofline reporting) ---------- */

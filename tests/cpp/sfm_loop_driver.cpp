@@ -99,13 +99,17 @@ int main(int argc, char** argv) {
     std::vector<size_t> kpCount(F);
     for (int f = 0; f < F; ++f) kpCount[f] = graph->Get((unsigned)f)->GetFeatures().size();
     ResidentMatchGraph rg(ctx, pairs, g, kpCount);
-    auto refresh = [&](unsigned f) {
+    auto state_of = [&](unsigned f) {
         auto* n = graph->Get(f);
-        std::vector<uint8_t> has3d(n->GetFeatures().size(), 0);
-        for (const auto& kv : n->GetPoints3d()) has3d[kv.first] = !n->IsPoint3dTwoView(kv.first);
-        rg.SetFrame(f, n->IsValid(), has3d);
+        ResidentMatchGraph::FrameState st{f, n->IsValid(), std::vector<uint8_t>(n->GetFeatures().size(), 0)};
+        for (const auto& kv : n->GetPoints3d()) st.has3d[kv.first] = !n->IsPoint3dTwoView(kv.first);
+        return st;
     };
-    for (int f = 0; f < F; ++f) refresh((unsigned)f);
+    {
+        std::vector<ResidentMatchGraph::FrameState> all;
+        for (int f = 0; f < F; ++f) all.push_back(state_of((unsigned)f));
+        rg.SetFrames(all);
+    }
     auto best_pair = [&](const std::set<unsigned>& excluded) { return rg.Query(excluded); };
     std::set<unsigned> excluded{prevId, currentId};
     BestPair bp = best_pair(excluded);
@@ -132,8 +136,11 @@ int main(int argc, char** argv) {
             ++pnp_failed;
         }
         ta = std::chrono::steady_clock::now();
-        refresh(bp.id2);
-        for (const auto& f : graph->Get(bp.id2)->GetFactors()) refresh(f.first);
+        {
+            std::vector<ResidentMatchGraph::FrameState> changed{state_of(bp.id2)};
+            for (const auto& f : graph->Get(bp.id2)->GetFactors()) changed.push_back(state_of(f.first));
+            rg.SetFrames(changed);
+        }
         bp = best_pair(excluded);
         ms_query += since(ta);
         if (bp.id > graph->Size() || bp.id2 > graph->Size()) break;

@@ -155,6 +155,14 @@ int eacham_graph_set_frame(eacham_graph* g, int frame, int valid, const uint8_t*
     g->valid[frame] = valid != 0;
     return EACHAM_OK;
 }
+int eacham_graph_set_frames(eacham_graph* g, int n, const int32_t* frames, const uint8_t* valid, const uint8_t* has3d, const int64_t* has3d_offsets) {
+    if (!g || n < 0) return EACHAM_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        const int rc = eacham_graph_set_frame(g, frames[i], valid[i], has3d ? has3d + has3d_offsets[i] : nullptr, (int)(has3d_offsets[i + 1] - has3d_offsets[i]));
+        if (rc != EACHAM_OK) return rc;
+    }
+    return EACHAM_OK;
+}
 int eacham_graph_query(eacham_graph* g, const int32_t* excluded_frames, int n_excluded, uint32_t* best) {
     if (!g || !best) return EACHAM_ERR_INVALID;
     std::vector<uint8_t> ex(g->n_frames, 0);

@@ -48,6 +48,19 @@ def test_resident_graph_follows_the_state_frame_by_frame(ctx, n_frames, seed):
         state_valid[0] = 1
         want, _ = O.graph_best_pair(n_frames, pairs, counts, offsets, q, t, state_valid, state_h, None)
         assert rg.query() == want
+        # the batched form (eacham_graph_set_frames): a few frames changed at once, as after a frame of the loop
+        group = [int(f) for f in rng.permutation(n_frames)[:min(7, n_frames)]]
+        for f in group:
+            state_valid[f] ^= 1
+            state_h[f] = (rng.random(len(state_h[f])) < 0.5).astype(np.uint8)
+        rg.set_frames(group, [state_valid[f] for f in group], [state_h[f] for f in group])
+        want, _ = O.graph_best_pair(n_frames, pairs, counts, offsets, q, t, state_valid, state_h, None)
+        assert rg.query() == want == G.best_pair_for_valid(ctx, n_frames, pairs, counts, offsets, q, t, state_valid, state_h, None)
+        rg.set_frames([], [], [])
+        with pytest.raises(capi.EachamError):
+            rg.set_frames([n_frames], [1], [np.zeros(3, np.uint8)])
+        with pytest.raises(capi.EachamError):
+            rg.set_frames([0], [1], [np.zeros(len(has3d[0]) + 1, np.uint8)])
         with pytest.raises(capi.EachamError):
             rg.set_frame(n_frames, True)
         with pytest.raises(capi.EachamError):
