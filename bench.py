@@ -3,9 +3,13 @@
 
 Metric (BASELINE.json): image-pairs matched/s (+ BA iters/s) on the 200-frame / 50k-landmark
 synthetic scene S200. One "step" = one pass of the matching hot path over ALL 19,900 unordered
-frame pairs of S200 (2000 keypoints x 256-D per frame): int8-MFMA distance tiles with fused
-row/column top-2, ratio test, mutual cross-check, CSR compaction — and, for N > 1, the RCCL
-all-gather of the match graph. Inputs are resident in HBM before the timed region.
+frame pairs of S200 (2000 keypoints x 256-D per frame): the operand-swapped int8-MFMA row sweep
+(match_sweep_kernel: per query row the two smallest distances + the tile of the minimum), ratio
+test, the column direction for the candidates' columns only, mutual cross-check, CSR compaction —
+and, for N > 1, the RCCL all-gather of the match graph. Inputs are resident in HBM before the
+timed region. Every number comes with its parity gate: `parity` = a seeded sample of the LAST
+timed step's match graph (incl. the pairs at every launch boundary) against the CPU oracle, bit
+for bit; `ba.parity` = the device's solve against the oracle's (1e-5 relative).
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -292,6 +296,7 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int, gather_at_o
     fence()
     elapsed = D.max_f(time.perf_counter() - t0)
     ctx.profile_enable(False)
+    batches = ctx.match_batches(npairs, stats=False) if kind == "i8" else (np.zeros(1, np.int32), 1)
     launches, tile_ms = ctx.profile_get(capi.KERNEL_MATCH_TILE)
     _, fin_ms = ctx.profile_get(capi.KERNEL_MATCH_FINALIZE)
     gathered_ok = None
@@ -300,12 +305,43 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int, gather_at_o
         mine_c = st["g_counts"][rank * shard_max:(rank + 1) * shard_max]
         mine_e = st["g_edges"][rank * edge_cap * 2:(rank + 1) * edge_cap * 2]
         gathered_ok = bool(torch.equal(mine_c, st["counts"]) and torch.equal(mine_e, st["edges"]))
-    out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms,
+    st = sets[(step_no[0] - 1) % len(sets)]  # the LAST timed step's match graph of this rank's shard, for the parity gate
+    graph = {"pairs": pairs, "counts": st["counts"][:npairs].cpu().numpy(), "offsets": offsets.cpu().numpy(),
+             "edges": st["edges"].cpu().numpy().view(np.uint32).reshape(-1, 2), "force_f32": 0 if kind == "i8" else 2}
+    out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms, "graph": graph, "batch_starts": batches[0], "slots": batches[1],
            "gathered": gather, "gathered_ok": gathered_ok,
            "fin_ms": fin_ms, "matches": int(total.item()), "pairs_all": pairs_all, "edge_cap": edge_cap, "upload_s": t_up,
            "upload_bytes": int(sum(d.nbytes for d in descs))}
     ctx.close()
     return out
+
+
+def parity_matching(descs, graph, idx, want=None):
+    """The parity gate printed with every matching number: pairs `idx` (indices into this rank's shard) of the
+    match graph the LAST timed step left on the device against the CPU oracle (oracle/match_oracle.c) — counts and every (q, t),
+    bit for bit. `want` = an oracle result for exactly those pairs that somebody already computed (the cpu_baseline leg)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    idx = np.asarray(idx, dtype=np.int64)
+    if want is None:
+        want = O.match_all_pairs(descs, graph["pairs"][idx], nthreads=host_cores(), force_f32=graph["force_f32"])
+    c, o, e = graph["counts"], graph["offsets"], graph["edges"]
+    ok = bool(np.array_equal(c[idx], want[0]))
+    got_q = np.concatenate([e[o[p]:o[p] + c[p], 0] for p in idx]) if len(idx) else np.zeros(0, np.uint32)
+    got_t = np.concatenate([e[o[p]:o[p] + c[p], 1] for p in idx]) if len(idx) else np.zeros(0, np.uint32)
+    ok = ok and bool(np.array_equal(got_q, want[2]) and np.array_equal(got_t, want[3]))
+    return {"pairs_checked": int(len(idx)), "edges_checked": int((want[0] > 0).sum()), "matches_checked": int(want[0].sum()),
+            "bit_exact": ok, "against": "oracle/match_oracle.c on the last timed step's match graph"}
+
+
+def parity_sample(ctx_batches, npairs, n, seed):
+    """Seeded pair indices incl. both sides of every launch boundary of the job (eacham_match_debug_batches)."""
+    rng = np.random.default_rng(seed)
+    pick = {0, npairs - 1}
+    for s0 in ctx_batches:
+        pick.update(int(s0) + d for d in (-1, 0))
+    pick.update(rng.choice(npairs, min(n, npairs), replace=False).tolist())
+    return np.array(sorted(p for p in pick if 0 <= p < npairs), dtype=np.int64)
 
 
 def sweep_kernel(dim: int) -> str:
@@ -316,9 +352,15 @@ def sweep_kernel(dim: int) -> str:
     return f"match_sweep_kernel<{ks}>"
 
 
-def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str, gather_at_one: bool = False):
-    """One matching sub-line: value + roofline against the MFMA peak of the arithmetic used."""
+def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str, gather_at_one: bool = False,
+                  parity_pairs: int = 48):
+    """One matching sub-line: value + roofline against the MFMA peak of the arithmetic used + the parity gate (rank 0: a seeded
+    sample of the last step's graph incl. the pairs at every launch boundary against the CPU oracle; parity_pairs = 0 leaves it
+    to the caller, who has an oracle result already)."""
     r = run_matching(D, descs, kind, steps, warmup, gather_at_one)
+    parity = None
+    if D.rank == 0 and parity_pairs > 0 and r["npairs"] > 0:
+        parity = parity_matching(descs, r["graph"], parity_sample(r["batch_starts"], r["npairs"], parity_pairs, len(descs) + dim))
     n = np.array([d.shape[0] for d in descs], dtype=np.float64)
     # algorithmic work of this rank's launches: 2 * N1 * N2 * D per unordered pair (SURVEY.md §8(d))
     ops = 2.0 * dim * float(np.mean(n)) ** 2 * r["npairs"] * steps
@@ -327,6 +369,8 @@ def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, 
     return {"workload": workload, "value": r["npairs_total"] * steps / r["elapsed"], "unit": "image-pairs/s",
             "dtype": kind, "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3, "pairs": r["npairs_total"],
             "pairs_per_rank": r["npairs"], "mutual_matches_rank0": r["matches"],
+            "launches_per_step": int(len(r["batch_starts"])), "workspace_slots": int(r["slots"]),
+            **({"parity": parity} if parity is not None else {}),
             **({"all_gather": {"collective": D.collective_name, "world": D.world, "gathered_equals_local_shard": r["gathered_ok"]}} if r["gathered"] else {}),
             # the descriptor hand-over happens once per job, before the timed steps (host fp32 -> HBM int8 / fp32 fragments)
             "upload_once": {"seconds": r["upload_s"], "host_bytes": r["upload_bytes"],
@@ -406,7 +450,7 @@ def bench_ba(D: Dist, ctx, scene, solves: int, cfg, label: str, with_traffic=Tru
     traffic, src = (None, "not collected for this window")
     if with_traffic:
         traffic, src = ba_measured_traffic()
-    return {"value": rate, "unit": "LM outer iters/s", "replicas": D.world, "solves": solves,
+    return {"_outcome": first, "value": rate, "unit": "LM outer iters/s", "replicas": D.world, "solves": solves,
             "outer_iters_per_solve": outer / solves, "inner_iters_per_solve": inner / solves,
             "inner_iters_per_s": D.sum_f(inner / dt), "timed_region_s": dt,
             "ms_per_inner_iter": dt / max(inner, 1) * 1e3, "dtype": "f64",
@@ -495,7 +539,22 @@ def cpu_baseline_ba(scene):
     dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "LM outer iters/s", "cores": cores, "kind": "port",
             "sample": f"{solves} whole RefineBA calls (each builds its own observation lists, as the device call does) = {iters} LM "
-                      f"iterations of the same window (Schur + dense Cholesky, OpenMP), {dt:.1f} s"}
+                      f"iterations of the same window (Schur + dense Cholesky, OpenMP), {dt:.1f} s"}, out
+
+
+def parity_ba(got, ref):
+    """The parity gate of the BA numbers: the device's solve of the benchmarked window against the oracle's solve of the same
+    window (oracle/ba_oracle.c, the run the cpu_baseline leg makes anyway): same LM decisions, poses / points / K within the
+    north-star tolerance of 1e-5 relative."""
+    def rel(a, b):
+        return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+    r = {"rel_poses": rel(got.cam_T_wc, ref.cam_T_wc), "rel_points": rel(got.points, ref.points), "rel_K": rel(got.K, ref.K),
+         "rel_final_error": abs(got.final_error - ref.final_error) / max(abs(ref.final_error), 1e-300),
+         "same_iterations": (got.outer_iterations, got.inner_iterations) == (ref.outer_iterations, ref.inner_iterations),
+         "same_decisions": bool(got.trace.shape == ref.trace.shape and np.array_equal(got.trace[:, 3:], ref.trace[:, 3:])),
+         "tolerance": 1e-5, "against": "oracle/ba_oracle.c on the same window and options"}
+    r["within_tolerance"] = bool(r["same_iterations"] and r["same_decisions"] and max(r["rel_poses"], r["rel_points"], r["rel_K"]) < 1e-5)
+    return r
 
 
 def cpu_baseline(descs, pairs_all, args):
@@ -506,13 +565,14 @@ def cpu_baseline(descs, pairs_all, args):
     cores = host_cores()
     n = args.cpu_pairs if args.cpu_pairs > 0 else 400 * cores  # ~10 s of CPU work on the GPU box's share
     n = min(n, len(pairs_all))
-    sel = pairs_all[np.linspace(0, len(pairs_all) - 1, n).astype(np.int64)]
+    idx = np.linspace(0, len(pairs_all) - 1, n).astype(np.int64)
+    sel = pairs_all[idx]
     O.match_all_pairs(descs, sel[:cores], nthreads=cores)  # warm-up (threads, page faults)
     t0 = time.perf_counter()
     res = O.match_all_pairs(descs, sel, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "image-pairs/s", "cores": int(res[5]), "kind": "port",
-            "sample": f"{n} of {len(pairs_all)} pairs of the same workload, exact brute-force 2-NN + ratio + mutual check, {dt:.1f} s"}
+            "sample": f"{n} of {len(pairs_all)} pairs of the same workload, exact brute-force 2-NN + ratio + mutual check, {dt:.1f} s"}, idx, res
 
 
 def self_launch(args):
@@ -650,7 +710,7 @@ def main():
     head, r = matching_line(D, descs, "i8", args.dim, args.steps, args.warmup,
                             f"S200 matching: {args.frames} frames x {args.kpts} kpts x {args.dim}-D, "
                             f"{len(synth.all_pairs(args.frames))} unordered pairs (both directions + mutual check)",
-                            sweep_kernel(args.dim))
+                            sweep_kernel(args.dim), parity_pairs=0 if (D.world == 1 and args.cpu_pairs != 0) else 48)
     if args.kpts == 2000 and args.dim == 256:
         head["roofline"]["traffic"], head["roofline"]["traffic_source"] = measured_traffic("eacham::" + sweep_kernel(256))
     else:
@@ -668,7 +728,10 @@ def main():
         if D.rank == 0:
             print(json.dumps({"line": name, **obj}), flush=True)
 
+    ba_first = None
     if ba_out is not None:
+        ba_first = ba_out.pop("_outcome")
+        ba_out["global_ba"].pop("_outcome", None)
         emit("ba", ba_out)
 
     def leg(name, fn):
@@ -709,8 +772,12 @@ def main():
 
     leg("c3_tum", tum_line)
     leg("c3_sfm_loop", lambda: early_loop if early_loop is not None else {"value": 0.0, "unit": "frames/s", "roofline": {"frac": 0.0}})
-    leg("c4_ba", lambda: bench_ba(D, ctx, synth.make_scene(500, 100_000, 10, seed=4), max(3, args.ba_solves // 10),
-                                  ba.OptimizerConfig.refine_ba(), "BASELINE configs[3]", with_traffic=False))
+    def c4_line():
+        o = bench_ba(D, ctx, synth.make_scene(500, 100_000, 10, seed=4), max(3, args.ba_solves // 10),
+                     ba.OptimizerConfig.refine_ba(), "BASELINE configs[3]", with_traffic=False)
+        o.pop("_outcome", None)
+        return o
+    leg("c4_ba", c4_line)
 
     def kitti_line():
         # config/ConfigKITTI.json:3,29: 100 frames x 1500 features; sharded over the ranks + all-gather
@@ -760,7 +827,15 @@ def main():
             "kernel_source_sha": kernel_source_sha(),
         }
         if D.world == 1 and args.cpu_pairs != 0:
-            out["cpu_baseline"] = cpu_baseline(descs, r["pairs_all"], args)
+            # the CPU-baseline leg's oracle output IS the parity sample of the headline: the same pairs of the last timed step's graph
+            out["cpu_baseline"], cb_idx, cb_res = cpu_baseline(descs, r["pairs_all"], args)
+            par = parity_matching(descs, r["graph"], cb_idx, want=cb_res)
+            edge = parity_matching(descs, r["graph"], parity_sample(r["batch_starts"], r["npairs"], 0, 0))  # both sides of every launch boundary
+            out["parity"] = {"pairs_checked": par["pairs_checked"] + edge["pairs_checked"], "matches_checked": par["matches_checked"] + edge["matches_checked"],
+                             "bit_exact": par["bit_exact"] and edge["bit_exact"], "against": par["against"],
+                             "launch_boundaries": [int(x) for x in r["batch_starts"]], "workspace_slots": int(r["slots"])}
+        elif "parity" in head:
+            out["parity"] = head["parity"]
         if ba_out is not None:  # compact: the full record is the {"line": "ba"} line above
             g = ba_out["global_ba"]
             out["ba"] = {"value": ba_out["value"], "unit": ba_out["unit"], "ms_per_inner_iter": round(ba_out["ms_per_inner_iter"], 5),
@@ -776,7 +851,8 @@ def main():
                                        "ms_per_solve_incl_prepare": round(g["ms_per_solve_incl_prepare"], 4),
                                        "iters_per_s_incl_prepare": g["iters_per_s_incl_prepare"]}}
             if D.world == 1 and args.cpu_pairs != 0:
-                out["ba"]["cpu_baseline"] = cpu_baseline_ba(scene)
+                out["ba"]["cpu_baseline"], ref_out = cpu_baseline_ba(scene)
+                out["ba"]["parity"] = parity_ba(ba_first, ref_out)
         if sub:  # one value and one roofline fraction per sub-line; the full records are the lines above
             out["lines"] = {}
             for name, v in sub.items():
@@ -791,6 +867,9 @@ def main():
                     c["sfm_loop_frames_per_s"] = v["sfm_loop"]["frames_per_s"]
                 if "all_gather" in v:
                     c["all_gather_ok"] = v["all_gather"]["gathered_equals_local_shard"]
+                if "parity" in v:
+                    c["parity"] = {k: v["parity"][k] for k in ("pairs_checked", "bit_exact") if k in v["parity"]} \
+                        if "pairs_checked" in v["parity"] else v["parity"]
                 out["lines"][name] = c
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
     L.eacham_match_all_pairs.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64), vp]
     L.eacham_match_pairs_directed.argtypes = [vp, vp, i32, dbl, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.eacham_match_all_pairs_dev.argtypes = [vp, vp, i32, dbl, i32, i32, vp, vp, vp, i64, vp, vp]
+    L.eacham_match_debug_batches.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.eacham_ba_solve.argtypes = [vp, vp, vp, vp]
     L.eacham_ba_prepare.argtypes = [vp, vp, C.POINTER(vp)]
     L.eacham_ba_run.argtypes = [vp, vp, vp, vp]

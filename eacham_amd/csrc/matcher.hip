@@ -1490,6 +1490,16 @@ static MatchPlan make_plan(const eacham_ctx* ctx, int npairs, bool full_cols) {
     return pl;
 }
 
+// Pairs of the launch that starts at `first`: full batches, the job's last one cut short (an eighth of a full one) when two
+// workspace slots are in use. One definition for run_match and for eacham_match_debug_batches.
+static int next_batch(const MatchPlan& pl, int first, int npairs) {
+    const int tail_pairs = std::max(pl.round_pairs, pl.batch / 8 / pl.round_pairs * pl.round_pairs);
+    int nb = std::min(pl.batch, npairs - first);
+    if (pl.slots == 2 && first + nb == npairs && nb > 2 * tail_pairs)
+        nb = (nb - tail_pairs + pl.round_pairs - 1) / pl.round_pairs * pl.round_pairs;  // leave the tail for one more, short launch
+    return nb;
+}
+
 template <int KS>
 static void launch_tile(eacham_ctx* ctx, const MatchPlan& pl, const int2* pairs_dev, int nb, char* ws, bool col) {
     if (!col)  // the sweep without its column direction: the candidate-only pass follows (or nothing, for directed lists)
@@ -1539,12 +1549,9 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
     // The work behind a batch's sweep (rows / candidate columns / finalize / compaction) runs on the second stream beside the NEXT
     // batch's sweep — except the last batch's, which nothing hides: the job's last batch is cut short (an eighth of a full one),
     // so the exposed tail is that of ~1 500 pairs instead of ~10 000 (0.8 ms of a 21 ms S200 step).
-    const int tail_pairs = std::max(pl.round_pairs, pl.batch / 8 / pl.round_pairs * pl.round_pairs);
     int b = 0;
     for (int first = 0, nb = 0; first < npairs; first += nb, ++b) {
-        nb = std::min(pl.batch, npairs - first);
-        if (pl.slots == 2 && first + nb == npairs && nb > 2 * tail_pairs)
-            nb = (nb - tail_pairs + pl.round_pairs - 1) / pl.round_pairs * pl.round_pairs;  // leave the tail for one more, short launch
+        nb = next_batch(pl, first, npairs);
         const int slot = b % pl.slots;
         char* ws = (char*)ctx->ws + (size_t)slot * pl.slot_bytes;
         const int2* pb = pairs_dev + first;
@@ -1799,6 +1806,23 @@ int eacham_match_all_pairs(eacham_ctx* ctx, const int32_t* pairs, int npairs, do
     std::lock_guard<std::mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
     return match_pairs_host(ctx, pairs, npairs, ratio, min_dir, min_mutual, 0, counts, offsets, out_q, out_t, cap, out_total, stats);
+}
+
+int eacham_match_debug_batches(eacham_ctx* ctx, int npairs, int with_stats, int32_t* starts, int cap, int* n_batches, int* n_slots) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (npairs < 0 || !n_batches || cap < 0 || (cap > 0 && !starts)) return ctx->fail(EACHAM_ERR_INVALID, "bad arguments to match_debug_batches");
+    if (ctx->kind_common == 1) return ctx->fail(EACHAM_ERR_UNSUPPORTED, "the fp32 path plans its batches on its own");
+    const bool full_cols = ctx->match_full_columns || with_stats != 0;
+    MatchPlan pl = make_plan(ctx, std::max(npairs, 1), full_cols);
+    int b = 0;
+    for (int first = 0, nb = 0; first < npairs; first += nb, ++b) {
+        nb = next_batch(pl, first, npairs);
+        if (b < cap) starts[b] = first;
+    }
+    *n_batches = b;
+    if (n_slots) *n_slots = pl.slots;
+    return EACHAM_OK;
 }
 
 int eacham_match_pairs_directed(eacham_ctx* ctx, const int32_t* pairs, int npairs, double ratio, int32_t* counts,

@@ -130,6 +130,14 @@ class HipContext:
             offsets.ctypes.data, q.ctypes.data, t.ctypes.data, cap, C.byref(total), st.ctypes.data if stats else None))
         return counts, offsets, q[:total.value].copy(), t[:total.value].copy(), st
 
+    def match_batches(self, npairs: int, stats: bool = False):
+        """(starts, slots): first pair of every launch the library would cut a job of `npairs` pairs into, and the number of
+        workspace slots the launches rotate through (eacham_match_debug_batches)."""
+        starts = np.zeros(4096, dtype=np.int32)
+        nb, ns = C.c_int(0), C.c_int(0)
+        self._check(self._L.eacham_match_debug_batches(self._h, npairs, int(stats), starts.ctypes.data, len(starts), C.byref(nb), C.byref(ns)))
+        return starts[:min(nb.value, len(starts))].copy(), ns.value
+
     def match_pairs_directed(self, frames, ordered_pairs, ratio: float = RATIO, f32: bool = False) -> list:
         """Uploads `frames` (list of N x D matrices) as frames 0.. and runs every ordered pair (i, j) as one directed
         Match(frames[i], frames[j]) in ONE launch sequence; returns a list of {queryIdx: trainIdx} dicts."""

@@ -128,6 +128,13 @@ int eacham_match_all_pairs_dev(eacham_ctx* ctx, const int32_t* pairs_dev, int np
                                uint32_t* edges_dev, int64_t edge_cap, int64_t* total_dev,
                                int32_t* stats_dev);
 
+/* Debug getter (tests, bench.py's parity gate): how a job of `npairs` pairs of the frames resident NOW would be cut into
+ * launches by eacham_match_all_pairs[_dev] (with_stats = 1: the full-column form that the `stats` argument selects). starts[b] =
+ * index of the first pair of launch b (the first `cap` of them are written), *n_batches = launches, *n_slots = workspace copies
+ * they rotate through (2: the work behind launch b runs on a second stream beside launch b + 1). Lets a parity test place its
+ * oracle samples on both sides of every launch boundary of the job of apps/sfm/main.cpp:84-147. */
+int eacham_match_debug_batches(eacham_ctx* ctx, int npairs, int with_stats, int32_t* starts, int cap, int* n_batches, int* n_slots);
+
 /* ---- bundle adjustment: RefineBA (modules/sfm/reconstruction/BundleAdjuster.cpp:40-250) --------
  *
  * The caller (the C++ adapter in include/eacham/BundleAdjusterHip.hpp) performs the reference's
