@@ -185,7 +185,11 @@ class PreparedBA:
                  "obs_cam": (4, np.uint32), "obs_lm": (5, np.uint32), "obs_uv": (6, np.float64), "cam_uv": (7, np.float64),
                  "cam_lm": (8, np.int32), "pos_cam": (9, np.int32), "cam_chunks": (10, np.int32), "cam_chunk_ptr": (11, np.int32),
                  "blocks": (12, np.int32), "pair_chunks": (13, np.int32), "pair_entries": (14, np.int32), "pose0": (15, np.float64),
-                 "pt0": (16, np.float64), "lmprior": (17, np.float64), "K0": (18, np.float64), "fixed": (19, np.int32)}
+                 "pt0": (16, np.float64), "lmprior": (17, np.float64), "K0": (18, np.float64), "fixed": (19, np.int32),
+                 # the landmark-major structure of the Schur stage (csrc/ba_groups.hpp); empty when the pair lists serve
+                 "g_groups": (20, np.int32), "g_lmid": (21, np.int32), "g_lmrow": (22, np.int32), "g_rowinfo": (23, np.int32),
+                 "g_uv": (24, np.float64), "g_ent": (25, np.uint32), "g_chunks": (26, np.int32), "g_laneinfo": (27, np.uint32),
+                 "g_blk": (28, np.int32), "g_longblk": (29, np.int32)}
 
     def structure(self, name: str) -> np.ndarray:
         """eacham_ba_debug_structure: one array of the device-side structure (tests)."""

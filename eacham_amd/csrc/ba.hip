@@ -26,6 +26,7 @@
 // (HBM-bound); see DESIGN.md for the per-kernel byte counts.
 #include "context.hpp"
 #include "ba_plan.hpp"
+#include "ba_groups.hpp"
 #include "devprim.hpp"
 
 #include <cstdlib>
@@ -223,6 +224,18 @@ struct BaDev {
     const int4* pair_chunks;  // {block id, first entry, count, chunk index within block}
     const int4* blocks;       // {c, c', first chunk, n chunks}
     int n_chunks, n_blocks;
+    // the landmark-major form of the Schur stage (ba_groups.hpp; g_rows == 0: the pair lists above serve)
+    int g_rows, g_ngroups, g_nblk, g_nparts, g_nchunks, g_nlong;
+    long long g_nent4;
+    const BaGroup* g_groups;
+    const int *g_lmid, *g_lmrow;    // [group][rows / 4]: landmark t of the group (-1: none), local row of its own row
+    const int2* g_rowinfo;          // [group][rows]: {camera (nc: a landmark's own row, -1: no row), landmark index inside the group}
+    const double* g_uv;             // [group][rows][2]
+    const BaChunk* g_chunks;        // {first uint4-row of the chunk's entries, steps of 4 entries}
+    const uint32_t* g_ent;          // [uint4-row][lane][4]: r1 | r2 << 16, local rows (null row = g_rows)
+    const uint32_t* g_laneinfo;     // [chunk][lane]: lanes after this one in its segment << 28 | (slot + 1 at a segment's first lane)
+    const int4* g_blk;              // {c1, c2 (nc = the calibration / right-hand-side pseudo-camera), first slot, count}
+    const int* g_longblk;           // blocks with more than GRP_LONG partials
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
@@ -620,9 +633,11 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
             et[3 * a + 1] = m1 * e0 + m2 * e1;
             et[3 * a + 2] = m3 * e0 + m4 * e1 + m5 * e2;
         }
+#ifndef EXP_NO_ET_STORE  // (knock-out, timing only: what the 72 MB store costs)
         double2* out = reinterpret_cast<double2*>(D.Et + 18 * (size_t)p);
 #pragma unroll
         for (int k = 0; k < 9; ++k) out[k] = double2{et[2 * k], et[2 * k + 1]};
+#endif
     }
     mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
     double *sa = stA[wave], *sb = stB[wave];
@@ -712,7 +727,11 @@ __global__ __launch_bounds__(TPB) void ba_schur_pairs(BaDev D) {
         for (int it = 0; it < 18; ++it) {
             const int c = 64 * it + lane, r = c / 9, piece = c - 9 * r;  // piece of row r = side (r & 1) of entry r >> 1
             const int rx = __shfl(pr.x, r >> 1), ry = __shfl(pr.y, r >> 1);
+#ifdef EXP_PAIRS_LOCAL  // (knock-out, timing only: every row comes from a 74 KB window — the gathers as if Et sat in LDS / L1)
+            const double* src = D.Et + 18 * (size_t)(((r & 1) ? ry : rx) & 511) + 2 * piece;
+#else
             const double* src = D.Et + 18 * (size_t)((r & 1) ? ry : rx) + 2 * piece;
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(buf + 128 * it), 16, 0, 0);
         }
@@ -839,6 +858,276 @@ __global__ __launch_bounds__(TPB) void ba_assemble(BaDev D, double lambda, unsig
     if (blockIdx.x < n_block_groups) assemble_blocks(D, lambda, blockIdx.x);
     else assemble_border(D, lambda, (int)(blockIdx.x - n_block_groups));
 }
+
+// ---- The Schur stage, landmark-major (round 5): ONE launch for K-C, K-C2 and K-D1 ------------------------------------------
+// A workgroup owns a group of landmarks (ba_groups.hpp): consecutive landmarks of an order that keeps their camera sets close,
+// <= g_rows rows. Phase 0 (thread = landmark): the 3x3 elimination of ba_eliminate_landmarks — Linv, gt, EKt -> lmtry (the
+// step's back-substitution reads it) and, in LDS, Linv, the point and the landmark's own row Y = [EKt; gt]. Phase A (thread =
+// observation row): Jacobians recomputed at the linearisation point, Et = E Linv^T -> the row's 144 bytes IN LDS (rounds 1-4
+// wrote them to HBM: 72 MB per try, and gathered two rows per entry from there). Phase B (wave = chunk of 64 slices, lane =
+// one slice = <= GRP_SLICE entries of ONE block): the 6x6 products X Y^T out of LDS, summed in the lane in entry order -> the
+// lane's partial, 288 bytes. No cross-lane step at all (a transposed segment sum over lanes was tried first: it cost 1.5 x the
+// products whatever its form). Camera blocks, the calibration border, the right-hand side and the K corner are all the same
+// sum (the landmark rows act as the observations of a pseudo-camera). Fixed order everywhere, no atomics.
+// The per-group arrays are padded to the group bounds, so a thread's first loads need nothing but its block index; the launch
+// also clears the tiles of S and carries the linearisation's second stage, as ba_eliminate_landmarks does.
+__host__ __device__ inline size_t schur_groups_lds_bytes(int rows) {
+    return sizeof(double) * ((size_t)18 * (rows + 1) + (size_t)9 * (rows / 4));
+}
+template <int NR>  // rows per thread in phase A: g_rows <= NR * TPB
+__global__ __launch_bounds__(TPB, 4 - NR) void ba_schur_groups(BaDev D, double lambda, const double* __restrict__ clpart, int n_finish) {
+    extern __shared__ __attribute__((aligned(16))) double g_lds[];
+    const int n_grp_blocks = (int)gridDim.x - n_finish;
+    if ((int)blockIdx.x >= n_grp_blocks) {  // workgroup-uniform
+        if (threadIdx.x < 64) finish_linearize_block(D, clpart, (int)blockIdx.x - n_grp_blocks, (int)threadIdx.x);
+        return;
+    }
+    const int g = blockIdx.x, R = D.g_rows, LMAX = R / 4, tid = threadIdx.x;
+    const bool live = g < D.g_ngroups;
+    // everything below that comes from memory and needs only the block index is requested first
+    int2 ari[NR];
+    double2 auv[NR];
+    int lmj = -1, lmr = 0;
+    BaGroup G = BaGroup{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < NR; ++it) ari[it] = make_int2(-1, 0), auv[it] = double2{0.0, 0.0};
+    if (live) {
+        G = D.g_groups[g];
+#pragma unroll
+        for (int it = 0; it < NR; ++it)
+            if (tid + it * TPB < R) {
+                ari[it] = D.g_rowinfo[(size_t)g * R + tid + it * TPB];
+                auv[it] = reinterpret_cast<const double2*>(D.g_uv)[(size_t)g * R + tid + it * TPB];
+            }
+        if (tid < LMAX) {
+            lmj = D.g_lmid[(size_t)g * LMAX + tid];
+            lmr = D.g_lmrow[(size_t)g * LMAX + tid];
+        }
+    }
+    {
+        double2* S2 = reinterpret_cast<double2*>(D.T);
+        const size_t total = (size_t)D.sp_ntiles * (PB * PB / 2);
+        for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (size_t)n_grp_blocks * TPB) S2[e] = make_double2(0.0, 0.0);
+    }
+    if (!live) return;
+    double* rows = g_lds;
+    double* linv = rows + 18 * (R + 1);
+    double* ptl = linv + 6 * LMAX;
+    const int lane = tid & 63, wave = tid >> 6;
+    bool arow[NR];  // an observation row (a landmark's own row is written in phase 0)
+    double axr[NR][12];
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+        arow[it] = ari[it].x >= 0 && ari[it].x < D.nc;
+        const double* x = D.pose + 12 * (size_t)(arow[it] ? ari[it].x : 0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) axr[it][k] = x[k];
+    }
+    // ---- phase 0: the group's landmarks (one per thread: a group has at most g_rows / 4 <= TPB) ----
+    if (lmj >= 0) {
+        const int t = tid, j = lmj;
+        double* lrw = rows + 18 * lmr;  // the landmark's own row
+        const double* in = D.lmlin + (size_t)LMLIN * j;
+        double* out = D.lmtry + (size_t)LMLIN * j;
+        double h0 = in[0], h1 = in[1], h2 = in[2], h3 = in[3], h4 = in[4], h5 = in[5];
+        h0 += lambda * clampd(h0, 1e-6, 1e32);
+        h3 += lambda * clampd(h3, 1e-6, 1e32);
+        h5 += lambda * clampd(h5, 1e-6, 1e32);
+        bool ok = h0 > 0.0;
+        const double l00 = sqrt(ok ? h0 : 1.0);
+        const double l10 = h1 / l00, l20 = h2 / l00;
+        const double d1 = h3 - l10 * l10;
+        ok = ok && d1 > 0.0;
+        const double l11 = sqrt(d1 > 0.0 ? d1 : 1.0);
+        const double l21 = (h4 - l20 * l10) / l11;
+        const double d2 = h5 - l20 * l20 - l21 * l21;
+        ok = ok && d2 > 0.0;
+        const double l22 = sqrt(d2 > 0.0 ? d2 : 1.0);
+        if (!ok) atomicOr(D.flags, 1);
+        const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+        const double m10 = -l10 * m00 * m11;
+        const double m21 = -l21 * m11 * m22;
+        const double m20 = -(l20 * m00 + l21 * m10) * m22;
+        out[0] = m00; out[1] = m10; out[2] = m11; out[3] = m20; out[4] = m21; out[5] = m22;
+        double* lv = linv + 6 * t;
+        lv[0] = m00; lv[1] = m10; lv[2] = m11; lv[3] = m20; lv[4] = m21; lv[5] = m22;
+        const double g0 = in[6], g1 = in[7], g2 = in[8];
+        const double t0 = m00 * g0, t1 = m10 * g0 + m11 * g1, t2 = m20 * g0 + m21 * g1 + m22 * g2;
+        out[6] = t0; out[7] = t1; out[8] = t2;
+        lrw[15] = t0; lrw[16] = t1; lrw[17] = t2;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {  // EKt[a] = Linv * ElK[a]
+            const double e0 = in[9 + 3 * a], e1 = in[10 + 3 * a], e2 = in[11 + 3 * a];
+            const double k0 = m00 * e0, k1 = m10 * e0 + m11 * e1, k2 = m20 * e0 + m21 * e1 + m22 * e2;
+            out[9 + 3 * a] = k0; out[10 + 3 * a] = k1; out[11 + 3 * a] = k2;
+            lrw[3 * a] = k0; lrw[3 * a + 1] = k1; lrw[3 * a + 2] = k2;
+        }
+        ptl[3 * t] = D.pt[3 * (size_t)j]; ptl[3 * t + 1] = D.pt[3 * (size_t)j + 1]; ptl[3 * t + 2] = D.pt[3 * (size_t)j + 2];
+    }
+    if (tid >= TPB - 18) rows[18 * R + (tid - (TPB - 18))] = 0.0;  // the null row of the padding entries
+    __syncthreads();
+    // ---- phase A: Et of the group's observation rows (NR per thread) ----
+#pragma unroll
+    for (int it = 0; it < NR; ++it)
+    if (arow[it]) {
+        double K[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
+        const int lt = ari[it].y;
+        const double l[3] = {ptl[3 * lt], ptl[3 * lt + 1], ptl[3 * lt + 2]};
+        const double* m = linv + 6 * lt;
+        const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
+        double Ap[12], Al[6], Ak[10], b[2], et[18];
+        obs_factor(axr[it], l, K, auv[it].x, auv[it].y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double e0 = Ap[a] * Al[0] + Ap[6 + a] * Al[3], e1 = Ap[a] * Al[1] + Ap[6 + a] * Al[4], e2 = Ap[a] * Al[2] + Ap[6 + a] * Al[5];
+            et[3 * a] = m0 * e0;
+            et[3 * a + 1] = m1 * e0 + m2 * e1;
+            et[3 * a + 2] = m3 * e0 + m4 * e1 + m5 * e2;
+        }
+        double2* out = reinterpret_cast<double2*>(rows + 18 * (tid + it * TPB));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = double2{et[2 * k], et[2 * k + 1]};
+    }
+    __syncthreads();
+    // ---- phase B: the slices, one per lane ----
+#ifdef EXP_GRP_NO_B  // (knock-out, timing only)
+    if (lambda > -1.0) return;
+#endif
+    for (int c = wave; c < G.nchunks; c += TPB / 64) {
+        const BaChunk ch = D.g_chunks[G.chunk0 + c];
+        const uint32_t info = D.g_laneinfo[(size_t)(G.chunk0 + c) * 64 + lane];
+        const uint4* ep = reinterpret_cast<const uint4*>(D.g_ent) + (size_t)ch.ent0 * 64 + lane;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+        uint4 e4 = ep[0];
+        for (int i4 = 0; i4 < ch.n4; ++i4) {  // (wave-uniform trip count: shorter slices carry null entries)
+            const uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
+            if (i4 + 1 < ch.n4) e4 = ep[(size_t)(i4 + 1) * 64];  // the next step's entries fly under this step's products
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const double2* xp = reinterpret_cast<const double2*>(rows + 18 * (ent[i] & 0xffffu));
+                const double2* yp = reinterpret_cast<const double2*>(rows + 18 * (ent[i] >> 16));
+                double x[18], y[18];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const double2 a = xp[k], b = yp[k];
+                    x[2 * k] = a.x, x[2 * k + 1] = a.y, y[2 * k] = b.x, y[2 * k + 1] = b.y;
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) acc[6 * a + b] += x[3 * a] * y[3 * b] + x[3 * a + 1] * y[3 * b + 1] + x[3 * a + 2] * y[3 * b + 2];
+            }
+        }
+        // the lanes of a segment (adjacent, at most GRP_SEG): lane i takes [i, i + 2 d) in step d — after three steps the
+        // segment's first lane holds its sum, in a fixed tree order
+        const int after = (int)(info >> 28);
+        static_assert(GRP_SEG == 8, "three steps");
+#pragma unroll
+        for (int d = 1; d < GRP_SEG; d <<= 1) {
+            const bool take = after >= d;
+#pragma unroll
+            for (int k = 0; k < 36; ++k) {
+                const double o = __shfl_down(acc[k], d);
+                acc[k] += take ? o : 0.0;
+            }
+        }
+        const int slot = (int)(info & 0x0fffffffu) - 1;
+        if (slot >= 0) {
+            double2* dst = reinterpret_cast<double2*>(D.partial + (size_t)36 * slot);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) dst[k] = double2{acc[2 * k], acc[2 * k + 1]};
+        }
+    }
+}
+
+// One WAVE per block: lane l adds the block's partials l, l + 64, ... (288 contiguous bytes each; a block's partials are contiguous)
+// in that order, the 64 lane sums are folded by a fixed xor butterfly; lanes 0..35 then place one element each. Blocks with more
+// than GRP_LONG partials — the pseudo-camera's and the diagonal ones collect a partial from nearly every group a camera appears
+// in — get a whole WORKGROUP (thread t adds partials t, t + 256, ...; the four waves' sums are added in wave order): walked by one
+// thread per element such a list alone took 0.67 ms on S200, by one wave 90 us.
+__device__ __forceinline__ void place_group_block(const BaDev& D, double lambda, const int4 B, int el, double s) {
+    const int a = el / 6, b = el % 6;
+    if (B.y < D.nc) {  // camera block
+        double v = -s;
+        if (B.x == B.y) {
+            const double h = D.camlin[(size_t)CAMLIN * B.x + 6 * a + b];
+            v += h;
+            if (a == b) v += lambda * clampd(h, 1e-6, 1e32);
+        }
+        const int r = D.sp_pos[B.x] + a, q = D.sp_pos[B.y] + b;
+        sp_store(D, r, q, v);
+        if (B.x != B.y) sp_store(D, q, r, v);
+    } else if (B.x < D.nc) {  // (c, K): border | right-hand side of camera c
+        const double* cl = D.camlin + (size_t)CAMLIN * B.x;
+        if (b < 5) {
+            const double v = cl[36 + 5 * a + b] - s;
+            sp_store(D, D.sp_pos[B.x] + a, D.sp_posK + b, v);
+            sp_store(D, D.sp_posK + b, D.sp_pos[B.x] + a, v);
+        } else {
+            sp_store(D, D.sp_rhs_row, D.sp_pos[B.x] + a, cl[66 + a] - s);
+        }
+    } else if (a < 5) {  // (K, K): K corner | right-hand side of K
+        if (b < 5) {
+            double v = D.klin[5 * a + b] - s;
+            if (a == b) v += lambda * clampd(D.klin[5 * a + b], 1e-6, 1e32);
+            sp_store(D, D.sp_posK + a, D.sp_posK + b, v);
+        } else {
+            sp_store(D, D.sp_rhs_row, D.sp_posK + a, D.klin[25 + a] - s);
+        }
+    }
+}
+// A block's partials are contiguous: element el of partial k sits at partial[36 (first + k) + el], so 36 adjacent threads read 288
+// contiguous bytes per k and every thread adds ITS element in k order (eight independent loads in flight per thread).
+constexpr int ASM_TPB = 1024;  // workgroup of ba_assemble_groups: 16 blocks of the table (a wave each), or ONE long block
+__device__ __forceinline__ double sum_partials(const double* __restrict__ pp, int first, int n, int stride) {
+    double s = 0.0;
+    int k = first;
+    for (; k + 7 * stride < n; k += 8 * stride) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pp[(size_t)36 * (k + i * stride)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; k < n; k += stride) s += pp[(size_t)36 * k];
+    return s;
+}
+__device__ __forceinline__ void assemble_group_blocks(const BaDev& D, double lambda, unsigned block) {
+    const int blk = (int)block * (ASM_TPB / 64) + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blk >= D.g_nblk || lane >= 36) return;
+    const int4 B = D.g_blk[blk];
+    if (B.w > GRP_LONG) return;  // assemble_long_block's
+    place_group_block(D, lambda, B, lane, sum_partials(D.partial + (size_t)36 * B.z + lane, 0, B.w, 1));
+}
+// A block with more than GRP_LONG partials — the pseudo-camera's blocks and the diagonal ones collect a partial from nearly
+// every group a camera appears in — gets a WORKGROUP: thread (sub, el) adds partials sub, sub + 28, ... of element el, the 28
+// sub-sums are added in order. (Walked by one thread per element such a list alone took 0.67 ms on S200.)
+__device__ __forceinline__ void assemble_long_block(const BaDev& D, double lambda, int which) {
+    constexpr int NSUB = ASM_TPB / 36;  // 28
+    __shared__ double wsum[NSUB][36];
+    const int4 B = D.g_blk[D.g_longblk[which]];
+    const int sub = threadIdx.x / 36, el = threadIdx.x % 36;
+    if (sub < NSUB) wsum[sub][el] = sum_partials(D.partial + (size_t)36 * B.z + el, sub, B.w, NSUB);
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NSUB; ++w) s += wsum[w][threadIdx.x];
+        place_group_block(D, lambda, B, (int)threadIdx.x, s);
+    }
+}
+__global__ __launch_bounds__(ASM_TPB) void ba_assemble_groups(BaDev D, double lambda, unsigned n_block_groups) {
+    // the long blocks first (they are the launch's critical path), then sixteen blocks per workgroup, then the padding columns'
+    // identity and the pivot of the right-hand-side row
+    if ((int)blockIdx.x < D.g_nlong) assemble_long_block(D, lambda, (int)blockIdx.x);
+    else if (blockIdx.x - D.g_nlong < n_block_groups) assemble_group_blocks(D, lambda, blockIdx.x - D.g_nlong);
+    else if (threadIdx.x < TPB) assemble_border(D, lambda, D.nc + 1);
+}
+
 
 // ---- K-E: the building blocks of the factorisation of a 64x64 diagonal tile -------------------------------------------
 // (factor_32: one wave factorises a 32x32 block in MFMA accumulators; invert_behind_factor: a second wave inverts the
@@ -2437,6 +2726,7 @@ struct eacham_ba_handle {
     size_t upload_end = 0;     // end of the last uploaded array in the arena (the uploads come first in the sequence)
     std::vector<char> stage;   // small problems: host image of the uploaded arrays, sent with ONE copy
     std::vector<int> lm_order;  // landmark-sorted observation index -> caller's observation index
+    eacham::BaGroups groups;    // host-built problems: the landmark-major structure of the Schur stage (device-built: sizes only)
     double *kpart = nullptr, *err_cam = nullptr, *lin_cam = nullptr;
     bool finish_pending = false;  // the linearisation's second stage has not run yet: the next try's first launch carries it
     double* scal_host = nullptr;  // pinned: the per-try scalar read-back sits on the LM loop's critical path
@@ -2555,6 +2845,28 @@ static int ba_upload_plan(eacham_ctx* ctx, eacham_ba_handle* h, const BaPlan& pl
     TRY(dev_upload(ctx, h, &h->sp_col_dest, plan.col_dest));
     return EACHAM_OK;
 }
+template <class T, class U>
+static int dev_upload_as(eacham_ctx* ctx, eacham_ba_handle* h, const T** p, const std::vector<U>& v) {  // same-layout PODs (GrpI2 = int2, ...)
+    static_assert(sizeof(T) == sizeof(U), "layout");
+    return dev_upload(ctx, h, p, reinterpret_cast<const std::vector<T>&>(v));
+}
+static int ba_upload_groups(eacham_ctx* ctx, eacham_ba_handle* h, const BaGroups& GR) {
+    BaDev& D = h->D;
+    D.g_rows = GR.rows; D.g_ngroups = (int)GR.groups.size(); D.g_nblk = GR.n_blk; D.g_nparts = GR.n_parts;
+    D.g_nchunks = GR.n_chunks; D.g_nlong = (int)GR.longblk.size(); D.g_nent4 = GR.n_ent4;
+    if (GR.rows == 0) return EACHAM_OK;
+    TRY(dev_upload(ctx, h, &D.g_groups, GR.groups));
+    TRY(dev_upload(ctx, h, &D.g_lmid, GR.lmid));
+    TRY(dev_upload(ctx, h, &D.g_lmrow, GR.lmrow));
+    TRY(dev_upload_as(ctx, h, &D.g_rowinfo, GR.rowinfo));
+    TRY(dev_upload(ctx, h, &D.g_uv, GR.uv));
+    TRY(dev_upload(ctx, h, &D.g_chunks, GR.chunks));
+    TRY(dev_upload(ctx, h, &D.g_ent, GR.ent));
+    TRY(dev_upload(ctx, h, &D.g_laneinfo, GR.laneinfo));
+    TRY(dev_upload_as(ctx, h, &D.g_blk, GR.blk));
+    TRY(dev_upload(ctx, h, &D.g_longblk, GR.longblk));
+    return EACHAM_OK;
+}
 static int ba_alloc_work_a(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     const int nc = D.nc, nl = D.nl, no = D.no;
@@ -2610,7 +2922,16 @@ static int ba_alloc_work_b(eacham_ctx* ctx, eacham_ba_handle* h) {
     TRY(dev_alloc(ctx, h, &D.Xrow, (size_t)plan.npan * NB * NB));       // X = -W_b L_ba W_a, row-major
     TRY(dev_alloc(ctx, h, &D.Wops, (size_t)plan.npan * TILE_OPS));      // W_a, W_b, X of every panel in MFMA operand order
     TRY(dev_alloc(ctx, h, &D.zsol, (size_t)plan.npan * PB));
-    TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * std::max(D.n_chunks, 1)));
+    TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * std::max(D.g_rows > 0 ? D.g_nparts : D.n_chunks, 1)));
+    if (!h->planning && D.g_rows > 0) {
+        // landmarks without observations are never visited by ba_schur_groups and keep a zero record
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.lmtry, 0, sizeof(double) * LMLIN * (size_t)D.nl, ctx->stream));
+        if (!ctx->ba_groups_lds_set) {  // (the kernel asks for more than the default dynamic LDS limit)
+            EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)ba_schur_groups<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_groups_lds_bytes(TPB)));
+            EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)ba_schur_groups<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_groups_lds_bytes(2 * TPB)));
+            ctx->ba_groups_lds_set = true;
+        }
+    }
     TRY(dev_alloc(ctx, h, &D.bpart, (size_t)36 * std::max(D.n_cam_chunks, 1)));
     TRY(dev_alloc(ctx, h, &D.pcg_p2, (size_t)6 * std::max(D.n_cam_chunks, 1)));
     TRY(dev_alloc(ctx, h, &D.flags, (size_t)N_STATUS + plan.npan));  // [0..3] status, [4 + P] hand-off flag of panel P
@@ -2686,10 +3007,14 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         cam_uv[2 * (size_t)p] = obs_uv[2 * (size_t)cam_obs[p]];
         cam_uv[2 * (size_t)p + 1] = obs_uv[2 * (size_t)cam_obs[p] + 1];
     }
+    // ---- the landmark-major structure of the Schur stage (ba_groups.hpp); the pair lists below only when it does not apply ----
+    BaGroups& GR = h->groups;
+    const bool use_groups = ctx->ba_schur_mode != 2 && build_groups(nc, nl, lm_ptr.data(), obs_cam.data(), obs_uv.data(), GR, ctx->ba_group_rows);
+    if (!use_groups) GR = BaGroups();
     // ---- camera-pair lists of the Schur complement: block (c <= c') -> (o, o') pairs, landmark order ----
     // (two passes over every observation pair of every landmark — count, then fill: this loop is most of the host time of
     // preparing a local window, hence the flat 32-bit index arithmetic; entries are written as Et positions directly)
-    const long long nblk_all = (long long)nc * (nc + 1) / 2;
+    const long long nblk_all = use_groups ? 0 : (long long)nc * (nc + 1) / 2;
     if (nblk_all > 0x7fffffffLL) {
         delete h;
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "too many cameras (%d) for the camera-block index", nc);
@@ -2698,7 +3023,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
     for (int c = 0; c < nc; ++c) rowoff[c] = (int)((long long)c * nc - (long long)c * (c - 1) / 2 - c);
     auto bid = [&](int c, int c2) { return rowoff[c] + c2; };
     std::vector<int> bcount((size_t)nblk_all + 1, 0);
-    {
+    if (!use_groups) {
         const unsigned* oc = obs_cam.data();
         int* bc = bcount.data() + 1;
         for (int j = 0; j < nl; ++j) {
@@ -2723,7 +3048,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "Schur pair list too large (%lld entries)", n_entries);
     }
     std::vector<int2> entries((size_t)n_entries);
-    {
+    if (!use_groups) {
         std::vector<int> pos((size_t)nblk_all);
         for (long long b = 0; b < nblk_all; ++b) pos[b] = (int)bstart[b];
         const unsigned* oc = obs_cam.data();
@@ -2749,7 +3074,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         }
     }
     std::vector<int4> chunks, blocks;
-    for (int c = 0; c < nc; ++c)
+    for (int c = 0; c < (use_groups ? 0 : nc); ++c)
         for (int c2 = c; c2 < nc; ++c2) {
             const long long b = bid(c, c2);
             const long long cnt = bstart[b + 1] - bstart[b];
@@ -2767,9 +3092,11 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
     h->prep_us[0] = us_since(t_begin);
     {
         std::vector<std::pair<int, int>> cam_edges;
-        cam_edges.reserve(blocks.size());
+        cam_edges.reserve(blocks.size() + GR.blk.size());
         for (const int4& b : blocks)
             if (b.x != b.y) cam_edges.emplace_back(b.x, b.y);
+        for (const GrpI4& b : GR.blk)
+            if (b.x != b.y && b.y < nc) cam_edges.emplace_back(b.x, b.y);
         int hint = P->ordering;
         if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
         if (hint < EACHAM_BA_ORDER_AUTO || hint > EACHAM_BA_ORDER_ND) {
@@ -2828,6 +3155,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         TRY(dev_upload(ctx, h, &D.pair_entries, entries));
         TRY(dev_upload(ctx, h, &D.pair_chunks, chunks));
         TRY(dev_upload(ctx, h, &D.blocks, blocks));
+        TRY(ba_upload_groups(ctx, h, GR));
         TRY(ba_upload_plan(ctx, h, plan, bs_ent));
         TRY(ba_alloc_work_a(ctx, h));
         TRY(ba_alloc_work_b(ctx, h));
@@ -3467,12 +3795,19 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
     {
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
         const int n_finish = h->finish_pending ? KLIN + D.nc : 0;
-        ba_eliminate_landmarks<<<D.n_lm_blocks + n_finish, TPB, 0, ctx->stream>>>(D, lambda, h->kpart, n_finish);
         h->finish_pending = false;
-        if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
-        if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
-        const unsigned nbg = (unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB);
-        ba_assemble<<<nbg + D.nc + 2, TPB, 0, ctx->stream>>>(D, lambda, nbg);  // camera blocks | border per camera | K corner | padding
+        if (D.g_rows > 0) {  // landmark groups: elimination, Et (in LDS) and the pair products in one launch
+            if (D.g_rows <= TPB) ba_schur_groups<1><<<std::max(D.g_ngroups, 1) + n_finish, TPB, schur_groups_lds_bytes(D.g_rows), ctx->stream>>>(D, lambda, h->kpart, n_finish);
+            else ba_schur_groups<2><<<std::max(D.g_ngroups, 1) + n_finish, TPB, schur_groups_lds_bytes(D.g_rows), ctx->stream>>>(D, lambda, h->kpart, n_finish);
+            const unsigned nbg = (unsigned)((D.g_nblk + ASM_TPB / 64 - 1) / (ASM_TPB / 64));  // a wave per block
+            ba_assemble_groups<<<D.g_nlong + nbg + 1, ASM_TPB, 0, ctx->stream>>>(D, lambda, nbg);
+        } else {
+            ba_eliminate_landmarks<<<D.n_lm_blocks + n_finish, TPB, 0, ctx->stream>>>(D, lambda, h->kpart, n_finish);
+            if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
+            if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
+            const unsigned nbg = (unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB);
+            ba_assemble<<<nbg + D.nc + 2, TPB, 0, ctx->stream>>>(D, lambda, nbg);  // camera blocks | border per camera | K corner | padding
+        }
     }
     if (S_copy) {  // diagnostic read-back: S and its right-hand side in the caller's order, from the tiles
         const BaPlan& pl = h->plan;
@@ -3874,6 +4209,17 @@ int eacham_ba_debug_structure(eacham_ctx* ctx, const eacham_ba_handle* h, int wh
         case 17: src = D.lmprior; bytes = sizeof(double) * 2 * (size_t)D.nl; break;
         case 18: src = D.K0; bytes = sizeof(double) * 5; break;
         case 19: src = D.fixed; bytes = sizeof(int) * (size_t)D.nc; break;
+        // the landmark-major structure of the Schur stage (ba_groups.hpp); all empty when the pair lists serve
+        case 20: src = D.g_groups; bytes = D.g_rows ? sizeof(BaGroup) * (size_t)D.g_ngroups : 0; break;
+        case 21: src = D.g_lmid; bytes = D.g_rows ? sizeof(int) * (size_t)D.g_ngroups * (D.g_rows / 4) : 0; break;
+        case 22: src = D.g_lmrow; bytes = D.g_rows ? sizeof(int) * (size_t)D.g_ngroups * (D.g_rows / 4) : 0; break;
+        case 23: src = D.g_rowinfo; bytes = D.g_rows ? sizeof(int2) * (size_t)D.g_ngroups * D.g_rows : 0; break;
+        case 24: src = D.g_uv; bytes = D.g_rows ? sizeof(double) * 2 * (size_t)D.g_ngroups * D.g_rows : 0; break;
+        case 25: src = D.g_ent; bytes = D.g_rows ? sizeof(uint32_t) * 256 * (size_t)D.g_nent4 : 0; break;
+        case 26: src = D.g_chunks; bytes = D.g_rows ? sizeof(BaChunk) * (size_t)D.g_nchunks : 0; break;
+        case 27: src = D.g_laneinfo; bytes = D.g_rows ? sizeof(uint32_t) * 64 * (size_t)D.g_nchunks : 0; break;
+        case 28: src = D.g_blk; bytes = D.g_rows ? sizeof(int4) * (size_t)D.g_nblk : 0; break;
+        case 29: src = D.g_longblk; bytes = D.g_rows ? sizeof(int) * (size_t)D.g_nlong : 0; break;
         default: return ctx->fail(EACHAM_ERR_INVALID, "unknown structure array %d", which);
     }
     *out_bytes = (int64_t)bytes;

@@ -1,0 +1,308 @@
+// ba_groups.hpp — the landmark-major structure of the Schur stage (round 5), pure C++ (host form + the definition the device form
+// of eacham_ba_prepare reproduces bit for bit; tests/cpp/groups_driver.cpp executes it in plain doubles on the CPU).
+//
+// What it replaces: RefineBA's reduced camera system (the landmark elimination GTSAM's multifrontal solver performs for
+// modules/sfm/reconstruction/BundleAdjuster.cpp:182-216) needs S_ab -= sum_j Et_a(j) Et_b(j)^T over the landmarks j seen by both
+// cameras a and b. Rounds 1-4 wrote Et (144 B per observation) to HBM and gathered two rows per (landmark, a, b) entry from
+// block-ordered pair lists: 353 of the 520 MB an LM iteration moved. Here a WORKGROUP owns a group of landmarks — consecutive in
+// an order that keeps their camera sets close — recomputes their Jacobians, keeps Et of the group's <= `rows` observations in
+// LDS and multiplies the group's entries out of LDS: a LANE owns a slice (<= GRP_SLICE consecutive entries of ONE camera block) and
+// sums its products in entry order, the <= GRP_SEG adjacent lanes of a segment (slices of one block) are folded by three
+// shift-and-add steps, the segment's first lane writes one 6x6 partial; ba_assemble_groups adds a block's partials (contiguous
+// in memory) in a fixed order. No atomics, every sum has one order.
+//
+// The calibration border and the right-hand side are the same sum with one more "camera": every landmark gets a row of its own,
+// Y_j = [EKt_j (5x3); gt_j (1x3)] (what Et would be for a pseudo-camera with the 5 calibration columns + the right-hand side),
+// so block (c, K) = sum Et_c Y^T = [border | rhs share] and block (K, K) = sum Y Y^T = [K corner | rhs_K; . ] come out of the
+// same entries.
+//
+// Definition (both forms of eacham_ba_prepare produce exactly this):
+//  1. used landmarks (>= 1 observation) in stable order of key = morton(min camera, max camera) of their observations;
+//  2. landmark k (sorted rank) owns rows_k = m_k + 1 consecutive ROWS (its observations in landmark order, then its own row)
+//     and e_k entries (every row pair a <= b; two for a != b in the same camera); cost_k = max(rows_k, 4, ceil(e_k rows / ent_max));
+//     group(k) = floor(prefix cost(k) / R0), R0 = rows - max cost + 1: a group holds <= rows rows, <= rows / 4 landmarks and
+//     <= ent_max entries; if max cost > rows / 2 the structure is not built (the pair-list path of rounds 1-4 serves).
+//     Per-group arrays are PADDED to these bounds (row r of group g at g rows + r, landmark t at g rows / 4 + t): a thread's
+//     loads do not wait for the group record;
+//  3. a group's entries (block key = c1 (nc + 1) + c2 with c1 <= c2, pseudo-camera = nc; local rows r1, r2 with camera(r1) = c1)
+//     sorted by (block key, emission index); a run of L entries of one block is cut into n = ceil(L / GRP_SLICE) slices of
+//     balanced length (the first L mod n one longer) that take n consecutive LANES; the group's lanes — the runs of more than four
+//     entries in block order, then the runs of at most four in block order — fill chunks of 64; a SEGMENT = consecutive lanes of one block, at most GRP_SEG of them, never across a chunk boundary; chunk n4 =
+//     ceil(longest slice / 4) steps; entries are stored [chunk][step][lane][4] (one 16-byte load per lane and step), shorter
+//     slices padded with null entries (row `rows` = zeros);
+//  4. laneinfo[64 chunk + lane] = (lanes after this one in its segment) << 28 | (slot + 1 for a segment's first lane, else 0):
+//     slot = where the segment's partial is stored: all segments in (group, lane) order stably sorted by block key, so that a
+//     block's partials are CONTIGUOUS (blk = {c1, c2, first slot, count}); the mandatory blocks ((c, c), (c, K), (K, K)) are in the
+//     table even without entries (count 0); longblk = the blocks with more than GRP_LONG partials.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace eacham {
+
+constexpr int GRP_SLICE = 8;              // entries of one block a lane multiplies at most
+constexpr int GRP_SEG = 8;                // lanes of one block folded into one partial at most (three shift-and-add steps)
+constexpr int GRP_ENT_PER_ROW = 16;       // ent_max = GRP_ENT_PER_ROW * rows
+constexpr int GRP_LONG = 48;              // a block with more partials than this is added by a workgroup, not a wave
+
+struct BaGroup { int lm0, nlm, row0, nrows, chunk0, nchunks, n_entries, n_segments; };
+struct BaChunk { int ent0, n4; };         // first uint4-row (of 64 lanes) of the chunk's entries; steps of 4 entries
+struct GrpI2 { int x, y; };
+struct GrpI4 { int x, y, z, w; };
+
+struct BaGroups {
+    int rows = 0;        // rows per group (0: not built, the pair lists serve)
+    int n_used = 0, n_rows = 0, n_chunks = 0, n_parts = 0, n_blk = 0;
+    long long n_entries = 0, n_ent4 = 0;   // real entries; uint4-rows (64 lanes x 4 entries each) of the padded entry array
+    std::vector<BaGroup> groups;
+    std::vector<int> lm;                   // [n_used] landmark of sorted rank k
+    std::vector<int> lrow;                 // [n_used + 1] first row of rank k
+    std::vector<int> lmid;                 // [groups x rows / 4] landmark t of group g (-1 beyond nlm)
+    std::vector<int> lmrow;                // [groups x rows / 4] local row of that landmark's own row
+    std::vector<GrpI2> rowinfo;            // [groups x rows] {camera (nc: a landmark's own row, -1: no row), landmark index inside the group}
+    std::vector<double> uv;                // [2 x groups x rows]
+    std::vector<BaChunk> chunks;           // [n_chunks]
+    std::vector<uint32_t> ent;             // [n_ent4 x 64 x 4] r1 | r2 << 16 (local rows; null row = rows)
+    std::vector<uint32_t> laneinfo;        // [64 n_chunks] lanes after this one in its segment << 28 | (slot + 1 at a segment's first lane)
+    std::vector<GrpI4> blk;                // {c1, c2, first slot, count}, ascending block key
+    std::vector<int> longblk;              // indices of the blocks with more than GRP_LONG partials (a whole workgroup adds those)
+};
+
+inline uint32_t grp_morton(uint32_t a, uint32_t b) {  // a in the odd bits, b in the even bits (16 bits each)
+    auto spread = [](uint32_t x) {
+        x &= 0xffffu;
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    return (spread(a) << 1) | spread(b);
+}
+inline int grp_rows_for(long long total_rows) { return total_rows <= 32768 ? 128 : 256; }
+
+// lm_ptr / obs_cam / obs_uv: the landmark-ordered observation arrays of the problem. Returns false (out.rows = 0) when a
+// landmark is too heavy for a group.
+inline bool build_groups(int nc, int nl, const int* lm_ptr, const unsigned* obs_cam, const double* obs_uv, BaGroups& out, int rows_override = 0) {
+    out = BaGroups();
+    if (nc >= 65535) return false;
+    // 1. order
+    std::vector<uint32_t> key;
+    std::vector<int> used;
+    long long total_rows = 0;
+    for (int j = 0; j < nl; ++j) {
+        const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1];
+        if (a1 == a0) continue;
+        unsigned mn = obs_cam[a0], mx = obs_cam[a0];
+        for (int a = a0 + 1; a < a1; ++a) mn = std::min(mn, obs_cam[a]), mx = std::max(mx, obs_cam[a]);
+        used.push_back(j);
+        key.push_back(grp_morton(mn, mx));
+        total_rows += a1 - a0 + 1;
+    }
+    const int nu = (int)used.size();
+    if (total_rows > 0x7fffffffLL) return false;
+    std::vector<int> order(nu);
+    for (int k = 0; k < nu; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    const int rows = rows_override > 0 ? rows_override : grp_rows_for(total_rows), ent_max = GRP_ENT_PER_ROW * rows;
+    if (rows % 4 != 0 || rows > 32767) return false;
+    // 2. costs, groups
+    std::vector<int> cost(nu), ecount(nu);
+    out.lm.resize(nu);
+    out.lrow.assign(nu + 1, 0);
+    int cmax = 4;
+    for (int k = 0; k < nu; ++k) {
+        const int j = used[order[k]];
+        out.lm[k] = j;
+        const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1], m = a1 - a0;
+        long long e = (long long)(m + 1) * (m + 2) / 2;
+        for (int a = a0; a < a1; ++a)
+            for (int b = a + 1; b < a1; ++b) e += obs_cam[a] == obs_cam[b] ? 1 : 0;
+        if (e > ent_max) return false;
+        ecount[k] = (int)e;
+        cost[k] = std::max(std::max(m + 1, 4), (int)((e * rows + ent_max - 1) / ent_max));
+        cmax = std::max(cmax, cost[k]);
+        out.lrow[k + 1] = out.lrow[k] + m + 1;
+    }
+    if (cmax > rows / 2) return false;
+    const int R0 = rows - cmax + 1;
+    std::vector<int> grp(nu);
+    {
+        long long c = 0;
+        for (int k = 0; k < nu; ++k) grp[k] = (int)(c / R0), c += cost[k];
+    }
+    const int ng = nu ? grp[nu - 1] + 1 : 0;
+    out.rows = rows;
+    out.n_used = nu;
+    out.n_rows = out.lrow[nu];
+    out.groups.assign(ng, BaGroup{0, 0, 0, 0, 0, 0, 0, 0});
+    for (int g = 0, k = 0; g < ng; ++g) {  // empty groups are legal (a landmark's cost may span a whole window)
+        while (k < nu && grp[k] < g) ++k;
+        int k1 = k;
+        while (k1 < nu && grp[k1] == g) ++k1;
+        BaGroup& G = out.groups[g];
+        G.lm0 = k; G.nlm = k1 - k; G.row0 = out.lrow[k]; G.nrows = out.lrow[k1] - out.lrow[k];
+    }
+    // rows and landmarks, padded per group
+    const int lmax = rows / 4;
+    out.rowinfo.assign((size_t)ng * rows, GrpI2{-1, 0});
+    out.uv.assign(2 * (size_t)ng * rows, 0.0);
+    out.lmid.assign((size_t)ng * lmax, -1);
+    out.lmrow.assign((size_t)ng * lmax, 0);
+    for (int g = 0; g < ng; ++g) {
+        const BaGroup& G = out.groups[g];
+        for (int t = 0; t < G.nlm; ++t) {
+            const int k = G.lm0 + t, j = out.lm[k], a0 = lm_ptr[j], m = lm_ptr[j + 1] - a0;
+            const size_t base = (size_t)g * rows + (out.lrow[k] - G.row0);
+            for (int i = 0; i < m; ++i) {
+                out.rowinfo[base + i] = GrpI2{(int)obs_cam[a0 + i], t};
+                out.uv[2 * (base + i)] = obs_uv[2 * (size_t)(a0 + i)];
+                out.uv[2 * (base + i) + 1] = obs_uv[2 * (size_t)(a0 + i) + 1];
+            }
+            out.rowinfo[base + m] = GrpI2{nc, t};
+            out.lmid[(size_t)g * lmax + t] = j;
+            out.lmrow[(size_t)g * lmax + t] = out.lrow[k] - G.row0 + m;
+        }
+    }
+    // 3. entries: per group a stable counting sort over the group's own camera pairs (local camera ids in ascending camera
+    //    order, so the local pair order is the order of the block keys), runs cut into slices, slices dealt to lanes
+    struct Seg { uint32_t key; int where; };  // where = 64 chunk + lane
+    struct Slice { uint32_t key; int first, len; };
+    std::vector<Seg> segs;
+    std::vector<int> stamp(nc + 1, -1), local(nc + 1, 0), cams;
+    std::vector<uint32_t> e_key, e_val, sorted;
+    std::vector<int> cnt;
+    std::vector<Slice> slices, short_runs;
+    const uint32_t null_ent = (uint32_t)rows | ((uint32_t)rows << 16);
+    const uint32_t W = (uint32_t)nc + 1;
+    for (int g = 0; g < ng; ++g) {
+        BaGroup& G = out.groups[g];
+        cams.clear();
+        e_key.clear();
+        e_val.clear();
+        for (int t = 0; t < G.nlm; ++t) {
+            const int k = G.lm0 + t, r0 = out.lrow[k] - G.row0, m = out.lrow[k + 1] - out.lrow[k] - 1;
+            const GrpI2* ri = &out.rowinfo[(size_t)g * rows + r0];
+            for (int a = 0; a <= m; ++a) {
+                const int ca = ri[a].x;
+                if (stamp[ca] != g) stamp[ca] = g, cams.push_back(ca);
+                e_key.push_back((uint32_t)ca * W + ca);
+                e_val.push_back((uint32_t)(r0 + a) | ((uint32_t)(r0 + a) << 16));
+                for (int b = a + 1; b <= m; ++b) {
+                    const int cb = ri[b].x;
+                    const uint32_t ra = (uint32_t)(r0 + a), rb = (uint32_t)(r0 + b);
+                    if (ca < cb) e_key.push_back((uint32_t)ca * W + cb), e_val.push_back(ra | (rb << 16));
+                    else if (ca > cb) e_key.push_back((uint32_t)cb * W + ca), e_val.push_back(rb | (ra << 16));
+                    else {
+                        e_key.push_back((uint32_t)ca * W + ca), e_val.push_back(ra | (rb << 16));
+                        e_key.push_back((uint32_t)ca * W + ca), e_val.push_back(rb | (ra << 16));
+                    }
+                }
+            }
+        }
+        const int ne = (int)e_key.size();
+        G.n_entries = ne;
+        out.n_entries += ne;
+        std::sort(cams.begin(), cams.end());
+        const int U = (int)cams.size();
+        for (int i = 0; i < U; ++i) local[cams[i]] = i;
+        cnt.assign((size_t)U * U + 1, 0);
+        auto lp = [&](uint32_t key2) { return local[key2 / W] * U + local[key2 % W]; };
+        for (int i = 0; i < ne; ++i) cnt[lp(e_key[i]) + 1]++;
+        slices.clear();
+        short_runs.clear();
+        {
+            int pos = 0;
+            for (int q = 0; q < U * U; ++q) {   // cnt[q + 1]: count -> running cursor of pair q; the run's slices
+                const int L = cnt[q + 1];
+                cnt[q + 1] = pos;
+                if (L > 4) {
+                    const uint32_t key2 = (uint32_t)cams[q / U] * W + (uint32_t)cams[q % U];
+                    const int n = (L + GRP_SLICE - 1) / GRP_SLICE;
+                    for (int i = 0, at = pos; i < n; ++i) {
+                        const int len = L / n + (i < L % n ? 1 : 0);
+                        slices.push_back(Slice{key2, at, len});
+                        at += len;
+                    }
+                } else if (L > 0) {  // runs of at most four entries (one step) take the group's LAST lanes: the chunks that hold
+                                     // only such lanes run one step of four entries instead of two
+                    short_runs.push_back(Slice{(uint32_t)cams[q / U] * W + (uint32_t)cams[q % U], pos, L});
+                }
+                pos += L;
+            }
+            slices.insert(slices.end(), short_runs.begin(), short_runs.end());
+        }
+        sorted.assign((size_t)ne, 0);
+        for (int i = 0; i < ne; ++i) sorted[cnt[lp(e_key[i]) + 1]++] = e_val[i];
+        const int ns = (int)slices.size();   // = lanes, in block order
+        G.chunk0 = out.n_chunks;
+        G.nchunks = (ns + 63) / 64;
+        G.n_segments = 0;
+        for (int c = 0; c < G.nchunks; ++c) {
+            int longest = 0;
+            for (int l = 64 * c; l < std::min(ns, 64 * c + 64); ++l) longest = std::max(longest, slices[l].len);
+            const int n4 = (longest + 3) / 4;
+            out.chunks.push_back(BaChunk{(int)out.n_ent4, n4});
+            out.ent.resize(out.ent.size() + (size_t)n4 * 256, null_ent);
+            uint32_t* dst = out.ent.data() + (size_t)out.n_ent4 * 256;
+            for (int l = 0; l < 64; ++l) {
+                const int si = 64 * c + l;
+                if (si >= ns) {
+                    out.laneinfo.push_back(0);
+                    continue;
+                }
+                const Slice& S = slices[si];
+                for (int i = 0; i < S.len; ++i) dst[(size_t)(i / 4) * 256 + 4 * l + (i % 4)] = sorted[S.first + i];
+                // the segment this lane belongs to: lanes [h, e) with the lane's key, h = the last segment start at or before it
+                int h = si;   // walk back to the run's first lane in this chunk, then forward in steps of GRP_SEG
+                while (h > 64 * c && slices[h - 1].key == S.key) --h;
+                h += (si - h) / GRP_SEG * GRP_SEG;
+                int e = h;
+                while (e < std::min(ns, 64 * c + 64) && e < h + GRP_SEG && slices[e].key == S.key) ++e;
+                uint32_t info = (uint32_t)(e - 1 - si) << 28;
+                if (si == h) {
+                    segs.push_back(Seg{S.key, 64 * (G.chunk0 + c) + l});
+                    ++G.n_segments;
+                    info |= 1u;  // (the slot is filled in below)
+                }
+                out.laneinfo.push_back(info);
+            }
+            out.n_ent4 += n4;
+        }
+        out.n_chunks += G.nchunks;
+    }
+    out.n_parts = (int)segs.size();
+    // slots: the slices in stable order of their block key; the block table = that order's runs merged with the mandatory blocks
+    std::vector<int> ord(segs.size());
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return segs[a].key < segs[b].key; });
+    for (size_t i = 0; i < ord.size(); ++i) out.laneinfo[segs[ord[i]].where] = (out.laneinfo[segs[ord[i]].where] & 0xf0000000u) | (uint32_t)(i + 1);
+    {
+        size_t i = 0;
+        auto runs_below = [&](uint32_t limit, bool inclusive) {  // emit the runs with key < limit (<= limit)
+            while (i < ord.size() && (segs[ord[i]].key < limit || (inclusive && segs[ord[i]].key == limit))) {
+                const uint32_t kk = segs[ord[i]].key;
+                size_t e = i;
+                while (e < ord.size() && segs[ord[e]].key == kk) ++e;
+                out.blk.push_back(GrpI4{(int)(kk / W), (int)(kk % W), (int)i, (int)(e - i)});
+                i = e;
+            }
+        };
+        auto mandatory = [&](uint32_t kk) {
+            runs_below(kk, false);
+            if (i < ord.size() && segs[ord[i]].key == kk) runs_below(kk, true);
+            else out.blk.push_back(GrpI4{(int)(kk / W), (int)(kk % W), (int)i, 0});
+        };
+        for (int c = 0; c < nc; ++c) mandatory((uint32_t)c * W + c), mandatory((uint32_t)c * W + nc);
+        mandatory((uint32_t)nc * W + nc);
+        runs_below(0xffffffffu, true);
+    }
+    out.n_blk = (int)out.blk.size();
+    for (int b = 0; b < out.n_blk; ++b)
+        if (out.blk[b].w > GRP_LONG) out.longblk.push_back(b);
+    return true;
+}
+
+}  // namespace eacham

@@ -9,5 +9,5 @@ for l in "$@"; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_${tag}_$i -- python3 tools/ba_only.py 5 > gpurun_out/ab_${tag}_$i.log 2>&1 || exit 1
   n=$(grep "inner iterations" gpurun_out/ab_${tag}_$i.log | awk '{print $3}')
   echo "== $l"
-  python3 tools/kernel_stats.py gpurun_out/ab_${tag}_$i $n | grep -E "chol_|total" | tee -a gpurun_out/ab_${tag}.txt
+  python3 tools/kernel_stats.py gpurun_out/ab_${tag}_$i $n | tee -a gpurun_out/ab_${tag}.txt
 done
