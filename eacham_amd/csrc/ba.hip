@@ -3446,6 +3446,590 @@ struct Bump {  // carves 256-byte aligned arrays out of a scratch buffer (base =
     }
 };
 
+// ---- device form of the landmark-major structure (ba_groups.hpp holds the definition; these kernels reproduce build_groups
+// bit for bit: tests/test_ba_prepare_gpu.py compares every array) -------------------------------------------------------------
+struct GrpCounters {
+    int cmax, emax;            // largest landmark cost / entry count (atomicMax: order-free)
+    int ng, n_long, cost_total, row_total;
+    int any_dup, pad;          // some landmark sees a camera twice: the sort-free entries kernel does not apply
+    prim::I3 item_totals;      // {mandatory items, blocks, .} of the sorted item list
+    prim::I3 totals;           // {chunks, uint4-rows of entries, segments} over all groups
+};
+
+// per landmark: sort key, rows, entries, cost (ba_groups.hpp step 1-2)
+__global__ __launch_bounds__(TPB) void prep_grp_keys(int nl, const int* __restrict__ lm_ptr, const unsigned* __restrict__ obs_cam,
+                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* __restrict__ cost,
+                                                     GrpCounters* __restrict__ gc) {
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    if (j >= nl) return;
+    const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1], m = a1 - a0;
+    vals[j] = (uint32_t)j;
+    if (m == 0) {
+        keys[j] = 0xffffffffu;
+        cost[j] = 0;
+        return;
+    }
+    unsigned mn = obs_cam[a0], mx = mn;
+    long long e = (long long)(m + 1) * (m + 2) / 2;
+    for (int a = a0; a < a1; ++a) {
+        const unsigned ca = obs_cam[a];
+        mn = min(mn, ca), mx = max(mx, ca);
+        for (int b = a + 1; b < a1; ++b) e += obs_cam[b] == ca ? 1 : 0;
+    }
+    if (e != (long long)(m + 1) * (m + 2) / 2) gc->any_dup = 1;  // (benign race: every writer stores 1)
+    keys[j] = grp_morton(mn, mx);
+    const int ec = e > 0x3fffffffLL ? 0x3fffffff : (int)e;
+    const int c = max(max(m + 1, 4), (ec + GRP_ENT_PER_ROW - 1) / GRP_ENT_PER_ROW);  // ceil(e rows / ent_max), ent_max = 16 rows
+    cost[j] = c;
+    atomicMax(&gc->cmax, c);
+    atomicMax(&gc->emax, ec);
+}
+// in sorted order: rows and cost of rank k (zero beyond the used landmarks, which the key puts last)
+__global__ __launch_bounds__(TPB) void prep_grp_sorted(int nl, const uint32_t* __restrict__ lm_sorted, const int* __restrict__ lm_ptr,
+                                                       const int* __restrict__ cost, int* __restrict__ rowsS, int* __restrict__ costS) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= nl) return;
+    const int j = (int)lm_sorted[k], m = lm_ptr[j + 1] - lm_ptr[j];
+    rowsS[k] = m > 0 ? m + 1 : 0;
+    costS[k] = cost[j];
+}
+// group g starts at the first rank whose cost prefix reaches g R0 (empty groups: the rank behind them); lm0[ng] = n_used
+__global__ __launch_bounds__(TPB) void prep_grp_bounds(int nu, const int* __restrict__ cstart, int R0, int* __restrict__ lm0, GrpCounters* __restrict__ gc) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= nu) return;
+    const int g = cstart[k] / R0, gp = k > 0 ? cstart[k - 1] / R0 : -1;
+    for (int gg = gp + 1; gg <= g; ++gg) lm0[gg] = k;   // (a group no rank starts in is empty: lm0[gg] = lm0[gg + 1])
+    if (k == nu - 1) {
+        lm0[g + 1] = nu;
+        gc->ng = g + 1;
+    }
+}
+// per rank: the padded per-group arrays (landmark ids, own rows, row records, measurements) and the group record's first half
+__global__ __launch_bounds__(TPB) void prep_grp_fill(int nu, int nc, int R, int R0, const uint32_t* __restrict__ lm_sorted, const int* __restrict__ cstart,
+                                                     const int* __restrict__ rstart, const int* __restrict__ lm0, const int* __restrict__ lm_ptr,
+                                                     const unsigned* __restrict__ obs_cam, const double* __restrict__ obs_uv, int* __restrict__ lmid,
+                                                     int* __restrict__ lmrow, int2* __restrict__ rowinfo, double* __restrict__ uv) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= nu) return;
+    const int g = cstart[k] / R0, k0 = lm0[g], t = k - k0, j = (int)lm_sorted[k];
+    const int a0 = lm_ptr[j], m = lm_ptr[j + 1] - a0, r0 = rstart[k] - rstart[k0];
+    const int LMAX = R / 4;
+    lmid[(size_t)g * LMAX + t] = j;
+    lmrow[(size_t)g * LMAX + t] = r0 + m;
+    const size_t base = (size_t)g * R + r0;
+    for (int i = 0; i < m; ++i) {
+        rowinfo[base + i] = make_int2((int)obs_cam[a0 + i], t);
+        uv[2 * (base + i)] = obs_uv[2 * (size_t)(a0 + i)];
+        uv[2 * (base + i) + 1] = obs_uv[2 * (size_t)(a0 + i) + 1];
+    }
+    rowinfo[base + m] = make_int2(nc, t);
+}
+
+__global__ __launch_bounds__(TPB) void prep_grp_records(const GrpCounters* __restrict__ gc, const int* __restrict__ lm0, const int* __restrict__ rstart,
+                                                        BaGroup* __restrict__ groups) {
+    const int g = blockIdx.x * TPB + threadIdx.x;
+    if (g >= gc->ng) return;
+    const int k0 = lm0[g], k1 = lm0[g + 1];  // (rstart has an entry behind the last rank: the total)
+    groups[g] = BaGroup{k0, k1 - k0, rstart[k0], rstart[k1] - rstart[k0], 0, 0, 0, 0};
+}
+
+// One workgroup per group: ba_groups.hpp step 3-4. The group's entries are generated as 64-bit words
+//   block key << 31 | emission index << 18 | r1 << 9 | r2        (rows <= 511, <= 8192 entries)
+// and sorted by a bitonic network in LDS (the word order IS (block key, emission index)); runs, slices, lanes, segments and
+// chunks follow from scans over the sorted list. PASS 0 only counts ({chunks, uint4-rows, segments} -> counts[g]); PASS 1, given
+// the scanned bases, writes the chunk table, the entries, the lane records and the (key, where) list of the segments.
+constexpr int GE_THREADS = 256;
+constexpr int GE_MAXE = 8192;   // most entries of a group the kernel is ever asked for (rows <= 512)
+template <class T>
+__device__ __forceinline__ T ge_block_scan(T v, T* lds, T* total) {  // exclusive scan over the workgroup, GE_THREADS values
+    const int tid = threadIdx.x;
+    lds[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < GE_THREADS; off <<= 1) {
+        const T u = tid >= off ? lds[tid - off] : T(0);
+        __syncthreads();
+        lds[tid] += u;
+        __syncthreads();
+    }
+    const T incl = lds[tid];
+    *total = lds[GE_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+template <int PASS>
+__global__ __launch_bounds__(GE_THREADS) void prep_grp_entries(int emax /* power of two >= the group bound on entries */, int nc, int R, const GrpCounters* __restrict__ gc, BaGroup* __restrict__ groups,
+                                                               const int2* __restrict__ rowinfo, const int* __restrict__ lmrow,
+                                                               prim::I3* __restrict__ counts, const prim::I3* __restrict__ bases,
+                                                               BaChunk* __restrict__ chunks, uint32_t* __restrict__ ent, uint32_t* __restrict__ laneinfo,
+                                                               uint32_t* __restrict__ seg_key, uint32_t* __restrict__ seg_where, int seg_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long ge_lds[];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (g >= gc->ng) {
+        if (PASS == 0 && tid == 0) counts[g] = prim::I3{0, 0, 0};
+        return;
+    }
+    const BaGroup G = groups[g];
+    const int LMAX = R / 4;
+    unsigned long long* words = ge_lds;                         // [emax]
+    uint32_t* lane_key = reinterpret_cast<uint32_t*>(ge_lds + emax);                // [emax] (a lane holds at least one entry)
+    unsigned short* lane_first = reinterpret_cast<unsigned short*>(lane_key + emax);  // [emax]
+    unsigned char* lane_len = reinterpret_cast<unsigned char*>(lane_first + emax);    // [emax]
+    int* scan_buf = reinterpret_cast<int*>(lane_len + emax);    // [GE_THREADS]
+    int* eoff = scan_buf + GE_THREADS;                          // [LMAX] first entry of landmark t
+    // ---- entries per landmark (recomputed from the rows: cheap) and their offsets ----
+    int my_e = 0, my_r0 = 0, my_m = 0;
+    if (tid < G.nlm) {
+        const int own = lmrow[(size_t)g * LMAX + tid];
+        const int prev = tid > 0 ? lmrow[(size_t)g * LMAX + tid - 1] + 1 : 0;
+        my_r0 = prev, my_m = own - prev;
+        my_e = (my_m + 1) * (my_m + 2) / 2;
+        const int2* ri = rowinfo + (size_t)g * R + my_r0;
+        for (int a = 0; a < my_m; ++a)
+            for (int b = a + 1; b < my_m; ++b) my_e += ri[a].x == ri[b].x ? 1 : 0;
+    }
+    int ne = 0;
+    {
+        // LMAX may exceed GE_THREADS only for rows > 1024 (not supported): one landmark per thread
+        const int off = ge_block_scan<int>(my_e, scan_buf, &ne);
+        if (tid < G.nlm) eoff[tid] = off;
+    }
+    __syncthreads();
+    int npow = 64;
+    while (npow < ne) npow <<= 1;
+    const unsigned long long W = (unsigned long long)nc + 1;
+    for (int i = tid; i < npow; i += GE_THREADS) words[i] = ~0ull;
+    __syncthreads();
+    if (tid < G.nlm) {
+        const int2* ri = rowinfo + (size_t)g * R + my_r0;
+        unsigned long long idx = (unsigned long long)eoff[tid];
+        auto emit = [&](unsigned long long c1, unsigned long long c2, int r1, int r2) {
+            words[idx] = ((c1 * W + c2) << 31) | (idx << 18) | ((unsigned long long)r1 << 9) | (unsigned long long)r2;
+            ++idx;
+        };
+        for (int a = 0; a <= my_m; ++a) {
+            const int ca = ri[a].x, ra = my_r0 + a;
+            emit(ca, ca, ra, ra);
+            for (int b = a + 1; b <= my_m; ++b) {
+                const int cb = ri[b].x, rb = my_r0 + b;
+                if (ca < cb) emit(ca, cb, ra, rb);
+                else if (ca > cb) emit(cb, ca, rb, ra);
+                else emit(ca, ca, ra, rb), emit(ca, ca, rb, ra);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- bitonic sort, ascending ----
+    for (int kk = 2; kk <= npow; kk <<= 1)
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < npow; i += GE_THREADS) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const unsigned long long a = words[i], b = words[ixj];
+                    const bool up = (i & kk) == 0;
+                    if ((a > b) == up) words[i] = b, words[ixj] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // ---- runs -> lanes ----
+    // per sorted position: run start flag; every thread handles a contiguous strip of positions
+    const int per = (npow + GE_THREADS - 1) / GE_THREADS;  // positions per thread (strip)
+    const int p0 = tid * per, p1 = min(p0 + per, ne);
+    // pass over the strip: number of runs that START in it, by class (long: L > 4 counted in lanes; short: lanes = 1)
+    // Run lengths need the next start: a thread finishes a run that started in its strip by walking on (runs are short: <= rows).
+    int lanes_long = 0, lanes_short = 0;
+    for (int i = p0; i < p1; ++i) {
+        const unsigned long long key = words[i] >> 31;
+        if (i > 0 && (words[i - 1] >> 31) == key) continue;
+        int e = i + 1;
+        while (e < ne && (words[e] >> 31) == key) ++e;
+        const int L = e - i;
+        if (L > 4) lanes_long += (L + GRP_SLICE - 1) / GRP_SLICE;
+        else lanes_short += 1;
+    }
+    int tot_long = 0, tot_short = 0;
+    const int off_long = ge_block_scan<int>(lanes_long, scan_buf, &tot_long);
+    const int off_short = ge_block_scan<int>(lanes_short, scan_buf, &tot_short);
+    const int nlanes = tot_long + tot_short, nchunks = (nlanes + 63) / 64;
+    {
+        int ll = off_long, ls = tot_long + off_short;
+        for (int i = p0; i < p1; ++i) {
+            const unsigned long long key = words[i] >> 31;
+            if (i > 0 && (words[i - 1] >> 31) == key) continue;
+            int e = i + 1;
+            while (e < ne && (words[e] >> 31) == key) ++e;
+            const int L = e - i;
+            if (L > 4) {
+                const int n = (L + GRP_SLICE - 1) / GRP_SLICE;
+                for (int q = 0, at = i; q < n; ++q) {
+                    const int len = L / n + (q < L % n ? 1 : 0);
+                    lane_first[ll] = (unsigned short)at, lane_len[ll] = (unsigned char)len, lane_key[ll] = (uint32_t)key;
+                    at += len, ++ll;
+                }
+            } else {
+                lane_first[ls] = (unsigned short)i, lane_len[ls] = (unsigned char)L, lane_key[ls] = (uint32_t)key;
+                ++ls;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- chunks: steps per chunk, segments ----
+    // thread c < nchunks: longest lane of chunk c (nchunks <= GE_MAXE / 64 = 128 <= GE_THREADS)
+    int my_n4 = 0;
+    if (tid < nchunks) {
+        int longest = 0;
+        for (int l = 64 * tid; l < min(nlanes, 64 * tid + 64); ++l) longest = max(longest, (int)lane_len[l]);
+        my_n4 = (longest + 3) / 4;
+    }
+    int tot_n4 = 0;
+    const int off_n4 = ge_block_scan<int>(my_n4, scan_buf, &tot_n4);
+    __shared__ int s_chunk_ent0[GE_MAXE / 64], s_chunk_n4[GE_MAXE / 64];
+    if (tid < nchunks) s_chunk_ent0[tid] = off_n4, s_chunk_n4[tid] = my_n4;
+    // segment heads: lane li is a head iff (li - h0) % GRP_SEG == 0, h0 = first lane of its key at or after the chunk start
+    int my_heads = 0;
+    const int lper = (nlanes + GE_THREADS - 1) / GE_THREADS;
+    const int l0 = tid * lper, l1 = min(l0 + lper, nlanes);
+    for (int li = l0; li < l1; ++li) {
+        const uint32_t key = lane_key[li];
+        int h = li;
+        const int cs = li & ~63;
+        while (h > cs && lane_key[h - 1] == key) --h;
+        if (((li - h) % GRP_SEG) == 0) ++my_heads;
+    }
+    int tot_heads = 0;
+    const int off_heads = ge_block_scan<int>(my_heads, scan_buf, &tot_heads);
+    if (PASS == 0) {
+        if (tid == 0) counts[g] = prim::I3{nchunks, tot_n4, tot_heads};
+        return;
+    }
+    __syncthreads();
+    // ---- PASS 1: write ----
+    const prim::I3 base = bases[g];   // {first chunk, first uint4-row, first segment}
+    if (tid == 0) {
+        groups[g].chunk0 = base.a; groups[g].nchunks = nchunks; groups[g].n_entries = ne; groups[g].n_segments = tot_heads;
+    }
+    if (tid < nchunks) chunks[base.a + tid] = BaChunk{base.b + s_chunk_ent0[tid], s_chunk_n4[tid]};
+    // lanes: records + segment list
+    {
+        int hs = off_heads;
+        for (int li = l0; li < l1; ++li) {
+            const uint32_t key = lane_key[li];
+            const int cs = li & ~63, ce = min(nlanes, cs + 64);
+            int h = li;
+            while (h > cs && lane_key[h - 1] == key) --h;
+            h += (li - h) / GRP_SEG * GRP_SEG;
+            int e = h;
+            while (e < ce && e < h + GRP_SEG && lane_key[e] == key) ++e;
+            uint32_t info = (uint32_t)(e - 1 - li) << 28;
+            const size_t where = (size_t)64 * base.a + li;
+            if (li == h) {
+                seg_key[seg_off + base.c + hs] = key;
+                seg_where[seg_off + base.c + hs] = (uint32_t)where;
+                ++hs;
+                info |= 1u;  // (prep_grp_slots writes the slot)
+            }
+            laneinfo[where] = info;
+        }
+        for (int li = nlanes + tid; li < 64 * nchunks; li += GE_THREADS) laneinfo[(size_t)64 * base.a + li] = 0;
+    }
+    // entries: [chunk][step][lane][4], null beyond a slice
+    const uint32_t null_ent = (uint32_t)R | ((uint32_t)R << 16);
+    for (int c = 0; c < nchunks; ++c) {
+        const int n4 = s_chunk_n4[c];
+        uint32_t* dst = ent + (size_t)(base.b + s_chunk_ent0[c]) * 256;
+        for (int x = tid; x < n4 * 256; x += GE_THREADS) {
+            const int step = x >> 8, l = (x >> 2) & 63, i = 4 * step + (x & 3), li = 64 * c + l;
+            uint32_t v = null_ent;
+            if (li < nlanes && i < (int)lane_len[li]) {
+                const unsigned long long w = words[lane_first[li] + i];
+                v = (uint32_t)((w >> 9) & 0x1ffu) | ((uint32_t)(w & 0x1ffu) << 16);
+            }
+            dst[x] = v;
+        }
+    }
+}
+// The same two passes WITHOUT a sort, for problems in which no landmark sees a camera twice (prep_grp_keys knows; the general
+// kernel above serves the others): with the group's cameras numbered locally in ascending order, the run of block (la, lb) is
+// the landmarks that see both — M[la] & M[lb] for per-camera bit masks over the group's <= 128 landmarks — in ascending
+// landmark order, which IS the (block key, emission index) order of the definition. Pairs are walked in key order by strips,
+// lanes / chunks / segments follow from scans as above, and a lane's entries are read off the mask (the bits from its start
+// position on; the two rows by a search through the landmark's few rows). 0.56 ms per pass on S200 with the bitonic sort,
+// the per-group time here is a small sort of the <= 512 row cameras and a few scans.
+__device__ __forceinline__ int gf_pairs_before(int la, int U) { return la * U - la * (la - 1) / 2; }
+template <int PASS>
+__global__ __launch_bounds__(GE_THREADS) void prep_grp_entries_fast(int lane_cap, int nc, int R, const GrpCounters* __restrict__ gc, BaGroup* __restrict__ groups,
+                                                                    const int2* __restrict__ rowinfo, const int* __restrict__ lmrow,
+                                                                    prim::I3* __restrict__ counts, const prim::I3* __restrict__ bases,
+                                                                    BaChunk* __restrict__ chunks, uint32_t* __restrict__ ent, uint32_t* __restrict__ laneinfo,
+                                                                    uint32_t* __restrict__ seg_key, uint32_t* __restrict__ seg_where, int seg_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long gf_lds[];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (g >= gc->ng) {
+        if (PASS == 0 && tid == 0) counts[g] = prim::I3{0, 0, 0};
+        return;
+    }
+    const BaGroup G = groups[g];
+    const int LMAX = R / 4;
+    int RP2 = 64;
+    while (RP2 < R) RP2 <<= 1;
+    unsigned long long* mask = gf_lds;                                   // [2 R] landmarks that see local camera la (two words)
+    int* camsort = reinterpret_cast<int*>(mask + 2 * R);                 // [RP2]
+    int* ucam = camsort + RP2;                                           // [R] local camera -> camera
+    int* scan_buf = ucam + R;                                            // [GE_THREADS]
+    uint32_t* lane_q = reinterpret_cast<uint32_t*>(scan_buf + GE_THREADS);  // [lane_cap] pair of the lane
+    unsigned short* row_la = reinterpret_cast<unsigned short*>(lane_q + lane_cap);  // [R] local camera of a row
+    unsigned short* lm_r0 = row_la + R;                                  // [LMAX + 1] first row of landmark t
+    unsigned char* lane_at = reinterpret_cast<unsigned char*>(lm_r0 + LMAX + 2);    // [lane_cap] first position of the lane inside its run
+    unsigned char* lane_len = lane_at + lane_cap;                        // [lane_cap]
+    __shared__ int s_chunk_ent0[GE_MAXE / 64], s_chunk_n4[GE_MAXE / 64];
+    // ---- the group's cameras, ascending, without repetition ----
+    for (int r = tid; r < RP2; r += GE_THREADS) {
+        const int c = r < G.nrows ? rowinfo[(size_t)g * R + r].x : 0x7fffffff;
+        camsort[r] = c;
+    }
+    for (int t = tid; t <= G.nlm; t += GE_THREADS) lm_r0[t] = (unsigned short)(t == 0 ? 0 : lmrow[(size_t)g * LMAX + t - 1] + 1);
+    for (int i = tid; i < 2 * R; i += GE_THREADS) mask[i] = 0ull;
+    __syncthreads();
+    for (int kk = 2; kk <= RP2; kk <<= 1)
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < RP2; i += GE_THREADS) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const int a = camsort[i], b = camsort[ixj];
+                    if ((a > b) == ((i & kk) == 0)) camsort[i] = b, camsort[ixj] = a;
+                }
+            }
+            __syncthreads();
+        }
+    int U = 0;
+    {
+        const int per = RP2 / GE_THREADS > 0 ? RP2 / GE_THREADS : 1;   // consecutive elements per thread
+        const int i0 = tid * per, i1 = min(i0 + per, RP2);
+        int mine = 0;
+        for (int i = i0; i < i1; ++i) mine += (camsort[i] != 0x7fffffff && (i == 0 || camsort[i] != camsort[i - 1])) ? 1 : 0;
+        int at = ge_block_scan<int>(i0 < RP2 ? mine : 0, scan_buf, &U);
+        for (int i = i0; i < i1; ++i)
+            if (camsort[i] != 0x7fffffff && (i == 0 || camsort[i] != camsort[i - 1])) ucam[at++] = camsort[i];
+    }
+    __syncthreads();
+    for (int r = tid; r < G.nrows; r += GE_THREADS) {
+        const int2 ri = rowinfo[(size_t)g * R + r];
+        int lo = 0, hi = U - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ucam[mid] < ri.x) lo = mid + 1;
+            else hi = mid;
+        }
+        row_la[r] = (unsigned short)lo;
+        atomicOr(&mask[2 * lo + (ri.y >> 6)], 1ull << (ri.y & 63));
+    }
+    __syncthreads();
+    // ---- pairs (la <= lb) in key order, by strips ----
+    const int P = U * (U + 1) / 2;
+    const int per = (P + GE_THREADS - 1) / GE_THREADS;
+    const int q0 = min(tid * per, P), q1 = min(q0 + per, P);
+    auto pair_of = [&](int q, int& la, int& lb) {
+        int lo = 0, hi = U - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (gf_pairs_before(mid, U) <= q) lo = mid;
+            else hi = mid - 1;
+        }
+        la = lo, lb = lo + (q - gf_pairs_before(lo, U));
+    };
+    auto run_len = [&](int la, int lb) {
+        return __popcll(mask[2 * la] & mask[2 * lb]) + __popcll(mask[2 * la + 1] & mask[2 * lb + 1]);
+    };
+    int lanes_long = 0, lanes_short = 0, my_entries = 0;
+    if (q0 < q1) {
+        int la, lb;
+        pair_of(q0, la, lb);
+        for (int q = q0; q < q1; ++q) {
+            const int L = run_len(la, lb);
+            my_entries += L;
+            if (L > 4) lanes_long += (L + GRP_SLICE - 1) / GRP_SLICE;
+            else if (L > 0) lanes_short += 1;
+            if (++lb == U) ++la, lb = la;
+        }
+    }
+    int tot_long = 0, tot_short = 0, ne = 0;
+    const int off_long = ge_block_scan<int>(lanes_long, scan_buf, &tot_long);
+    const int off_short = ge_block_scan<int>(lanes_short, scan_buf, &tot_short);
+    (void)ge_block_scan<int>(my_entries, scan_buf, &ne);
+    const int nlanes = tot_long + tot_short, nchunks = (nlanes + 63) / 64;
+    if (q0 < q1) {
+        int la, lb, ll = off_long, ls = tot_long + off_short;
+        pair_of(q0, la, lb);
+        for (int q = q0; q < q1; ++q) {
+            const int L = run_len(la, lb);
+            if (L > 4) {
+                const int n = (L + GRP_SLICE - 1) / GRP_SLICE;
+                for (int k = 0, at = 0; k < n; ++k) {
+                    const int len = L / n + (k < L % n ? 1 : 0);
+                    lane_q[ll] = (uint32_t)q, lane_at[ll] = (unsigned char)at, lane_len[ll] = (unsigned char)len;
+                    at += len, ++ll;
+                }
+            } else if (L > 0) {
+                lane_q[ls] = (uint32_t)q, lane_at[ls] = 0, lane_len[ls] = (unsigned char)L;
+                ++ls;
+            }
+            if (++lb == U) ++la, lb = la;
+        }
+    }
+    __syncthreads();
+    // ---- chunks and segments, as in the general kernel (a lane's block = its pair) ----
+    int my_n4 = 0;
+    if (tid < nchunks) {
+        int longest = 0;
+        for (int l = 64 * tid; l < min(nlanes, 64 * tid + 64); ++l) longest = max(longest, (int)lane_len[l]);
+        my_n4 = (longest + 3) / 4;
+    }
+    int tot_n4 = 0;
+    const int off_n4 = ge_block_scan<int>(my_n4, scan_buf, &tot_n4);
+    if (tid < nchunks) s_chunk_ent0[tid] = off_n4, s_chunk_n4[tid] = my_n4;
+    int my_heads = 0;
+    const int lper = (nlanes + GE_THREADS - 1) / GE_THREADS;
+    const int l0 = min(tid * lper, nlanes), l1 = min(l0 + lper, nlanes);
+    for (int li = l0; li < l1; ++li) {
+        const uint32_t q = lane_q[li];
+        int h = li;
+        const int cs = li & ~63;
+        while (h > cs && lane_q[h - 1] == q) --h;
+        if (((li - h) % GRP_SEG) == 0) ++my_heads;
+    }
+    int tot_heads = 0;
+    const int off_heads = ge_block_scan<int>(my_heads, scan_buf, &tot_heads);
+    if (PASS == 0) {
+        if (tid == 0) counts[g] = prim::I3{nchunks, tot_n4, tot_heads};
+        return;
+    }
+    __syncthreads();
+    // ---- PASS 1: write ----
+    const prim::I3 base = bases[g];   // {first chunk, first uint4-row, first segment}
+    if (tid == 0) {
+        groups[g].chunk0 = base.a; groups[g].nchunks = nchunks; groups[g].n_entries = ne; groups[g].n_segments = tot_heads;
+    }
+    if (tid < nchunks) chunks[base.a + tid] = BaChunk{base.b + s_chunk_ent0[tid], s_chunk_n4[tid]};
+    const uint32_t W = (uint32_t)nc + 1;
+    {
+        int hs = off_heads;
+        for (int li = l0; li < l1; ++li) {
+            const uint32_t q = lane_q[li];
+            const int cs = li & ~63, ce = min(nlanes, cs + 64);
+            int h = li;
+            while (h > cs && lane_q[h - 1] == q) --h;
+            h += (li - h) / GRP_SEG * GRP_SEG;
+            int e = h;
+            while (e < ce && e < h + GRP_SEG && lane_q[e] == q) ++e;
+            uint32_t info = (uint32_t)(e - 1 - li) << 28;
+            const size_t where = (size_t)64 * base.a + li;
+            if (li == h) {
+                int la, lb;
+                pair_of((int)q, la, lb);
+                seg_key[seg_off + base.c + hs] = (uint32_t)ucam[la] * W + (uint32_t)ucam[lb];
+                seg_where[seg_off + base.c + hs] = (uint32_t)where;
+                ++hs;
+                info |= 1u;  // (prep_grp_slots writes the slot)
+            }
+            laneinfo[where] = info;
+        }
+        for (int li = nlanes + tid; li < 64 * nchunks; li += GE_THREADS) laneinfo[(size_t)64 * base.a + li] = 0;
+    }
+    // entries, a lane per thread: the landmarks of the run from position lane_at on; the two rows by a search through the landmark's rows
+    const uint32_t null_ent = (uint32_t)R | ((uint32_t)R << 16);
+    for (int li = tid; li < 64 * nchunks; li += GE_THREADS) {
+        const int c = li >> 6, l = li & 63, n4 = s_chunk_n4[c];
+        uint4* dst = reinterpret_cast<uint4*>(ent + (size_t)(base.b + s_chunk_ent0[c]) * 256) + l;
+        int len = 0, la = 0, lb = 0;
+        unsigned long long m0 = 0, m1 = 0;
+        if (li < nlanes) {
+            pair_of((int)lane_q[li], la, lb);
+            m0 = mask[2 * la] & mask[2 * lb], m1 = mask[2 * la + 1] & mask[2 * lb + 1];
+            len = lane_len[li];
+            for (int skip = lane_at[li]; skip > 0; --skip) {  // drop the run's first lane_at landmarks
+                if (m0) m0 &= m0 - 1;
+                else m1 &= m1 - 1;
+            }
+        }
+        for (int step = 0; step < n4; ++step) {
+            uint32_t v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = null_ent;
+                if (4 * step + i < len) {
+                    int t;
+                    if (m0) t = __builtin_ctzll(m0), m0 &= m0 - 1;
+                    else t = 64 + __builtin_ctzll(m1), m1 &= m1 - 1;
+                    int r1 = 0, r2 = 0;
+                    for (int r = lm_r0[t]; r < (int)lm_r0[t + 1]; ++r) {
+                        const int x = row_la[r];
+                        r1 = x == la ? r : r1;
+                        r2 = x == lb ? r : r2;
+                    }
+                    v[i] = (uint32_t)r1 | ((uint32_t)r2 << 16);
+                }
+            }
+            dst[(size_t)step * 64] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+__host__ inline size_t grp_entries_fast_lds_bytes(int lane_cap, int R) {
+    int RP2 = 64;
+    while (RP2 < R) RP2 <<= 1;
+    return sizeof(unsigned long long) * 2 * R + sizeof(int) * ((size_t)RP2 + R + GE_THREADS) + sizeof(uint32_t) * (size_t)lane_cap +
+           sizeof(unsigned short) * ((size_t)R + R / 4 + 2) + 2 * (size_t)lane_cap + 16;
+}
+__host__ inline size_t grp_entries_lds_bytes(int emax, int R) {
+    return (size_t)emax * (8 + 4 + 2 + 1) + sizeof(int) * ((size_t)GE_THREADS + R / 4 + 8);
+}
+
+// the mandatory blocks, first in the input of the stable sort by block key: (c, c), (c, K) for every camera, then (K, K)
+__global__ __launch_bounds__(TPB) void prep_grp_mandatory(int nc, uint32_t* __restrict__ seg_key, uint32_t* __restrict__ seg_where) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i > 2 * nc) return;
+    const uint32_t W = (uint32_t)nc + 1;
+    seg_key[i] = i == 2 * nc ? (uint32_t)nc * W + nc : (i & 1) ? (uint32_t)(i >> 1) * W + nc : (uint32_t)(i >> 1) * W + (i >> 1);
+    seg_where[i] = 0xffffffffu;
+}
+// over the sorted items: {mandatory, run start, 0} flags for the scan
+__global__ __launch_bounds__(TPB) void prep_grp_flags(int n, const uint32_t* __restrict__ key, const uint32_t* __restrict__ where, prim::I3* __restrict__ f) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    f[i] = prim::I3{where[i] == 0xffffffffu ? 1 : 0, (i == 0 || key[i - 1] != key[i]) ? 1 : 0, 0};
+}
+// slot of every segment (its rank among the segments in sorted order) into its lane record; the block table from the runs
+__global__ __launch_bounds__(TPB) void prep_grp_slots(int n, int nc, const uint32_t* __restrict__ key, const uint32_t* __restrict__ where,
+                                                      const prim::I3* __restrict__ s, uint32_t* __restrict__ laneinfo, int4* __restrict__ blk,
+                                                      int* __restrict__ blk_first_item) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const prim::I3 at = s[i];  // {mandatory items before i, run starts before i, .}
+    if (where[i] != 0xffffffffu) laneinfo[where[i]] = (laneinfo[where[i]] & 0xf0000000u) | (uint32_t)(i - at.a + 1);
+    if (i == 0 || key[i - 1] != key[i]) {
+        const uint32_t W = (uint32_t)nc + 1;
+        blk[at.b] = make_int4((int)(key[i] / W), (int)(key[i] % W), i - at.a, 0);
+        blk_first_item[at.b] = i;
+    }
+}
+// count of every block = items of its run - its mandatory item; the long-block flags
+__global__ __launch_bounds__(TPB) void prep_grp_blk_counts(const GrpCounters* __restrict__ gc, int n_items, const uint32_t* __restrict__ where,
+                                                           const int* __restrict__ blk_first_item, int4* __restrict__ blk, int* __restrict__ longflag) {
+    const int b = blockIdx.x * TPB + threadIdx.x, nblk = gc->item_totals.b;
+    if (b >= n_items) return;
+    if (b >= nblk) {
+        longflag[b] = 0;
+        return;
+    }
+    const int i0 = blk_first_item[b], i1 = b + 1 < nblk ? blk_first_item[b + 1] : n_items;
+    const int cnt = i1 - i0 - (where[i0] == 0xffffffffu ? 1 : 0);  // (the mandatory item, if any, is the run's first: stable sort, first in the input)
+    blk[b].w = cnt;
+    longflag[b] = cnt > GRP_LONG ? 1 : 0;
+}
+__global__ __launch_bounds__(TPB) void prep_grp_long(const GrpCounters* __restrict__ gc, const int* __restrict__ longflag, const int* __restrict__ pos, int* __restrict__ longblk) {
+    const int b = blockIdx.x * TPB + threadIdx.x;
+    if (b < gc->item_totals.b && longflag[b]) longblk[pos[b]] = b;
+}
+
 static int ba_scratch(eacham_ctx* ctx, int which, size_t bytes, void** out) {
     BaScratch& sc = ctx->ba_scratch[which];
     if (bytes > sc.bytes) {
@@ -3543,6 +4127,10 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     long long *pcnt, *poff, *pws;
     PrepCounters* cnt;
     unsigned char* adj_dev;
+    uint32_t *gkA, *gkB, *gvA, *gvB;
+    int *gcost, *growsS, *gcostS, *gcstart, *grstart, *gscan_ws, *gsort_ws;
+    GrpCounters* gcnt;
+    const bool try_groups = ctx->ba_schur_mode != 2 && nc < 65535 && no > 0;
     auto carve0 = [&](void* base) {
         Bump b(base);
         raw_pt = b.take<uint32_t>(no); raw_cam = b.take<uint32_t>(no); raw_uv = b.take<double>(2 * (size_t)no);
@@ -3553,6 +4141,12 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         pcnt = b.take<long long>(no); poff = b.take<long long>((size_t)no + 1); pws = b.take<long long>(prim::scan_ws_elems(no));
         cnt = b.take<PrepCounters>(1);
         adj_dev = b.take<unsigned char>((size_t)nc * nc);
+        // the landmark order of the group structure (ba_groups.hpp): keys, ranks, per-rank rows / costs and their prefixes
+        gkA = b.take<uint32_t>(nl); gkB = b.take<uint32_t>(nl); gvA = b.take<uint32_t>(nl); gvB = b.take<uint32_t>(nl);
+        gcost = b.take<int>(nl); growsS = b.take<int>(nl); gcostS = b.take<int>(nl);
+        gcstart = b.take<int>((size_t)nl + 1); grstart = b.take<int>((size_t)nl + 1); gscan_ws = b.take<int>(prim::scan_ws_elems(nl));
+        gsort_ws = b.take<int>(prim::radix_ws_ints(nl));
+        gcnt = b.take<GrpCounters>(1);
         return b.off;
     };
     rc = ba_scratch(ctx, 0, carve0(nullptr), &s0);
@@ -3589,13 +4183,24 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     if (no > 0) {
         const uint32_t *cs = w_cam ? lm_sorted : ck, *co = w_cam ? lm_order : cv;
         prep_gather_cam<<<gobs, TPB, 0, st>>>(no, nc, cs, co, obs_lm, obs_uv, cam_obs, obs_pos, pos_cam, cam_lm, cam_uv, cam_ptr);
-        prep_pair_counts<<<gobs, TPB, 0, st>>>(no, obs_cam, obs_lm, lm_ptr, pcnt);
+        if (!try_groups) prep_pair_counts<<<gobs, TPB, 0, st>>>(no, obs_cam, obs_lm, lm_ptr, pcnt);
+    }
+    int w_g = 0;
+    if (try_groups) {  // ba_groups.hpp steps 1-2 as far as they go without the group size: order, rows, costs, their prefixes
+        HIPQ(hipMemsetAsync(gcnt, 0, sizeof(GrpCounters), st));
+        const unsigned glm = (unsigned)((nl + TPB - 1) / TPB);
+        prep_grp_keys<<<glm, TPB, 0, st>>>(nl, lm_ptr, obs_cam, gkA, gvA, gcost, gcnt);
+        w_g = prim::radix_sort_pairs<uint32_t>(st, gkA, gvA, gkB, gvB, nl, 32, gsort_ws);
+        prep_grp_sorted<<<glm, TPB, 0, st>>>(nl, w_g ? gvB : gvA, lm_ptr, gcost, growsS, gcostS);
+        prim::exclusive_scan<int>(st, gcostS, gcstart, nl, gscan_ws, &gcnt->cost_total);
+        prim::exclusive_scan<int>(st, growsS, grstart, nl, gscan_ws, &gcnt->row_total);
+        HIPQ(hipMemcpyAsync(grstart + nl, &gcnt->row_total, sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     prep_cam_chunk_counts<<<(unsigned)((nc + TPB) / TPB), TPB, 0, st>>>(nc, cam_ptr, nchunk);
     prim::exclusive_scan<int>(st, nchunk, cam_chunk_ptr, nc, nchunk_ws, &cnt->n_cam_chunks);
     HIPQ(hipMemcpyAsync(cam_chunk_ptr + nc, &cnt->n_cam_chunks, sizeof(int), hipMemcpyDeviceToDevice, st));
     prep_cam_chunk_fill<<<(unsigned)((nc + TPB) / TPB), TPB, 0, st>>>(nc, cam_ptr, cam_chunk_ptr, cam_chunks);
-    prim::exclusive_scan<long long>(st, pcnt, poff, no, pws, &cnt->n_entries);
+    if (!try_groups) prim::exclusive_scan<long long>(st, pcnt, poff, no, pws, &cnt->n_entries);
     // ---- the host's share, beside the device's: ordering, panels, symbolic factor, level schedule (ba_plan.hpp) ----
     int hint = P->ordering;
     if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
@@ -3615,47 +4220,122 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     });
     // ---- read-back 1: the number of pair entries sizes the next stage ----
     PrepCounters hc;
+    GrpCounters hg;
+    memset(&hg, 0, sizeof(hg));
     HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+    if (try_groups) HIPQ(hipMemcpyAsync(&hg, gcnt, sizeof(hg), hipMemcpyDeviceToHost, st));
     HIPQ(hipStreamSynchronize(st));
     if (hc.bad) return fail(ctx->fail(EACHAM_ERR_INVALID, "an observation references a camera/point out of range"));
+    // the landmark-major structure applies unless a landmark is too heavy for a group (ba_groups.hpp step 2)
+    const long long total_rows = (long long)no + hc.n_used;
+    const int R = ctx->ba_group_rows > 0 ? ctx->ba_group_rows : grp_rows_for(total_rows);
+    const bool use_groups = try_groups && total_rows <= 0x7fffffffLL && R % 4 == 0 && hg.emax <= GRP_ENT_PER_ROW * R && hg.cmax <= R / 2 && std::max(hg.cmax, 4) >= 4;
+    if (try_groups && !use_groups) {  // the pair lists of rounds 1-4 after all: their counts were not taken yet
+        prep_pair_counts<<<gobs, TPB, 0, st>>>(no, obs_cam, obs_lm, lm_ptr, pcnt);
+        prim::exclusive_scan<long long>(st, pcnt, poff, no, pws, &cnt->n_entries);
+        HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIPQ(hipStreamSynchronize(st));
+    }
+    if (use_groups) hc.n_entries = 0;
     if (hc.n_entries > 0x7fffffffLL) return fail(ctx->fail(EACHAM_ERR_UNSUPPORTED, "Schur pair list too large (%lld entries)", hc.n_entries));
     const int n_entries = (int)hc.n_entries;
     h->n_landmarks_used = hc.n_used;
     D.n_cam_chunks = hc.n_cam_chunks;
-    // ---- scratch 1: expansion, sort by camera block, block / chunk tables ----
+    // ---- scratch 1: expansion, sort by camera block, block / chunk tables (the pair lists: only when the groups do not apply) ----
     const int max_blocks = (int)std::min<long long>(nblk, (long long)n_entries + nc);
     const int max_chunks = n_entries / PAIR_CHUNK + max_blocks + 1;
     void* s1 = nullptr;
-    uint32_t *ekA, *ekB;
-    int2 *evA, *evB;
+    uint32_t *ekA = nullptr, *ekB = nullptr;
+    int2 *evA = nullptr, *evB = nullptr;
     int *esort_ws, *bcount, *bfirst, *blast;
     prim::I3 *bt, *bs, *bws;
-    int4 *blocks_tmp, *chunks_tmp;
-    auto carve1 = [&](void* base) {
-        Bump b(base);
-        ekA = b.take<uint32_t>(n_entries); ekB = b.take<uint32_t>(n_entries); evA = b.take<int2>(n_entries); evB = b.take<int2>(n_entries);
-        esort_ws = b.take<int>(prim::radix_ws_ints(n_entries));
-        bcount = b.take<int>(nblk); bfirst = b.take<int>(2 * (size_t)nblk); blast = bfirst ? bfirst + nblk : nullptr; bt = b.take<prim::I3>(nblk); bs = b.take<prim::I3>(nblk); bws = b.take<prim::I3>(prim::scan_ws_elems(nblk));
-        blocks_tmp = b.take<int4>(max_blocks); chunks_tmp = b.take<int4>(max_chunks);
-        return b.off;
-    };
-    rc = ba_scratch(ctx, 1, carve1(nullptr), &s1);
-    if (rc) return fail(rc);
-    (void)carve1(s1);
-    HIPQ(hipMemsetAsync(bfirst, 0, sizeof(int) * 2 * (size_t)std::max(nblk, 1), st));
-    if (no > 0) prep_expand<<<gobs, TPB, 0, st>>>(no, nc, obs_cam, obs_lm, lm_ptr, obs_pos, poff, ekA, evA);
-    const int w_e = prim::radix_sort_pairs<int2>(st, ekA, evA, ekB, evB, n_entries, bits_for(std::max(nblk, 2)), esort_ws);
-    if (n_entries > 0) prep_block_runs<<<(unsigned)((n_entries + TPB - 1) / TPB), TPB, 0, st>>>(n_entries, w_e ? ekB : ekA, bfirst, blast);
-    const unsigned gblk = (unsigned)((nblk + TPB) / TPB);
-    if (nblk > 0) prep_block_counts<<<gblk, TPB, 0, st>>>(nc, nblk, bfirst, blast, bcount, bt);
-    prim::exclusive_scan<prim::I3>(st, bt, bs, nblk, bws, &cnt->totals);
-    if (nblk > 0) prep_block_fill<<<gblk, TPB, 0, st>>>(nc, nblk, bcount, bs, blocks_tmp, chunks_tmp);
-    // ---- read-back 2: the table sizes ----
-    HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
-    HIPQ(hipStreamSynchronize(st));
-    if (hc.totals.a != n_entries) return fail(ctx->fail(EACHAM_ERR_HIP, "BA structure build: %d pair entries counted, %d placed", n_entries, hc.totals.a));
-    D.n_blocks = hc.totals.b;
-    D.n_chunks = hc.totals.c;
+    int4 *blocks_tmp = nullptr, *chunks_tmp = nullptr;
+    int w_e = 0;
+    if (!use_groups) {
+        auto carve1 = [&](void* base) {
+            Bump b(base);
+            ekA = b.take<uint32_t>(n_entries); ekB = b.take<uint32_t>(n_entries); evA = b.take<int2>(n_entries); evB = b.take<int2>(n_entries);
+            esort_ws = b.take<int>(prim::radix_ws_ints(n_entries));
+            bcount = b.take<int>(nblk); bfirst = b.take<int>(2 * (size_t)nblk); blast = bfirst ? bfirst + nblk : nullptr; bt = b.take<prim::I3>(nblk); bs = b.take<prim::I3>(nblk); bws = b.take<prim::I3>(prim::scan_ws_elems(nblk));
+            blocks_tmp = b.take<int4>(max_blocks); chunks_tmp = b.take<int4>(max_chunks);
+            return b.off;
+        };
+        rc = ba_scratch(ctx, 1, carve1(nullptr), &s1);
+        if (rc) return fail(rc);
+        (void)carve1(s1);
+        HIPQ(hipMemsetAsync(bfirst, 0, sizeof(int) * 2 * (size_t)std::max(nblk, 1), st));
+        if (no > 0) prep_expand<<<gobs, TPB, 0, st>>>(no, nc, obs_cam, obs_lm, lm_ptr, obs_pos, poff, ekA, evA);
+        w_e = prim::radix_sort_pairs<int2>(st, ekA, evA, ekB, evB, n_entries, bits_for(std::max(nblk, 2)), esort_ws);
+        if (n_entries > 0) prep_block_runs<<<(unsigned)((n_entries + TPB - 1) / TPB), TPB, 0, st>>>(n_entries, w_e ? ekB : ekA, bfirst, blast);
+        const unsigned gblk = (unsigned)((nblk + TPB) / TPB);
+        if (nblk > 0) prep_block_counts<<<gblk, TPB, 0, st>>>(nc, nblk, bfirst, blast, bcount, bt);
+        prim::exclusive_scan<prim::I3>(st, bt, bs, nblk, bws, &cnt->totals);
+        if (nblk > 0) prep_block_fill<<<gblk, TPB, 0, st>>>(nc, nblk, bcount, bs, blocks_tmp, chunks_tmp);
+        // ---- read-back 2: the table sizes ----
+        HIPQ(hipMemcpyAsync(&hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIPQ(hipStreamSynchronize(st));
+        if (hc.totals.a != n_entries) return fail(ctx->fail(EACHAM_ERR_HIP, "BA structure build: %d pair entries counted, %d placed", n_entries, hc.totals.a));
+        D.n_blocks = hc.totals.b;
+        D.n_chunks = hc.totals.c;
+    }
+    // ---- the landmark-major structure (ba_groups.hpp steps 2-4 on the device), first half: groups, padded per-group arrays,
+    // the counting pass over every group's entries ----
+    const int nu = hc.n_used, LMAXg = R / 4, R0g = R - std::max(hg.cmax, 4) + 1;
+    const int ng_max = use_groups ? hg.cost_total / R0g + 1 : 0;
+    int g_emax = 64;
+    while (g_emax < GRP_ENT_PER_ROW * R) g_emax <<= 1;
+    BaGroup* tg_groups = nullptr;
+    int *tg_lmid = nullptr, *tg_lmrow = nullptr, *tg_lm0 = nullptr;
+    int2* tg_rowinfo = nullptr;
+    double* tg_uv = nullptr;
+    prim::I3 *tg_counts = nullptr, *tg_bases = nullptr, *tg_ws = nullptr;
+    int n_items = 0;
+    if (use_groups) {
+        if (g_emax > GE_MAXE || R > 511) return fail(ctx->fail(EACHAM_ERR_UNSUPPORTED, "group size %d rows is beyond the device construction", R));
+        void* s2 = nullptr;
+        auto carve2 = [&](void* base) {
+            Bump b(base);
+            tg_groups = b.take<BaGroup>(ng_max); tg_lmid = b.take<int>((size_t)ng_max * LMAXg); tg_lmrow = b.take<int>((size_t)ng_max * LMAXg);
+            tg_rowinfo = b.take<int2>((size_t)ng_max * R); tg_uv = b.take<double>(2 * (size_t)ng_max * R);
+            tg_lm0 = b.take<int>((size_t)ng_max + 2);
+            tg_counts = b.take<prim::I3>(ng_max); tg_bases = b.take<prim::I3>(ng_max); tg_ws = b.take<prim::I3>(prim::scan_ws_elems(ng_max));
+            return b.off;
+        };
+        rc = ba_scratch(ctx, 2, carve2(nullptr), &s2);
+        if (rc) return fail(rc);
+        (void)carve2(s2);
+        HIPQ(hipMemsetAsync(tg_groups, 0, sizeof(BaGroup) * (size_t)ng_max, st));
+        HIPQ(hipMemsetAsync(tg_lmid, 0xff, sizeof(int) * (size_t)ng_max * LMAXg, st));
+        HIPQ(hipMemsetAsync(tg_lmrow, 0, sizeof(int) * (size_t)ng_max * LMAXg, st));
+        HIPQ(hipMemsetAsync(tg_rowinfo, 0xff, sizeof(int2) * (size_t)ng_max * R, st));
+        HIPQ(hipMemsetAsync(tg_uv, 0, sizeof(double) * 2 * (size_t)ng_max * R, st));
+        const uint32_t* g_sorted = w_g ? gvB : gvA;
+        const unsigned gnu = (unsigned)((nu + TPB - 1) / TPB);
+        if (nu > 0) {
+            prep_grp_bounds<<<gnu, TPB, 0, st>>>(nu, gcstart, R0g, tg_lm0, gcnt);
+            prep_grp_records<<<(unsigned)((ng_max + TPB - 1) / TPB), TPB, 0, st>>>(gcnt, tg_lm0, grstart, tg_groups);
+            prep_grp_fill<<<gnu, TPB, 0, st>>>(nu, nc, R, R0g, g_sorted, gcstart, grstart, tg_lm0, lm_ptr, obs_cam, obs_uv, tg_lmid, tg_lmrow, tg_rowinfo, tg_uv);
+        }
+        if (hg.any_dup) {  // the general form: sorts every group's entries
+            const size_t ge_lds = grp_entries_lds_bytes(g_emax, R);
+            HIPQ(hipFuncSetAttribute((const void*)prep_grp_entries<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ge_lds));
+            HIPQ(hipFuncSetAttribute((const void*)prep_grp_entries<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ge_lds));
+            prep_grp_entries<0><<<ng_max, GE_THREADS, ge_lds, st>>>(g_emax, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, tg_counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        } else {
+            const size_t gf_lds = grp_entries_fast_lds_bytes(GRP_ENT_PER_ROW * R, R);
+            HIPQ(hipFuncSetAttribute((const void*)prep_grp_entries_fast<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_lds));
+            HIPQ(hipFuncSetAttribute((const void*)prep_grp_entries_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_lds));
+            prep_grp_entries_fast<0><<<ng_max, GE_THREADS, gf_lds, st>>>(GRP_ENT_PER_ROW * R, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, tg_counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        }
+        prim::exclusive_scan<prim::I3>(st, tg_counts, tg_bases, ng_max, tg_ws, &gcnt->totals);
+        // ---- read-back 2: groups, chunks, entry rows, segments ----
+        HIPQ(hipMemcpyAsync(&hg, gcnt, sizeof(hg), hipMemcpyDeviceToHost, st));
+        HIPQ(hipStreamSynchronize(st));
+        if (nu == 0) hg.ng = 0;
+        if (hg.ng > ng_max) return fail(ctx->fail(EACHAM_ERR_HIP, "BA structure build: %d groups, %d expected at most", hg.ng, ng_max));
+        D.g_rows = R; D.g_ngroups = hg.ng; D.g_nchunks = hg.totals.a; D.g_nent4 = hg.totals.b; D.g_nparts = hg.totals.c;
+        n_items = 2 * nc + 1 + hg.totals.c;
+    }
     h->prep_us[0] = us_since(t_begin);
     plan_thread.join();  // prep_us[1] = the plan's own time; what of it was not hidden behind the device shows in [2]
     const auto t_upload = std::chrono::steady_clock::now();
@@ -3667,10 +4347,30 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     // ---- arena B: the pair lists, the plan's tables, what is sized by them ----
     int2* pair_entries = nullptr;
     int4 *pair_chunks = nullptr, *blocks = nullptr;
+    BaGroup* fg_groups = nullptr;
+    int *fg_lmid = nullptr, *fg_lmrow = nullptr, *fg_longblk = nullptr;
+    int2* fg_rowinfo = nullptr;
+    double* fg_uv = nullptr;
+    BaChunk* fg_chunks = nullptr;
+    uint32_t *fg_ent = nullptr, *fg_laneinfo = nullptr;
+    int4* fg_blk = nullptr;
+    const int ngf = D.g_ngroups;
     auto layout_b = [&]() -> int {
         TRY(dev_alloc(ctx, h, &pair_entries, (size_t)n_entries));
         TRY(dev_alloc(ctx, h, &pair_chunks, (size_t)D.n_chunks));
         TRY(dev_alloc(ctx, h, &blocks, (size_t)D.n_blocks));
+        if (use_groups) {
+            TRY(dev_alloc(ctx, h, &fg_groups, (size_t)ngf));
+            TRY(dev_alloc(ctx, h, &fg_lmid, (size_t)ngf * LMAXg));
+            TRY(dev_alloc(ctx, h, &fg_lmrow, (size_t)ngf * LMAXg));
+            TRY(dev_alloc(ctx, h, &fg_rowinfo, (size_t)ngf * R));
+            TRY(dev_alloc(ctx, h, &fg_uv, 2 * (size_t)ngf * R));
+            TRY(dev_alloc(ctx, h, &fg_chunks, (size_t)D.g_nchunks));
+            TRY(dev_alloc(ctx, h, &fg_ent, 256 * (size_t)D.g_nent4));
+            TRY(dev_alloc(ctx, h, &fg_laneinfo, 64 * (size_t)D.g_nchunks));
+            TRY(dev_alloc(ctx, h, &fg_blk, (size_t)n_items));                      // (blocks <= items)
+            TRY(dev_alloc(ctx, h, &fg_longblk, (size_t)D.g_nparts / GRP_LONG + 1));  // (a long block holds more than GRP_LONG segments)
+        }
         TRY(ba_upload_plan(ctx, h, plan, bs_ent));
         TRY(ba_alloc_work_b(ctx, h));
         return EACHAM_OK;
@@ -3693,6 +4393,54 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     if (D.n_chunks > 0) HIPQ(hipMemcpyAsync(pair_chunks, chunks_tmp, sizeof(int4) * (size_t)D.n_chunks, hipMemcpyDeviceToDevice, st));
     if (D.n_blocks > 0) HIPQ(hipMemcpyAsync(blocks, blocks_tmp, sizeof(int4) * (size_t)D.n_blocks, hipMemcpyDeviceToDevice, st));
     D.pair_entries = pair_entries; D.pair_chunks = pair_chunks; D.blocks = blocks;
+    if (use_groups) {
+        // ---- second half of the landmark-major structure: the writing pass over the groups, the slots, the block table ----
+        if (ngf > 0) {
+            HIPQ(hipMemcpyAsync(fg_lmid, tg_lmid, sizeof(int) * (size_t)ngf * LMAXg, hipMemcpyDeviceToDevice, st));
+            HIPQ(hipMemcpyAsync(fg_lmrow, tg_lmrow, sizeof(int) * (size_t)ngf * LMAXg, hipMemcpyDeviceToDevice, st));
+            HIPQ(hipMemcpyAsync(fg_rowinfo, tg_rowinfo, sizeof(int2) * (size_t)ngf * R, hipMemcpyDeviceToDevice, st));
+            HIPQ(hipMemcpyAsync(fg_uv, tg_uv, sizeof(double) * 2 * (size_t)ngf * R, hipMemcpyDeviceToDevice, st));
+        }
+        void* s1 = nullptr;
+        uint32_t *ikA, *ikB, *iwA, *iwB;
+        int *isort_ws, *blk_first, *longflag, *longpos, *long_ws;
+        prim::I3 *ifl, *isc, *iws;
+        auto carve1g = [&](void* base) {
+            Bump b(base);
+            ikA = b.take<uint32_t>(n_items); ikB = b.take<uint32_t>(n_items); iwA = b.take<uint32_t>(n_items); iwB = b.take<uint32_t>(n_items);
+            isort_ws = b.take<int>(prim::radix_ws_ints(n_items));
+            ifl = b.take<prim::I3>(n_items); isc = b.take<prim::I3>(n_items); iws = b.take<prim::I3>(prim::scan_ws_elems(n_items));
+            blk_first = b.take<int>(n_items); longflag = b.take<int>(n_items); longpos = b.take<int>(n_items); long_ws = b.take<int>(prim::scan_ws_elems(n_items));
+            return b.off;
+        };
+        rc = ba_scratch(ctx, 1, carve1g(nullptr), &s1);
+        if (rc) return fail(rc);
+        (void)carve1g(s1);
+        const int n_mand = 2 * nc + 1;
+        prep_grp_mandatory<<<(unsigned)((n_mand + TPB - 1) / TPB), TPB, 0, st>>>(nc, ikA, iwA);
+        if (ngf > 0) {
+            if (hg.any_dup)
+                prep_grp_entries<1><<<ngf, GE_THREADS, grp_entries_lds_bytes(g_emax, R), st>>>(g_emax, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, nullptr, tg_bases, fg_chunks, fg_ent, fg_laneinfo, ikA, iwA, n_mand);
+            else
+                prep_grp_entries_fast<1><<<ngf, GE_THREADS, grp_entries_fast_lds_bytes(GRP_ENT_PER_ROW * R, R), st>>>(GRP_ENT_PER_ROW * R, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, nullptr, tg_bases, fg_chunks, fg_ent, fg_laneinfo, ikA, iwA, n_mand);
+            HIPQ(hipMemcpyAsync(fg_groups, tg_groups, sizeof(BaGroup) * (size_t)ngf, hipMemcpyDeviceToDevice, st));
+        }
+        const int w_i = prim::radix_sort_pairs<uint32_t>(st, ikA, iwA, ikB, iwB, n_items, bits_for((long long)(nc + 1) * (nc + 1)), isort_ws);
+        const uint32_t *skey = w_i ? ikB : ikA, *swhere = w_i ? iwB : iwA;
+        const unsigned git = (unsigned)((n_items + TPB - 1) / TPB);
+        prep_grp_flags<<<git, TPB, 0, st>>>(n_items, skey, swhere, ifl);
+        prim::exclusive_scan<prim::I3>(st, ifl, isc, n_items, iws, &gcnt->item_totals);
+        prep_grp_slots<<<git, TPB, 0, st>>>(n_items, nc, skey, swhere, isc, fg_laneinfo, fg_blk, blk_first);
+        prep_grp_blk_counts<<<git, TPB, 0, st>>>(gcnt, n_items, swhere, blk_first, fg_blk, longflag);
+        prim::exclusive_scan<int>(st, longflag, longpos, n_items, long_ws, &gcnt->n_long);
+        prep_grp_long<<<git, TPB, 0, st>>>(gcnt, longflag, longpos, fg_longblk);
+        // ---- read-back 3: blocks, long blocks ----
+        HIPQ(hipMemcpyAsync(&hg, gcnt, sizeof(hg), hipMemcpyDeviceToHost, st));
+        HIPQ(hipStreamSynchronize(st));
+        D.g_nblk = hg.item_totals.b; D.g_nlong = hg.n_long;
+        D.g_groups = fg_groups; D.g_lmid = fg_lmid; D.g_lmrow = fg_lmrow; D.g_rowinfo = fg_rowinfo; D.g_uv = fg_uv; D.g_chunks = fg_chunks;
+        D.g_ent = fg_ent; D.g_laneinfo = fg_laneinfo; D.g_blk = fg_blk; D.g_longblk = fg_longblk;
+    }
     HIPQ(hipStreamSynchronize(st));  // the plan's tables were copied out of host vectors
     h->prep_us[2] = us_since(t_upload);
 #undef HIPQ

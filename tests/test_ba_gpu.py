@@ -395,3 +395,83 @@ def test_config4_size_properties(hip_ctx):
     assert np.median(err) < 0.35 * np.median(err0), (np.median(err), np.median(err0), err.max())
     assert np.isclose(dl.final_error, out.final_error, rtol=1e-4)
     assert (np.diff(out.trace[out.trace[:, 3] == 1, 1]) < 0).all()   # accepted steps only ever lower the error
+
+
+def _ctx_with(**env):
+    """A context of its own created under the given environment switches (they are read once, at eacham_ctx_create)."""
+    from eacham_amd import HipContext
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        return HipContext(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("prepare", ["host", "device"])
+def test_both_forms_of_the_schur_stage_solve_the_same_system(hip_ctx, prepare):
+    """The landmark-major form (ba_schur_groups: Et in LDS, one partial per segment of a camera block) and the pair-list form of
+    rounds 1-4 (Et through HBM) add the same products in different orders: the reduced system, the step and a whole LM run agree
+    to rounding, both with the oracle; group sizes other than the default change the order again, not the answer."""
+    sc, A = scene_arrays(seed=31, n_cams=40, n_lm=1800, k=7, pixel_noise=1.0)
+    cfg = ba.OptimizerConfig.refine_ba()
+    ref = O.ba_solve(A, cfg)
+    So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
+    outs = []
+    for env in [dict(EACHAM_BA_SCHUR="groups"), dict(EACHAM_BA_SCHUR="pairs"), dict(EACHAM_BA_GROUP_ROWS="64"), dict(EACHAM_BA_GROUP_ROWS="256"),
+                dict(EACHAM_BA_GROUP_ROWS="480")]:
+        ctx = _ctx_with(EACHAM_BA_PREPARE=prepare, **env)
+        try:
+            pb = ba.PreparedBA(ctx, A)
+            groups = pb.structure("g_groups").reshape(-1, 8)
+            assert (len(groups) == 0) == (env.get("EACHAM_BA_SCHUR") == "pairs") and (len(pb.structure("blocks")) == 0) == (len(groups) > 0)
+            if "EACHAM_BA_GROUP_ROWS" in env:
+                assert groups[:, 3].max() <= int(env["EACHAM_BA_GROUP_ROWS"]) and groups[:, 1].max() <= int(env["EACHAM_BA_GROUP_ROWS"]) // 4
+            pb.close()
+            S, g, dc, dl, err, lin = ba.debug_step(ctx, A, 1e-3)
+            assert rel(S, So) < 1e-11 and rel(g, go) < 1e-11 and rel(dc, dco) < 1e-8 and rel(dl, dlo) < 1e-8
+            out = ba.RefineBA(ctx, A, cfg)
+            assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+            assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :2], ref.trace[:, :2], rtol=1e-6)
+            assert rel(out.cam_T_wc, ref.cam_T_wc) < 1e-7 and rel(out.points, ref.points) < 1e-7
+            again = ba.RefineBA(ctx, A, cfg)     # and bit for bit from run to run
+            assert np.array_equal(out.points, again.points) and np.array_equal(out.cam_T_wc, again.cam_T_wc) and np.array_equal(out.trace, again.trace)
+            outs.append(out)
+        finally:
+            ctx.close()
+    for o in outs[1:]:
+        assert rel(o.points, outs[0].points) < 1e-9 and rel(o.cam_T_wc, outs[0].cam_T_wc) < 1e-9
+
+
+@pytest.mark.parametrize("prepare", ["host", "device"])
+def test_a_landmark_too_heavy_for_a_group_takes_the_pair_lists(prepare):
+    """A landmark seen by 90 of 100 cameras has 4186 entries: more than a 128-row group may hold (2048). The problem then keeps
+    the pair lists of rounds 1-4 (ba_groups.hpp step 2) — same answer as the oracle, no group structure."""
+    sc = synth.make_scene(100, 400, 6, seed=41, pixel_noise=1.0)
+    A = ba.BaArrays.from_scene(sc)
+    cams = np.arange(90, dtype=np.uint32)
+    T = A.cam_T_wc[cams]
+    X = np.append(A.points[7], 1.0)
+    pc = np.einsum("nij,j->ni", T, X)
+    uv = np.stack([A.K[0] * pc[:, 0] / pc[:, 2] + A.K[2], A.K[1] * pc[:, 1] / pc[:, 2] + A.K[3]], 1)
+    keep = (A.obs_point != 7) & np.ones(len(A.obs_point), bool)
+    A.obs_cam = np.concatenate([A.obs_cam[keep], cams]).astype(np.uint32)
+    A.obs_point = np.concatenate([A.obs_point[keep], np.full(90, 7)]).astype(np.uint32)
+    A.obs_uv = np.concatenate([A.obs_uv[keep], uv.astype(np.float32).astype(np.float64)])
+    A.point_observers[7] = 90
+    cfg = ba.OptimizerConfig.refine_ba()
+    ref = O.ba_solve(A, cfg)
+    ctx = _ctx_with(EACHAM_BA_PREPARE=prepare)
+    try:
+        pb = ba.PreparedBA(ctx, A)
+        assert len(pb.structure("g_groups")) == 0 and len(pb.structure("blocks")) > 0
+        pb.close()
+        out = ba.RefineBA(ctx, A, cfg)
+        assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+        assert rel(out.cam_T_wc, ref.cam_T_wc) < 1e-7 and rel(out.points, ref.points) < 1e-7
+    finally:
+        ctx.close()

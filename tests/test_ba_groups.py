@@ -38,9 +38,9 @@ def test_structure_reproduces_the_direct_schur_sums(driver, nc, nl, max_obs, dup
         assert out["padded"] >= out["entries"] and out["blocks"] >= 2 * nc + 1
 
 
-def test_large_problems_take_256_row_groups(driver):
+def test_large_problems_take_480_row_groups(driver):
     out = run(driver, 100, 6000, 3, 10, 0)      # > 32 768 rows
-    assert out["built"] and out["rows"] == 256 and out["bad"] == 0 and out["worst"] < 1e-12
+    assert out["built"] and out["rows"] == 480 and out["bad"] == 0 and out["worst"] < 1e-12
 
 
 def test_a_landmark_too_heavy_for_a_group_is_refused(driver):
