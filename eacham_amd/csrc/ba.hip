@@ -1006,10 +1006,15 @@ __global__ __launch_bounds__(TPB, 4 - NR) void ba_schur_groups(BaDev D, double l
         for (int i4 = 0; i4 < ch.n4; ++i4) {  // (wave-uniform trip count: shorter slices carry null entries)
             const uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
             if (i4 + 1 < ch.n4) e4 = ep[(size_t)(i4 + 1) * 64];  // the next step's entries fly under this step's products
+            // (holding the rows of two entries at once — the second's loads under the first's products, 235 registers, which the two
+            // waves per SIMD of the 480-row form could afford — measured no gain: 75 against 72.7 us)
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
-                const double2* xp = reinterpret_cast<const double2*>(rows + 18 * (ent[i] & 0xffffu));
-                const double2* yp = reinterpret_cast<const double2*>(rows + 18 * (ent[i] >> 16));
+                uint32_t e = ent[0];  // (selected, not indexed: a runtime index would put the four words in scratch)
+#pragma unroll
+                for (int w = 1; w < 4; ++w) e = i == w ? ent[w] : e;
+                const double2* xp = reinterpret_cast<const double2*>(rows + 18 * (e & 0xffffu));
+                const double2* yp = reinterpret_cast<const double2*>(rows + 18 * (e >> 16));
                 double x[18], y[18];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
@@ -1029,6 +1034,10 @@ __global__ __launch_bounds__(TPB, 4 - NR) void ba_schur_groups(BaDev D, double l
 #pragma unroll
         for (int d = 1; d < GRP_SEG; d <<= 1) {
             const bool take = after >= d;
+#ifdef EXP_GRP_NO_FOLD  // (knock-out, timing only)
+            if (lambda > -1.0) continue;
+#endif
+            if (!__ballot(take)) continue;  // (wave-uniform: nobody in this chunk reaches that far — chunks of one-lane segments skip all three)
 #pragma unroll
             for (int k = 0; k < 36; ++k) {
                 const double o = __shfl_down(acc[k], d);
