@@ -3018,7 +3018,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
     }
     // ---- the landmark-major structure of the Schur stage (ba_groups.hpp); the pair lists below only when it does not apply ----
     BaGroups& GR = h->groups;
-    const bool use_groups = ctx->ba_schur_mode != 2 && build_groups(nc, nl, lm_ptr.data(), obs_cam.data(), obs_uv.data(), GR, ctx->ba_group_rows);
+    const bool use_groups = ctx->ba_schur_mode == 1 && build_groups(nc, nl, lm_ptr.data(), obs_cam.data(), obs_uv.data(), GR, ctx->ba_group_rows);
     if (!use_groups) GR = BaGroups();
     // ---- camera-pair lists of the Schur complement: block (c <= c') -> (o, o') pairs, landmark order ----
     // (two passes over every observation pair of every landmark — count, then fill: this loop is most of the host time of

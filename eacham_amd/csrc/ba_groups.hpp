@@ -94,24 +94,21 @@ inline int grp_rows_for(long long total_rows) { return total_rows <= 32768 ? 128
 inline bool build_groups(int nc, int nl, const int* lm_ptr, const unsigned* obs_cam, const double* obs_uv, BaGroups& out, int rows_override = 0) {
     out = BaGroups();
     if (nc >= 65535) return false;
-    // 1. order
-    std::vector<uint32_t> key;
-    std::vector<int> used;
+    // 1. order (a plain sort of key << 32 | landmark: stable by construction)
+    std::vector<unsigned long long> order;
+    order.reserve(nl);
     long long total_rows = 0;
     for (int j = 0; j < nl; ++j) {
         const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1];
         if (a1 == a0) continue;
         unsigned mn = obs_cam[a0], mx = obs_cam[a0];
         for (int a = a0 + 1; a < a1; ++a) mn = std::min(mn, obs_cam[a]), mx = std::max(mx, obs_cam[a]);
-        used.push_back(j);
-        key.push_back(grp_morton(mn, mx));
+        order.push_back((unsigned long long)grp_morton(mn, mx) << 32 | (unsigned)j);
         total_rows += a1 - a0 + 1;
     }
-    const int nu = (int)used.size();
+    const int nu = (int)order.size();
     if (total_rows > 0x7fffffffLL) return false;
-    std::vector<int> order(nu);
-    for (int k = 0; k < nu; ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    std::sort(order.begin(), order.end());
     const int rows = rows_override > 0 ? rows_override : grp_rows_for(total_rows), ent_max = GRP_ENT_PER_ROW * rows;
     if (rows % 4 != 0 || rows > 32767) return false;
     // 2. costs, groups
@@ -119,13 +116,15 @@ inline bool build_groups(int nc, int nl, const int* lm_ptr, const unsigned* obs_
     out.lm.resize(nu);
     out.lrow.assign(nu + 1, 0);
     int cmax = 4;
+    bool any_dup = false;  // some landmark sees a camera twice: the entries then go through the general (sorting) form below
     for (int k = 0; k < nu; ++k) {
-        const int j = used[order[k]];
+        const int j = (int)(order[k] & 0xffffffffu);
         out.lm[k] = j;
         const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1], m = a1 - a0;
         long long e = (long long)(m + 1) * (m + 2) / 2;
         for (int a = a0; a < a1; ++a)
             for (int b = a + 1; b < a1; ++b) e += obs_cam[a] == obs_cam[b] ? 1 : 0;
+        any_dup = any_dup || e != (long long)(m + 1) * (m + 2) / 2;
         if (e > ent_max) return false;
         ecount[k] = (int)e;
         cost[k] = std::max(std::max(m + 1, 4), (int)((e * rows + ent_max - 1) / ent_max));
@@ -172,119 +171,171 @@ inline bool build_groups(int nc, int nl, const int* lm_ptr, const unsigned* obs_
             out.lmrow[(size_t)g * lmax + t] = out.lrow[k] - G.row0 + m;
         }
     }
-    // 3. entries: per group a stable counting sort over the group's own camera pairs (local camera ids in ascending camera
-    //    order, so the local pair order is the order of the block keys), runs cut into slices, slices dealt to lanes
+    // 3. entries. Two forms of the same definition: with a landmark that sees a camera twice somewhere, the general one — a
+    //    stable counting sort of every entry over the group's own camera pairs (local camera ids in ascending camera order, so
+    //    the local pair order is the order of the block keys); otherwise the run of block (la, lb) is the landmarks that see
+    //    both cameras — the AND of two per-camera masks over the group's landmarks — in ascending order, and the entries are
+    //    read off the mask (no entry list, no sort: 1.1 -> 0.2 ms for a 19-camera window on the host).
     struct Seg { uint32_t key; int where; };  // where = 64 chunk + lane
-    struct Slice { uint32_t key; int first, len; };
+    struct Slice { uint32_t key; int first, len; int la, lb; };  // general: first = position in `sorted`; masks: position inside the run
     std::vector<Seg> segs;
     std::vector<int> stamp(nc + 1, -1), local(nc + 1, 0), cams;
     std::vector<uint32_t> e_key, e_val, sorted;
     std::vector<int> cnt;
     std::vector<Slice> slices, short_runs;
+    const int mw = (lmax + 63) / 64;                        // mask words per camera
+    std::vector<unsigned long long> mask;
+    std::vector<unsigned short> rowtab;                     // [la][t]: the row of landmark t in local camera la (valid where the mask bit is set)
     const uint32_t null_ent = (uint32_t)rows | ((uint32_t)rows << 16);
     const uint32_t W = (uint32_t)nc + 1;
+    segs.reserve((size_t)out.n_rows);
+    out.ent.reserve(2 * (size_t)out.n_rows * 8);
+    out.laneinfo.reserve((size_t)out.n_rows * 2);
     for (int g = 0; g < ng; ++g) {
         BaGroup& G = out.groups[g];
+        // the group's cameras in ascending order -> local ids
         cams.clear();
-        e_key.clear();
-        e_val.clear();
-        for (int t = 0; t < G.nlm; ++t) {
-            const int k = G.lm0 + t, r0 = out.lrow[k] - G.row0, m = out.lrow[k + 1] - out.lrow[k] - 1;
-            const GrpI2* ri = &out.rowinfo[(size_t)g * rows + r0];
-            for (int a = 0; a <= m; ++a) {
-                const int ca = ri[a].x;
-                if (stamp[ca] != g) stamp[ca] = g, cams.push_back(ca);
-                e_key.push_back((uint32_t)ca * W + ca);
-                e_val.push_back((uint32_t)(r0 + a) | ((uint32_t)(r0 + a) << 16));
-                for (int b = a + 1; b <= m; ++b) {
-                    const int cb = ri[b].x;
-                    const uint32_t ra = (uint32_t)(r0 + a), rb = (uint32_t)(r0 + b);
-                    if (ca < cb) e_key.push_back((uint32_t)ca * W + cb), e_val.push_back(ra | (rb << 16));
-                    else if (ca > cb) e_key.push_back((uint32_t)cb * W + ca), e_val.push_back(rb | (ra << 16));
-                    else {
-                        e_key.push_back((uint32_t)ca * W + ca), e_val.push_back(ra | (rb << 16));
-                        e_key.push_back((uint32_t)ca * W + ca), e_val.push_back(rb | (ra << 16));
-                    }
-                }
-            }
+        for (int r = 0; r < G.nrows; ++r) {
+            const int c = out.rowinfo[(size_t)g * rows + r].x;
+            if (stamp[c] != g) stamp[c] = g, cams.push_back(c);
         }
-        const int ne = (int)e_key.size();
-        G.n_entries = ne;
-        out.n_entries += ne;
         std::sort(cams.begin(), cams.end());
         const int U = (int)cams.size();
         for (int i = 0; i < U; ++i) local[cams[i]] = i;
-        cnt.assign((size_t)U * U + 1, 0);
-        auto lp = [&](uint32_t key2) { return local[key2 / W] * U + local[key2 % W]; };
-        for (int i = 0; i < ne; ++i) cnt[lp(e_key[i]) + 1]++;
         slices.clear();
         short_runs.clear();
-        {
+        int ne = 0;
+        auto add_run = [&](int la, int lb, int pos, int L) {  // a run of L > 0 entries of local pair (la, lb)
+            const uint32_t key2 = (uint32_t)cams[la] * W + (uint32_t)cams[lb];
+            if (L > 4) {
+                const int n = (L + GRP_SLICE - 1) / GRP_SLICE;
+                for (int i = 0, at = pos; i < n; ++i) {
+                    const int len = L / n + (i < L % n ? 1 : 0);
+                    slices.push_back(Slice{key2, at, len, la, lb});
+                    at += len;
+                }
+            } else {  // runs of at most four entries (one step) take the group's LAST lanes: the chunks that hold only such
+                      // lanes run one step of four entries instead of two
+                short_runs.push_back(Slice{key2, pos, L, la, lb});
+            }
+        };
+        if (any_dup) {
+            e_key.clear();
+            e_val.clear();
+            cnt.assign((size_t)U * U + 1, 0);
+            for (int t = 0; t < G.nlm; ++t) {
+                const int k = G.lm0 + t, r0 = out.lrow[k] - G.row0, m = out.lrow[k + 1] - out.lrow[k] - 1;
+                const GrpI2* ri = &out.rowinfo[(size_t)g * rows + r0];
+                for (int a = 0; a <= m; ++a) {
+                    const int la = local[ri[a].x];
+                    const uint32_t ra = (uint32_t)(r0 + a);
+                    e_key.push_back((uint32_t)(la * U + la));
+                    e_val.push_back(ra | (ra << 16));
+                    for (int b = a + 1; b <= m; ++b) {
+                        const int lb = local[ri[b].x];
+                        const uint32_t rb = (uint32_t)(r0 + b);
+                        if (la < lb) e_key.push_back((uint32_t)(la * U + lb)), e_val.push_back(ra | (rb << 16));
+                        else if (la > lb) e_key.push_back((uint32_t)(lb * U + la)), e_val.push_back(rb | (ra << 16));
+                        else {
+                            e_key.push_back((uint32_t)(la * U + la)), e_val.push_back(ra | (rb << 16));
+                            e_key.push_back((uint32_t)(la * U + la)), e_val.push_back(rb | (ra << 16));
+                        }
+                    }
+                }
+            }
+            ne = (int)e_key.size();
+            for (int i = 0; i < ne; ++i) cnt[e_key[i] + 1]++;
             int pos = 0;
             for (int q = 0; q < U * U; ++q) {   // cnt[q + 1]: count -> running cursor of pair q; the run's slices
                 const int L = cnt[q + 1];
                 cnt[q + 1] = pos;
-                if (L > 4) {
-                    const uint32_t key2 = (uint32_t)cams[q / U] * W + (uint32_t)cams[q % U];
-                    const int n = (L + GRP_SLICE - 1) / GRP_SLICE;
-                    for (int i = 0, at = pos; i < n; ++i) {
-                        const int len = L / n + (i < L % n ? 1 : 0);
-                        slices.push_back(Slice{key2, at, len});
-                        at += len;
-                    }
-                } else if (L > 0) {  // runs of at most four entries (one step) take the group's LAST lanes: the chunks that hold
-                                     // only such lanes run one step of four entries instead of two
-                    short_runs.push_back(Slice{(uint32_t)cams[q / U] * W + (uint32_t)cams[q % U], pos, L});
-                }
+                if (L > 0) add_run(q / U, q % U, pos, L);
                 pos += L;
             }
-            slices.insert(slices.end(), short_runs.begin(), short_runs.end());
+            sorted.assign((size_t)ne, 0);
+            for (int i = 0; i < ne; ++i) sorted[cnt[e_key[i] + 1]++] = e_val[i];
+        } else {
+            mask.assign((size_t)U * mw, 0ull);
+            if (rowtab.size() < (size_t)U * lmax) rowtab.resize((size_t)U * lmax);
+            for (int r = 0; r < G.nrows; ++r) {
+                const GrpI2 ri = out.rowinfo[(size_t)g * rows + r];
+                const int la = local[ri.x];
+                mask[(size_t)la * mw + (ri.y >> 6)] |= 1ull << (ri.y & 63);
+                rowtab[(size_t)la * lmax + ri.y] = (unsigned short)r;
+            }
+            for (int la = 0; la < U; ++la)
+                for (int lb = la; lb < U; ++lb) {
+                    int L = 0;
+                    for (int w = 0; w < mw; ++w) L += __builtin_popcountll(mask[(size_t)la * mw + w] & mask[(size_t)lb * mw + w]);
+                    if (L > 0) add_run(la, lb, 0, L);
+                    ne += L;
+                }
         }
-        sorted.assign((size_t)ne, 0);
-        for (int i = 0; i < ne; ++i) sorted[cnt[lp(e_key[i]) + 1]++] = e_val[i];
+        slices.insert(slices.end(), short_runs.begin(), short_runs.end());
+        G.n_entries = ne;
+        out.n_entries += ne;
         const int ns = (int)slices.size();   // = lanes, in block order
         G.chunk0 = out.n_chunks;
         G.nchunks = (ns + 63) / 64;
         G.n_segments = 0;
         for (int c = 0; c < G.nchunks; ++c) {
+            const int l_end = std::min(ns, 64 * c + 64);
             int longest = 0;
-            for (int l = 64 * c; l < std::min(ns, 64 * c + 64); ++l) longest = std::max(longest, slices[l].len);
+            for (int l = 64 * c; l < l_end; ++l) longest = std::max(longest, slices[l].len);
             const int n4 = (longest + 3) / 4;
             out.chunks.push_back(BaChunk{(int)out.n_ent4, n4});
             out.ent.resize(out.ent.size() + (size_t)n4 * 256, null_ent);
             uint32_t* dst = out.ent.data() + (size_t)out.n_ent4 * 256;
-            for (int l = 0; l < 64; ++l) {
-                const int si = 64 * c + l;
-                if (si >= ns) {
-                    out.laneinfo.push_back(0);
-                    continue;
-                }
+            const size_t info0 = out.laneinfo.size();
+            out.laneinfo.resize(info0 + 64, 0);
+            // segments: consecutive lanes of one block, at most GRP_SEG, inside this chunk; one forward pass
+            for (int h = 64 * c; h < l_end;) {
+                int e = h + 1;
+                while (e < l_end && e < h + GRP_SEG && slices[e].key == slices[h].key) ++e;
+                for (int si = h; si < e; ++si) out.laneinfo[info0 + (si - 64 * c)] = (uint32_t)(e - 1 - si) << 28;
+                out.laneinfo[info0 + (h - 64 * c)] |= 1u;  // (the slot is filled in below)
+                segs.push_back(Seg{slices[h].key, 64 * (G.chunk0 + c) + (h - 64 * c)});
+                ++G.n_segments;
+                h = e;
+            }
+            for (int si = 64 * c; si < l_end; ++si) {
                 const Slice& S = slices[si];
-                for (int i = 0; i < S.len; ++i) dst[(size_t)(i / 4) * 256 + 4 * l + (i % 4)] = sorted[S.first + i];
-                // the segment this lane belongs to: lanes [h, e) with the lane's key, h = the last segment start at or before it
-                int h = si;   // walk back to the run's first lane in this chunk, then forward in steps of GRP_SEG
-                while (h > 64 * c && slices[h - 1].key == S.key) --h;
-                h += (si - h) / GRP_SEG * GRP_SEG;
-                int e = h;
-                while (e < std::min(ns, 64 * c + 64) && e < h + GRP_SEG && slices[e].key == S.key) ++e;
-                uint32_t info = (uint32_t)(e - 1 - si) << 28;
-                if (si == h) {
-                    segs.push_back(Seg{S.key, 64 * (G.chunk0 + c) + l});
-                    ++G.n_segments;
-                    info |= 1u;  // (the slot is filled in below)
+                const int l = si - 64 * c;
+                if (any_dup) {
+                    for (int i = 0; i < S.len; ++i) dst[(size_t)(i / 4) * 256 + 4 * l + (i % 4)] = sorted[S.first + i];
+                } else {  // the landmarks of the run from position S.first on
+                    int skip = S.first, i = 0;
+                    for (int w = 0; w < mw && i < S.len; ++w) {
+                        unsigned long long m = mask[(size_t)S.la * mw + w] & mask[(size_t)S.lb * mw + w];
+                        for (; m && i < S.len; m &= m - 1) {
+                            if (skip > 0) {
+                                --skip;
+                                continue;
+                            }
+                            const int t = 64 * w + __builtin_ctzll(m);
+                            dst[(size_t)(i / 4) * 256 + 4 * l + (i % 4)] =
+                                (uint32_t)rowtab[(size_t)S.la * lmax + t] | ((uint32_t)rowtab[(size_t)S.lb * lmax + t] << 16);
+                            ++i;
+                        }
+                    }
                 }
-                out.laneinfo.push_back(info);
             }
             out.n_ent4 += n4;
         }
         out.n_chunks += G.nchunks;
     }
     out.n_parts = (int)segs.size();
-    // slots: the slices in stable order of their block key; the block table = that order's runs merged with the mandatory blocks
+    // slots: the segments in stable order of their block key (a plain sort of key << 32 | sequence number); the block table = that
+    // order's runs merged with the mandatory blocks
+    std::vector<unsigned long long> sord(segs.size());
+    for (size_t i = 0; i < sord.size(); ++i) sord[i] = (unsigned long long)segs[i].key << 32 | (unsigned long long)i;
+    std::sort(sord.begin(), sord.end());
     std::vector<int> ord(segs.size());
-    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return segs[a].key < segs[b].key; });
-    for (size_t i = 0; i < ord.size(); ++i) out.laneinfo[segs[ord[i]].where] = (out.laneinfo[segs[ord[i]].where] & 0xf0000000u) | (uint32_t)(i + 1);
+    for (size_t i = 0; i < ord.size(); ++i) {
+        ord[i] = (int)(sord[i] & 0xffffffffu);
+        const int where = segs[ord[i]].where;
+        out.laneinfo[where] = (out.laneinfo[where] & 0xf0000000u) | (uint32_t)(i + 1);
+    }
     {
         size_t i = 0;
         auto runs_below = [&](uint32_t limit, bool inclusive) {  // emit the runs with key < limit (<= limit)

@@ -111,8 +111,10 @@ struct eacham_ctx {
                               // default: device for >= 65536 observations), read at create
     bool ba_groups_lds_set = false;  // ba_schur_groups has been granted its dynamic LDS size on this context's device
     int ba_group_rows = 0;    // EACHAM_BA_GROUP_ROWS=<n> (diagnostic): rows per landmark group instead of ba_groups.hpp's choice
-    int ba_schur_mode = 0;    // EACHAM_BA_SCHUR=groups|pairs (diagnostic / tests): 0 = landmark groups (ba_groups.hpp) whenever the problem allows,
-                              // 2 = always the pair lists of rounds 1-4 (ba_schur_pairs)
+    int ba_schur_mode = 0;    // EACHAM_BA_SCHUR=groups|pairs (diagnostic / tests). 0 = by problem size: the landmark groups of ba_groups.hpp for the
+                              // problems eacham_ba_prepare builds on the device, the pair lists of rounds 1-4 (ba_schur_pairs) for the
+                              // small ones it builds with host loops (a local window: building the group structure on the host costs
+                              // more than the 13 us per LM iteration it saves there); 1 = groups whenever they apply, 2 = always pairs
     int ba_ordering = 0;  // EACHAM_BA_ORDERING=natural|rcm|nd read ONCE at eacham_ctx_create (diagnostic override of
                           // eacham_ba_problem.ordering == AUTO); nothing on the solve path reads the environment
     int ba_lpl_lin = 0;             // EACHAM_BA_LPL_LIN=1|2|4|8 (diagnostic: lanes per landmark of the linearisation), read at create

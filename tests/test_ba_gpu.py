@@ -422,8 +422,8 @@ def test_both_forms_of_the_schur_stage_solve_the_same_system(hip_ctx, prepare):
     ref = O.ba_solve(A, cfg)
     So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
     outs = []
-    for env in [dict(EACHAM_BA_SCHUR="groups"), dict(EACHAM_BA_SCHUR="pairs"), dict(EACHAM_BA_GROUP_ROWS="64"), dict(EACHAM_BA_GROUP_ROWS="256"),
-                dict(EACHAM_BA_GROUP_ROWS="480")]:
+    for env in [dict(EACHAM_BA_SCHUR="groups"), dict(EACHAM_BA_SCHUR="pairs"), dict(EACHAM_BA_SCHUR="groups", EACHAM_BA_GROUP_ROWS="64"),
+                dict(EACHAM_BA_SCHUR="groups", EACHAM_BA_GROUP_ROWS="256"), dict(EACHAM_BA_SCHUR="groups", EACHAM_BA_GROUP_ROWS="480")]:
         ctx = _ctx_with(EACHAM_BA_PREPARE=prepare, **env)
         try:
             pb = ba.PreparedBA(ctx, A)
@@ -465,7 +465,7 @@ def test_a_landmark_too_heavy_for_a_group_takes_the_pair_lists(prepare):
     A.point_observers[7] = 90
     cfg = ba.OptimizerConfig.refine_ba()
     ref = O.ba_solve(A, cfg)
-    ctx = _ctx_with(EACHAM_BA_PREPARE=prepare)
+    ctx = _ctx_with(EACHAM_BA_PREPARE=prepare, EACHAM_BA_SCHUR="groups")
     try:
         pb = ba.PreparedBA(ctx, A)
         assert len(pb.structure("g_groups")) == 0 and len(pb.structure("blocks")) > 0

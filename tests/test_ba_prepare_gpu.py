@@ -14,19 +14,24 @@ from eacham_amd import HipContext, ba, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx_pair():
-    old = os.environ.get("EACHAM_BA_PREPARE")
+@pytest.fixture(scope="module", params=["groups", "pairs"])
+def ctx_pair(request):
+    """(host-built, device-built) contexts under one form of the Schur stage: the landmark groups of csrc/ba_groups.hpp (what the
+    device form builds by default) or the pair lists of rounds 1-4 (what the host form builds by default) — either form of the
+    construction must reproduce either structure."""
+    old = {k: os.environ.get(k) for k in ("EACHAM_BA_PREPARE", "EACHAM_BA_SCHUR")}
     try:
+        os.environ["EACHAM_BA_SCHUR"] = request.param
         os.environ["EACHAM_BA_PREPARE"] = "host"
         host = HipContext(0)
         os.environ["EACHAM_BA_PREPARE"] = "device"
         dev = HipContext(0)
     finally:
-        if old is None:
-            os.environ.pop("EACHAM_BA_PREPARE", None)
-        else:
-            os.environ["EACHAM_BA_PREPARE"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     yield host, dev
     host.close()
     dev.close()
