@@ -297,6 +297,7 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int, gather_at_o
     elapsed = D.max_f(time.perf_counter() - t0)
     ctx.profile_enable(False)
     batches = ctx.match_batches(npairs, stats=False) if kind == "i8" else (np.zeros(1, np.int32), 1)
+    stream2 = ctx.stream2_info()
     launches, tile_ms = ctx.profile_get(capi.KERNEL_MATCH_TILE)
     _, fin_ms = ctx.profile_get(capi.KERNEL_MATCH_FINALIZE)
     gathered_ok = None
@@ -308,7 +309,7 @@ def run_matching(D: Dist, descs, kind: str, steps: int, warmup: int, gather_at_o
     st = sets[(step_no[0] - 1) % len(sets)]  # the LAST timed step's match graph of this rank's shard, for the parity gate
     graph = {"pairs": pairs, "counts": st["counts"][:npairs].cpu().numpy(), "offsets": offsets.cpu().numpy(),
              "edges": st["edges"].cpu().numpy().view(np.uint32).reshape(-1, 2), "force_f32": 0 if kind == "i8" else 2}
-    out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms, "graph": graph, "batch_starts": batches[0], "slots": batches[1],
+    out = {"elapsed": elapsed, "npairs_total": npairs_total, "npairs": npairs, "launches": launches, "tile_ms": tile_ms, "graph": graph, "batch_starts": batches[0], "slots": batches[1], "stream2": stream2,
            "gathered": gather, "gathered_ok": gathered_ok,
            "fin_ms": fin_ms, "matches": int(total.item()), "pairs_all": pairs_all, "edge_cap": edge_cap, "upload_s": t_up,
            "upload_bytes": int(sum(d.nbytes for d in descs))}
@@ -370,6 +371,7 @@ def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, 
             "dtype": kind, "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3, "pairs": r["npairs_total"],
             "pairs_per_rank": r["npairs"], "mutual_matches_rank0": r["matches"],
             "launches_per_step": int(len(r["batch_starts"])), "workspace_slots": int(r["slots"]),
+            "second_stream": r["stream2"],  # which candidate the context's search kept and whether it has a hardware queue of its own
             **({"parity": parity} if parity is not None else {}),
             **({"all_gather": {"collective": D.collective_name, "world": D.world, "gathered_equals_local_shard": r["gathered_ok"]}} if r["gathered"] else {}),
             # the descriptor hand-over happens once per job, before the timed steps (host fp32 -> HBM int8 / fp32 fragments)
@@ -825,6 +827,7 @@ def main():
                        "parallelism": f"pairs sharded over {D.world} GPU(s)" + (f" + all-gather ({D.collective_name})" if D.world > 1 else "")},
             "roofline": compact_roofline(head["roofline"]),
             "kernel_source_sha": kernel_source_sha(),
+            "second_stream": head["second_stream"],
         }
         if D.world == 1 and args.cpu_pairs != 0:
             # the CPU-baseline leg's oracle output IS the parity sample of the headline: the same pairs of the last timed step's graph

@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
     L.eacham_last_error.argtypes = [vp]
     L.eacham_last_error.restype = C.c_char_p
     L.eacham_ctx_sync.argtypes = [vp]
+    L.eacham_ctx_stream2_info.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float)]
     L.eacham_ctx_stream.argtypes = [vp]
     L.eacham_ctx_stream.restype = vp
     L.eacham_version.restype = C.c_char_p

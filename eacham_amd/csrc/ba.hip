@@ -3112,7 +3112,12 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
             delete h;
             return ctx->fail(EACHAM_ERR_INVALID, "unknown BA ordering %d", hint);
         }
-        build_ba_plan(nc, cam_edges, hint, h->plan);
+        try {
+            build_ba_plan(nc, cam_edges, hint, h->plan);
+        } catch (...) {  // (no exception crosses the C-ABI)
+            delete h;
+            return ctx->fail(EACHAM_ERR_HIP, "BA preparation: the analysis of the reduced system ran out of memory or threads");
+        }
     }
     h->prep_us[1] = us_since(t_plan);
     const auto t_upload = std::chrono::steady_clock::now();
@@ -4218,15 +4223,27 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     HIPQ(hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));
     if (nc > 0) HIPQ(hipMemcpyAsync(adj_h.data(), adj_dev, (size_t)nc * nc, hipMemcpyDeviceToHost, ctx->stream2));
     HIPQ(hipStreamSynchronize(ctx->stream2));
-    plan_thread = std::thread([&, hint]() {   // (no HIP call in here)
-        const auto t_plan = std::chrono::steady_clock::now();
-        std::vector<std::pair<int, int>> cam_edges;
-        for (int c = 0; c < nc; ++c)
-            for (int c2 = c + 1; c2 < nc; ++c2)
-                if (adj_h[(size_t)c * nc + c2]) cam_edges.emplace_back(c, c2);
-        build_ba_plan(nc, cam_edges, hint, h->plan);
-        h->prep_us[1] = us_since(t_plan);
-    });
+    // (no HIP call in there, and no exception may leave it: a failed allocation or thread start inside the analysis comes back as
+    // an error code of the call — std::terminate in a process that holds the GPU is not an answer)
+    bool plan_failed = false;
+    auto plan_body = [&, hint]() {
+        try {
+            const auto t_plan = std::chrono::steady_clock::now();
+            std::vector<std::pair<int, int>> cam_edges;
+            for (int c = 0; c < nc; ++c)
+                for (int c2 = c + 1; c2 < nc; ++c2)
+                    if (adj_h[(size_t)c * nc + c2]) cam_edges.emplace_back(c, c2);
+            build_ba_plan(nc, cam_edges, hint, h->plan);
+            h->prep_us[1] = us_since(t_plan);
+        } catch (...) {
+            plan_failed = true;
+        }
+    };
+    try {
+        plan_thread = std::thread(plan_body);
+    } catch (const std::system_error&) {
+        plan_body();  // no thread to be had: the analysis runs here, before the rest of the device work is queued
+    }
     // ---- read-back 1: the number of pair entries sizes the next stage ----
     PrepCounters hc;
     GrpCounters hg;
@@ -4346,7 +4363,8 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         n_items = 2 * nc + 1 + hg.totals.c;
     }
     h->prep_us[0] = us_since(t_begin);
-    plan_thread.join();  // prep_us[1] = the plan's own time; what of it was not hidden behind the device shows in [2]
+    if (plan_thread.joinable()) plan_thread.join();  // prep_us[1] = the plan's own time; what of it was not hidden behind the device shows in [2]
+    if (plan_failed) return fail(ctx->fail(EACHAM_ERR_HIP, "BA preparation: the analysis of the reduced system ran out of memory or threads"));
     const auto t_upload = std::chrono::steady_clock::now();
     const BaPlan& plan = h->plan;
     D.sp_npan = plan.npan; D.sp_ntiles = plan.ntiles; D.sp_posK = plan.posK; D.sp_rhs_row = plan.rhs_row;

@@ -29,7 +29,9 @@
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
+#include <exception>
 #include <mutex>
+#include <system_error>
 #include <numeric>
 #include <utility>
 #include <thread>
@@ -250,9 +252,32 @@ inline void dissect_tree(const Adj& adj, std::vector<int>& mark, int& next_tag, 
     T.kids.resize(2);
     if (par > 0 && (int)left.size() > 4 * min_leaf && (int)right.size() > 4 * min_leaf) {
         int tag_r = next_tag + (1 << (18 + par));
-        std::thread other([&] { dissect_tree(adj, mark, tag_r, right, min_leaf, T.kids[1], lev, variants, par - 1); });
-        dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants, par - 1);
-        other.join();
+        // The second side on a thread of its own when one can be had (the box limits threads: std::system_error -> both sides
+        // here, one after the other). Nothing may leave a joinable thread behind or throw on it: an exception on either side is
+        // carried to this thread and rethrown after the join.
+        std::exception_ptr err_other, err_here;
+        std::thread other;
+        bool spawned = false;
+        try {
+            other = std::thread([&] {
+                try {
+                    dissect_tree(adj, mark, tag_r, right, min_leaf, T.kids[1], lev, variants, par - 1);
+                } catch (...) {
+                    err_other = std::current_exception();
+                }
+            });
+            spawned = true;
+        } catch (const std::system_error&) {
+        }
+        try {
+            dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants, spawned ? par - 1 : 0);
+        } catch (...) {
+            err_here = std::current_exception();
+        }
+        if (spawned) other.join();
+        if (err_here) std::rethrow_exception(err_here);
+        if (err_other) std::rethrow_exception(err_other);
+        if (!spawned) dissect_tree(adj, mark, next_tag, right, min_leaf, T.kids[1], lev, variants, 0);
     } else {
         dissect_tree(adj, mark, next_tag, left, min_leaf, T.kids[0], lev, variants, 0);
         dissect_tree(adj, mark, next_tag, right, min_leaf, T.kids[1], lev, variants, 0);
@@ -600,6 +625,7 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     size_t pending = queue.size() + (with_nd ? 8 : 0);
     std::mutex mu;
     std::condition_variable cv;
+    std::exception_ptr failure;  // the first exception of a task: the queue is drained, every worker leaves, it is rethrown after the joins
     auto worker = [&]() {
         for (;;) {
             int task;
@@ -610,10 +636,22 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
                 task = queue.front();
                 queue.erase(queue.begin());
             }
-            if (task < 0) build_tree(-task - 1);
-            else evaluate(cands[task]);
+            try {
+                if (task < 0) build_tree(-task - 1);
+                else evaluate(cands[task]);
+            } catch (...) {
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (!failure) failure = std::current_exception();
+                    queue.clear();
+                    pending = 0;
+                }
+                cv.notify_all();
+                return;
+            }
             {
                 std::lock_guard<std::mutex> lock(mu);
+                if (pending == 0) return;  // (another task failed meanwhile)
                 --pending;
                 if (task < 0)
                     for (int i = 0; i < 4; ++i) queue.push_back((int)nd_first + 4 * (-task - 1) + i);
@@ -623,12 +661,19 @@ inline void build_ba_plan(int nc, const std::vector<std::pair<int, int>>& edges,
     };
     if (with_nd && nc > 4 * cams_per_panel) {
         std::vector<std::thread> th;
-        for (int k = 0; k < 3; ++k) th.emplace_back(worker);
+        for (int k = 0; k < 3; ++k) {
+            try {
+                th.emplace_back(worker);
+            } catch (const std::system_error&) {  // no more threads to be had: the ones there are (at least this one) do all of it
+                break;
+            }
+        }
         worker();
         for (auto& t : th) t.join();
     } else {
         worker();
     }
+    if (failure) std::rethrow_exception(failure);
     size_t best = 0;
     for (size_t k = 1; k < cands.size(); ++k)
         if (cands[k].force || cands[k].plan.est_us < cands[best].plan.est_us - 1e-9) best = k;

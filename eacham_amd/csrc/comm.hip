@@ -323,6 +323,13 @@ int eacham_comm_match_run(eacham_comm* c, const int32_t* pairs, int npairs, doub
         rows_q[k] = r1;
         weight[k] = (int64_t)r1 * r2;  // the pair's distance matrix: what the tile kernel's time is proportional to
     }
+    // every device holds every frame at the same size (a partial upload would otherwise lose matches silently: a pair naming a
+    // frame that is missing on ITS device is redirected to the empty stand-in by the kernels' own sanitising)
+    for (int r = 1; r < world; ++r)
+        for (int f = 0; f <= max_frame; ++f)
+            if (rows[f] >= 0 && eacham_frame_rows(c->ctx[r], f) != rows[f])
+                return c->fail(EACHAM_ERR_INVALID, "frame %d has %d rows on device 0 and %d on device %d: upload it through the communicator", f, rows[f],
+                               eacham_frame_rows(c->ctx[r], f), r);
     std::vector<int32_t>& bnd = c->run_bounds;
     bnd.assign((size_t)world + 1, 0);
     int rc = eacham_shard_bounds_weighted(npairs, world, balance ? weight.data() : nullptr, bnd.data());

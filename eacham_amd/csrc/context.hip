@@ -279,17 +279,22 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     // shares the queue and is set aside (destroyed after the search, so that the next candidate gets the next queue).
     int stream2_mode = 0;   // 0 = probe for a stream on a queue of its own (default); 1 / -1 = high / low priority, no probe (A/B: EACHAM_STREAM2_PRIORITY)
     if (const char* sp = getenv("EACHAM_STREAM2_PRIORITY")) stream2_mode = !strcmp(sp, "high") ? 1 : !strcmp(sp, "low") ? -1 : !strcmp(sp, "noprobe") ? 2 : 0;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    auto bail = [&]() {   // whatever exists by now goes with the context
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        for (hipEvent_t e : {ctx->ev_tile[0], ctx->ev_tile[1], ctx->ev_fin[0], ctx->ev_fin[1], ctx->ev_join})
+            if (e) (void)hipEventDestroy(e);
+        if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
         delete ctx;
         return EACHAM_ERR_HIP;
-    }
+    };
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail();
     if (stream2_mode == 1 || stream2_mode == -1) {
         int prio_least = 0, prio_greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
-            hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, stream2_mode > 0 ? prio_greatest : prio_least) != hipSuccess) {
-            delete ctx;
-            return EACHAM_ERR_HIP;
-        }
+            hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, stream2_mode > 0 ? prio_greatest : prio_least) != hipSuccess)
+            return bail();
+        ctx->stream2_attempt = -1;
     } else {
         hipStream_t rejected[4];
         int n_rejected = 0;
@@ -299,26 +304,28 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
             hipStream_t cand = nullptr;
             if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
             bool beside = stream2_mode == 2 || attempt == 4;   // (the last candidate is kept whatever it does)
+            float ms = -1.f;   // from the probe's end to the spin's end
             if (!beside) {
                 stream_spin_kernel<<<1, 64, 0, ctx->stream>>>(4000);   // 40 us of the 100 MHz wall clock
                 ok = ok && hipEventRecord(e_spin, ctx->stream) == hipSuccess;
                 stream_probe_kernel<<<1, 64, 0, cand>>>();
                 ok = ok && hipEventRecord(e_probe, cand) == hipSuccess;
                 ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess;
-                float ms = 0.f;   // from the probe's end to the spin's end
                 ok = ok && hipEventElapsedTime(&ms, e_probe, e_spin) == hipSuccess;
                 beside = ok && ms > 0.010f;
             }
-            if (beside) { ctx->stream2 = cand; break; }
+            if (beside) {   // what the search decided stays with the context (eacham_ctx_stream2_info: the bench line reports it)
+                ctx->stream2 = cand;
+                ctx->stream2_attempt = attempt;
+                ctx->stream2_lead_ms = ms;
+                break;
+            }
             rejected[n_rejected++] = cand;
         }
         for (int k = 0; k < n_rejected; ++k) (void)hipStreamDestroy(rejected[k]);
         if (e_spin) (void)hipEventDestroy(e_spin);
         if (e_probe) (void)hipEventDestroy(e_probe);
-        if (!ok || !ctx->stream2) {
-            delete ctx;
-            return EACHAM_ERR_HIP;
-        }
+        if (!ok || !ctx->stream2) return bail();
     }
     if (
         hipEventCreateWithFlags(&ctx->ev_tile[0], hipEventDisableTiming) != hipSuccess ||
@@ -328,11 +335,16 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&ctx->flag_dev, 64 * sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->flag_dev, 0, 64 * sizeof(int), ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        delete ctx;
-        return EACHAM_ERR_HIP;
-    }
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return bail();
     *out_ctx = ctx;
+    return EACHAM_OK;
+}
+
+int eacham_ctx_stream2_info(const eacham_ctx* ctx, int* attempt, float* lead_ms) {
+    if (!ctx) return EACHAM_ERR_INVALID;
+    if (attempt) *attempt = ctx->stream2_attempt;
+    if (lead_ms) *lead_ms = ctx->stream2_lead_ms;
     return EACHAM_OK;
 }
 

@@ -109,6 +109,9 @@ struct eacham_ctx {
     eacham::BaScratch ba_scratch[3];
     int ba_prepare_mode = 0;  // EACHAM_BA_PREPARE=host|device (diagnostic / tests: force one form of the structure construction;
                               // default: device for >= 65536 observations), read at create
+    int stream2_attempt = -1;        // which candidate of the second-stream search was kept (0..4; 4 = the last, kept unprobed; -1 = no search)
+    float stream2_lead_ms = -1.f;    // how long before the spin's end the probe on it finished (> 0.010: a hardware queue of its own)
+    bool io_busy = false;            // an IoPack call has not reached its finish(): copies out of the pinned mirror may be in flight
     bool ba_groups_lds_set = false;  // ba_schur_groups has been granted its dynamic LDS size on this context's device
     int ba_group_rows = 0;    // EACHAM_BA_GROUP_ROWS=<n> (diagnostic): rows per landmark group instead of ba_groups.hpp's choice
     int ba_schur_mode = 0;    // EACHAM_BA_SCHUR=groups|pairs (diagnostic / tests). 0 = by problem size: the landmark groups of ba_groups.hpp for the
@@ -166,26 +169,43 @@ struct IoPack {
     char* dev;
     hipStream_t st;
     size_t in_lo = ~(size_t)0, in_hi = 0, out_lo = ~(size_t)0, out_hi = 0;
+    size_t direct_lo = ~(size_t)0, direct_hi = 0;  // what has been copied directly so far: a packed span must not cover it
     struct Out { void* dst; size_t off, bytes; };
+    struct In { size_t off, bytes; };
     Out outs[8];
-    int n_outs = 0;
-    IoPack(eacham_ctx* c, hipStream_t s) : ctx(c), dev((char*)c->io), st(s) {}
+    In ins[16];
+    int n_outs = 0, n_ins = 0;
+    IoPack(eacham_ctx* c, hipStream_t s) : ctx(c), dev((char*)c->io), st(s) {
+        // a call that returned on an error may have left a copy out of the mirror in flight: wait before writing into it again
+        if (ctx->io_busy) (void)hipStreamSynchronize(st);
+        ctx->io_busy = true;
+    }
     // host -> device: packed (memcpy now, one copy at flush_in) or direct
     int in(size_t off, const void* src, size_t bytes) {
         if (bytes == 0) return EACHAM_OK;
-        if (bytes <= PACK_MAX && off + bytes <= ctx->io_host_bytes) {
+        if (bytes <= PACK_MAX && off + bytes <= ctx->io_host_bytes && n_ins < 16) {
             memcpy((char*)ctx->io_host + off, src, bytes);
             in_lo = std::min(in_lo, off), in_hi = std::max(in_hi, off + bytes);
+            ins[n_ins++] = In{off, bytes};
             return EACHAM_OK;
         }
-        // (a packed span never straddles a directly copied array: what has been packed so far goes first)
+        // (what has been packed so far goes first; the direct copy is remembered: a later packed span that would cover it — the
+        // gaps of the mirror hold stale bytes — is sent piece by piece instead)
         if (int rc = flush_in()) return rc;
         EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dev + off, src, bytes, hipMemcpyHostToDevice, st));
+        direct_lo = std::min(direct_lo, off), direct_hi = std::max(direct_hi, off + bytes);
         return EACHAM_OK;
     }
     int flush_in() {
-        if (in_hi > in_lo) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dev + in_lo, (char*)ctx->io_host + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
-        in_lo = ~(size_t)0, in_hi = 0;
+        if (in_hi > in_lo) {
+            if (in_lo < direct_hi && direct_lo < in_hi) {
+                for (int k = 0; k < n_ins; ++k)
+                    EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dev + ins[k].off, (char*)ctx->io_host + ins[k].off, ins[k].bytes, hipMemcpyHostToDevice, st));
+            } else {
+                EACHAM_HIP_TRY(ctx, hipMemcpyAsync(dev + in_lo, (char*)ctx->io_host + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
+            }
+        }
+        in_lo = ~(size_t)0, in_hi = 0, n_ins = 0;
         return EACHAM_OK;
     }
     // device -> host: registered now, moved by finish()
@@ -203,6 +223,7 @@ struct IoPack {
         if (out_hi > out_lo) EACHAM_HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->io_host + out_lo, dev + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, st));
         EACHAM_HIP_TRY(ctx, hipStreamSynchronize(st));
         for (int k = 0; k < n_outs; ++k) memcpy(outs[k].dst, (char*)ctx->io_host + outs[k].off, outs[k].bytes);
+        ctx->io_busy = false;  // (an early error return leaves it set: the next IoPack waits for the stream first)
         return EACHAM_OK;
     }
 };

@@ -219,10 +219,12 @@ extern "C" int eacham_graph_set_frame(eacham_graph* g, int frame, int valid, con
     const long long nk = g->kp_offsets_h[frame + 1] - g->kp_offsets_h[frame];
     if (has3d && n_keypoints != nk) return ctx->fail(EACHAM_ERR_INVALID, "graph_set_frame: frame %d has %lld keypoints, got %d flags", frame, nk, n_keypoints);
     (void)hipSetDevice(ctx->device);
-    // (small pageable copies: staged by the runtime before the call returns, so the caller's buffer may die)
     const unsigned char v = valid ? 1 : 0;
     EACHAM_HIP_TRY(ctx, hipMemcpyAsync(g->valid + frame, &v, 1, hipMemcpyHostToDevice, ctx->stream));
     if (has3d && nk > 0) EACHAM_HIP_TRY(ctx, hipMemcpyAsync(g->has3d + g->kp_offsets_h[frame], has3d, (size_t)nk, hipMemcpyHostToDevice, ctx->stream));
+    // the sources are a stack byte and the caller's buffer: both may die when this call returns, and whether the runtime has
+    // staged a pageable copy by then is its business — wait (eacham_graph_set_frames, what the loop calls, goes through the pinned mirror)
+    EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return EACHAM_OK;
 }
 
@@ -276,6 +278,7 @@ extern "C" int eacham_graph_set_frames(eacham_graph* g, int n, const int32_t* fr
     // (the staging buffer is the context's: the next call that uses it is ordered behind this kernel on the same stream, and the
     // pinned mirror is rewritten only after a call that synchronised — every user of IoPack ends with finish() or is this one)
     EACHAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->io_busy = false;  // (synchronised: nothing reads the mirror any more)
     return EACHAM_OK;
 }
 

@@ -72,6 +72,12 @@ class HipContext:
     def stream(self) -> int:
         return int(self._L.eacham_ctx_stream(self._h) or 0)
 
+    def stream2_info(self) -> dict:
+        """What the second-stream search of eacham_ctx_create decided (eacham_ctx_stream2_info)."""
+        a, ms = C.c_int(-1), C.c_float(-1.0)
+        self._check(self._L.eacham_ctx_stream2_info(self._h, C.byref(a), C.byref(ms)))
+        return {"attempt": a.value, "lead_ms": round(ms.value, 4), "own_queue": bool(ms.value > 0.010)}
+
     def sync(self):
         self._check(self._L.eacham_ctx_sync(self._h))
 

@@ -50,6 +50,11 @@ void eacham_ctx_destroy(eacham_ctx* ctx);
 const char* eacham_last_error(const eacham_ctx* ctx);
 /* Blocks until everything enqueued on the context stream has finished. */
 int eacham_ctx_sync(eacham_ctx* ctx);
+/* Diagnostic: what the search for a second stream on a hardware queue of its own decided at eacham_ctx_create (the work behind a
+ * batch's distance sweep runs on it beside the next sweep). *attempt = which candidate was kept (0..3 probed, 4 = the last one,
+ * kept unprobed; -1 = no search: EACHAM_STREAM2_PRIORITY), *lead_ms = how long before the end of a 40 us spin on the first stream
+ * the empty kernel on it finished (above 0.010: the two do not share a queue; -1 = not measured). */
+int eacham_ctx_stream2_info(const eacham_ctx* ctx, int* attempt, float* lead_ms);
 /* Returns the hipStream_t of the context (as void*), so callers can order their own work. */
 void* eacham_ctx_stream(eacham_ctx* ctx);
 /* Library / build identification ("eacham_hip <version> gfx950"). */
