@@ -2733,7 +2733,8 @@ struct eacham_ba_handle {
     size_t arena_off = 0;      // bump pointer (planning pass: the total)
     bool planning = false;     // first pass over the allocation sequence: sizes only
     size_t upload_end = 0;     // end of the last uploaded array in the arena (the uploads come first in the sequence)
-    std::vector<char> stage;   // small problems: host image of the uploaded arrays, sent with ONE copy
+    std::vector<char> stage;   // host image of uploaded arrays [stage_base, stage_base + size) of the arena, sent with ONE copy
+    size_t stage_base = 0;
     std::vector<int> lm_order;  // landmark-sorted observation index -> caller's observation index
     eacham::BaGroups groups;    // host-built problems: the landmark-major structure of the Schur stage (device-built: sizes only)
     double *kpart = nullptr, *err_cam = nullptr, *lin_cam = nullptr;
@@ -2771,7 +2772,9 @@ static int dev_upload(eacham_ctx* ctx, eacham_ba_handle* h, const T** p, const s
     if (h->planning) {
         h->upload_end = h->arena_off;
     } else if (!v.empty()) {
-        if (!h->stage.empty()) memcpy(h->stage.data() + ((char*)q - h->arena), v.data(), v.size() * sizeof(T));
+        const size_t off = (size_t)((char*)q - h->arena);
+        if (!h->stage.empty() && off >= h->stage_base && off + v.size() * sizeof(T) <= h->stage_base + h->stage.size())
+            memcpy(h->stage.data() + (off - h->stage_base), v.data(), v.size() * sizeof(T));
         else EACHAM_HIP_TRY(ctx, hipMemcpyAsync(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     }
     *p = q;
@@ -4204,7 +4207,9 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         HIPQ(hipMemsetAsync(gcnt, 0, sizeof(GrpCounters), st));
         const unsigned glm = (unsigned)((nl + TPB - 1) / TPB);
         prep_grp_keys<<<glm, TPB, 0, st>>>(nl, lm_ptr, obs_cam, gkA, gvA, gcost, gcnt);
-        w_g = prim::radix_sort_pairs<uint32_t>(st, gkA, gvA, gkB, gvB, nl, 32, gsort_ws);
+        // (the key interleaves two camera ids: 2 bits_for(nc + 1) bits; landmarks without observations carry the largest key of that width)
+        const int gkey_bits = std::min(32, 2 * bits_for((long long)nc + 1));
+        w_g = prim::radix_sort_pairs<uint32_t>(st, gkA, gvA, gkB, gvB, nl, gkey_bits, gsort_ws);
         prep_grp_sorted<<<glm, TPB, 0, st>>>(nl, w_g ? gvB : gvA, lm_ptr, gcost, growsS, gcostS);
         prim::exclusive_scan<int>(st, gcostS, gcstart, nl, gscan_ws, &gcnt->cost_total);
         prim::exclusive_scan<int>(st, growsS, grstart, nl, gscan_ws, &gcnt->row_total);
@@ -4382,6 +4387,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     uint32_t *fg_ent = nullptr, *fg_laneinfo = nullptr;
     int4* fg_blk = nullptr;
     const int ngf = D.g_ngroups;
+    size_t plan_lo = 0, plan_hi = 0;   // the plan's eleven tables in the arena: sent as ONE copy of their host image
     auto layout_b = [&]() -> int {
         TRY(dev_alloc(ctx, h, &pair_entries, (size_t)n_entries));
         TRY(dev_alloc(ctx, h, &pair_chunks, (size_t)D.n_chunks));
@@ -4398,7 +4404,9 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
             TRY(dev_alloc(ctx, h, &fg_blk, (size_t)n_items));                      // (blocks <= items)
             TRY(dev_alloc(ctx, h, &fg_longblk, (size_t)D.g_nparts / GRP_LONG + 1));  // (a long block holds more than GRP_LONG segments)
         }
+        plan_lo = h->arena_off;
         TRY(ba_upload_plan(ctx, h, plan, bs_ent));
+        plan_hi = h->arena_off;
         TRY(ba_alloc_work_b(ctx, h));
         return EACHAM_OK;
     };
@@ -4413,8 +4421,11 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     h->arena = (char*)ctx->ba_pool[h->block2].dev;
     h->planning = false;
     h->arena_off = 0;
+    h->stage_base = plan_lo;
+    h->stage.assign(plan_hi - plan_lo, 0);
     rc = layout_b();
     if (rc) return fail(rc);
+    if (!h->stage.empty()) HIPQ(hipMemcpyAsync(h->arena + h->stage_base, h->stage.data(), h->stage.size(), hipMemcpyHostToDevice, st));
     (void)arena_a; (void)off_a;
     if (n_entries > 0) HIPQ(hipMemcpyAsync(pair_entries, w_e ? evB : evA, sizeof(int2) * (size_t)n_entries, hipMemcpyDeviceToDevice, st));
     if (D.n_chunks > 0) HIPQ(hipMemcpyAsync(pair_chunks, chunks_tmp, sizeof(int4) * (size_t)D.n_chunks, hipMemcpyDeviceToDevice, st));

@@ -250,6 +250,8 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     ctx->match_full_columns = getenv("EACHAM_MATCH_FULL_COLUMNS") != nullptr;
     ctx->exp_all_candidates = getenv("EACHAM_EXP_ALL_CANDIDATES") != nullptr;
     ctx->match_tile_sweep = getenv("EACHAM_MATCH_TILE_SWEEP") != nullptr;
+    if (const char* v = getenv("EACHAM_EXP_SWEEP_PRIO")) ctx->exp_sweep_prio = std::max(0, std::min(3, atoi(v)));
+    if (const char* v = getenv("EACHAM_EXP_STREAM2_CUS")) ctx->exp_stream2_cus = std::max(0, std::min(256, atoi(v)));
     if (const char* b = getenv("EACHAM_MATCH_BUDGET_MB")) {
         const int v = atoi(b);
         if (v >= 16 && v <= 65536) ctx->match_budget_mb = v;
@@ -302,7 +304,12 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
         bool ok = hipEventCreate(&e_spin) == hipSuccess && hipEventCreate(&e_probe) == hipSuccess;
         for (int attempt = 0; ok && attempt < 5; ++attempt) {
             hipStream_t cand = nullptr;
-            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
+            if (ctx->exp_stream2_cus > 0) {  // (A/B: n CUs spread evenly over the 256 — every (256 / n)-th bit of the mask)
+                uint32_t cu_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int stride = std::max(1, 256 / ctx->exp_stream2_cus);
+                for (int cu = 0; cu < 256; cu += stride) cu_mask[cu >> 5] |= 1u << (cu & 31);
+                if (hipExtStreamCreateWithCUMask(&cand, 8, cu_mask) != hipSuccess) { ok = false; break; }
+            } else if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { ok = false; break; }
             bool beside = stream2_mode == 2 || attempt == 4;   // (the last candidate is kept whatever it does)
             float ms = -1.f;   // from the probe's end to the spin's end
             if (!beside) {

@@ -124,6 +124,8 @@ struct eacham_ctx {
     int ba_lpl_step = 0;            // EACHAM_BA_LPL_STEP=1|2|4|8 (diagnostic: lanes per landmark of the step's tail kernels), read at create
     bool exp_no_coltop2 = false;    // EACHAM_EXP_NO_COLTOP2 (diagnostic, WRONG RESULTS: the tile sweep without its column direction — timing only)
     bool exp_all_candidates = false;  // EACHAM_EXP_ALL_CANDIDATES (diagnostic, timing only: every row is a candidate of the column pass)
+    int exp_sweep_prio = 0;           // EACHAM_EXP_SWEEP_PRIO=1..3 (diagnostic A/B): s_setprio of the sweep's waves (the candidate pass beside it stays at 0)
+    int exp_stream2_cus = 0;          // EACHAM_EXP_STREAM2_CUS=<n> (diagnostic A/B): the second stream may use n of the 256 CUs only (hipExtStreamCreateWithCUMask)
     bool match_tile_sweep = false;    // EACHAM_MATCH_TILE_SWEEP (diagnostic A/B: the lean form's sweep by match_tile_kernel, the first round-4 form)
     bool match_full_columns = false;  // EACHAM_MATCH_FULL_COLUMNS (diagnostic A/B: every column's top-2 from the sweep, the round-1..3 form)
     int match_budget_mb = 1024;     // EACHAM_MATCH_BUDGET_MB (diagnostic: workspace budget of one batch of pairs), read at create

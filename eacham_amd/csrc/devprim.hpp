@@ -95,6 +95,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_sums(T* __restrict__ sums, 
     if (threadIdx.x == 0 && total) *total = carry;
 }
 
+// single workgroup, any (small) n: out[i] = exclusive prefix of in (out may alias in), grand total to *total (may be null).
+// The three-launch form below costs three launch latencies (14 us) whatever n; up to SCAN_SMALL elements one workgroup is faster.
+constexpr int SCAN_SMALL = 8 * SCAN_TILE;
+template <class T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_small(const T* __restrict__ in, T* __restrict__ out, int n, T* __restrict__ total) {
+    __shared__ T lds[SCAN_THREADS];
+    T carry;
+    zero(carry);
+    for (int t0 = 0; t0 < n; t0 += SCAN_TILE) {
+        const int base = t0 + threadIdx.x * SCAN_ITEMS;
+        T v[SCAN_ITEMS], s;
+        zero(s);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            zero(v[i]);
+            if (base + i < n) v[i] = in[base + i];
+            s = s + v[i];
+        }
+        T all;
+        T run = carry + block_exclusive(s, lds, &all);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            if (base + i < n) out[base + i] = run;
+            run = run + v[i];
+        }
+        carry = carry + all;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
 // out[i] = sums[tile] + exclusive prefix inside the tile (out may alias in); out[n] is NOT written (see `total`)
 template <class T>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const T* __restrict__ in, T* __restrict__ out, int n,
@@ -124,6 +154,10 @@ template <class T>
 inline void exclusive_scan(hipStream_t st, const T* in, T* out, int n, T* ws, T* total_dev) {
     if (n <= 0) {
         if (total_dev) (void)hipMemsetAsync(total_dev, 0, sizeof(T), st);
+        return;
+    }
+    if (n <= SCAN_SMALL) {
+        scan_small<T><<<1, SCAN_THREADS, 0, st>>>(in, out, n, total_dev);
         return;
     }
     const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;

@@ -550,7 +550,10 @@ __device__ __forceinline__ void top2_merge(int& m1, int& m2, int s1, int s2) {
 
 template <int KS>
 __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kernel(const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
-                                                                   int wgs_per_pair, uint4* __restrict__ rowres, int row_stride) {
+                                                                   int wgs_per_pair, uint4* __restrict__ rowres, int row_stride, int prio) {
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);  // (A/B switch EACHAM_EXP_SWEEP_PRIO: workgroup-uniform, off by default)
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 3) __builtin_amdgcn_s_setprio(3);
     constexpr int NSUB = 2;
     constexpr int TILE_V4 = KS * 64;
     constexpr int ROWS_WAVE = 32 * NSUB, ROWS_WG = WAVES * ROWS_WAVE;
@@ -1562,9 +1565,9 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
             const bool col = full_cols && !ctx->exp_no_coltop2;
             if (row_sweep) {
                 switch (ctx->ks_common) {
-                    case 2: match_sweep_kernel<2><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride); break;
-                    case 4: match_sweep_kernel<4><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride); break;
-                    default: match_sweep_kernel<8><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride); break;
+                    case 2: match_sweep_kernel<2><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio); break;
+                    case 4: match_sweep_kernel<4><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio); break;
+                    default: match_sweep_kernel<8><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio); break;
                 }
             } else {
                 switch (ctx->ks_common) {
