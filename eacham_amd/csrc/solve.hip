@@ -951,9 +951,12 @@ __device__ static int epnp_front(int m, const int* idx, const double* obj, const
     return 1;
 }
 
-template <bool LANE>
-__device__ static int epnp_back(int m, const int* idx, const double* obj, const double* img, const double* K, const PnpFrame& F,
-                                const double* ev, const double* L, size_t es, double* red, double* Rt) {
+// One linearised start of the back half (variant 0 / 1 / 2 = the first 1 / 2 / 3 null vectors' leading terms): least squares for
+// the start, five Gauss-Newton steps, Horn's absolute orientation, the reprojection error. Returns the error (< 0: no pose) and
+// the pose in cand[12].
+template <bool LANE, int variant>
+__device__ static double epnp_back_variant(int m, const int* idx, const double* obj, const double* img, const double* K, const PnpFrame& F,
+                                           const double* ev, const double* L, size_t es, double* red, double* cand) {
     const int lane = LANE ? 0 : (int)(threadIdx.x & 63);
     const int kstep = LANE ? 1 : 64;
     const int terms = m < 64 ? m : 64;
@@ -963,9 +966,7 @@ __device__ static int epnp_back(int m, const int* idx, const double* obj, const 
     const double (&ax)[3][3] = F.ax;
     const double (&sc)[3] = F.sc;
     const double (&rho)[6] = F.rho;
-    double best_err = -1.0;
-#pragma unroll
-    for (int variant = 0; variant < 3; ++variant) {
+    {
         /* linearised start: the products b_i b_j that involve only the first 1 / 2 / 3 null vectors' leading terms */
         constexpr int ncol[3] = {4, 3, 5};
         constexpr int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
@@ -976,11 +977,11 @@ __device__ static int epnp_back(int m, const int* idx, const double* obj, const 
             for (int j = 0; j < 5; ++j)
                 if (j < ncol[variant]) A[p * ncol[variant] + j] = L[(size_t)(10 * p + cols[variant][j]) * es];
         const int solved = variant == 0 ? lsq6<4>(A, rho, x) : (variant == 1 ? lsq6<3>(A, rho, x) : lsq6<5>(A, rho, x));
-        if (!solved) continue;
+        if (!solved) return -1.0;
         if (variant == 0) {  /* x = b00 b01 b02 b03 */
             const double s = x[0] < 0.0 ? -1.0 : 1.0;
             beta[0] = sqrt(s * x[0]);
-            if (!(beta[0] > 0.0)) continue;
+            if (!(beta[0] > 0.0)) return -1.0;
 #pragma unroll
             for (int k = 1; k < 4; ++k) beta[k] = s * x[k] / beta[0];
         } else {             /* x = b00 b01 b11 (b02 b12) */
@@ -988,7 +989,7 @@ __device__ static int epnp_back(int m, const int* idx, const double* obj, const 
             beta[0] = sqrt(s * x[0]);
             beta[1] = s * x[2] > 0.0 ? sqrt(s * x[2]) : 0.0;
             if (x[1] < 0.0) beta[0] = -beta[0];
-            if (!(beta[0] != 0.0)) continue;
+            if (!(beta[0] != 0.0)) return -1.0;
             if (variant == 2) beta[2] = x[3] / beta[0];
         }
         for (int it = 0; it < 5; ++it) {  /* Gauss-Newton on the six distance equations */
@@ -1059,7 +1060,6 @@ __device__ static int epnp_back(int m, const int* idx, const double* obj, const 
 #pragma unroll
         for (int k = 1; k < 4; ++k)
             if (w4[k] > wtop) wtop = w4[k], q0 = V4[k], qx = V4[4 + k], qy = V4[8 + k], qz = V4[12 + k];
-        double cand[12];
         cand[0] = q0 * q0 + qx * qx - qy * qy - qz * qz, cand[1] = 2.0 * (qx * qy - q0 * qz), cand[2] = 2.0 * (qx * qz + q0 * qy);
         cand[3] = 2.0 * (qy * qx + q0 * qz), cand[4] = q0 * q0 - qx * qx + qy * qy - qz * qz, cand[5] = 2.0 * (qy * qz - q0 * qx);
         cand[6] = 2.0 * (qz * qx - q0 * qy), cand[7] = 2.0 * (qz * qy + q0 * qx), cand[8] = q0 * q0 - qx * qx - qy * qy + qz * qz;
@@ -1075,14 +1075,28 @@ __device__ static int epnp_back(int m, const int* idx, const double* obj, const 
             err += sqrt(eu * eu + evv * evv);
         }
         err = total(err);
-        if (!(err < 1e300)) continue;
-        if (best_err < 0.0 || err < best_err) {
+        if (!(err < 1e300)) return -1.0;
+        return err;
+    }
+}
+#undef EPNP_ALPHAS
+
+// the three starts in order; the first with the strictly smallest reprojection error is the sample's pose
+template <bool LANE>
+__device__ static int epnp_back(int m, const int* idx, const double* obj, const double* img, const double* K, const PnpFrame& F,
+                                const double* ev, const double* L, size_t es, double* red, double* Rt) {
+    double best_err = -1.0;
+    double cand[12];
+    auto take = [&](double err) {
+        if (err >= 0.0 && (best_err < 0.0 || err < best_err)) {
             best_err = err;
 #pragma unroll
             for (int i = 0; i < 12; ++i) Rt[i] = cand[i];
         }
-    }
-#undef EPNP_ALPHAS
+    };
+    take(epnp_back_variant<LANE, 0>(m, idx, obj, img, K, F, ev, L, es, red, cand));
+    take(epnp_back_variant<LANE, 1>(m, idx, obj, img, K, F, ev, L, es, red, cand));
+    take(epnp_back_variant<LANE, 2>(m, idx, obj, img, K, F, ev, L, es, red, cand));
     return best_err >= 0.0 ? 1 : 0;
 }
 
@@ -1130,19 +1144,24 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_pnp_front_kernel(const
     }
 }
 
+// One instantiation per linearised start (0..2), three launches: a lane per (sample, start). As one lane per sample with the three
+// starts in a row the kernel needed ~380 registers, spilled 122 of them (324 B of scratch per lane) and ran one wave per SIMD.
+// The starts' errors and poses go to `tmp` ([start][sample][13]); solve_pnp_select_kernel takes the first strictly smallest, as
+// the CPU restatement's loop over the starts does.
+template <int variant>
 __global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __restrict__ obj, const double* __restrict__ img,
                                                             const double* __restrict__ K, int sample_size, int n_samples,
                                                             const int* __restrict__ idx, const double* __restrict__ frame,
-                                                            double* __restrict__ models, int* __restrict__ n_models) {
+                                                            double* __restrict__ tmp) {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n_samples) return;
     const size_t ns = (size_t)n_samples;
     const double* src = frame + s;
     const double K4[4] = {K[0], K[1], K[2], K[3]};
-    double out[12];
+    double cand[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    int n = 0;
+    for (int k = 0; k < 12; ++k) cand[k] = 0.0;
+    double err = -1.0;
     if (src[PNP_F_VALID * ns] != 0.0) {
         PnpFrame F;
 #pragma unroll
@@ -1153,11 +1172,25 @@ __global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __rest
             for (int e = 0; e < 3; ++e) F.ax[k][e] = src[(3 + 3 * k + e) * ns];
 #pragma unroll
         for (int q = 0; q < 6; ++q) F.rho[q] = src[(15 + q) * ns];
-        n = epnp_back<true>(sample_size, idx + (size_t)s * sample_size, obj, img, K4, F, src + PNP_F_EV * ns, src + PNP_F_L * ns, ns, nullptr, out);
+        const int* rows_idx = idx + (size_t)s * sample_size;
+        err = epnp_back_variant<true, variant>(sample_size, rows_idx, obj, img, K4, F, src + PNP_F_EV * ns, src + PNP_F_L * ns, ns, nullptr, cand);
     }
+    double* dst = tmp + ((size_t)variant * ns + s) * 13;
+    dst[0] = err;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
-    n_models[s] = n;
+    for (int k = 0; k < 12; ++k) dst[1 + k] = cand[k];
+}
+__global__ __launch_bounds__(256) void solve_pnp_select_kernel(int n_samples, const double* __restrict__ tmp, double* __restrict__ models, int* __restrict__ n_models) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_samples) return;
+    double best = -1.0;
+    int which = -1;
+    for (int v = 0; v < 3; ++v) {
+        const double err = tmp[((size_t)v * n_samples + s) * 13];
+        if (err >= 0.0 && (best < 0.0 || err < best)) best = err, which = v;
+    }
+    for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = which >= 0 ? tmp[((size_t)which * n_samples + s) * 13 + 1 + k] : 0.0;
+    n_models[s] = which >= 0 ? 1 : 0;
 }
 
 // samples of more than 64 points (the all-inlier refit): one wave per workgroup, a partial M^T M per lane
@@ -1300,6 +1333,7 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
     const size_t o_a = take(sizeof(double) * 3 * (size_t)n_points), o_b = take(sizeof(double) * 2 * (size_t)n_points), o_K = take(sizeof(double) * 4);
     const size_t o_i = take(sizeof(int) * (size_t)total), o_m = take(sizeof(double) * 12 * (size_t)n_samples), o_n = take(sizeof(int) * (size_t)n_samples);
     const size_t o_f = take(sample_size <= 64 ? sizeof(double) * PNP_FRAME * (size_t)n_samples : 0);   // the samples' frames between the two launches
+    const size_t o_t = take(sample_size <= 64 ? sizeof(double) * 3 * 13 * (size_t)n_samples : 0);        // error + pose of the three starts
     if (int rc = ensure_io(ctx, off)) return rc;
     if (int rc = ensure_io_host(ctx, o_f)) return rc;   // everything but the samples' frames, which never leave the device
     char* base = (char*)ctx->io;
@@ -1319,9 +1353,15 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
                                      sizeof(double) * SOLVE_WAVES * 24 * (size_t)std::min(sample_size, 64), st>>>(
                 (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
                 (const int*)(base + o_i), (double*)(base + o_f));
-            solve_pnp_back_kernel<<<(unsigned)((n_samples + 63) / 64), 64, 0, st>>>(
-                (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
-                (const int*)(base + o_i), (const double*)(base + o_f), (double*)(base + o_m), (int*)(base + o_n));
+            const unsigned gb = (unsigned)((n_samples + 63) / 64);
+#define EACHAM_PNP_BACK(V)                                                                                                          \
+    solve_pnp_back_kernel<V><<<gb, 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), \
+                                                sample_size, n_samples, (const int*)(base + o_i), (const double*)(base + o_f), (double*)(base + o_t))
+            EACHAM_PNP_BACK(0);
+            EACHAM_PNP_BACK(1);
+            EACHAM_PNP_BACK(2);
+#undef EACHAM_PNP_BACK
+            solve_pnp_select_kernel<<<(unsigned)((n_samples + 255) / 256), 256, 0, st>>>(n_samples, (const double*)(base + o_t), (double*)(base + o_m), (int*)(base + o_n));
         }
         else
             solve_pnp_big_kernel<<<(unsigned)n_samples, 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
