@@ -81,7 +81,7 @@ def parse():
 SOURCE_GROUPS = {"match": ("matcher.hip", "matcher_f32.hip", "context.hip", "context.hpp"),
                  "ba": ("ba.hip", "ba_plan.hpp", "devprim.hpp", "context.hpp"),
                  "solve": ("solve.hip", "score.hip", "context.hpp")}
-PROFILE_ROUND = "r04"  # profiles/<round>_pmc_*.json read for roofline.traffic
+PROFILE_ROUND = "r05"  # profiles/<round>_pmc_*.json read for roofline.traffic
 
 
 def kernel_source_sha(group: str | None = None) -> str:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage: tools/pmc_sq_json.py [tiles] [round] [prefix] [kernel]
+"""usage: tools/pmc_sq_json.py [tiles] [round] [prefix] [kernel] [suffix] [dim]
 Builds profiles/<round>_pmc_sq_<kernel>.json (kernel defaults to match_sweep_kernel) from the three SQ counter passes of tools/pmc.sh
 (gpurun_out/<prefix>_a, _b, _c; defaults r01, sq): mean per dispatch of the LARGEST-grid launch of that kernel + the
 derived fractions quoted in DESIGN.md (formulas in the `derived_from` field)."""
@@ -10,6 +10,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 prefix = sys.argv[3] if len(sys.argv) > 3 else "sq"
 kernel = sys.argv[4] if len(sys.argv) > 4 else "match_sweep_kernel"
+suffix = sys.argv[5] if len(sys.argv) > 5 else ""      # e.g. _d128: profiles/<round>_pmc_sq_<kernel>_d128.json
+dim = sys.argv[6] if len(sys.argv) > 6 else "256"
 for d in (prefix + "_a", prefix + "_b", prefix + "_c"):
     for fn in glob.glob(os.path.join(root, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
         with open(fn) as f:
@@ -22,7 +24,7 @@ tiles = float(sys.argv[1]) if len(sys.argv) > 1 else 64.0
 cyc = c["GRBM_GUI_ACTIVE"] / 8.0
 simds = 256 * 4
 out = {
-    "kernel": f"{kernel} (256-D), grid {grid} threads, 64-frame reduced S200 set (tools/pmc.sh, three --pmc passes)",
+    "kernel": f"{kernel} ({dim}-D), grid {grid} threads, 64-frame reduced S200 set (tools/pmc.sh, three --pmc passes)",
     "counters_mean_per_dispatch": dict(sorted(c.items())),
     "derived": {
         "gpu_cycles_per_dispatch": cyc,
@@ -40,7 +42,7 @@ out = {
     "derived_from": "cycles = GRBM_GUI_ACTIVE/8 (sum over 8 XCDs); SQ_ACTIVE_*/SQ_WAVE_CYCLES/SQ_WAIT_* count quad-cycles; "
                     "busy fractions are per SIMD (1024 SIMDs); per-wave-tile counts divide by SQ_WAVES and the tiles of a sweep",
 }
-dst = os.path.join(root, "profiles", f"{rnd}_pmc_sq_{kernel}.json")
+dst = os.path.join(root, "profiles", f"{rnd}_pmc_sq_{kernel}{suffix}.json")
 with open(dst, "w") as f:
     json.dump(out, f, indent=1)
 print(dst, json.dumps(out["derived"]))
