@@ -243,17 +243,34 @@ static inline void lm_prior_params(int observers, double* sigma, double* k) {
     *k = (double)(3.0f / o);
 }
 
+/* Sums over the observations run in fixed blocks: a block is added up in order by one thread, the block sums are added in block
+ * order afterwards — the result does not depend on the number of threads or on their timing (an OpenMP `reduction` combines the
+ * threads' partial sums in whatever order they finish: the last bits of graph.error then varied from run to run, which a test on
+ * a marginal accept / reject decision of LM saw as a rare failure). */
+#define OBS_BLOCK 4096
+
 /* ---- nonlinear error: graph.error(values) (Appendix A.3) ---------------------------------------- */
 static double graph_error(const ba_t* B, const state_t* S) {
     const eacham_ba_problem* P = B->P;
     double err = 0.0;
     const double sig = (double)PIX_SIGMA, kh = (double)PIX_HUBER;
-#pragma omp parallel for reduction(+ : err) schedule(static)
-    for (int o = 0; o < S->no; ++o) {
-        double r[2];
-        reproj_eval(&S->pose[P->obs_cam[o]], S->pt + 3 * (size_t)P->obs_point[o], S->K, P->obs_uv + 2 * (size_t)o, r, 0, 0, 0);
-        const double n = sqrt(r[0] * r[0] + r[1] * r[1]) / sig;
-        err += huber_loss(n, kh);
+    {
+        const int nb = (S->no + OBS_BLOCK - 1) / OBS_BLOCK;
+        double* part = (double*)malloc(sizeof(double) * (size_t)(nb > 0 ? nb : 1));
+#pragma omp parallel for schedule(static)
+        for (int blk = 0; blk < nb; ++blk) {
+            double e = 0.0;
+            const int o1 = (blk + 1) * OBS_BLOCK < S->no ? (blk + 1) * OBS_BLOCK : S->no;
+            for (int o = blk * OBS_BLOCK; o < o1; ++o) {
+                double r[2];
+                reproj_eval(&S->pose[P->obs_cam[o]], S->pt + 3 * (size_t)P->obs_point[o], S->K, P->obs_uv + 2 * (size_t)o, r, 0, 0, 0);
+                const double n = sqrt(r[0] * r[0] + r[1] * r[1]) / sig;
+                e += huber_loss(n, kh);
+            }
+            part[blk] = e;
+        }
+        for (int blk = 0; blk < nb; ++blk) err += part[blk];
+        free(part);
     }
     for (int i = 0; i < S->nc; ++i) {
         double xi[6], n2 = 0.0;
@@ -639,8 +656,14 @@ static double linear_error(const ba_t* B, const lin_t* L, const double* dc, cons
     const state_t* S = &B->S;
     const int nc = S->nc;
     double err = 0.0;
-#pragma omp parallel for reduction(+ : err) schedule(static)
-    for (int o = 0; o < S->no; ++o) {
+    {
+        const int nb = (S->no + OBS_BLOCK - 1) / OBS_BLOCK;
+        double* part = (double*)malloc(sizeof(double) * (size_t)(nb > 0 ? nb : 1));
+#pragma omp parallel for schedule(static)
+        for (int blk = 0; blk < nb; ++blk) {
+            double e = 0.0;
+            const int o1 = (blk + 1) * OBS_BLOCK < S->no ? (blk + 1) * OBS_BLOCK : S->no;
+            for (int o = blk * OBS_BLOCK; o < o1; ++o) {
         const int c = (int)P->obs_cam[o], j = (int)P->obs_point[o];
         const double *Ap = L->Ap + 12 * (size_t)o, *Al = L->Al + 6 * (size_t)o, *Ak = L->Ak + 10 * (size_t)o;
         double r0 = -L->b[2 * (size_t)o], r1 = -L->b[2 * (size_t)o + 1];
@@ -649,7 +672,12 @@ static double linear_error(const ba_t* B, const lin_t* L, const double* dc, cons
             for (int a = 0; a < 3; ++a) { r0 += Al[a] * dl[3 * j + a]; r1 += Al[3 + a] * dl[3 * j + a]; }
             for (int a = 0; a < 5; ++a) { r0 += Ak[a] * dc[6 * nc + a]; r1 += Ak[5 + a] * dc[6 * nc + a]; }
         }
-        err += 0.5 * (r0 * r0 + r1 * r1);
+                e += 0.5 * (r0 * r0 + r1 * r1);
+            }
+            part[blk] = e;
+        }
+        for (int blk = 0; blk < nb; ++blk) err += part[blk];
+        free(part);
     }
     for (int i = 0; i < nc; ++i)
         for (int a = 0; a < 6; ++a) {
@@ -706,15 +734,26 @@ static double hessian_form(const ba_t* B, const lin_t* L, const double* xc, cons
     const state_t* S = &B->S;
     const int nc = S->nc;
     double tot = 0.0;
-#pragma omp parallel for reduction(+ : tot) schedule(static)
-    for (int o = 0; o < S->no; ++o) {
+    {
+        const int nb = (S->no + OBS_BLOCK - 1) / OBS_BLOCK;
+        double* part = (double*)malloc(sizeof(double) * (size_t)(nb > 0 ? nb : 1));
+#pragma omp parallel for schedule(static)
+        for (int blk = 0; blk < nb; ++blk) {
+            double e = 0.0;
+            const int o1 = (blk + 1) * OBS_BLOCK < S->no ? (blk + 1) * OBS_BLOCK : S->no;
+            for (int o = blk * OBS_BLOCK; o < o1; ++o) {
         const int c = (int)P->obs_cam[o], j = (int)P->obs_point[o];
         const double *Ap = L->Ap + 12 * (size_t)o, *Al = L->Al + 6 * (size_t)o, *Ak = L->Ak + 10 * (size_t)o;
         double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         for (int a = 0; a < 6; ++a) { x0 += Ap[a] * xc[6 * c + a]; x1 += Ap[6 + a] * xc[6 * c + a]; y0 += Ap[a] * yc[6 * c + a]; y1 += Ap[6 + a] * yc[6 * c + a]; }
         for (int a = 0; a < 3; ++a) { x0 += Al[a] * xl[3 * j + a]; x1 += Al[3 + a] * xl[3 * j + a]; y0 += Al[a] * yl[3 * j + a]; y1 += Al[3 + a] * yl[3 * j + a]; }
         for (int a = 0; a < 5; ++a) { x0 += Ak[a] * xc[6 * nc + a]; x1 += Ak[5 + a] * xc[6 * nc + a]; y0 += Ak[a] * yc[6 * nc + a]; y1 += Ak[5 + a] * yc[6 * nc + a]; }
-        tot += x0 * y0 + x1 * y1;
+                e += x0 * y0 + x1 * y1;
+            }
+            part[blk] = e;
+        }
+        for (int blk = 0; blk < nb; ++blk) tot += part[blk];
+        free(part);
     }
     for (int i = 0; i < nc; ++i)
         for (int a = 0; a < 6; ++a) tot += L->Pw[6 * i + a] * L->Pw[6 * i + a] * xc[6 * i + a] * yc[6 * i + a];
