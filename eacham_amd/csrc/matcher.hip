@@ -703,12 +703,24 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[(ks + PH) % 3]));
                 const int j = ks + DIST;
                 lds_read_frag(bq[(j + PH) % 3], j < KS ? nxtB : nnB, (j % KS) * 1024);
+#ifndef EXP_SWEEP_NO_MFMA   // (knock-out, timing only: the epilogue, the LDS traffic and the staging without the matrix pipes)
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s)
                     nxt[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[(ks + PH) % 3], a[s][ks], nxt[s], 0, 0, 0);
+#else
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) asm volatile("" : "+v"(nxt[s]) : "v"(bq[(ks + PH) % 3]), "v"(a[s][ks]));
+#endif
 #pragma unroll
                 for (int idx = key_lo(ks); idx < key_lo(ks + 1); ++idx) {
+#ifdef EXP_SWEEP_NO_EPI    // (knock-out, timing only: the MFMA chains and the data movement without the top-2 epilogue)
+                    if (idx % 16 == 15) {
+                        asm volatile("" : "+v"(cur[idx / 16]));
+                        x1[idx / 16] = imin(x1[idx / 16], cur[idx / 16][0]);
+                    }
+#else
                     consume(cur, idx, t, pend, before);
+#endif
                     if (idx % 16 == 15) cur[idx / 16] = cinit_of(slot_nn);   // done with these accumulators: tile t + 2's constants, for the next call's chains
                 }
                 __builtin_amdgcn_sched_barrier(0);
