@@ -512,14 +512,51 @@ __global__ __launch_bounds__(64) void ba_finish_linearize(BaDev D, const double*
 // The FIRST try after a linearisation also carries that linearisation's second stage (finish_linearize_block: n_finish
 // extra workgroups, one wave of each at work): it depends on the linearisation only, like this kernel, and as a launch of its own
 // it was 4.6 (window) / 6.9 us (S200) on the chain of the iteration.
-__global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double lambda, const double* __restrict__ clpart, int n_finish) {
-    __shared__ double sm[(TPB / 64) * 30];
-    const int n_lm_blocks = (int)gridDim.x - n_finish;
-    if ((int)blockIdx.x >= n_lm_blocks) {  // workgroup-uniform
-        if (threadIdx.x < 64) finish_linearize_block(D, clpart, (int)blockIdx.x - n_lm_blocks, (int)threadIdx.x);
-        return;
+// the 3x3 elimination of one landmark for one lambda: Linv (lower: m00; m10 m11; m20 m21 m22), gt = Linv gl, EKt[a] = Linv ElK[a].
+// ONE definition for every kernel that needs it (the thread that owns the landmark, and — in the pair-list form — every observation
+// of it, which recomputes these 24 numbers instead of waiting for a launch that stores them): same instructions, same bits.
+struct LmElim {
+    double m[6], gt[3], ek[15];
+    bool ok;
+};
+__device__ __forceinline__ LmElim eliminate_landmark(const double* __restrict__ in /* lmlin record */, double lambda) {
+    LmElim r;
+    double h0 = in[0], h1 = in[1], h2 = in[2], h3 = in[3], h4 = in[4], h5 = in[5];
+    h0 += lambda * clampd(h0, 1e-6, 1e32);
+    h3 += lambda * clampd(h3, 1e-6, 1e32);
+    h5 += lambda * clampd(h5, 1e-6, 1e32);
+    // 3x3 Cholesky, lower: [l00; l10 l11; l20 l21 l22]
+    bool ok = h0 > 0.0;
+    const double l00 = sqrt(ok ? h0 : 1.0);
+    const double l10 = h1 / l00, l20 = h2 / l00;
+    const double d1 = h3 - l10 * l10;
+    ok = ok && d1 > 0.0;
+    const double l11 = sqrt(d1 > 0.0 ? d1 : 1.0);
+    const double l21 = (h4 - l20 * l10) / l11;
+    const double d2 = h5 - l20 * l20 - l21 * l21;
+    ok = ok && d2 > 0.0;
+    const double l22 = sqrt(d2 > 0.0 ? d2 : 1.0);
+    r.ok = ok;
+    const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+    const double m10 = -l10 * m00 * m11;
+    const double m21 = -l21 * m11 * m22;
+    const double m20 = -(l20 * m00 + l21 * m10) * m22;
+    r.m[0] = m00; r.m[1] = m10; r.m[2] = m11; r.m[3] = m20; r.m[4] = m21; r.m[5] = m22;
+    const double g0 = in[6], g1 = in[7], g2 = in[8];
+    r.gt[0] = m00 * g0; r.gt[1] = m10 * g0 + m11 * g1; r.gt[2] = m20 * g0 + m21 * g1 + m22 * g2;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        const double e0 = in[9 + 3 * a], e1 = in[10 + 3 * a], e2 = in[11 + 3 * a];
+        r.ek[3 * a] = m00 * e0;
+        r.ek[3 * a + 1] = m10 * e0 + m11 * e1;
+        r.ek[3 * a + 2] = m20 * e0 + m21 * e1 + m22 * e2;
     }
-    const int j = blockIdx.x * TPB + threadIdx.x;
+    return r;
+}
+
+__device__ __forceinline__ void eliminate_landmarks_block(const BaDev& D, double lambda, int block, int n_lm_blocks) {
+    __shared__ double sm[(TPB / 64) * 30];
+    const int j = block * TPB + threadIdx.x;
     {
         double2* S2 = reinterpret_cast<double2*>(D.T);
         const size_t total = (size_t)D.sp_ntiles * (PB * PB / 2);
@@ -532,41 +569,16 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
         const int o0 = D.lm_ptr[j], o1 = D.lm_ptr[j + 1];
         double* out = D.lmtry + (size_t)LMLIN * j;
         if (o1 > o0) {
-            const double* in = D.lmlin + (size_t)LMLIN * j;
-            double h0 = in[0], h1 = in[1], h2 = in[2], h3 = in[3], h4 = in[4], h5 = in[5];
-            h0 += lambda * clampd(h0, 1e-6, 1e32);
-            h3 += lambda * clampd(h3, 1e-6, 1e32);
-            h5 += lambda * clampd(h5, 1e-6, 1e32);
-            // 3x3 Cholesky, lower: [l00; l10 l11; l20 l21 l22]
-            bool ok = h0 > 0.0;
-            const double l00 = sqrt(ok ? h0 : 1.0);
-            const double l10 = h1 / l00, l20 = h2 / l00;
-            const double d1 = h3 - l10 * l10;
-            ok = ok && d1 > 0.0;
-            const double l11 = sqrt(d1 > 0.0 ? d1 : 1.0);
-            const double l21 = (h4 - l20 * l10) / l11;
-            const double d2 = h5 - l20 * l20 - l21 * l21;
-            ok = ok && d2 > 0.0;
-            const double l22 = sqrt(d2 > 0.0 ? d2 : 1.0);
-            if (!ok) atomicOr(D.flags, 1);
-            // Linv (lower): m00; m10 m11; m20 m21 m22
-            const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
-            const double m10 = -l10 * m00 * m11;
-            const double m21 = -l21 * m11 * m22;
-            const double m20 = -(l20 * m00 + l21 * m10) * m22;
-            out[0] = m00; out[1] = m10; out[2] = m11; out[3] = m20; out[4] = m21; out[5] = m22;
-            const double g0 = in[6], g1 = in[7], g2 = in[8];
-            const double t0 = m00 * g0, t1 = m10 * g0 + m11 * g1, t2 = m20 * g0 + m21 * g1 + m22 * g2;
-            out[6] = t0; out[7] = t1; out[8] = t2;
-            double ek[15];
+            const LmElim e = eliminate_landmark(D.lmlin + (size_t)LMLIN * j, lambda);
+            if (!e.ok) atomicOr(D.flags, 1);
 #pragma unroll
-            for (int a = 0; a < 5; ++a) {  // EKt[a] = Linv * ElK[a]
-                const double e0 = in[9 + 3 * a], e1 = in[10 + 3 * a], e2 = in[11 + 3 * a];
-                ek[3 * a] = m00 * e0;
-                ek[3 * a + 1] = m10 * e0 + m11 * e1;
-                ek[3 * a + 2] = m20 * e0 + m21 * e1 + m22 * e2;
-                out[9 + 3 * a] = ek[3 * a]; out[10 + 3 * a] = ek[3 * a + 1]; out[11 + 3 * a] = ek[3 * a + 2];
-            }
+            for (int k = 0; k < 6; ++k) out[k] = e.m[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[6 + k] = e.gt[k];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) out[9 + k] = e.ek[k];
+            const double t0 = e.gt[0], t1 = e.gt[1], t2 = e.gt[2];
+            const double* ek = e.ek;
 #pragma unroll
             for (int a = 0; a < 5; ++a) {
 #pragma unroll
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
     }
     block_sum<30>(kk, sm);
     if (threadIdx.x == 0)
-        for (int k = 0; k < 30; ++k) D.kk_part[(size_t)30 * blockIdx.x + k] = kk[k];
+        for (int k = 0; k < 30; ++k) D.kk_part[(size_t)30 * block + k] = kk[k];
 }
 
 // ---- K-C2: Et_o = E_o Linv^T and the calibration border, fused (thread = observation, camera order) -------------
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_landmarks(BaDev D, double la
 // Et with the same gathers (ba_border_partials, 36 us on S200). Workgroups are CAMERA-ALIGNED chunks of <= 256
 // observations (cam_chunks, built once per problem): a block sum per chunk -> bpart[chunk][36], added per camera in
 // chunk order by assemble_border (ba_assemble). Fixed order, no atomics.
-__global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev D) {
+__device__ __forceinline__ void eliminate_observations_block(const BaDev& D, double lambda, int block) {
     // The border share of an observation is Et_o (6 x 3) M_o (3 x 6), M_o = [EKt^T | gt]; its sum over the chunk runs
     // on v_mfma_f64_16x16x4_f64 with TWO observations per instruction: rows 0..5 / 8..13 of the A operand hold Et of
     // the even / odd observation of a pair, columns 0..5 / 8..13 of the B operand their M, the K index (3 used of 4)
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
     // per operand: the operands of step t are lds[48 t + lane] for the lanes of k = lane >> 4 < 3, zero otherwise.
     __shared__ __attribute__((aligned(16))) double stA[TPB / 64][8 * 48], stB[TPB / 64][8 * 48];  // 2 x 3 KB per wave: 16 observations per round
     __shared__ double wsum[TPB / 64][4][64];
-    const int2 ch = D.cam_chunks[blockIdx.x];  // {first position, count}
+    const int2 ch = D.cam_chunks[block];  // {first position, count}
     const int p = ch.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool valid = (int)threadIdx.x < ch.y;
@@ -614,16 +626,20 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
         const double* x = D.pose + 12 * (size_t)D.pos_cam[p];
         const double* lp = D.pt + 3 * (size_t)lm;
         const double2 uv = *reinterpret_cast<const double2*>(&D.cam_uv[2 * (size_t)p]);
-        const double* m = D.lmtry + (size_t)LMLIN * lm;  // Linv (lower): m00; m10 m11; m20 m21 m22 | gt (3) | EKt (5 x 3)
+        // Linv, gt, EKt of the observation's landmark: recomputed from its linearisation record (the same 192 bytes the stored
+        // result would be, ~100 flops), so that this role does not wait for the landmark role — both run in ONE launch
+        const LmElim le = eliminate_landmark(D.lmlin + (size_t)LMLIN * lm, lambda);
         double xr[12], K[5];
 #pragma unroll
         for (int k = 0; k < 12; ++k) xr[k] = x[k];
 #pragma unroll
         for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
         const double l[3] = {lp[0], lp[1], lp[2]};
-        const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
+        const double m0 = le.m[0], m1 = le.m[1], m2 = le.m[2], m3 = le.m[3], m4 = le.m[4], m5 = le.m[5];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) lv[k] = m[6 + k];
+        for (int k = 0; k < 3; ++k) lv[k] = le.gt[k];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) lv[3 + k] = le.ek[k];
         double Ap[12], Al[6], Ak[10], b[2];
         obs_factor(xr, l, K, uv.x, uv.y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
 #pragma unroll
@@ -682,8 +698,19 @@ __global__ __launch_bounds__(TPB) void ba_eliminate_observations_recompute(BaDev
 #pragma unroll
         for (int w = 0; w < TPB / 64; ++w)
             v += wsum[w][a >> 2][b + 16 * (a & 3)] + wsum[w][2 + (a >> 2)][8 + b + 16 * (a & 3)];
-        D.bpart[(size_t)36 * blockIdx.x + k] = v;
+        D.bpart[(size_t)36 * block + k] = v;
     }
+}
+
+// K-C + K-C2 of the pair-list form in ONE launch (round 5; two launches before: 11.6 + 10.4 us on the chain of a local window's
+// try): workgroups [0, n_cam_chunks) take the observation role (the longer one), the next n_lm_blocks the landmark role (lmtry for
+// the step's back-substitution, the K-corner partials, the clearing of S), the last n_finish the linearisation's second stage.
+__global__ __launch_bounds__(TPB) void ba_eliminate(BaDev D, double lambda, const double* __restrict__ clpart, int n_lm_blocks, int n_finish) {
+    const int b = (int)blockIdx.x;  // (every branch below is workgroup-uniform)
+    if (b < D.n_cam_chunks) eliminate_observations_block(D, lambda, b);
+    else if (b < D.n_cam_chunks + n_lm_blocks) eliminate_landmarks_block(D, lambda, b - D.n_cam_chunks, n_lm_blocks);
+    else if (threadIdx.x < 64) finish_linearize_block(D, clpart, b - D.n_cam_chunks - n_lm_blocks, (int)threadIdx.x);
+    (void)n_finish;
 }
 
 // ---- K-D1: Schur pair products (wave = chunk of <= 256 entries of one camera block's pair list) ------
@@ -861,7 +888,7 @@ __global__ __launch_bounds__(TPB) void ba_assemble(BaDev D, double lambda, unsig
 
 // ---- The Schur stage, landmark-major (round 5): ONE launch for K-C, K-C2 and K-D1 ------------------------------------------
 // A workgroup owns a group of landmarks (ba_groups.hpp): consecutive landmarks of an order that keeps their camera sets close,
-// <= g_rows rows. Phase 0 (thread = landmark): the 3x3 elimination of ba_eliminate_landmarks — Linv, gt, EKt -> lmtry (the
+// <= g_rows rows. Phase 0 (thread = landmark): the 3x3 elimination (eliminate_landmark) — Linv, gt, EKt -> lmtry (the
 // step's back-substitution reads it) and, in LDS, Linv, the point and the landmark's own row Y = [EKt; gt]. Phase A (thread =
 // observation row): Jacobians recomputed at the linearisation point, Et = E Linv^T -> the row's 144 bytes IN LDS (rounds 1-4
 // wrote them to HBM: 72 MB per try, and gathered two rows per entry from there). Phase B (wave = chunk of 64 slices, lane =
@@ -870,7 +897,7 @@ __global__ __launch_bounds__(TPB) void ba_assemble(BaDev D, double lambda, unsig
 // products whatever its form). Camera blocks, the calibration border, the right-hand side and the K corner are all the same
 // sum (the landmark rows act as the observations of a pseudo-camera). Fixed order everywhere, no atomics.
 // The per-group arrays are padded to the group bounds, so a thread's first loads need nothing but its block index; the launch
-// also clears the tiles of S and carries the linearisation's second stage, as ba_eliminate_landmarks does.
+// also clears the tiles of S and carries the linearisation's second stage, as ba_eliminate does.
 __host__ __device__ inline size_t schur_groups_lds_bytes(int rows) {
     return sizeof(double) * ((size_t)18 * (rows + 1) + (size_t)9 * (rows / 4));
 }
@@ -4566,7 +4593,7 @@ static void launch_linearize(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     ProfileScope ps(ctx, EACHAM_KERNEL_BA_LINEARIZE);
     launch_linearize_both(ctx, D, h->kpart);
-    h->finish_pending = true;  // rides in the next ba_eliminate_landmarks (launch_try) or is flushed by finish_linearize_now
+    h->finish_pending = true;  // rides in the next try's first launch (launch_try) or is flushed by finish_linearize_now
 }
 static void finish_linearize_now(eacham_ctx* ctx, eacham_ba_handle* h) {
     if (!h->finish_pending) return;
@@ -4590,8 +4617,7 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
             const unsigned nbg = (unsigned)((D.g_nblk + ASM_TPB / 64 - 1) / (ASM_TPB / 64));  // a wave per block
             ba_assemble_groups<<<D.g_nlong + nbg + 1, ASM_TPB, 0, ctx->stream>>>(D, lambda, nbg);
         } else {
-            ba_eliminate_landmarks<<<D.n_lm_blocks + n_finish, TPB, 0, ctx->stream>>>(D, lambda, h->kpart, n_finish);
-            if (D.n_cam_chunks > 0) ba_eliminate_observations_recompute<<<D.n_cam_chunks, TPB, 0, ctx->stream>>>(D);
+            ba_eliminate<<<D.n_cam_chunks + D.n_lm_blocks + n_finish, TPB, 0, ctx->stream>>>(D, lambda, h->kpart, D.n_lm_blocks, n_finish);
             if (D.n_chunks > 0) ba_schur_pairs<<<((D.n_chunks + TPB / 64 - 1) / (TPB / 64) + 7) / 8 * 8, TPB, 0, ctx->stream>>>(D);
             const unsigned nbg = (unsigned)(((long long)D.n_blocks * 36 + TPB - 1) / TPB);
             ba_assemble<<<nbg + D.nc + 2, TPB, 0, ctx->stream>>>(D, lambda, nbg);  // camera blocks | border per camera | K corner | padding

@@ -39,7 +39,7 @@ print(dst, len(out), "kernel/grid entries")
 # ---- bundle adjustment: HBM bytes of one LM inner iteration (= one tryLambda) of the S200 window ----------
 ba = {k: v for k, v in out.items() if k.startswith("eacham::ba_") or k.startswith("eacham::sp_")}
 # a tryLambda() starts with ba_schur_groups (landmark groups, round 5) or ba_eliminate_landmarks (pair lists)
-tries = sum(v.get("dispatches_FETCH_SIZE", 0) for k, v in ba.items() if k.startswith("eacham::ba_eliminate_landmarks") or k.startswith("eacham::ba_schur_groups"))
+tries = sum(v.get("dispatches_FETCH_SIZE", 0) for k, v in ba.items() if (k.startswith("eacham::ba_eliminate") and "grid" in k) or k.startswith("eacham::ba_schur_groups"))
 per_kernel, total = {}, 0.0
 for k, v in sorted(ba.items()):
     n = v.get("dispatches_FETCH_SIZE", 0)
