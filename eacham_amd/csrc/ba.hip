@@ -1060,19 +1060,27 @@ __global__ __launch_bounds__(TPB, 4 - NR) void ba_schur_groups(BaDev D, double l
         // segment's first lane holds its sum, in a fixed tree order
         const int after = (int)(info >> 28);
         static_assert(GRP_SEG == 8, "three steps");
-#pragma unroll
-        for (int d = 1; d < GRP_SEG; d <<= 1) {
+        // (a segment never leaves its row of 16 lanes, so "the value d lanes up" is a DPP row shift — two v_mov_dpp per double — and not
+        // two ds_bpermute through the LDS pipe the other waves' row reads are using)
+        auto fold_step = [&](auto DC) {
+            constexpr int d = decltype(DC)::value;
             const bool take = after >= d;
 #ifdef EXP_GRP_NO_FOLD  // (knock-out, timing only)
-            if (lambda > -1.0) continue;
+            if (lambda > -1.0) return;
 #endif
-            if (!__ballot(take)) continue;  // (wave-uniform: nobody in this chunk reaches that far — chunks of one-lane segments skip all three)
+            if (!__ballot(take)) return;  // (wave-uniform: nobody in this chunk reaches that far — chunks of one-lane segments skip all three)
 #pragma unroll
             for (int k = 0; k < 36; ++k) {
-                const double o = __shfl_down(acc[k], d);
+                const int lo = __double2loint(acc[k]), hi = __double2hiint(acc[k]);
+                const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + d, 0xf, 0xf, true);   // row_shl:d, out-of-row sources read 0
+                const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + d, 0xf, 0xf, true);
+                const double o = __hiloint2double(shi, slo);
                 acc[k] += take ? o : 0.0;
             }
-        }
+        };
+        fold_step(std::integral_constant<int, 1>{});
+        fold_step(std::integral_constant<int, 2>{});
+        fold_step(std::integral_constant<int, 4>{});
         const int slot = (int)(info & 0x0fffffffu) - 1;
         if (slot >= 0) {
             double2* dst = reinterpret_cast<double2*>(D.partial + (size_t)36 * slot);
@@ -3738,7 +3746,7 @@ __global__ __launch_bounds__(GE_THREADS) void prep_grp_entries(int emax /* power
     for (int li = l0; li < l1; ++li) {
         const uint32_t key = lane_key[li];
         int h = li;
-        const int cs = li & ~63;
+        const int cs = li & ~(GRP_ROW - 1);   // a segment stays inside its row of 16 lanes
         while (h > cs && lane_key[h - 1] == key) --h;
         if (((li - h) % GRP_SEG) == 0) ++my_heads;
     }
@@ -3760,7 +3768,7 @@ __global__ __launch_bounds__(GE_THREADS) void prep_grp_entries(int emax /* power
         int hs = off_heads;
         for (int li = l0; li < l1; ++li) {
             const uint32_t key = lane_key[li];
-            const int cs = li & ~63, ce = min(nlanes, cs + 64);
+            const int cs = li & ~(GRP_ROW - 1), ce = min(nlanes, cs + GRP_ROW);
             int h = li;
             while (h > cs && lane_key[h - 1] == key) --h;
             h += (li - h) / GRP_SEG * GRP_SEG;
@@ -3939,7 +3947,7 @@ __global__ __launch_bounds__(GE_THREADS) void prep_grp_entries_fast(int lane_cap
     for (int li = l0; li < l1; ++li) {
         const uint32_t q = lane_q[li];
         int h = li;
-        const int cs = li & ~63;
+        const int cs = li & ~(GRP_ROW - 1);   // a segment stays inside its row of 16 lanes
         while (h > cs && lane_q[h - 1] == q) --h;
         if (((li - h) % GRP_SEG) == 0) ++my_heads;
     }
@@ -3961,7 +3969,7 @@ __global__ __launch_bounds__(GE_THREADS) void prep_grp_entries_fast(int lane_cap
         int hs = off_heads;
         for (int li = l0; li < l1; ++li) {
             const uint32_t q = lane_q[li];
-            const int cs = li & ~63, ce = min(nlanes, cs + 64);
+            const int cs = li & ~(GRP_ROW - 1), ce = min(nlanes, cs + GRP_ROW);
             int h = li;
             while (h > cs && lane_q[h - 1] == q) --h;
             h += (li - h) / GRP_SEG * GRP_SEG;

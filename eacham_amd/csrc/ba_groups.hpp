@@ -27,7 +27,7 @@
 //  3. a group's entries (block key = c1 (nc + 1) + c2 with c1 <= c2, pseudo-camera = nc; local rows r1, r2 with camera(r1) = c1)
 //     sorted by (block key, emission index); a run of L entries of one block is cut into n = ceil(L / GRP_SLICE) slices of
 //     balanced length (the first L mod n one longer) that take n consecutive LANES; the group's lanes — the runs of more than four
-//     entries in block order, then the runs of at most four in block order — fill chunks of 64; a SEGMENT = consecutive lanes of one block, at most GRP_SEG of them, never across a chunk boundary; chunk n4 =
+//     entries in block order, then the runs of at most four in block order — fill chunks of 64; a SEGMENT = consecutive lanes of one block, at most GRP_SEG of them, inside one row of GRP_ROW lanes of a chunk; chunk n4 =
 //     ceil(longest slice / 4) steps; entries are stored [chunk][step][lane][4] (one 16-byte load per lane and step), shorter
 //     slices padded with null entries (row `rows` = zeros);
 //  4. laneinfo[64 chunk + lane] = (lanes after this one in its segment) << 28 | (slot + 1 for a segment's first lane, else 0):
@@ -44,6 +44,7 @@ namespace eacham {
 
 constexpr int GRP_SLICE = 8;              // entries of one block a lane multiplies at most
 constexpr int GRP_SEG = 8;                // lanes of one block folded into one partial at most (three shift-and-add steps)
+constexpr int GRP_ROW = 16;               // a segment stays inside a row of 16 lanes (the fold shifts with DPP row operations)
 constexpr int GRP_ENT_PER_ROW = 16;       // ent_max = GRP_ENT_PER_ROW * rows
 constexpr int GRP_LONG = 48;              // a block with more partials than this is added by a workgroup, not a wave
 
@@ -288,10 +289,10 @@ inline bool build_groups(int nc, int nl, const int* lm_ptr, const unsigned* obs_
             uint32_t* dst = out.ent.data() + (size_t)out.n_ent4 * 256;
             const size_t info0 = out.laneinfo.size();
             out.laneinfo.resize(info0 + 64, 0);
-            // segments: consecutive lanes of one block, at most GRP_SEG, inside this chunk; one forward pass
+            // segments: consecutive lanes of one block, at most GRP_SEG, inside one row of GRP_ROW lanes; one forward pass
             for (int h = 64 * c; h < l_end;) {
                 int e = h + 1;
-                while (e < l_end && e < h + GRP_SEG && slices[e].key == slices[h].key) ++e;
+                while (e < l_end && e < h + GRP_SEG && e / GRP_ROW == h / GRP_ROW && slices[e].key == slices[h].key) ++e;
                 for (int si = h; si < e; ++si) out.laneinfo[info0 + (si - 64 * c)] = (uint32_t)(e - 1 - si) << 28;
                 out.laneinfo[info0 + (h - 64 * c)] |= 1u;  // (the slot is filled in below)
                 segs.push_back(Seg{slices[h].key, 64 * (G.chunk0 + c) + (h - 64 * c)});

@@ -113,7 +113,7 @@ int main() {
                 }
                 const uint32_t info = G.laneinfo[64 * (size_t)(gr.chunk0 + c) + l];
                 after[l] = (int)(info >> 28);
-                bad += len > GRP_SLICE || after[l] >= GRP_SEG || l + after[l] > 63 || (len == 0 && info != 0);
+                bad += len > GRP_SLICE || after[l] >= GRP_SEG || (l + after[l]) / GRP_ROW != l / GRP_ROW || (len == 0 && info != 0);
             }
             for (int d = 1; d < GRP_SEG; d <<= 1) {   // what the kernel does with shuffles
                 std::vector<double> nx(acc);
