@@ -189,7 +189,10 @@ class PreparedBA:
                  # the landmark-major structure of the Schur stage (csrc/ba_groups.hpp); empty when the pair lists serve
                  "g_groups": (20, np.int32), "g_lmid": (21, np.int32), "g_lmrow": (22, np.int32), "g_rowinfo": (23, np.int32),
                  "g_uv": (24, np.float64), "g_ent": (25, np.uint32), "g_chunks": (26, np.int32), "g_laneinfo": (27, np.uint32),
-                 "g_blk": (28, np.int32), "g_longblk": (29, np.int32)}
+                 "g_blk": (28, np.int32), "g_longblk": (29, np.int32),
+                 # the dense form for a local window (csrc/ba_window.hpp); empty when another form serves
+                 "w_groups": (30, np.int32), "w_lmid": (31, np.int32), "w_lmrow": (32, np.int32), "w_rowinfo": (33, np.int32),
+                 "w_uv": (34, np.float64)}
 
     def structure(self, name: str) -> np.ndarray:
         """eacham_ba_debug_structure: one array of the device-side structure (tests)."""

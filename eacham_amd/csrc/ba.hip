@@ -27,6 +27,7 @@
 #include "context.hpp"
 #include "ba_plan.hpp"
 #include "ba_groups.hpp"
+#include "ba_window.hpp"
 #include "devprim.hpp"
 
 #include <cstdlib>
@@ -64,6 +65,9 @@ static Noise make_noise() {
     return nz;
 }
 
+#ifndef EXP_WD_STOP
+#define EXP_WD_STOP 0
+#endif
 constexpr int TPB = 256;           // threads per block of the streaming kernels
 constexpr int PAIR_CHUNK = 256;    // pair-list entries summed by one wave (lane e takes entries e, e+64, ...)
 constexpr int NB = 32;             // Cholesky block size
@@ -236,6 +240,13 @@ struct BaDev {
     const uint32_t* g_laneinfo;     // [chunk][lane]: lanes after this one in its segment << 28 | (slot + 1 at a segment's first lane)
     const int4* g_blk;              // {c1, c2 (nc = the calibration / right-hand-side pseudo-camera), first slot, count}
     const int* g_longblk;           // blocks with more than GRP_LONG partials
+    // the dense form of the Schur stage (ba_window.hpp; w_rows == 0: not in use): padded per-group arrays as above, dense partials
+    int w_rows, w_ngroups, w_stride;
+    const int2* w_groups;           // {landmarks, rows}
+    const int2* w_rowinfo;
+    const double* w_uv;
+    const int *w_lmid, *w_lmrow;
+    double* w_part;                 // [w_ngroups][w_stride]
     // linearisation
     double *E, *lmlin, *camlin, *klin;
     // per try
@@ -1175,6 +1186,570 @@ __global__ __launch_bounds__(ASM_TPB) void ba_assemble_groups(BaDev D, double la
 }
 
 
+// sum of v over aligned groups of W lanes inside a 16-lane DPP row; valid in each group's last lane
+template <int W>
+__device__ __forceinline__ double dpp_row_sum(double v) {
+    static_assert(W == 8 || W == 16, "row_shr steps 1, 2, 4 (, 8)");
+#define EACHAM_DPP_STEP(ctrl)                                                                       \
+    {                                                                                               \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);     \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);     \
+        v += __hiloint2double(hi, lo);                                                              \
+    }
+    EACHAM_DPP_STEP(0x111)  // row_shr:1
+    EACHAM_DPP_STEP(0x112)  // row_shr:2
+    EACHAM_DPP_STEP(0x114)  // row_shr:4
+    if (W == 16) EACHAM_DPP_STEP(0x118)  // row_shr:8
+#undef EACHAM_DPP_STEP
+    return v;
+}
+
+// v of lane (lane ^ 1), (lane ^ 2) inside a quad
+__device__ __forceinline__ double dpp_quad_xor1(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_quad_xor2(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int SRC>  // v of lane SRC of the quad
+__device__ __forceinline__ double dpp_quad_bcast(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), SRC * 0x55, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), SRC * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- The Schur stage, DENSE form (round 5; ba_window.hpp): a local window's try up to the partial sums of the reduced system in ONE
+// launch, from the VALUES — no linearisation launch, no pair lists, no entry lists. Per-frame RefineBA (apps/sfm/main.cpp:207) solves
+// a NEW window every frame: what a launch saves per try has to be paid for by the structure built per window, and this form's
+// structure is the landmark-ordered rows alone. A workgroup owns a group of landmarks (<= w_rows rows, <= 64 landmarks: their
+// observations in camera order, then a row of their own) and forms its share of EVERY 6x6 block of the system ((nc + 1)(nc + 2) / 2
+// with the calibration + right-hand-side pseudo-camera nc):
+//   A1 (thread = row)        Jacobians at the current values; Al | Ak | b -> the row (for the landmark's thread), Ap^T and Q^T =
+//                            [Ak; b]^T (6x2 each) -> the row (the Hessian terms of phase B); the row's landmark bit -> its camera's
+//                            mask, its index -> rowtab[camera][landmark]
+//   0  (thread = landmark)   Hll, gl, ElK summed over its rows in row order (+ its prior) -> lmlin; the 3x3 elimination
+//                            (eliminate_landmark) -> lmtry, Linv in LDS, its own row Y = [EKt; gt]
+//   A2 (thread = row)        Et = Ap^T Al Linv^T -> the row; the calibration Hessian HKK, gK by a block sum
+//   B  (nine lanes = a block, 28 blocks at a time, a 2x2 piece per lane) the landmarks that see both cameras of block (c1, c2) are
+//      mask[c1] & mask[c2]; in ascending landmark order  acc -= Et_r1 Et_r2^T  (r = rowtab[c][t]) in REGISTERS, and the Hessian
+//      terms where they belong: (c, c) += Ap^T Ap, (c, K) += Ap^T Q; the piece goes straight to the group's partial. The heavy
+//      blocks ((K, K): every landmark; (c, K), (c, c): every landmark camera c sees) come first, together.
+// No atomics on data, every sum in one order. -> w_part[group] (win_stride(nc) doubles), summed over the groups by ba_assemble_dense.
+#ifdef EXP_WD_STAMPS  // (diagnostic build: wall-clock stamps of workgroup 0 at the phase boundaries, 10 ns units; printed by ba_run)
+__device__ unsigned long long g_wd_stamp[16];
+#define WD_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); if (blockIdx.x == 0) g_wd_stamp[i] = t_; \
+    if ((i) == 0) atomicMin(&g_wd_stamp[10], t_); if ((i) == 8) atomicMax(&g_wd_stamp[11], t_); if ((i) == 7) atomicMax(&g_wd_stamp[12], t_); if ((i) == 4) atomicMax(&g_wd_stamp[13], t_); } } while (0)
+#else
+#define WD_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(WIN_TPB) void ba_schur_dense(BaDev D, double lambda) {
+    extern __shared__ __attribute__((aligned(16))) double w_lds[];
+    WD_STAMP(0);
+    const int g = blockIdx.x, R = D.w_rows, LMAX = R / 4, tid = threadIdx.x, nc = D.nc;
+    const int lane = tid & 63, wave = tid >> 6;
+    int2 ri = make_int2(-1, 0);
+    double2 uv = double2{0.0, 0.0};
+    int lmj = -1, lmr = 0, lmprev = -1;
+    if (tid < R) {
+        ri = D.w_rowinfo[(size_t)g * R + tid];
+        uv = reinterpret_cast<const double2*>(D.w_uv)[(size_t)g * R + tid];
+    }
+    const int lt = tid >> 2, lsub = tid & 3;  // four lanes per landmark in phase 0 (tid < 4 LMAX = R)
+    if (tid < R) {
+        lmj = D.w_lmid[(size_t)g * LMAX + lt];
+        lmr = D.w_lmrow[(size_t)g * LMAX + lt];
+        if (lt > 0) lmprev = D.w_lmrow[(size_t)g * LMAX + lt - 1];
+    }
+    {   // S is rebuilt for every lambda (the factorisation works in place): cleared here, filled by ba_assemble_dense
+        double2* S2 = reinterpret_cast<double2*>(D.T);
+        const size_t total = (size_t)D.sp_ntiles * (PB * PB / 2);
+        for (size_t e = (size_t)blockIdx.x * WIN_TPB + threadIdx.x; e < total; e += (size_t)gridDim.x * WIN_TPB) S2[e] = make_double2(0.0, 0.0);
+    }
+    const int nblk = win_nblk(nc);
+    double* rows = w_lds;
+    double* linv = rows + WIN_ROW * R;
+    double* ptl = linv + 6 * LMAX;
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(ptl + 3 * LMAX);   // [nc + 1] landmarks of the group a camera sees
+    unsigned char* rowtab = reinterpret_cast<unsigned char*>(mask + nc + 1);             // [nc + 1][LMAX] its row of that landmark
+    uint32_t* vis = reinterpret_cast<uint32_t*>(reinterpret_cast<double*>(mask + nc + 1) + ((nc + 1) * LMAX + 7) / 8);  // the visit list of phase B
+    unsigned short* gstart = reinterpret_cast<unsigned short*>(reinterpret_cast<double*>(vis) + (win_visits_max(nc, R) + 1) / 2);  // [WIN_LANE_GROUPS + 1] first visit of a lane group
+    unsigned char* npiece = reinterpret_cast<unsigned char*>(gstart + WIN_LANE_GROUPS + 2);                                        // [2 nc] pieces of a long block
+    double* piece = reinterpret_cast<double*>(gstart) + (2 * (WIN_LANE_GROUPS + 2) + 2 * nc + 7) / 8;                              // [2 nc][WIN_PIECES][42] their sums
+    double* bsum = piece + 42 * WIN_PIECES * 2 * nc;  // [4 (WIN_TPB / 64)][WIN_KK] (+ 8 for the scan below)
+    if (tid <= nc) mask[tid] = 0ull;
+    const bool arow = ri.x >= 0 && ri.x < nc;
+    double xr[12], K[5];
+    {
+        const double* x = D.pose + 12 * (size_t)(arow ? ri.x : 0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) xr[k] = x[k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) K[k] = D.Kc[k];
+    }
+    double lp[3] = {0.0, 0.0, 0.0};
+    if (lmj >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lp[k] = D.pt[3 * (size_t)lmj + k];
+        if (lsub == 0) ptl[3 * lt] = lp[0], ptl[3 * lt + 1] = lp[1], ptl[3 * lt + 2] = lp[2];
+    }
+    __syncthreads();
+#if EXP_WD_STOP == 1  // (knock-outs, timing only: the kernel up to here)
+    return;
+#endif
+    WD_STAMP(1);
+    // ---- A1 ----
+    if (ri.x >= 0) {
+        atomicOr(&mask[ri.x], 1ull << ri.y);  // (bits: any order gives the same word)
+        rowtab[ri.x * LMAX + ri.y] = (unsigned char)tid;
+    }
+    double Ap[12], Al[6];
+    double* rw = rows + WIN_ROW * tid;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Ap[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Al[k] = 0.0;
+    double kk[WIN_KK];
+#pragma unroll
+    for (int k = 0; k < WIN_KK; ++k) kk[k] = 0.0;
+    if (arow) {
+        const double l[3] = {ptl[3 * ri.y], ptl[3 * ri.y + 1], ptl[3 * ri.y + 2]};
+        double Ak[10], b[2];
+        obs_factor(xr, l, K, uv.x, uv.y, D.nz.pix_sigma, D.nz.pix_huber, Ap, Al, Ak, b);
+        double2* r2 = reinterpret_cast<double2*>(rw);
+        r2[0] = double2{Al[0], Al[1]}; r2[1] = double2{Al[2], Al[3]}; r2[2] = double2{Al[4], Al[5]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) r2[3 + k] = double2{Ak[2 * k], Ak[2 * k + 1]};
+        r2[8] = double2{b[0], b[1]};
+#pragma unroll
+        for (int a = 0; a < 6; ++a) r2[9 + a] = double2{Ap[a], Ap[6 + a]};            // Ap^T[a][h]
+#pragma unroll
+        for (int a = 0; a < 5; ++a) r2[15 + a] = double2{Ak[a], Ak[5 + a]};           // Q^T[a][h], a < 5
+        r2[20] = double2{b[0], b[1]};                                                 // Q^T[5][h]
+        // the calibration Hessian: upper triangle (15) and gradient (5)
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int bb = a; bb < 5; ++bb) kk[q++] = Ak[a] * Ak[bb] + Ak[5 + a] * Ak[5 + bb];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) kk[15 + a] = Ak[a] * b[0] + Ak[5 + a] * b[1];
+    }
+    __syncthreads();
+#if EXP_WD_STOP == 2
+    return;
+#endif
+    WD_STAMP(2);
+    // ---- 0 ----
+    if (lmj >= 0) {
+        double rec[LMLIN];
+#pragma unroll
+        for (int k = 0; k < LMLIN; ++k) rec[k] = 0.0;
+        for (int r = lmprev + 1 + lsub; r < lmr; r += 4) {
+            const double2* s2 = reinterpret_cast<const double2*>(rows + WIN_ROW * r);
+            double v[18];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double2 t = s2[k];
+                v[2 * k] = t.x, v[2 * k + 1] = t.y;
+            }
+            const double* al = v;        // Al[h][c] = al[3 h + c]
+            const double* ak = v + 6;    // Ak[h][a] = ak[5 h + a]
+            const double* bv = v + 16;
+            rec[0] += al[0] * al[0] + al[3] * al[3];
+            rec[1] += al[0] * al[1] + al[3] * al[4];
+            rec[2] += al[0] * al[2] + al[3] * al[5];
+            rec[3] += al[1] * al[1] + al[4] * al[4];
+            rec[4] += al[1] * al[2] + al[4] * al[5];
+            rec[5] += al[2] * al[2] + al[5] * al[5];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) rec[6 + a] += al[a] * bv[0] + al[3 + a] * bv[1];
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rec[9 + 3 * a + c] += ak[a] * al[c] + ak[5 + a] * al[3 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < LMLIN; ++k) {  // the four lanes' shares, the same total in all of them (fixed butterfly)
+            rec[k] += dpp_quad_xor1(rec[k]);
+            rec[k] += dpp_quad_xor2(rec[k]);
+        }
+        {   // PriorFactor<Point3>, Robust(Huber(3/obs), Isotropic(1/obs)) — as linearize_landmark
+            const double sg = D.lmprior[2 * (size_t)lmj], kh = D.lmprior[2 * (size_t)lmj + 1];
+            double e[3], n2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                e[a] = (lp[a] - D.pt0[3 * (size_t)lmj + a]) / sg;
+                n2 += e[a] * e[a];
+            }
+            const double sw = sqrt(huber_weight(sqrt(n2), kh)), w = sw / sg;
+            rec[0] += w * w; rec[3] += w * w; rec[5] += w * w;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) rec[6 + a] += w * (-sw * e[a]);
+        }
+        const LmElim le = eliminate_landmark(rec, lambda);
+        if (lsub == 0) {
+        double* lout = D.lmlin + (size_t)LMLIN * lmj;
+#pragma unroll
+        for (int k = 0; k < LMLIN; ++k) lout[k] = rec[k];
+        if (!le.ok) atomicOr(D.flags, 1);
+        double* out = D.lmtry + (size_t)LMLIN * lmj;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = le.m[k], linv[6 * lt + k] = le.m[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[6 + k] = le.gt[k];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) out[9 + k] = le.ek[k];
+        double* lrw = rows + WIN_ROW * lmr;  // Y = [EKt; gt]
+#pragma unroll
+        for (int k = 0; k < 15; ++k) lrw[k] = le.ek[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lrw[15 + k] = le.gt[k];
+        // the landmark's share of block (K, K): EKt EKt^T and EKt gt (the longest sum of the system — every landmark — goes through the
+        // block sum below, not through one lane group of phase B)
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < 5; ++bb)
+                kk[20 + 5 * a + bb] = le.ek[3 * a] * le.ek[3 * bb] + le.ek[3 * a + 1] * le.ek[3 * bb + 1] + le.ek[3 * a + 2] * le.ek[3 * bb + 2];
+            kk[45 + a] = le.ek[3 * a] * le.gt[0] + le.ek[3 * a + 1] * le.gt[1] + le.ek[3 * a + 2] * le.gt[2];
+        }
+        }
+    }
+    __syncthreads();
+#if EXP_WD_STOP == 3
+    return;
+#endif
+    WD_STAMP(3);
+    // ---- A2 ----
+    if (arow) {
+        const double* m = linv + 6 * ri.y;
+        const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
+        double et[18];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double e0 = Ap[a] * Al[0] + Ap[6 + a] * Al[3], e1 = Ap[a] * Al[1] + Ap[6 + a] * Al[4], e2 = Ap[a] * Al[2] + Ap[6 + a] * Al[5];
+            et[3 * a] = m0 * e0;
+            et[3 * a + 1] = m1 * e0 + m2 * e1;
+            et[3 * a + 2] = m3 * e0 + m4 * e1 + m5 * e2;
+        }
+        double2* r2 = reinterpret_cast<double2*>(rw);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r2[k] = double2{et[2 * k], et[2 * k + 1]};
+    }
+    double* part = D.w_part + (size_t)D.w_stride * g;
+    {   // the WIN_KK sums over the workgroup: rows of 16 lanes by DPP shifts, the 16 row sums of a value added by ONE thread in order
+        // (a shuffle tree over the wave for every value — 600 trips through the LDS pipe — was 6.8 us of this kernel)
+#pragma unroll
+        for (int k = 0; k < WIN_KK; ++k) kk[k] = dpp_row_sum<16>(kk[k]);
+        if ((lane & 15) == 15) {
+            double* dst = bsum + WIN_KK * (4 * wave + (lane >> 4));
+#pragma unroll
+            for (int k = 0; k < WIN_KK; ++k) dst[k] = kk[k];
+        }
+        __syncthreads();  // (also puts every Et row in place before phase B)
+        if (tid < WIN_KK) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4 * (WIN_TPB / 64); ++r) t += bsum[WIN_KK * r + tid];
+            part[nblk * 36 + nc * 12 + tid] = t;
+        }
+    }
+#if EXP_WD_STOP == 4
+    return;
+#endif
+    WD_STAMP(4);
+    // ---- B ----
+    // The visits (block, landmark) of the group, block by block — (c, K) | (c, c) | (c1 < c2 < nc): the long sums first —, each
+    // block's landmarks in ascending order: thread = block counts mask[c1] & mask[c2], a scan gives the block's first visit, the
+    // thread writes its visits: rows r1 | r2 << 8, where the sum goes << 16, bit 30 on the last visit of a sum, bit 31 on the first.
+    // The 2 nc blocks of the first two kinds — every landmark that sees camera c: up to 64 visits, and they take the Hessian terms
+    // too — are cut into <= WIN_PIECES pieces of ~WIN_PIECE visits whose sums meet in LDS and are added in piece order after the
+    // loop (as one sum each they WERE the loop: 30 visits in one lane group while the others had six). Lane group l (three lanes:
+    // rows 2p, 2p + 1 of c1 against all six rows of c2, twelve sums per lane) takes the sums whose first visit lies in
+    // [l L, (l + 1) L), L = visits / 168: whole sums, every pass of the loop the same straight code for every lane — a visit's
+    // products, and stores where a sum ends. (Dealt out 28 blocks at a time the longest block of a round was the round's time;
+    // handed out one by one from a counter, the hand-out's dependent LDS trips were: 28 us of 40 either way.)
+    {
+        int* scan = reinterpret_cast<int*>(bsum + 4 * (WIN_TPB / 64) * WIN_KK);  // [WIN_TPB / 64]
+        int c1 = 0, c2 = nc, cnt = 0;
+        unsigned long long bm = 0ull;
+        const int idx = tid;  // (nblk - 1 <= 324 < WIN_TPB)
+        static_assert((WIN_NC_MAX + 1) * (WIN_NC_MAX + 2) / 2 - 1 <= WIN_TPB, "a thread per block");
+        if (idx < nblk - 1) {
+            if (idx < nc) c1 = idx;
+            else if (idx < 2 * nc) c1 = c2 = idx - nc;
+            else {
+                const int q = idx - 2 * nc;  // c2 (c2 - 1) / 2 + c1
+                c2 = (int)((1.0f + sqrtf(8.0f * (float)q + 1.0f)) * 0.5f);
+                while (c2 * (c2 - 1) / 2 > q) --c2;
+                while ((c2 + 1) * c2 / 2 <= q) ++c2;
+                c1 = q - c2 * (c2 - 1) / 2;
+            }
+            bm = mask[c1] & mask[c2];
+            cnt = __popcll(bm);
+        }
+        // exclusive scan of the counts in block order
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) scan[wave] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < WIN_TPB / 64; ++w) {
+            const int sw = scan[w];
+            if (w < wave) base += sw;
+            total += sw;
+        }
+        const int start_a = base + incl - cnt;
+        const int L = (total + WIN_LANE_GROUPS - 1) / WIN_LANE_GROUPS > 0 ? (total + WIN_LANE_GROUPS - 1) / WIN_LANE_GROUPS : 1;
+        WD_STAMP(5);
+        if (idx < nblk - 1) {
+            const int sb = c2 * (c2 + 1) / 2 + c1;
+            const bool heavy = idx < 2 * nc;  // (c, K), (c, c): Hessian terms, pieces
+            const unsigned char *u1 = rowtab + c1 * LMAX, *u2 = rowtab + c2 * LMAX;
+            int np = 1;
+            if (heavy) {
+                np = (cnt + WIN_PIECE - 1) / WIN_PIECE;
+                np = np > WIN_PIECES ? WIN_PIECES : np;
+                npiece[idx] = (unsigned char)np;  // (0: nobody contributes)
+            }
+            unsigned long long mm = bm;
+            int e = 0;
+            for (int q = 0; q < np; ++q) {
+                const int len = cnt / np + (q < cnt % np ? 1 : 0);
+                const uint32_t hi = heavy ? (uint32_t)(WIN_PIECES * idx + q) << 16 | 1u << 29 : (uint32_t)sb << 16;
+                for (int i = 0; i < len; ++i, ++e) {
+                    const int t = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    vis[start_a + e] = (uint32_t)u1[t] | (uint32_t)u2[t] << 8 | hi | (i == len - 1 ? 1u << 30 : 0u) | (i == 0 ? 1u << 31 : 0u);
+                }
+            }
+            if (cnt == 0) {  // nobody contributes: the block is zeros
+                double2* A = reinterpret_cast<double2*>(part + 36 * sb);
+                for (int i = 0; i < 18; ++i) A[i] = double2{0.0, 0.0};
+                if (heavy)
+                    for (int i = 0; i < 6; ++i) part[36 * nblk + 12 * c1 + (c1 == c2 ? 0 : 6) + i] = 0.0;
+            }
+        }
+        __syncthreads();
+        WD_STAMP(6);
+        // first visit of every lane group: the first sum that starts at or behind l L
+        if (tid <= WIN_LANE_GROUPS) {
+            int at = tid * L;
+            at = at < total ? at : total;
+            while (at < total && !(vis[at] >> 31)) ++at;
+            gstart[tid] = (unsigned short)at;
+        }
+        __syncthreads();
+        WD_STAMP(7);
+        const int v = lane / 3, p = lane - 3 * v, grp = 21 * wave + v;  // three lanes per block: rows 2p, 2p + 1 of c1 (lane 63 idles)
+        int pos = 0, end = 0;
+        if (v < 21) pos = gstart[grp], end = gstart[grp + 1];
+        double acc[12], h0 = 0.0, h1 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = 0.0;
+        uint32_t w = pos < end ? vis[pos] : 0u;
+        while (__ballot(pos < end)) {
+            if (pos < end) {
+                const int r1 = (int)(w & 0xffu), r2 = (int)((w >> 8) & 0xffu);
+                const bool hess = (w >> 29) & 1u, diag = r1 == r2, last = (w >> 30) & 1u;
+                const int sb = (int)((w >> 16) & 0x1ffu);  // block of the partial, or (hess) piece in LDS
+                const double2* X2 = reinterpret_cast<const double2*>(rows + WIN_ROW * r1 + 6 * p);
+                const double2* Y2 = reinterpret_cast<const double2*>(rows + WIN_ROW * r2);
+                const double2 x0 = X2[0], x1 = X2[1], x2 = X2[2];
+                double y[18];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const double2 t = Y2[e];
+                    y[2 * e] = t.x, y[2 * e + 1] = t.y;
+                }
+                double2 pa = double2{0.0, 0.0}, pb = pa;
+                double z[12];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) z[e] = 0.0;
+                if (hess) {
+                    const double2* P2 = reinterpret_cast<const double2*>(rows + WIN_ROW * r1 + 18 + 4 * p);
+                    const double2* Z2 = reinterpret_cast<const double2*>(rows + WIN_ROW * r1 + (diag ? 18 : 30));
+                    pa = P2[0], pb = P2[1];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        const double2 t = Z2[e];
+                        z[2 * e] = t.x, z[2 * e + 1] = t.y;
+                    }
+                }
+                ++pos;
+                if (pos < end) w = vis[pos];  // the next visit is looked up under these loads
+                // rows 2p: (x0.x x0.y x1.x), 2p + 1: (x1.y x2.x x2.y) against column b: y[3 b .. 3 b + 2]
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    acc[b] = __builtin_fma(-x1.x, y[3 * b + 2], __builtin_fma(-x0.y, y[3 * b + 1], __builtin_fma(-x0.x, y[3 * b], acc[b])));
+                    acc[6 + b] = __builtin_fma(-x2.y, y[3 * b + 2], __builtin_fma(-x2.x, y[3 * b + 1], __builtin_fma(-x1.y, y[3 * b], acc[6 + b])));
+                }
+                if (hess) {
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        acc[b] = __builtin_fma(pa.y, z[2 * b + 1], __builtin_fma(pa.x, z[2 * b], acc[b]));
+                        acc[6 + b] = __builtin_fma(pb.y, z[2 * b + 1], __builtin_fma(pb.x, z[2 * b], acc[6 + b]));
+                    }
+                    // the Hessian's own diagonal (damping, linearised cost change: elements (2p, 2p), (2p + 1, 2p + 1) of a diagonal
+                    // block) | its gradient (column 5 of (c, K))
+                    const int b0 = diag ? 2 * p : 5, b1 = diag ? 2 * p + 1 : 5;
+                    const double z00 = b0 == 0 ? z[0] : (b0 == 2 ? z[4] : (b0 == 4 ? z[8] : z[10]));
+                    const double z01 = b0 == 0 ? z[1] : (b0 == 2 ? z[5] : (b0 == 4 ? z[9] : z[11]));
+                    const double z10 = b1 == 1 ? z[2] : (b1 == 3 ? z[6] : z[10]);
+                    const double z11 = b1 == 1 ? z[3] : (b1 == 3 ? z[7] : z[11]);
+                    h0 = __builtin_fma(pa.y, z01, __builtin_fma(pa.x, z00, h0));
+                    h1 = __builtin_fma(pb.y, z11, __builtin_fma(pb.x, z10, h1));
+                }
+                if (last) {  // the sum is complete: its twelve values of this lane — to the partial, or to its piece —, and start the next one
+                    double2* A = reinterpret_cast<double2*>(hess ? piece + 42 * sb + 12 * p : part + 36 * sb + 12 * p);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) A[e] = double2{acc[2 * e], acc[2 * e + 1]};
+                    if (hess) *reinterpret_cast<double2*>(piece + 42 * sb + 36 + 2 * p) = double2{h0, h1};
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) acc[e] = 0.0;
+                    h0 = h1 = 0.0;
+                }
+            }
+        }
+        WD_STAMP(8);
+#ifdef EXP_WD_STAMPS
+        if (lane == 0 && blockIdx.x == 0) atomicMax(&g_wd_stamp[14], wall_clock64());  // the last wave of workgroup 0 out of the loop
+#endif
+        __syncthreads();
+        // the pieces of the long blocks, in piece order -> the partial
+        for (int e = tid; e < 2 * nc * 42; e += WIN_TPB) {
+            const int hb = e / 42, el = e - 42 * hb, np = npiece[hb];
+            if (np == 0) continue;
+            double t = 0.0;
+            for (int q = 0; q < np; ++q) t += piece[42 * (WIN_PIECES * hb + q) + el];
+            const int c = hb < nc ? hb : hb - nc, sb = hb < nc ? nc * (nc + 1) / 2 + c : c * (c + 1) / 2 + c;
+            if (el < 36) part[36 * sb + el] = t;
+            else part[36 * nblk + 12 * c + (hb < nc ? 6 : 0) + (el - 36)] = t;
+        }
+        __syncthreads();
+        WD_STAMP(9);
+    }
+}
+
+// Sum of the groups' partials of ba_schur_dense, the priors and the damping -> the tiles of S; SIXTEEN lanes per element of a block
+// (each adds every sixteenth group, the sums are folded by a fixed butterfly: a thread that walked all ~64 groups alone was the
+// launch's time). Also leaves what the step's tail reads of the linearisation: the cameras' Hessian diagonal and gradient (camlin),
+// the calibration's (klin) — with their priors, as finish_linearize_block leaves them in the other forms.
+constexpr int WIN_ASM_LANES = 16;
+__global__ __launch_bounds__(TPB) void ba_assemble_dense(BaDev D, double lambda, unsigned n_el_blocks) {
+    if (blockIdx.x >= n_el_blocks) {
+        assemble_border(D, lambda, D.nc + 1);  // identity on the padding columns, the pivot of the right-hand-side row
+        return;
+    }
+    const int nc = D.nc, nblk = win_nblk(nc), gid = (int)blockIdx.x * TPB + (int)threadIdx.x;
+    const int sub = gid % WIN_ASM_LANES;
+    const bool valid = gid / WIN_ASM_LANES < nblk * 36;
+    const int e = valid ? gid / WIN_ASM_LANES : 0;
+    const int blk = e / 36, el = e - 36 * blk, a = el / 6, b = el - 6 * a;
+    int c2 = (int)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+    while ((c2 + 1) * (c2 + 2) / 2 <= blk) ++c2;
+    while (c2 * (c2 + 1) / 2 > blk) --c2;
+    const int c1 = blk - c2 * (c2 + 1) / 2;
+    // the element's second sum: the Hessian's own part where the damping / the step's linearised cost need it apart from the Schur term
+    const int hbase = 36 * nblk, kbase = hbase + 12 * nc;
+    int off1 = e, off2 = e;
+    if (c2 < nc) {
+        if (c1 == c2 && a == b) off2 = hbase + 12 * c1 + a;
+    } else if (c1 < nc) {
+        if (b == 5) off2 = hbase + 12 * c1 + 6 + a;
+    } else if (a < 5) {
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        off2 = b < 5 ? kbase + 5 * lo - lo * (lo - 1) / 2 + (hi - lo) : kbase + 15 + a;
+        off1 = b < 5 ? kbase + 20 + 5 * a + b : kbase + 45 + a;  // the block's Schur sums came through the groups' block sums (positive)
+    }
+    // everything the placement needs is requested before the sums: column positions, and the camera's pose where its prior enters
+    const bool writer = valid && sub == 0;
+    const bool prior = writer && c1 < nc && ((c1 == c2 && a == b) || (c2 == nc && b == 5));
+    const int pos1 = D.sp_pos[c1 < nc ? c1 : 0], pos2 = D.sp_pos[c2 < nc ? c2 : 0];
+    double x[12], x0[12];
+    int fixedc = 0;
+    if (prior) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) x[k] = D.pose[12 * (size_t)c1 + k], x0[k] = D.pose0[12 * (size_t)c1 + k];
+        fixedc = D.fixed[c1];
+    }
+    const size_t stride = (size_t)D.w_stride;
+    const int ng = D.w_ngroups;
+    double s = 0.0, s2 = 0.0;
+    {
+        const double* p1 = D.w_part + off1;
+        const double* p2 = D.w_part + off2;
+        for (int k = sub; k < ng; k += 4 * WIN_ASM_LANES) {  // eight loads in flight
+            double v[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = k + i * WIN_ASM_LANES;
+                v[i] = kk < ng ? p1[stride * (size_t)kk] : 0.0;
+                w[i] = kk < ng ? p2[stride * (size_t)kk] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += v[i], s2 += w[i];
+        }
+#pragma unroll
+        for (int d = 1; d < WIN_ASM_LANES; d <<= 1) s += __shfl_xor(s, d), s2 += __shfl_xor(s2, d);
+    }
+    if (!writer) return;
+    if (c1 == nc) s = -s;
+    double pd = 0.0, pr = 0.0;
+    if (prior) {
+        // PriorFactor<Pose3>: e = -Local(x, prior), H = I; Robust(Huber 2.5) unless the node is fixed (finish_linearize_block)
+        double xi[6], n2 = 0.0;
+        pose_local(x, x0, xi);
+        const bool fx = fixedc != 0;
+        const double* sg = fx ? D.nz.fixed_sigma : D.nz.pose_sigma;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) n2 += (xi[k] / sg[k]) * (xi[k] / sg[k]);
+        const double sw = fx ? 1.0 : sqrt(huber_weight(sqrt(n2), D.nz.pose_huber));
+        pd = (sw / sg[a]) * (sw / sg[a]);
+        pr = (sw / sg[a]) * (-sw * (-xi[a] / sg[a]));
+    }
+    if (c2 < nc) {  // camera block
+        double v = s;
+        if (c1 == c2 && a == b) {
+            const double hd = s2 + pd;
+            v += pd + lambda * clampd(hd, 1e-6, 1e32);
+            D.camlin[(size_t)CAMLIN * c1 + 7 * a] = hd;
+        }
+        const int r = pos1 + a, q = pos2 + b;
+        sp_store(D, r, q, v);
+        if (c1 != c2) sp_store(D, q, r, v);
+    } else if (c1 < nc) {  // (c, K): border | right-hand side of camera c
+        if (b < 5) {
+            sp_store(D, pos1 + a, D.sp_posK + b, s);
+            sp_store(D, D.sp_posK + b, pos1 + a, s);
+        } else {
+            sp_store(D, D.sp_rhs_row, pos1 + a, s + pr);
+            D.camlin[(size_t)CAMLIN * c1 + 66 + a] = s2 + pr;
+        }
+    } else if (a < 5) {  // (K, K): K corner | right-hand side of K
+        if (b < 5) {
+            double h = s2;
+            if (a == b) h += 1.0 / (D.nz.k_sigma[a] * D.nz.k_sigma[a]);
+            double v = s + h;
+            if (a == b) {
+                v += lambda * clampd(h, 1e-6, 1e32);
+                D.klin[6 * a] = h;
+            }
+            sp_store(D, D.sp_posK + a, D.sp_posK + b, v);
+        } else {
+            const double gk = s2 + (1.0 / D.nz.k_sigma[a]) * (-(D.Kc[a] - D.K0[a]) / D.nz.k_sigma[a]);
+            sp_store(D, D.sp_rhs_row, D.sp_posK + a, s + gk);
+            D.klin[25 + a] = gk;
+        }
+    }
+}
+
 // ---- K-E: the building blocks of the factorisation of a 64x64 diagonal tile -------------------------------------------
 // (factor_32: one wave factorises a 32x32 block in MFMA accumulators; invert_behind_factor: a second wave inverts the
 // factor right behind it.) The sparse, level-scheduled factorisation that uses them follows further down (sp_diag /
@@ -1835,24 +2410,6 @@ __global__ __launch_bounds__(TPB, 2) void sp_level(double* __restrict__ T, const
     __shared__ __attribute__((aligned(16))) double lds[2 * 64 * LS2];
     if ((int)blockIdx.x < n_first) sp_level_item<true>(lds, T, items, srcs, Winv, Wops, Xrow, flags);
     else sp_level_item<false>(lds, T, items, srcs, Winv, Wops, Xrow, flags);
-}
-
-// sum of v over aligned groups of W lanes inside a 16-lane DPP row; valid in each group's last lane
-template <int W>
-__device__ __forceinline__ double dpp_row_sum(double v) {
-    static_assert(W == 8 || W == 16, "row_shr steps 1, 2, 4 (, 8)");
-#define EACHAM_DPP_STEP(ctrl)                                                                       \
-    {                                                                                               \
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);     \
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);     \
-        v += __hiloint2double(hi, lo);                                                              \
-    }
-    EACHAM_DPP_STEP(0x111)  // row_shr:1
-    EACHAM_DPP_STEP(0x112)  // row_shr:2
-    EACHAM_DPP_STEP(0x114)  // row_shr:4
-    if (W == 16) EACHAM_DPP_STEP(0x118)  // row_shr:8
-#undef EACHAM_DPP_STEP
-    return v;
 }
 
 // Back-substitution on the elimination tree, ONE launch: workgroup b solves panel J = order[b] (root first, a panel
@@ -2916,6 +3473,17 @@ static int ba_upload_groups(eacham_ctx* ctx, eacham_ba_handle* h, const BaGroups
     TRY(dev_upload(ctx, h, &D.g_longblk, GR.longblk));
     return EACHAM_OK;
 }
+static int ba_upload_window(eacham_ctx* ctx, eacham_ba_handle* h, const BaWin& WN) {
+    BaDev& D = h->D;
+    D.w_rows = WN.rows; D.w_ngroups = (int)WN.groups.size(); D.w_stride = WN.rows ? win_stride(D.nc) : 0;
+    if (WN.rows == 0) return EACHAM_OK;
+    TRY(dev_upload_as(ctx, h, &D.w_groups, WN.groups));
+    TRY(dev_upload_as(ctx, h, &D.w_rowinfo, WN.rowinfo));
+    TRY(dev_upload(ctx, h, &D.w_uv, WN.uv));
+    TRY(dev_upload(ctx, h, &D.w_lmid, WN.lmid));
+    TRY(dev_upload(ctx, h, &D.w_lmrow, WN.lmrow));
+    return EACHAM_OK;
+}
 static int ba_alloc_work_a(eacham_ctx* ctx, eacham_ba_handle* h) {
     BaDev& D = h->D;
     const int nc = D.nc, nl = D.nl, no = D.no;
@@ -2972,6 +3540,14 @@ static int ba_alloc_work_b(eacham_ctx* ctx, eacham_ba_handle* h) {
     TRY(dev_alloc(ctx, h, &D.Wops, (size_t)plan.npan * TILE_OPS));      // W_a, W_b, X of every panel in MFMA operand order
     TRY(dev_alloc(ctx, h, &D.zsol, (size_t)plan.npan * PB));
     TRY(dev_alloc(ctx, h, &D.partial, (size_t)36 * std::max(D.g_rows > 0 ? D.g_nparts : D.n_chunks, 1)));
+    TRY(dev_alloc(ctx, h, &D.w_part, (size_t)D.w_stride * std::max(D.w_ngroups, 1)));
+    if (!h->planning && D.w_rows > 0) {
+        EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.lmtry, 0, sizeof(double) * LMLIN * (size_t)D.nl, ctx->stream));  // (landmarks without observations)
+        if (!ctx->ba_dense_lds_set) {
+            EACHAM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)ba_schur_dense, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->ba_dense_lds_set = true;
+        }
+    }
     if (!h->planning && D.g_rows > 0) {
         // landmarks without observations are never visited by ba_schur_groups and keep a zero record
         EACHAM_HIP_TRY(ctx, hipMemsetAsync(D.lmtry, 0, sizeof(double) * LMLIN * (size_t)D.nl, ctx->stream));
@@ -2992,7 +3568,7 @@ static int ba_alloc_work_b(eacham_ctx* ctx, eacham_ba_handle* h) {
 // The structure built by host loops (the round-1..3 form): what a local window of a few thousand observations still uses —
 // a dozen dependent launches and three read-backs cost more than these loops on a problem that small — and the reference
 // the device-built structure is held against bit for bit (EACHAM_BA_PREPARE=host|device forces either form).
-static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
+static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out, bool allow_dense) {
     if (!P || P->n_cams < 0 || P->n_points < 0 || P->n_obs < 0) return ctx->fail(EACHAM_ERR_INVALID, "bad BA problem");
     const int nc = P->n_cams, nl = P->n_points, no = P->n_obs;
     if (no > 0 && (!P->obs_cam || !P->obs_point || !P->obs_uv)) return ctx->fail(EACHAM_ERR_INVALID, "null observation arrays");
@@ -3057,13 +3633,17 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         cam_uv[2 * (size_t)p + 1] = obs_uv[2 * (size_t)cam_obs[p] + 1];
     }
     // ---- the landmark-major structure of the Schur stage (ba_groups.hpp); the pair lists below only when it does not apply ----
+    // ---- the dense form for a local window (ba_window.hpp): its structure is these rows and nothing else ----
+    BaWin WN;
+    const bool use_dense = allow_dense && build_window(nc, nl, lm_ptr.data(), obs_cam.data(), obs_uv.data(), WN, ctx->ba_window_rows);
     BaGroups& GR = h->groups;
-    const bool use_groups = ctx->ba_schur_mode == 1 && build_groups(nc, nl, lm_ptr.data(), obs_cam.data(), obs_uv.data(), GR, ctx->ba_group_rows);
+    const bool use_groups = !use_dense && ctx->ba_schur_mode == 1 && build_groups(nc, nl, lm_ptr.data(), obs_cam.data(), obs_uv.data(), GR, ctx->ba_group_rows);
     if (!use_groups) GR = BaGroups();
     // ---- camera-pair lists of the Schur complement: block (c <= c') -> (o, o') pairs, landmark order ----
     // (two passes over every observation pair of every landmark — count, then fill: this loop is most of the host time of
     // preparing a local window, hence the flat 32-bit index arithmetic; entries are written as Et positions directly)
-    const long long nblk_all = use_groups ? 0 : (long long)nc * (nc + 1) / 2;
+    const bool use_pairs = !use_groups && !use_dense;
+    const long long nblk_all = use_pairs ? (long long)nc * (nc + 1) / 2 : 0;
     if (nblk_all > 0x7fffffffLL) {
         delete h;
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "too many cameras (%d) for the camera-block index", nc);
@@ -3072,7 +3652,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
     for (int c = 0; c < nc; ++c) rowoff[c] = (int)((long long)c * nc - (long long)c * (c - 1) / 2 - c);
     auto bid = [&](int c, int c2) { return rowoff[c] + c2; };
     std::vector<int> bcount((size_t)nblk_all + 1, 0);
-    if (!use_groups) {
+    if (use_pairs) {
         const unsigned* oc = obs_cam.data();
         int* bc = bcount.data() + 1;
         for (int j = 0; j < nl; ++j) {
@@ -3097,7 +3677,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         return ctx->fail(EACHAM_ERR_UNSUPPORTED, "Schur pair list too large (%lld entries)", n_entries);
     }
     std::vector<int2> entries((size_t)n_entries);
-    if (!use_groups) {
+    if (use_pairs) {
         std::vector<int> pos((size_t)nblk_all);
         for (long long b = 0; b < nblk_all; ++b) pos[b] = (int)bstart[b];
         const unsigned* oc = obs_cam.data();
@@ -3123,7 +3703,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         }
     }
     std::vector<int4> chunks, blocks;
-    for (int c = 0; c < (use_groups ? 0 : nc); ++c)
+    for (int c = 0; c < (use_pairs ? nc : 0); ++c)
         for (int c2 = c; c2 < nc; ++c2) {
             const long long b = bid(c, c2);
             const long long cnt = bstart[b + 1] - bstart[b];
@@ -3146,6 +3726,9 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
             if (b.x != b.y) cam_edges.emplace_back(b.x, b.y);
         for (const GrpI4& b : GR.blk)
             if (b.x != b.y && b.y < nc) cam_edges.emplace_back(b.x, b.y);
+        if (use_dense)  // every block is kept: the cameras of a window all share landmarks with the current frame
+            for (int c = 0; c < nc; ++c)
+                for (int c2 = c + 1; c2 < nc; ++c2) cam_edges.emplace_back(c, c2);
         int hint = P->ordering;
         if (hint == EACHAM_BA_ORDER_AUTO && ctx->ba_ordering != EACHAM_BA_ORDER_AUTO) hint = ctx->ba_ordering;
         if (hint < EACHAM_BA_ORDER_AUTO || hint > EACHAM_BA_ORDER_ND) {
@@ -3210,6 +3793,7 @@ static int ba_prepare_host(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_b
         TRY(dev_upload(ctx, h, &D.pair_chunks, chunks));
         TRY(dev_upload(ctx, h, &D.blocks, blocks));
         TRY(ba_upload_groups(ctx, h, GR));
+        TRY(ba_upload_window(ctx, h, WN));
         TRY(ba_upload_plan(ctx, h, plan, bs_ent));
         TRY(ba_alloc_work_a(ctx, h));
         TRY(ba_alloc_work_b(ctx, h));
@@ -4527,7 +5111,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     return EACHAM_OK;
 }
 
-static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out) {
+static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_handle** out, bool lm_direct = false) {
     if (!P || P->n_cams < 0 || P->n_points < 0 || P->n_obs < 0) return ctx->fail(EACHAM_ERR_INVALID, "bad BA problem");
     if (P->n_obs > 0 && (!P->obs_cam || !P->obs_point || !P->obs_uv)) return ctx->fail(EACHAM_ERR_INVALID, "null observation arrays");
     if ((P->n_cams > 0 && (!P->cam_T_wc || !P->cam_fixed)) || (P->n_points > 0 && (!P->points || !P->point_observers)))
@@ -4535,7 +5119,12 @@ static int ba_prepare(eacham_ctx* ctx, const eacham_ba_problem* P, eacham_ba_han
     // a local window (the reference's per-frame call, ~10 k observations) is cheaper through the host loops: the device
     // construction is ~45 dependent launches and three read-backs whatever the size
     const bool device = ctx->ba_prepare_mode == 2 || (ctx->ba_prepare_mode == 0 && P->n_obs >= 65536);
-    return device ? ba_prepare_device(ctx, P, out) : ba_prepare_host(ctx, P, out);
+    // the dense form of the Schur stage (ba_window.hpp) is a measured alternative, not the default: EACHAM_BA_SCHUR=dense selects it
+    // (it carries the direct Levenberg-Marquardt solve only). On the 19-camera windows of the TUM stand-in its one launch takes
+    // 39 us where ba_linearize + ba_eliminate + ba_schur_pairs take 28 (profiles/r05_ba_windows_dense_form.txt).
+    (void)lm_direct;
+    const bool allow_dense = ctx->ba_schur_mode == 3;
+    return device ? ba_prepare_device(ctx, P, out) : ba_prepare_host(ctx, P, out, allow_dense);
 }
 
 static void ba_release(eacham_ctx* ctx, eacham_ba_handle* h) {
@@ -4619,7 +5208,11 @@ static int launch_try(eacham_ctx* ctx, eacham_ba_handle* h, double lambda, doubl
         ProfileScope ps(ctx, EACHAM_KERNEL_BA_SCHUR);
         const int n_finish = h->finish_pending ? KLIN + D.nc : 0;
         h->finish_pending = false;
-        if (D.g_rows > 0) {  // landmark groups: elimination, Et (in LDS) and the pair products in one launch
+        if (D.w_rows > 0) {  // a local window: from the values to the groups' dense partials in one launch, then their sum
+            ba_schur_dense<<<D.w_ngroups, WIN_TPB, win_lds_bytes(D.nc, D.w_rows), ctx->stream>>>(D, lambda);
+            const unsigned neb = (unsigned)((win_nblk(D.nc) * 36 * WIN_ASM_LANES + TPB - 1) / TPB);
+            ba_assemble_dense<<<neb + 1, TPB, 0, ctx->stream>>>(D, lambda, neb);
+        } else if (D.g_rows > 0) {  // landmark groups: elimination, Et (in LDS) and the pair products in one launch
             if (D.g_rows <= TPB) ba_schur_groups<1><<<std::max(D.g_ngroups, 1) + n_finish, TPB, schur_groups_lds_bytes(D.g_rows), ctx->stream>>>(D, lambda, h->kpart, n_finish);
             else ba_schur_groups<2><<<std::max(D.g_ngroups, 1) + n_finish, TPB, schur_groups_lds_bytes(D.g_rows), ctx->stream>>>(D, lambda, h->kpart, n_finish);
             const unsigned nbg = (unsigned)((D.g_nblk + ASM_TPB / 64 - 1) / (ASM_TPB / 64));  // a wave per block
@@ -4762,6 +5355,8 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
     // use_preconditioner (BundleAdjuster.cpp:192-200) selects GTSAM's iterative solve, PCG + block-Jacobi at 1e-10, for
     // the LM steps (the option sits inside the LM branch of the reference: DogLeg never sees it)
     const bool pcg = O->method == EACHAM_BA_LM && O->use_preconditioner != 0;
+    if (D.w_rows > 0 && (pcg || O->method == EACHAM_BA_DOGLEG))
+        return ctx->fail(EACHAM_ERR_INVALID, "this problem was prepared for the direct Levenberg-Marquardt solve only (EACHAM_BA_SCHUR=dense)");
     long long pcg_iterations = 0;
     D.store_E = (O->method == EACHAM_BA_DOGLEG || pcg) ? 1 : 0;  // the dog-leg forms and the PCG operator read E after the linearisation
 
@@ -4886,7 +5481,7 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
     } else if (error > errorTol && iterations < O->max_iter) {
         for (;;) {  // NonlinearOptimizer::defaultOptimize
             currentError = newErrorOuter;
-            launch_linearize(ctx, h);  // iterate(): linearize once, then tryLambda until it returns true
+            if (D.w_rows == 0) launch_linearize(ctx, h);  // iterate(): linearize once, then tryLambda until it returns true (the dense form linearises inside the try)
             for (;;) {
                 bool success = false, stop = false;
                 double newError = INFINITY, linChange = NAN, fidelity = 0.0;
@@ -4946,6 +5541,23 @@ static int ba_run(eacham_ctx* ctx, eacham_ba_handle* h, const eacham_ba_options*
             if (!(iterations < O->max_iter) || converged || !std::isfinite(currentError)) break;
         }
     }
+#ifdef EXP_WD_STAMPS
+    if (D.w_rows > 0) {
+        unsigned long long st[16] = {0};
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(eacham::g_wd_stamp), sizeof(st));
+        fprintf(stderr, "[wd stamps, us]");
+        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %d:%.2f", i, (double)(st[i] - st[i - 1]) * 0.01);
+        fprintf(stderr, " 9:%.2f wg0-all-waves-out-of-loop-after-7:%.2f", (double)(st[9] - st[8]) * 0.01, (double)(st[14] - st[7]) * 0.01);
+        fprintf(stderr, " | over the workgroups of the last launch: first start -> last at 4: %.2f, at 7: %.2f, at 8: %.2f\n", (double)(st[13] - st[10]) * 0.01,
+                (double)(st[12] - st[10]) * 0.01, (double)(st[11] - st[10]) * 0.01);
+        {
+            unsigned long long init[16] = {0};
+            init[10] = ~0ull;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(eacham::g_wd_stamp), init, sizeof(init));
+        }
+    }
+#endif
     R->status = indeterminate ? EACHAM_BA_INDETERMINATE : EACHAM_BA_DONE;
     R->final_error = error;
     R->final_lambda = lambda;
@@ -5042,6 +5654,12 @@ int eacham_ba_debug_structure(eacham_ctx* ctx, const eacham_ba_handle* h, int wh
         case 27: src = D.g_laneinfo; bytes = D.g_rows ? sizeof(uint32_t) * 64 * (size_t)D.g_nchunks : 0; break;
         case 28: src = D.g_blk; bytes = D.g_rows ? sizeof(int4) * (size_t)D.g_nblk : 0; break;
         case 29: src = D.g_longblk; bytes = D.g_rows ? sizeof(int) * (size_t)D.g_nlong : 0; break;
+        // the dense form for a local window (ba_window.hpp); empty when another form serves
+        case 30: src = D.w_groups; bytes = D.w_rows ? sizeof(int2) * (size_t)D.w_ngroups : 0; break;
+        case 31: src = D.w_lmid; bytes = D.w_rows ? sizeof(int) * (size_t)D.w_ngroups * (D.w_rows / 4) : 0; break;
+        case 32: src = D.w_lmrow; bytes = D.w_rows ? sizeof(int) * (size_t)D.w_ngroups * (D.w_rows / 4) : 0; break;
+        case 33: src = D.w_rowinfo; bytes = D.w_rows ? sizeof(int2) * (size_t)D.w_ngroups * D.w_rows : 0; break;
+        case 34: src = D.w_uv; bytes = D.w_rows ? sizeof(double) * 2 * (size_t)D.w_ngroups * D.w_rows : 0; break;
         default: return ctx->fail(EACHAM_ERR_INVALID, "unknown structure array %d", which);
     }
     *out_bytes = (int64_t)bytes;
@@ -5056,7 +5674,8 @@ int eacham_ba_solve(eacham_ctx* ctx, const eacham_ba_problem* problem, const eac
     std::lock_guard<std::mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
     eacham_ba_handle* h = nullptr;
-    int rc = ba_prepare(ctx, problem, &h);
+    const bool lm_direct = options && options->method == EACHAM_BA_LM && options->use_preconditioner == 0;
+    int rc = ba_prepare(ctx, problem, &h, lm_direct);
     if (rc) return rc;
     rc = ba_run(ctx, h, options, result);
     ba_release(ctx, h);

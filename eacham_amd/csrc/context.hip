@@ -265,7 +265,11 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
         if (v == 1 || v == 2 || v == 4 || v == 8) ctx->ba_lpl_lin = v;
     }
     if (const char* m = getenv("EACHAM_BA_PREPARE")) ctx->ba_prepare_mode = !strcmp(m, "host") ? 1 : !strcmp(m, "device") ? 2 : 0;
-    if (const char* m = getenv("EACHAM_BA_SCHUR")) ctx->ba_schur_mode = !strcmp(m, "pairs") ? 2 : !strcmp(m, "groups") ? 1 : 0;
+    if (const char* m = getenv("EACHAM_BA_SCHUR")) ctx->ba_schur_mode = !strcmp(m, "pairs") ? 2 : !strcmp(m, "groups") ? 1 : !strcmp(m, "dense") ? 3 : 0;
+    if (const char* r = getenv("EACHAM_BA_WINDOW_ROWS")) {
+        const int v = atoi(r);
+        if (v >= 64 && v <= 256 && v % 4 == 0) ctx->ba_window_rows = v;
+    }
     if (const char* r = getenv("EACHAM_BA_GROUP_ROWS")) {
         const int v = atoi(r);
         if (v >= 16 && v <= 512 && v % 4 == 0) ctx->ba_group_rows = v;

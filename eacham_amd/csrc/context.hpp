@@ -113,11 +113,14 @@ struct eacham_ctx {
     float stream2_lead_ms = -1.f;    // how long before the spin's end the probe on it finished (> 0.010: a hardware queue of its own)
     bool io_busy = false;            // an IoPack call has not reached its finish(): copies out of the pinned mirror may be in flight
     bool ba_groups_lds_set = false;  // ba_schur_groups has been granted its dynamic LDS size on this context's device
+    bool ba_dense_lds_set = false;   // the same for ba_schur_dense
+    int ba_window_rows = 0;   // EACHAM_BA_WINDOW_ROWS=<n> (diagnostic): rows per group of the dense form instead of ba_window.hpp's choice
     int ba_group_rows = 0;    // EACHAM_BA_GROUP_ROWS=<n> (diagnostic): rows per landmark group instead of ba_groups.hpp's choice
-    int ba_schur_mode = 0;    // EACHAM_BA_SCHUR=groups|pairs (diagnostic / tests). 0 = by problem size: the landmark groups of ba_groups.hpp for the
+    int ba_schur_mode = 0;    // EACHAM_BA_SCHUR=groups|pairs|dense (diagnostic / tests). 0 = by problem size: the landmark groups of ba_groups.hpp for the
                               // problems eacham_ba_prepare builds on the device, the pair lists of rounds 1-4 (ba_schur_pairs) for the
                               // small ones it builds with host loops (a local window: building the group structure on the host costs
-                              // more than the 13 us per LM iteration it saves there); 1 = groups whenever they apply, 2 = always pairs
+                              // more than the 13 us per LM iteration it saves there); 1 = groups whenever they apply, 2 = always pairs,
+                              // 3 = the dense form of ba_window.hpp wherever it applies (by default: eacham_ba_solve with the direct LM solve)
     int ba_ordering = 0;  // EACHAM_BA_ORDERING=natural|rcm|nd read ONCE at eacham_ctx_create (diagnostic override of
                           // eacham_ba_problem.ordering == AUTO); nothing on the solve path reads the environment
     int ba_lpl_lin = 0;             // EACHAM_BA_LPL_LIN=1|2|4|8 (diagnostic: lanes per landmark of the linearisation), read at create

@@ -447,6 +447,74 @@ def test_both_forms_of_the_schur_stage_solve_the_same_system(hip_ctx, prepare):
         assert rel(o.points, outs[0].points) < 1e-9 and rel(o.cam_T_wc, outs[0].cam_T_wc) < 1e-9
 
 
+def test_the_dense_form_of_a_local_window_solves_the_same_system(hip_ctx):
+    """The dense form of the Schur stage for a local window (csrc/ba_window.hpp, EACHAM_BA_SCHUR=dense: a workgroup forms its share
+    of EVERY block of the reduced system straight from the values, no linearisation launch and no pair lists; measured slower than
+    the pair lists on the TUM stand-in's windows, hence not the default): the reduced system, the step and whole LM runs agree
+    with the oracle and with the pair-list form to rounding, whatever the group size; the structure is the one ba_window.hpp
+    defines; a problem the form does not cover (a camera seeing a landmark twice, more than 24 cameras, DogLeg) takes the pair lists."""
+    scene = synth.make_scene(60, 4000, 8, seed=5, pixel_noise=1.0)
+    W = synth.local_window(scene, 30, max_neighbours=18)
+    A = ba.BaArrays.from_scene(W)
+    A.obs_uv[::17] += 25.0
+    assert A.cam_T_wc.shape[0] == 19
+    cfg = ba.OptimizerConfig.refine_ba()
+    ref = O.ba_solve(A, cfg)
+    So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
+    outs = []
+    for env in [dict(EACHAM_BA_SCHUR="pairs"), dict(EACHAM_BA_SCHUR="dense"), dict(EACHAM_BA_SCHUR="dense", EACHAM_BA_WINDOW_ROWS="64"),
+                dict(EACHAM_BA_SCHUR="dense", EACHAM_BA_WINDOW_ROWS="256"), dict()]:
+        ctx = _ctx_with(**env)
+        try:
+            if env.get("EACHAM_BA_SCHUR") == "dense":
+                pb = ba.PreparedBA(ctx, A)
+                groups, lmid = pb.structure("w_groups").reshape(-1, 2), pb.structure("w_lmid")
+                rows = len(pb.structure("w_rowinfo")) // (2 * len(groups))
+                assert rows == int(env.get("EACHAM_BA_WINDOW_ROWS", rows)) and groups[:, 1].max() <= rows and groups[:, 0].max() <= rows // 4
+                ri = pb.structure("w_rowinfo").reshape(len(groups), rows, 2)
+                used = np.unique(A.obs_point)
+                assert np.array_equal(lmid[lmid >= 0], used) and len(pb.structure("blocks")) == 0   # every landmark once, in order; no pair lists
+                assert groups[:, 1].sum() == len(A.obs_cam) + len(used) and (ri[:, :, 0] == 19).sum() == len(used)
+                for g in range(len(groups)):   # a landmark's rows: ascending cameras, then its own row
+                    cams = ri[g, :groups[g, 1], 0]
+                    assert ((np.diff(cams) > 0) | (cams[:-1] == 19)).all() and cams[-1] == 19 and (ri[g, groups[g, 1]:, 0] == -1).all()
+                with pytest.raises(EachamError):   # the form carries the direct LM solve only
+                    pb.run(ba.OptimizerConfig(method="DogLeg", maxIter=5, maxTolerance=1e-5, delta=1.0, usePreconditioner=False))
+                pb.close()
+            if env:
+                S, g, dc, dl, err, lin = ba.debug_step(ctx, A, 1e-3)
+                assert rel(S, So) < 1e-11 and rel(g, go) < 1e-11 and rel(dc, dco) < 1e-8 and rel(dl, dlo) < 1e-8
+                assert np.isclose(err, erro, rtol=1e-12) and np.isclose(lin, lino, rtol=1e-9)
+            out = ba.RefineBA(ctx, A, cfg)
+            assert (out.outer_iterations, out.inner_iterations) == (ref.outer_iterations, ref.inner_iterations)
+            assert np.array_equal(out.trace[:, 3:], ref.trace[:, 3:]) and np.allclose(out.trace[:, :2], ref.trace[:, :2], rtol=1e-6)
+            assert rel(out.cam_T_wc, ref.cam_T_wc) < 1e-7 and rel(out.points, ref.points) < 1e-7 and rel(out.K, ref.K) < 1e-9
+            again = ba.RefineBA(ctx, A, cfg)     # and bit for bit from run to run
+            assert np.array_equal(out.points, again.points) and np.array_equal(out.cam_T_wc, again.cam_T_wc) and np.array_equal(out.trace, again.trace)
+            outs.append(out)
+        finally:
+            ctx.close()
+    for o in outs[1:]:
+        assert rel(o.points, outs[0].points) < 1e-9 and rel(o.cam_T_wc, outs[0].cam_T_wc) < 1e-9
+    assert np.array_equal(outs[0].points, outs[4].points)   # the default is the pair lists
+    # not covered: a camera that sees a landmark twice, 27 cameras — the pair lists serve (DogLeg on a dense handle is refused, above)
+    B = ba.BaArrays.from_scene(W)
+    B.obs_cam = np.append(B.obs_cam, B.obs_cam[0]).astype(np.uint32)
+    B.obs_point = np.append(B.obs_point, B.obs_point[0]).astype(np.uint32)
+    B.obs_uv = np.vstack([B.obs_uv, B.obs_uv[:1] + 0.5])
+    bref = O.ba_solve(B, cfg)
+    ctx = _ctx_with(EACHAM_BA_SCHUR="dense")
+    try:
+        for arrays in (B, ba.BaArrays.from_scene(synth.local_window(scene, 30, min_shared=3, max_neighbours=26))):
+            pb = ba.PreparedBA(ctx, arrays)
+            assert len(pb.structure("w_groups")) == 0 and len(pb.structure("blocks")) > 0
+            pb.close()
+        bout = ba.RefineBA(ctx, B, cfg)
+        assert bout.inner_iterations == bref.inner_iterations and rel(bout.points, bref.points) < 1e-7
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("prepare", ["host", "device"])
 def test_a_landmark_too_heavy_for_a_group_takes_the_pair_lists(prepare):
     """A landmark seen by 90 of 100 cameras has 4186 entries: more than a 128-row group may hold (2048). The problem then keeps
