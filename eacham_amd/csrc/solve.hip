@@ -543,13 +543,14 @@ __device__ static int essential5_wave(const double* p1, const double* p2, bool h
     return n;
 }
 
-/* least squares min |A x - b| for a 6 x C system (C <= 5), Householder QR on a copy, every loop unrolled: the working array and the
+/* least squares min |A x - b| for an R x C system (C <= R <= 6, C <= 5), Householder QR on a copy, every loop unrolled: the working array and the
  * callers' matrices stay in registers (as run-time-indexed arrays they are scratch memory). Returns 0 if a column collapses. Same
- * operations in the same order as lsq_small(6, C, ...) of the CPU restatement (solve_oracle.c). */
-template <int C>
-__device__ __forceinline__ int lsq6(const double* A, const double* b, double* x) {
-    constexpr int r = 6, c = C;
-    double Q[6][C + 1];
+ * operations in the same order as lsq_small(R, C, ...) of the CPU restatement (solve_oracle.c). */
+template <int R, int C>
+__device__ __forceinline__ int lsq_rc(const double* A, const double* b, double* x) {
+    constexpr int r = R, c = C;
+    static_assert(C <= R && R <= 6, "an over-determined or square system of at most six rows");
+    double Q[R][C + 1];
 #pragma unroll
     for (int i = 0; i < r; ++i) {
 #pragma unroll
@@ -595,6 +596,8 @@ __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x)
         if (!(fabs(x[j]) < 1e300)) return 0;
     return 1;
 }
+template <int C>
+__device__ __forceinline__ int lsq6(const double* A, const double* b, double* x) { return lsq_rc<6, C>(A, b, x); }
 
 // The N x N eigenproblem (N = 9, 12) by ONE WAVE on one shared copy of A and V, in the ROUND-ROBIN ordering of
 // the CPU restatement (solve_oracle.c)'s jacobi_eig_rr: a sweep is N' - 1 rounds of N' / 2 disjoint rotations (N' = N rounded up to even; position 0
@@ -781,6 +784,7 @@ __device__ __forceinline__ double ordered_wave_sum(double v, double* red, int te
 // control-point distances; the four null vectors (S.ev) and the distance system (S.L) stay in LDS.
 struct PnpFrame {
     double c0[3], ax[3][3], sc[3], rho[6];
+    bool planar;  // a coplanar point set: three control points (sc[2] == 0 marks it in the stored frame), see epnp_front
 };
 
 // Front half, ONE WAVE per sample: control points, M^T M (shared), its eigenvectors by jacobi_wave, the distance system.
@@ -819,18 +823,30 @@ __device__ static int epnp_front(int m, const int* idx, const double* obj, const
     double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
     wmax = wmax > w3[2] ? wmax : w3[2];
     /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
+    if (!(wmax > 0.0)) return 0;
+    const int kmin = w3[1] < w3[0] ? (w3[2] < w3[1] ? 2 : 1) : (w3[2] < w3[0] ? 2 : 0);  // the axis of the smallest spread (ties: the lower index)
+    if ((kmin != 0 && !(w3[0] > 1e-12 * wmax)) || (kmin != 1 && !(w3[1] > 1e-12 * wmax)) || (kmin != 2 && !(w3[2] > 1e-12 * wmax))) return 0;  // collinear / coincident
+    const double wflat = kmin == 0 ? w3[0] : (kmin == 1 ? w3[1] : w3[2]);
+    const bool planar = !(wflat > 1e-12 * wmax);
+    F.planar = planar;
+    /* A COPLANAR set takes the paper's three-control-point form inside the same arrays (solve_oracle.c's header): the flat axis goes
+     * last with length 0 — control point 3 coincides with the centroid and carries barycentric coordinate 0 — and its three
+     * diagonal entries of M^T M are set above every eigenvalue of the 9 x 9 part below. A set with volume keeps the axes as the
+     * eigenproblem leaves them. */
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (!(w3[k] > 1e-12 * wmax) || !(wmax > 0.0)) return 0;
-        sc[k] = sqrt(w3[k] / (double)m);
+        const int src = !planar ? k : (k == 0 ? (kmin == 0 ? 1 : 0) : (k == 1 ? (kmin == 2 ? 1 : 2) : kmin));
+        const double wk = src == 0 ? w3[0] : (src == 1 ? w3[1] : w3[2]);
+        sc[k] = (planar && k == 2) ? 0.0 : sqrt(wk / (double)m);
 #pragma unroll
-        for (int e = 0; e < 3; ++e) ax[k][e] = V3[3 * e + k];
+        for (int e = 0; e < 3; ++e) ax[k][e] = src == 0 ? V3[3 * e] : (src == 1 ? V3[3 * e + 1] : V3[3 * e + 2]);
     }
 #define EPNP_ALPHAS(i, al)                                                                        \
     {                                                                                             \
         double d_[3];                                                                             \
         _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) d_[e_] = obj[3 * (size_t)(i) + e_] - c0[e_];               \
-        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) (al)[k_ + 1] = (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                           \
+            (al)[k_ + 1] = (planar && k_ == 2) ? 0.0 : (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
         (al)[0] = 1.0 - (al)[1] - (al)[2] - (al)[3];                                              \
     }
     /* M^T M of the 2m x 12 projection system  sum_j alpha_j (fu Xc_j + (uc - u) Zc_j) = 0, same with v */
@@ -881,6 +897,14 @@ __device__ static int epnp_front(int m, const int* idx, const double* obj, const
             const int j = i + rem;
             S.A[12 * i + j] = t;
             S.A[12 * j + i] = t;
+        }
+        wave_sync_lds();
+    }
+    if (planar) {  // rows / columns 9..11 are exact zeros: their diagonal goes above every eigenvalue of the 9 x 9 part
+        if (lane == 0) {
+            double tr = 0.0;
+            for (int i = 0; i < 9; ++i) tr += S.A[13 * i];
+            for (int i = 9; i < 12; ++i) S.A[13 * i] = 2.0 * tr + 1.0;
         }
         wave_sync_lds();
     }
@@ -966,11 +990,52 @@ __device__ static double epnp_back_variant(int m, const int* idx, const double* 
     const double (&ax)[3][3] = F.ax;
     const double (&sc)[3] = F.sc;
     const double (&rho)[6] = F.rho;
+    const bool planar = F.planar;
     {
         /* linearised start: the products b_i b_j that involve only the first 1 / 2 / 3 null vectors' leading terms */
         constexpr int ncol[3] = {4, 3, 5};
         constexpr int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
         double A[30], x[5], beta[4] = {0, 0, 0, 0};
+        if (planar) {
+            /* three control points: the distance equations of the pairs (0,1), (0,2), (1,2) = rows 0, 1, 3; start 0 takes the first
+             * null vector alone (x = b00), start 1 the first two (x = b00 b01 b11, a square system); there is no third start.
+             * Gauss-Newton runs on the unknowns of the start (1 or 2 betas against three equations). */
+            if constexpr (variant == 2) {
+                return -1.0;
+            } else {
+                constexpr int rows3[3] = {0, 1, 3}, nb = variant + 1, nc3 = variant == 0 ? 1 : 3;
+                double l3[3][3], rho3[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    rho3[p] = rho[rows3[p]];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) l3[p][j] = L[(size_t)(10 * rows3[p] + j) * es];
+#pragma unroll
+                    for (int j = 0; j < nc3; ++j) A[p * nc3 + j] = l3[p][j];
+                }
+                if (!lsq_rc<3, nc3>(A, rho3, x)) return -1.0;
+                const double s = x[0] < 0.0 ? -1.0 : 1.0;
+                beta[0] = sqrt(s * x[0]);
+                if (variant == 1) {
+                    beta[1] = s * x[2] > 0.0 ? sqrt(s * x[2]) : 0.0;
+                    if (x[1] < 0.0) beta[0] = -beta[0];
+                }
+                if (!(beta[0] != 0.0)) return -1.0;
+                for (int it = 0; it < 5; ++it) {
+                    double J[6], r[3], dx[2];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const double* l = l3[p];
+                        J[nb * p] = 2.0 * l[0] * beta[0] + l[1] * beta[1];
+                        if (nb == 2) J[nb * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1];
+                        r[p] = rho3[p] - (l[0] * beta[0] * beta[0] + l[1] * beta[0] * beta[1] + l[2] * beta[1] * beta[1]);
+                    }
+                    if (!lsq_rc<3, nb>(J, r, dx)) break;
+#pragma unroll
+                    for (int k = 0; k < nb; ++k) beta[k] += dx[k];
+                }
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < 6; ++p)
 #pragma unroll
@@ -1010,6 +1075,7 @@ __device__ static double epnp_back_variant(int m, const int* idx, const double* 
             if (!lsq6<4>(J, r, dx)) break;
 #pragma unroll
             for (int k = 0; k < 4; ++k) beta[k] += dx[k];
+        }
         }
         /* control points in the camera frame, sign from the first point's depth */
         double cc[4][3];
@@ -1172,6 +1238,7 @@ __global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __rest
             for (int e = 0; e < 3; ++e) F.ax[k][e] = src[(3 + 3 * k + e) * ns];
 #pragma unroll
         for (int q = 0; q < 6; ++q) F.rho[q] = src[(15 + q) * ns];
+        F.planar = F.sc[2] == 0.0;
         const int* rows_idx = idx + (size_t)s * sample_size;
         err = epnp_back_variant<true, variant>(sample_size, rows_idx, obj, img, K4, F, src + PNP_F_EV * ns, src + PNP_F_L * ns, ns, nullptr, cand);
     }

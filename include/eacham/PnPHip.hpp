@@ -105,7 +105,7 @@ inline PnPResult SolvePnPRansac(Context& ctx, const std::vector<double>& object,
     double refit[12];
     int32_t rok = 0;
     ctx.check(eacham_solve_pnp(ctx.get(), n, object.data(), image.data(), K4, (int)rows.size(), 1, rows.data(), refit, &rok));
-    const double* pose = rok ? refit : best_model.data();   // (a coplanar inlier set cannot be refitted: keep the winner)
+    const double* pose = rok ? refit : best_model.data();   // (a collinear inlier set cannot be refitted: keep the winner)
     for (int e = 0; e < 9; ++e) out.R[e] = pose[e];
     for (int e = 0; e < 3; ++e) out.t[e] = pose[9 + e];
     out.rvec = RodriguesFromMatrix(out.R);

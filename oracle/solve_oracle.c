@@ -27,7 +27,15 @@
  *                (4 / 3 / 5 unknown products) each polished by five Gauss-Newton steps, absolute orientation, and the start
  *                with the smallest reprojection error wins. Own choices where the result set is the same: Jacobi instead of
  *                cv::SVD, Householder least squares, Horn's quaternion form for the absolute orientation (epnp.cpp: SVD of
- *                the 3 x 3 correlation with a row flip for det < 0); coplanar sets are reported degenerate (n_models = 0).
+ *                the 3 x 3 correlation with a row flip for det < 0). COPLANAR sets (the smallest spread of the object points is
+ *                <= 1e-12 of the largest) take the paper's planar form (section 3.4 there): THREE control points (centroid +
+ *                the two in-plane axes), the 2m x 9 system — carried inside the same 12 x 12 arrays: the fourth control point
+ *                gets barycentric coordinate 0 and its three diagonal entries of M^T M a value above every eigenvalue of the
+ *                9 x 9 part, so that its unit vectors are never rotated and never among the four smallest —, the three distance
+ *                equations of the control points (0,1), (0,2), (1,2), two linearised starts (N = 1: b00; N = 2: b00 b01 b11)
+ *                polished by Gauss-Newton on their own 1 / 2 unknowns. epnp.cpp 4.5.5 itself has no planar branch as far as
+ *                this restatement's author recalls (its control-point system is inverted with CV_SVD): unverifiable here.
+ *                Collinear / coincident sets are reported degenerate (n_models = 0).
  * Products and sums are NOT contracted into FMAs.
  */
 #pragma GCC optimize("fp-contract=off")
@@ -489,7 +497,7 @@ int oracle_essential5(const double* p1, const double* p2, const double* K, doubl
     return n;
 }
 
-/* least squares min |A x - b| for an r x c system (r <= 6, c <= 5), Householder QR on a copy; returns 0 if a column collapses */
+/* least squares min |A x - b| for an r x c system (c <= r <= 6, c <= 5), Householder QR on a copy; returns 0 if a column collapses */
 static int lsq_small(int r, int c, const double* A, const double* b, double* x) {
     double Q[6 * 6];  /* the r x (c + 1) working array [A | b] */
     for (int i = 0; i < r; ++i) {
@@ -529,7 +537,8 @@ static int lsq_small(int r, int c, const double* A, const double* b, double* x) 
 /* EPnP (Lepetit, Moreno-Noguer, Fua 2009) on the m >= 4 points idx[0..m) of obj (n x 3) / img (n x 2), K = fx fy cx cy.
  * Rt = R (row-major) | t of x_cam = R X + t. Every pass over the points recomputes the barycentric coordinates, so the
  * working set does not grow with m (the RANSAC kernel calls it with m = 5, the final refit with all inliers).
- * Returns 1, or 0 for a degenerate point set (coplanar / coincident points: the 4-control-point form needs volume). */
+ * Coplanar point sets take the three-control-point form (see the header). Returns 1, or 0 for a degenerate point set
+ * (collinear / coincident points). */
 int oracle_epnp(int m, const int* idx, const double* obj, const double* img, const double* K, double* Rt) {
     if (m < 4) return 0;
     /* Sums over the points: sequential for m <= 64; beyond that W = 64 strided partial sums (points l, l + 64, ... in
@@ -561,16 +570,26 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
     double wmax = w3[0] > w3[1] ? w3[0] : w3[1];
     wmax = wmax > w3[2] ? wmax : w3[2];
     double ax[3][3], sc[3];  /* ax[k] = unit axis k, sc[k] = its length: control point k+1 = c0 + sc[k] ax[k] */
+    if (!(wmax > 0.0)) return 0;
+    int kmin = 0;            /* the axis of the smallest spread (ties: the lower index) */
+    for (int k = 1; k < 3; ++k)
+        if (w3[k] < w3[kmin]) kmin = k;
+    for (int k = 0; k < 3; ++k)
+        if (k != kmin && !(w3[k] > 1e-12 * wmax)) return 0;  /* collinear / coincident points */
+    const int planar = !(w3[kmin] > 1e-12 * wmax);
+    /* a point set with volume keeps the axes as the eigenproblem leaves them; a plane's flat axis goes last and gets length 0:
+     * control point 3 then coincides with the centroid and carries barycentric coordinate 0 */
+    const int perm[3] = {planar ? (kmin == 0 ? 1 : 0) : 0, planar ? (kmin == 2 ? 1 : 2) : 1, planar ? kmin : 2};
     for (int k = 0; k < 3; ++k) {
-        if (!(w3[k] > 1e-12 * wmax) || !(wmax > 0.0)) return 0;
-        sc[k] = sqrt(w3[k] / (double)m);
-        for (int e = 0; e < 3; ++e) ax[k][e] = V3[3 * e + k];
+        sc[k] = (planar && k == 2) ? 0.0 : sqrt(w3[perm[k]] / (double)m);
+        for (int e = 0; e < 3; ++e) ax[k][e] = V3[3 * e + perm[k]];
     }
 #define EPNP_ALPHAS(i, al)                                                                        \
     {                                                                                             \
         double d_[3];                                                                             \
         for (int e_ = 0; e_ < 3; ++e_) d_[e_] = obj[3 * (size_t)(i) + e_] - c0[e_];               \
-        for (int k_ = 0; k_ < 3; ++k_) (al)[k_ + 1] = (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
+        for (int k_ = 0; k_ < 3; ++k_)                                                            \
+            (al)[k_ + 1] = (planar && k_ == 2) ? 0.0 : (ax[k_][0] * d_[0] + ax[k_][1] * d_[1] + ax[k_][2] * d_[2]) / sc[k_]; \
         (al)[0] = 1.0 - (al)[1] - (al)[2] - (al)[3];                                              \
     }
     /* M^T M of the 2m x 12 projection system  sum_j alpha_j (fu Xc_j + (uc - u) Zc_j) = 0, same with v */
@@ -594,6 +613,11 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
     }
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < i; ++j) MtM[12 * i + j] = MtM[12 * j + i];
+    if (planar) {  /* rows / columns 9..11 are exact zeros: their diagonal goes above every eigenvalue of the 9 x 9 part */
+        double tr = 0.0;
+        for (int i = 0; i < 9; ++i) tr += MtM[13 * i];
+        for (int i = 9; i < 12; ++i) MtM[13 * i] = 2.0 * tr + 1.0;
+    }
     jacobi_eig_rr(12, MtM, V, w);
     int ord[4];  /* the four smallest eigenvalues, ascending (ties: lower index first) */
     for (int k = 0; k < 4; ++k) {
@@ -635,6 +659,37 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
         const int ncol[3] = {4, 3, 5};
         const int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
         double A[30], x[5], beta[4] = {0, 0, 0, 0};
+        if (planar) {
+            /* three control points: the distance equations of the pairs (0,1), (0,2), (1,2) = rows 0, 1, 3; start 0 takes the first
+             * null vector alone (x = b00), start 1 the first two (x = b00 b01 b11, a square system); there is no third start.
+             * Gauss-Newton runs on the unknowns of the start (1 or 2 betas against three equations). */
+            if (variant == 2) continue;
+            const int rows3[3] = {0, 1, 3}, nb = variant + 1, nc3 = variant == 0 ? 1 : 3;
+            double rho3[3];
+            for (int p = 0; p < 3; ++p) {
+                rho3[p] = rho[rows3[p]];
+                for (int j = 0; j < nc3; ++j) A[p * nc3 + j] = L[rows3[p]][j];
+            }
+            if (!lsq_small(3, nc3, A, rho3, x)) continue;
+            const double s = x[0] < 0.0 ? -1.0 : 1.0;
+            beta[0] = sqrt(s * x[0]);
+            if (variant == 1) {
+                beta[1] = s * x[2] > 0.0 ? sqrt(s * x[2]) : 0.0;
+                if (x[1] < 0.0) beta[0] = -beta[0];
+            }
+            if (!(beta[0] != 0.0)) continue;
+            for (int it = 0; it < 5; ++it) {
+                double J[6], r[3], dx[2];
+                for (int p = 0; p < 3; ++p) {
+                    const double* l = L[rows3[p]];
+                    J[nb * p] = 2.0 * l[0] * beta[0] + l[1] * beta[1];
+                    if (nb == 2) J[nb * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1];
+                    r[p] = rho3[p] - (l[0] * beta[0] * beta[0] + l[1] * beta[0] * beta[1] + l[2] * beta[1] * beta[1]);
+                }
+                if (!lsq_small(3, nb, J, r, dx)) break;
+                for (int k = 0; k < nb; ++k) beta[k] += dx[k];
+            }
+        } else {
         for (int p = 0; p < 6; ++p)
             for (int j = 0; j < ncol[variant]; ++j) A[p * ncol[variant] + j] = L[p][cols[variant][j]];
         if (!lsq_small(6, ncol[variant], A, rho, x)) continue;
@@ -665,6 +720,7 @@ int oracle_epnp(int m, const int* idx, const double* obj, const double* img, con
             }
             if (!lsq_small(6, 4, J, r, dx)) break;
             for (int k = 0; k < 4; ++k) beta[k] += dx[k];
+        }
         }
         /* control points in the camera frame, sign from the first point's depth */
         double cc[4][3];

@@ -75,3 +75,16 @@ def pnp_case(n=500, n_models=64, seed=11, outliers=0.3):
     X = X.copy()
     X[0] = -T[:3, :3].T @ T[:3, 3]                  # an object point AT the camera centre of the true pose: z = 0 -> 1/z := 1
     return {"K": K, "X": X, "uv": uv, "models": models, "bad": bad}
+
+
+def planar_pnp_case(n=300, seed=3, noise=0.0):
+    """COPLANAR object points (a tilted plane through the scene of pnp_case), their pixels under a known pose + `noise` px of
+    Gaussian noise, K, that pose (R row-major | t). The planar form of EPnP (oracle/solve_oracle.c's header) is what solves these."""
+    c = pnp_case(n=n, seed=seed, outliers=0.0)
+    X, T, K = np.ascontiguousarray(c["X"][1:]).copy(), c["models"][0], np.asarray(c["K"], float)
+    X[:, 2] = 0.3 * X[:, 0] - 0.2 * X[:, 1] + 1.0
+    pc = X @ T[:9].reshape(3, 3).T + T[9:]
+    assert pc[:, 2].min() > 0.5
+    uv = np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1)
+    rng = np.random.default_rng(seed + 1000)
+    return X, uv + noise * rng.normal(size=uv.shape), K, T

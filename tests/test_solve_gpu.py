@@ -91,6 +91,34 @@ def test_epnp_bit_identical_at_the_reference_iteration_count_and_the_ransac_loop
         assert np.array_equal(gok, wok) and np.array_equal(got, want), m
 
 
+def test_epnp_on_coplanar_points_bit_identical_at_three_noise_levels(hip_ctx):
+    """A planar target (cv::solvePnPRansac(..., SOLVEPNP_EPNP) returns a pose for it, ReconstructionManager.cpp:227-228): the
+    three-control-point form, same bits as oracle/solve_oracle.c at every sample size class (a lane per start for the RANSAC
+    loop's five-point samples, a wave per sample, the all-inlier refit), exact pose from exact pixels, and planar and spatial
+    samples mixed in one batch (the branch is taken per sample)."""
+    rng = np.random.default_rng(5)
+    for noise, bound in ((0.0, 1e-9), (0.5, 0.05), (2.0, 0.2)):
+        X, uv, K, T = SC.planar_pnp_case(n=300, seed=3, noise=noise)
+        for m, count in ((5, 2000), (5, 300), (20, 40), (64, 3), (65, 3), (299, 2)):
+            rows = draw(rng, len(X), m, count)
+            got, gok = score.solve_pnp(hip_ctx, X, uv, K, rows)
+            want, wok = O.solve_pnp(X, uv, K, rows)
+            assert np.array_equal(gok, wok) and gok.all() and np.array_equal(got, want), (noise, m)
+            if m == 5:
+                assert np.median(np.abs(got - T).max(1)) < bound
+            if m == 299:
+                assert np.abs(got - T).max() < max(bound / 10, 1e-9)
+    # a batch whose samples are planar or not: the first 150 object points on the plane, the rest off it
+    X, uv, K, T = SC.planar_pnp_case(n=300, seed=3, noise=0.5)
+    c = SC.pnp_case(n=300, seed=3, outliers=0.0)
+    X2, uv2 = X.copy(), uv.copy()
+    X2[150:], uv2[150:] = c["X"][1:][150:], c["uv"][1:][150:]
+    rows = np.concatenate([draw(rng, 150, 5, 300), 150 + draw(rng, 149, 5, 300), draw(rng, 299, 5, 300)])
+    got, gok = score.solve_pnp(hip_ctx, X2, uv2, K, rows)
+    want, wok = O.solve_pnp(X2, uv2, K, rows)
+    assert np.array_equal(gok, wok) and np.array_equal(got, want)
+
+
 def test_epnp_arguments(hip_ctx):
     X, uv, K = np.zeros((8, 3)), np.zeros((8, 2)), np.array([500.0, 500.0, 320.0, 240.0])
     with pytest.raises(EachamError) as e:
@@ -100,5 +128,8 @@ def test_epnp_arguments(hip_ctx):
         score.solve_pnp(hip_ctx, X, uv, K, np.array([[0, 1, 2, 3, 8]], np.int32))              # index out of range
     m, ok = score.solve_pnp(hip_ctx, X, uv, K, np.array([[0, 1, 2, 3, 4]], np.int32))          # coincident points: degenerate
     assert ok[0] == 0 and not m.any()
+    X[:, 0] = np.arange(8.0)                                                                   # collinear points: degenerate
+    m, ok = score.solve_pnp(hip_ctx, X, uv, K, np.array([[0, 1, 2, 3, 4], [3, 4, 5, 6, 7]], np.int32))
+    assert not ok.any() and not m.any()
     m, ok = score.solve_pnp(hip_ctx, X, uv, K, np.zeros((0, 5), np.int32))
     assert m.shape == (0, 12)

@@ -142,9 +142,41 @@ def test_epnp_recovers_the_pose_exactly_and_averages_noise_down():
 
 def test_epnp_reports_degenerate_samples():
     X, uv, K, _ = exact_pnp(n=40, seed=3)
-    flat = X.copy()
-    flat[:, 2] = 0.3 * flat[:, 0] - 0.2 * flat[:, 1] + 1.0            # coplanar object points: no volume for four control points
+    line = X.copy()
+    line[:, 1] = 2.0 * line[:, 0] + 0.5                                # collinear object points: one axis of spread only
+    line[:, 2] = -0.7 * line[:, 0] + 4.0
     same = np.repeat(X[:1], 40, axis=0)                               # one point forty times
-    for pts in (flat, same):
+    for pts in (line, same):
         models, ok = O.solve_pnp(pts, uv, K, np.arange(10, dtype=np.int32).reshape(2, 5))
         assert not ok.any() and not models.any()
+
+
+def test_epnp_on_coplanar_points_takes_the_three_control_point_form():
+    """cv::solvePnPRansac(..., SOLVEPNP_EPNP) returns a pose for a planar target (ReconstructionManager.cpp:227-228); the
+    four-control-point form has no volume to work with there. Exact pixels of a plane -> the exact pose (no mirror solution:
+    the perspective of the scene decides), from 5 points up to all of them; noisy pixels -> an error that shrinks with the
+    sample size, as for a scene with volume; a plane in general position and the three axis-aligned planes (the flat axis is
+    each of the eigenproblem's three positions)."""
+    for noise, bounds in ((0.0, (1e-9, 1e-10, 1e-10)), (0.5, (0.05, 0.015, 3e-3)), (2.0, (0.2, 0.06, 0.012))):
+        X, uv, K, T = SC.planar_pnp_case(n=300, seed=3, noise=noise)
+        rng = np.random.default_rng(1)
+        med = []
+        for m in (5, 20, 299):
+            samples = np.array([rng.choice(len(X), m, replace=False) for _ in range(100)], np.int32)
+            models, ok = O.solve_pnp(X, uv, K, samples)
+            assert ok.all()
+            R = models[:, :9].reshape(-1, 3, 3)
+            assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(R) - 1).max() < 1e-12
+            med.append(np.median(np.abs(models - T).max(1)))
+        assert all(a < b for a, b in zip(med, bounds)), (noise, med)
+        if noise > 0:
+            assert med[0] > med[1] > med[2]
+    Xe, uve, K, T = exact_pnp(n=61, seed=5)                             # (the helper drops the scene's first point: 60 left)
+    Rm, t = T[:9].reshape(3, 3), T[9:]
+    for axis in range(3):
+        X = Xe.copy()
+        X[:, axis] = 0.25                                              # the plane x = c, y = c, z = c
+        pc = X @ Rm.T + t
+        uv = np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1)
+        models, ok = O.solve_pnp(X, uv, K, np.arange(60, dtype=np.int32).reshape(12, 5))
+        assert ok.all() and np.abs(models - T).max() < 1e-8, axis
