@@ -1,5 +1,5 @@
-// ba_window.hpp — the structure of the DENSE form of the Schur stage (round 5), pure C++ (tests/cpp/window_driver.cpp executes
-// the definition in plain doubles on the CPU).
+// ba_window.hpp — the structure of the DENSE form of the Schur stage (round 5), pure C++ (held against the oracle and the pair-list
+// form by tests/test_ba_gpu.py::test_the_dense_form_of_a_local_window_solves_the_same_system, which also walks the structure).
 //
 // What it serves: the per-frame RefineBA of a local window (apps/sfm/main.cpp:207 -> modules/sfm/reconstruction/BundleAdjuster.cpp:
 // 123-145: the current frame and its factor neighbours, ~20 cameras, ~10 k observations). There the reduced camera system has

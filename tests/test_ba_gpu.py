@@ -463,7 +463,7 @@ def test_the_dense_form_of_a_local_window_solves_the_same_system(hip_ctx):
     So, go, dco, dlo, erro, lino, ok = O.ba_step(A, 1e-3, 0)
     outs = []
     for env in [dict(EACHAM_BA_SCHUR="pairs"), dict(EACHAM_BA_SCHUR="dense"), dict(EACHAM_BA_SCHUR="dense", EACHAM_BA_WINDOW_ROWS="64"),
-                dict(EACHAM_BA_SCHUR="dense", EACHAM_BA_WINDOW_ROWS="256"), dict()]:
+                dict(EACHAM_BA_SCHUR="dense", EACHAM_BA_WINDOW_ROWS="200"), dict()]:   # (256 rows of a 19-camera window need 167 KB of LDS: not built)
         ctx = _ctx_with(**env)
         try:
             if env.get("EACHAM_BA_SCHUR") == "dense":
