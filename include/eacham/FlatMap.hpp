@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdint>
 #include <utility>
 #include <vector>
 
@@ -45,6 +46,38 @@ struct FlatMap {
         std::sort(v.begin(), v.end());
     }
     bool operator==(const FlatMap& o) const { return v == o.v; }
+};
+
+// unsigned -> uint32 table for ONE call's worth of keys (landmark id -> dense index in the glue's graph walks): open addressing
+// with a generation stamp per slot, so that a call clears it by bumping the generation — no allocation and no rehash per call once
+// it has grown to the size the calls need (std::unordered_map cost one node allocation per landmark and a pointer chase per
+// observation: 12 000 of each per local window).
+struct IdTable {
+    std::vector<unsigned> key;
+    std::vector<uint32_t> val, gen;
+    uint32_t cur = 0;
+    size_t mask = 0;
+    void reset(size_t expected_keys) {
+        size_t want = 1024;
+        while (want < 2 * expected_keys) want <<= 1;
+        if (key.size() < want) {
+            key.assign(want, 0u), val.assign(want, 0u), gen.assign(want, 0u);
+            cur = 0;
+        }
+        mask = key.size() - 1;
+        if (++cur == 0) {  // the stamp wrapped: every slot is stale by definition
+            std::fill(gen.begin(), gen.end(), 0u);
+            cur = 1;
+        }
+    }
+    // the value slot of k; `fresh` tells whether k was entered by this call (its value is then the caller's to set)
+    uint32_t& slot(unsigned k, bool& fresh) {
+        size_t h = ((size_t)k * 2654435761u) & mask;
+        while (gen[h] == cur && key[h] != k) h = (h + 1) & mask;
+        fresh = gen[h] != cur;
+        if (fresh) gen[h] = cur, key[h] = k;
+        return val[h];
+    }
 };
 
 }  // namespace hip

@@ -76,59 +76,93 @@ inline void matrix_to_rows(const Mat4& M, double* out) {
 template <class GraphT, class MapT, class MatT, class ConfigT>
 inline RefineBAReport RefineBA(const int currentFrameId, const std::shared_ptr<GraphT>& graph, const std::shared_ptr<MapT>& map,
                                MatT& K, const ConfigT& config) {
+#ifdef EACHAM_GLUE_TIMING
+    struct Tm { double walk = 0, solve = 0, back = 0; long n = 0; ~Tm() { if (n) std::fprintf(stderr, "RefineBA glue: %ld calls, graph walk %.3f ms, eacham_ba_solve %.3f ms, write-back %.3f ms per call\n", n, walk / n, solve / n, back / n); } };
+    static Tm tm;
+    const auto t_a = std::chrono::steady_clock::now();
+#endif
     std::vector<unsigned> frameIds;
     std::vector<double> camT, points, uv;
     std::vector<int32_t> camFixed, pointObservers;
     std::vector<uint32_t> obsCam, obsPoint;
     std::vector<unsigned> mapIds;                      // dense point index -> landmark id
-    std::unordered_map<unsigned, uint32_t> mapIndex;   // landmark id -> dense point index
     const auto& all = map->GetAll();                   // (Map::Get / GetStatus / GetObservers of the reference each take a lock and the last one copies the map)
-    std::vector<std::pair<unsigned, unsigned>> items;
-    auto frameAdder = [&](unsigned id, auto* node) {   // BundleAdjuster.cpp:57-121
-        const uint32_t cam = (uint32_t)frameIds.size();
-        frameIds.push_back(id);
-        double T[16];
-        matrix_to_rows(node->GetTransform(), T);
-        camT.insert(camT.end(), T, T + 16);
-        camFixed.push_back(graph->IsFixed(id) ? 1 : 0);
-        const auto& kps = node->GetFeatures();
-        items.assign(node->GetPoints3d().begin(), node->GetPoints3d().end());
-        std::sort(items.begin(), items.end());
-        for (const auto& kv : items) {
-            const unsigned id2d = kv.first, id3d = kv.second;
-            const auto it = all.find(id3d);
-            if (it == all.end()) throw std::runtime_error("Map: point is not found");
-            if (!it->second.isValid || it->second.observers.size() < 2) continue;   // :84
-            if ((size_t)id2d >= kps.size()) throw std::runtime_error("RefineBA: keypoint out of range");
-            auto ins = mapIndex.insert({id3d, (uint32_t)mapIds.size()});
-            if (ins.second) {                                                        // :100-117
-                mapIds.push_back(id3d);
-                points.push_back(it->second.point3d(0));
-                points.push_back(it->second.point3d(1));
-                points.push_back(it->second.point3d(2));
-                pointObservers.push_back((int32_t)it->second.observers.size());
-            }
-            obsCam.push_back(cam);
-            obsPoint.push_back(ins.first->second);
-            uv.push_back((double)kps[id2d].x);
-            uv.push_back((double)kps[id2d].y);
-        }
-    };
+    // the window's nodes first: their sizes bound the arrays and the landmark table
+    using NodeP = decltype(graph->Get(0u));
+    std::vector<std::pair<unsigned, NodeP>> window;
     if (currentFrameId > -1) {                          // local window (:123-145)
         auto* start = graph->Get((unsigned)currentFrameId);
         if (!start) throw std::runtime_error("Node is null");
-        frameAdder((unsigned)currentFrameId, start);
+        window.emplace_back((unsigned)currentFrameId, start);
         std::vector<unsigned> nb;
         for (const auto& f : start->GetFactors()) nb.push_back(f.first);
         std::sort(nb.begin(), nb.end());
         for (unsigned id : nb) {
             auto* node = graph->Get(id);
             if (!node) throw std::runtime_error("Node is null");
-            if (node->IsValid()) frameAdder(id, node);
+            if (node->IsValid()) window.emplace_back(id, node);
         }
     } else {                                            // global (:146-162)
         for (const auto& entry : graph->GetNodes())
-            if (entry.second->IsValid()) frameAdder(entry.first, entry.second);
+            if (entry.second->IsValid()) window.emplace_back(entry.first, entry.second);
+    }
+    size_t max_obs = 0;
+    for (const auto& w : window) max_obs += w.second->GetPoints3d().size();
+    // landmark id -> dense point index, or SKIP for a landmark the filter of :84 drops (decided once per landmark: nothing
+    // the walk reads changes while it runs). One table per thread, reused from call to call.
+    constexpr uint32_t SKIP = 0xffffffffu;
+    static thread_local IdTable mapIndex;
+    mapIndex.reset(max_obs);
+    camT.reserve(16 * window.size()), camFixed.reserve(window.size()), frameIds.reserve(window.size());
+    obsCam.reserve(max_obs), obsPoint.reserve(max_obs), uv.reserve(2 * max_obs);
+    constexpr unsigned NONE = 0xffffffffu;
+    std::vector<unsigned> byKeypoint;                  // a node's keypoint -> landmark map laid out by keypoint index
+    std::vector<std::pair<unsigned, unsigned>> beyond; // (entries whose keypoint index is past the node's features: an error if they survive the filter)
+    auto observe = [&](uint32_t cam, unsigned id2d, unsigned id3d, size_t n_kps, const auto& kps) {
+        bool fresh = false;
+        uint32_t& where = mapIndex.slot(id3d, fresh);
+        if (fresh) {
+            const auto it = all.find(id3d);
+            if (it == all.end()) throw std::runtime_error("Map: point is not found");
+            if (!it->second.isValid || it->second.observers.size() < 2) {               // :84
+                where = SKIP;
+            } else {                                                                     // :100-117
+                where = (uint32_t)mapIds.size();
+                mapIds.push_back(id3d);
+                points.push_back(it->second.point3d(0));
+                points.push_back(it->second.point3d(1));
+                points.push_back(it->second.point3d(2));
+                pointObservers.push_back((int32_t)it->second.observers.size());
+            }
+        }
+        if (where == SKIP) return;
+        if ((size_t)id2d >= n_kps) throw std::runtime_error("RefineBA: keypoint out of range");
+        obsCam.push_back(cam);
+        obsPoint.push_back(where);
+        uv.push_back((double)kps[id2d].x);
+        uv.push_back((double)kps[id2d].y);
+    };
+    for (const auto& w : window) {                     // BundleAdjuster.cpp:57-121
+        auto* node = w.second;
+        const uint32_t cam = (uint32_t)frameIds.size();
+        frameIds.push_back(w.first);
+        double T[16];
+        matrix_to_rows(node->GetTransform(), T);
+        camT.insert(camT.end(), T, T + 16);
+        camFixed.push_back(graph->IsFixed(w.first) ? 1 : 0);
+        const auto& kps = node->GetFeatures();
+        const size_t n_kps = kps.size();
+        // ascending keypoint order without a sort: the map's entries dropped into a table indexed by keypoint
+        byKeypoint.assign(n_kps, NONE);
+        beyond.clear();
+        for (const auto& kv : node->GetPoints3d()) {
+            if ((size_t)kv.first < n_kps) byKeypoint[kv.first] = kv.second;
+            else beyond.emplace_back(kv.first, kv.second);
+        }
+        for (size_t k = 0; k < n_kps; ++k)
+            if (byKeypoint[k] != NONE) observe(cam, (unsigned)k, byKeypoint[k], n_kps, kps);
+        std::sort(beyond.begin(), beyond.end());
+        for (const auto& kv : beyond) observe(cam, kv.first, kv.second, n_kps, kps);
     }
     RefineBAReport rep;
     rep.frames = frameIds.size();
@@ -162,7 +196,13 @@ inline RefineBAReport RefineBA(const int currentFrameId, const std::shared_ptr<G
     res.cam_T_wc = outT.data();
     res.points = outP.data();
     eacham_ctx* ctx = shared_context().get();
+#ifdef EACHAM_GLUE_TIMING
+    const auto t_b = std::chrono::steady_clock::now();
+#endif
     const int rc = eacham_ba_solve(ctx, &prob, &opt, &res);
+#ifdef EACHAM_GLUE_TIMING
+    const auto t_c = std::chrono::steady_clock::now();
+#endif
     if (rc != EACHAM_OK) throw std::runtime_error(std::string("eacham_hip: ") + eacham_last_error(ctx));
     rep.skipped = res.status == EACHAM_BA_SKIPPED;
     if (rep.skipped) return rep;  // fewer than 50 landmarks: the reference returns without touching anything (:166-169)
@@ -189,6 +229,15 @@ inline RefineBAReport RefineBA(const int currentFrameId, const std::shared_ptr<G
             for (int col = 0; col < 4; ++col) M(r, col) = outT[16 * i + 4 * r + col];
         node->SetTransform(M);
     }
+#ifdef EACHAM_GLUE_TIMING
+    {
+        const auto t_d = std::chrono::steady_clock::now();
+        tm.walk += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+        tm.solve += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+        tm.back += std::chrono::duration<double, std::milli>(t_d - t_c).count();
+        ++tm.n;
+    }
+#endif
     return rep;
 }
 
@@ -229,30 +278,59 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
         std::vector<std::pair<unsigned, unsigned>> matches;
     };
     std::vector<Nb> nbs;
+    const size_t n_cur = current->GetFeatures().size();
+    std::vector<unsigned> partnerOf(n_cur);   // a factor's matches laid out by the current frame's keypoint: ascending order without a sort
+    std::vector<char> matched(n_cur);
     for (const auto& f : current->GetFactors()) {
         auto* other = graph->Get(f.first);
         if (!other) throw std::runtime_error("Node is null");
         if (!other->IsValid()) continue;                 // :208-211
         Nb nb{f.first, other, {}};
         nb.matches.reserve(f.second.matches.size());
-        for (const auto& mm : f.second.matches) nb.matches.emplace_back(mm.first, mm.second);
-        std::sort(nb.matches.begin(), nb.matches.end());
+        std::fill(matched.begin(), matched.end(), 0);
+        bool in_range = true;
+        for (const auto& mm : f.second.matches) {
+            if ((size_t)mm.first < n_cur) partnerOf[mm.first] = mm.second, matched[mm.first] = 1;
+            else in_range = false;
+        }
+        if (in_range) {
+            for (size_t k = 0; k < n_cur; ++k)
+                if (matched[k]) nb.matches.emplace_back((unsigned)k, partnerOf[k]);
+        } else {                                         // (a match past the frame's keypoints: kept in order; it is an error further down if it is used)
+            for (const auto& mm : f.second.matches) nb.matches.emplace_back(mm.first, mm.second);
+            std::sort(nb.matches.begin(), nb.matches.end());
+        }
         nbs.push_back(std::move(nb));
     }
     std::sort(nbs.begin(), nbs.end(), [](const Nb& a, const Nb& b) { return a.id < b.id; });
     // ---- the re-observation gate (:213-240): errors of all candidates in one call, then the walk ----
+    // Pass one looks every match up ONCE (the partner's keypoint -> landmark map, the landmark in the map) and keeps what it found:
+    // pass two used to repeat both hash lookups per match. A landmark's record is held by address: the gate adds observers to
+    // records, never records to the map, so the addresses stay put and `observers.size()` read through them is the LIVE count.
     const auto& all = map->GetAll();
+    using PointRec = std::remove_reference_t<decltype(all.begin()->second)>;
     std::vector<unsigned> cand3d;     // the partner's map point per candidate, walk order
+    std::vector<const PointRec*> candRec;
     std::vector<uint32_t> cframe;
     std::vector<double> cpts, cuv;
+    std::vector<char> isCand;         // per match, walk order
+    size_t n_matches = 0;
+    unsigned max_kp = 0;
+    for (const Nb& nb : nbs) {
+        n_matches += nb.matches.size();
+        if (!nb.matches.empty()) max_kp = std::max(max_kp, nb.matches.back().first);   // (sorted by the current frame's keypoint)
+    }
+    isCand.reserve(n_matches);
     for (const Nb& nb : nbs) {
         const auto& p3 = nb.node->GetPoints3d();
         for (const auto& mm : nb.matches) {
             const auto has = p3.find(mm.second);
+            isCand.push_back(has != p3.end());
             if (has == p3.end()) continue;
             const auto mp = all.find(has->second);
             if (mp == all.end()) throw std::runtime_error("Map: point is not found");
             cand3d.push_back(has->second);
+            candRec.push_back(&mp->second);
             cframe.push_back(0);
             cpts.push_back(mp->second.point3d(0));
             cpts.push_back(mp->second.point3d(1));
@@ -267,27 +345,39 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
     double Tcur[16];
     matrix_to_rows(current->GetTransform(), Tcur);
     ctx.check(eacham_reprojection_errors(ctx.get(), Tcur, 1, (int)cand3d.size(), cframe.data(), cpts.data(), cuv.data(), K4, cerr.data()));
-    std::map<unsigned, FlatMap> observersFull;
+    // the observers of every keypoint of the current frame that goes on to triangulation, by keypoint index (ascending = the order
+    // of the std::map this used to be); the table is the thread's own and only the entries a call touched are cleared again
+    static thread_local std::vector<FlatMap> observersFull;
+    std::vector<unsigned> touched;
+    if (observersFull.size() <= (size_t)max_kp) observersFull.resize((size_t)max_kp + 1);
+    struct ClearTouched {   // (also on the exceptional exits)
+        std::vector<FlatMap>& table;
+        std::vector<unsigned>& keys;
+        ~ClearTouched() { for (unsigned k : keys) table[k].clear(); }
+    } clearTouched{observersFull, touched};
     {
-        size_t ci = 0;
+        size_t ci = 0, mi = 0;
         for (const Nb& nb : nbs) {
-            const auto& p3 = nb.node->GetPoints3d();   // (the gate only writes the CURRENT frame's points3d: a neighbour's is what pass one saw)
             for (const auto& mm : nb.matches) {
-                if (p3.find(mm.second) != p3.end()) {
+                if (isCand[mi++]) {   // (the gate only writes the CURRENT frame's points3d: a neighbour's is what pass one saw)
                     const unsigned id3d = cand3d[ci];
+                    const PointRec* rec = candRec[ci];
                     const float err = cerr[ci++];
-                    if (all.find(id3d)->second.observers.size() > 2 && err < maxReprError) {  // the LIVE observer count, in walk order (:218)
+                    if (rec->observers.size() > 2 && err < maxReprError) {  // the LIVE observer count, in walk order (:218)
                         current->SetPoint3d(mm.first, id3d, false);
                         map->AddObserver(frameId, mm.first, id3d);
                         ++rep.reobserved;
                         continue;
                     }
                 }
-                observersFull[mm.first][frameId] = mm.first;
-                observersFull[mm.first][nb.id] = mm.second;
+                FlatMap& obs = observersFull[mm.first];
+                if (obs.empty()) touched.push_back(mm.first);
+                obs[frameId] = mm.first;
+                obs[nb.id] = mm.second;
             }
         }
     }
+    std::sort(touched.begin(), touched.end());
 #ifdef EACHAM_GLUE_TIMING
     const auto t_b = std::chrono::steady_clock::now();
 #endif
@@ -298,9 +388,10 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
     std::vector<int32_t> trackPtr{0};
     std::vector<uint32_t> obsFrame;
     std::vector<const FlatMap*> trackObs;
-    for (const auto& kv : observersFull) {
-        if (kv.second.size() < minObservers) continue;
-        for (const auto& ob : kv.second) {
+    for (const unsigned kp : touched) {
+        const FlatMap& observers = observersFull[kp];
+        if (observers.size() < minObservers) continue;
+        for (const auto& ob : observers) {
             auto ins = frameRow.insert({ob.first, (uint32_t)frameRow.size()});
             if (ins.second) {
                 auto* n = graph->Get(ob.first);
@@ -317,7 +408,7 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
             uv.push_back(p[1]);
         }
         trackPtr.push_back((int32_t)obsFrame.size());
-        trackObs.push_back(&kv.second);
+        trackObs.push_back(&observers);
     }
     const int nTracks = (int)trackObs.size();
     std::vector<double> pts((size_t)nTracks * 3 + 3);

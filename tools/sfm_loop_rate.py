@@ -35,6 +35,9 @@ def run(F=100, kpts=600, nl=6000, kobs=10, inlier_px=4.0, debug=False, seed=3):
             f.write(struct.pack("i", kpts)); f.write(kp[fr].tobytes()); f.write(descs[fr].tobytes())
         f.write(np.array([K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1.0]).tobytes())
         f.write(np.array([0.8, 3.5, 3.0 * deg, 8.0, 3.0 * deg, 15, 100, inlier_px], dtype=np.float32).tobytes())
+    if os.environ.get("SFM_PREPARE_ONLY"):   # leave the driver and its input for a profiler run: `rocprofv3 ... -- <exe> <in> <out>`
+        print(exe, fin, fout)
+        sys.exit(0)
     t0 = time.perf_counter()
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=1000)
     dt = time.perf_counter() - t0
