@@ -1147,25 +1147,6 @@ __device__ static double epnp_back_variant(int m, const int* idx, const double* 
 }
 #undef EPNP_ALPHAS
 
-// the three starts in order; the first with the strictly smallest reprojection error is the sample's pose
-template <bool LANE>
-__device__ static int epnp_back(int m, const int* idx, const double* obj, const double* img, const double* K, const PnpFrame& F,
-                                const double* ev, const double* L, size_t es, double* red, double* Rt) {
-    double best_err = -1.0;
-    double cand[12];
-    auto take = [&](double err) {
-        if (err >= 0.0 && (best_err < 0.0 || err < best_err)) {
-            best_err = err;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) Rt[i] = cand[i];
-        }
-    };
-    take(epnp_back_variant<LANE, 0>(m, idx, obj, img, K, F, ev, L, es, red, cand));
-    take(epnp_back_variant<LANE, 1>(m, idx, obj, img, K, F, ev, L, es, red, cand));
-    take(epnp_back_variant<LANE, 2>(m, idx, obj, img, K, F, ev, L, es, red, cand));
-    return best_err >= 0.0 ? 1 : 0;
-}
-
 constexpr int SOLVE_WAVES = 4;   // samples (waves) per workgroup of the minimal-sample kernels
 
 // Samples of at most 64 points (the RANSAC loop's five-point samples) in two launches. Front: ONE WAVE per sample, SOLVE_WAVES samples
@@ -1210,15 +1191,16 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES) void solve_pnp_front_kernel(const
     }
 }
 
-// One instantiation per linearised start (0..2), three launches: a lane per (sample, start). As one lane per sample with the three
-// starts in a row the kernel needed ~380 registers, spilled 122 of them (324 B of scratch per lane) and ran one wave per SIMD.
-// The starts' errors and poses go to `tmp` ([start][sample][13]); solve_pnp_select_kernel takes the first strictly smallest, as
-// the CPU restatement's loop over the starts does.
+// A lane per (sample, linearised start): blockIdx.y is the start (0..2), ONE launch — as one lane per sample with the three starts in
+// a row the kernel needed ~380 registers, spilled 122 of them (324 B of scratch per lane) and ran one wave per SIMD; as three launches
+// (one instantiation each) the starts waited for one another on the stream: 36 + 32 + 32 us per RANSAC chunk of the incremental loop,
+// where a chunk is four waves per start. The starts' errors and poses go to `tmp` ([start][sample][13]); solve_pnp_select_kernel
+// takes the first strictly smallest, as the CPU restatement's loop over the starts does.
 template <int variant>
-__global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __restrict__ obj, const double* __restrict__ img,
-                                                            const double* __restrict__ K, int sample_size, int n_samples,
-                                                            const int* __restrict__ idx, const double* __restrict__ frame,
-                                                            double* __restrict__ tmp) {
+__device__ __forceinline__ void solve_pnp_back_body(const double* __restrict__ obj, const double* __restrict__ img,
+                                                    const double* __restrict__ K, int sample_size, int n_samples,
+                                                    const int* __restrict__ idx, const double* __restrict__ frame,
+                                                    double* __restrict__ tmp) {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n_samples) return;
     const size_t ns = (size_t)n_samples;
@@ -1247,6 +1229,14 @@ __global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __rest
 #pragma unroll
     for (int k = 0; k < 12; ++k) dst[1 + k] = cand[k];
 }
+__global__ __launch_bounds__(64) void solve_pnp_back_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                            const double* __restrict__ K, int sample_size, int n_samples,
+                                                            const int* __restrict__ idx, const double* __restrict__ frame,
+                                                            double* __restrict__ tmp) {
+    if (blockIdx.y == 0) solve_pnp_back_body<0>(obj, img, K, sample_size, n_samples, idx, frame, tmp);        // (workgroup-uniform)
+    else if (blockIdx.y == 1) solve_pnp_back_body<1>(obj, img, K, sample_size, n_samples, idx, frame, tmp);
+    else solve_pnp_back_body<2>(obj, img, K, sample_size, n_samples, idx, frame, tmp);
+}
 __global__ __launch_bounds__(256) void solve_pnp_select_kernel(int n_samples, const double* __restrict__ tmp, double* __restrict__ models, int* __restrict__ n_models) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_samples) return;
@@ -1260,25 +1250,52 @@ __global__ __launch_bounds__(256) void solve_pnp_select_kernel(int n_samples, co
     n_models[s] = which >= 0 ? 1 : 0;
 }
 
-// samples of more than 64 points (the all-inlier refit): one wave per workgroup, a partial M^T M per lane
-__global__ __launch_bounds__(64) void solve_pnp_big_kernel(const double* __restrict__ obj, const double* __restrict__ img,
-                                                           const double* __restrict__ K, int sample_size, const int* __restrict__ idx,
-                                                           double* __restrict__ models, int* __restrict__ n_models) {
+// samples of more than 64 points (the all-inlier refit): one workgroup of three waves per sample. Wave 0 runs the front half (a
+// partial M^T M per lane) and leaves the frame, the null vectors and the distance system in LDS; then every wave takes ONE
+// linearised start of the back half (its sums over the points spread over the wave's lanes, each wave with its own reduction
+// scratch) and thread 0 picks the first strictly smallest error — the order of epnp_back. One wave running the three starts in a row
+// was 234 us per refit of the incremental loop.
+__global__ __launch_bounds__(192) void solve_pnp_big_kernel(const double* __restrict__ obj, const double* __restrict__ img,
+                                                            const double* __restrict__ K, int sample_size, const int* __restrict__ idx,
+                                                            double* __restrict__ models, int* __restrict__ n_models) {
     __shared__ PnpLds lds;
     __shared__ double part[78 * 64];
-    const int s = blockIdx.x;
+    __shared__ PnpFrame frame;
+    __shared__ int front_ok;
+    __shared__ double red[3][64], result[3][13];
+    const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double K4[4] = {K[0], K[1], K[2], K[3]};
-    double out[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) out[k] = 0.0;
-    PnpFrame F;
     const int* rows_idx = idx + (size_t)s * sample_size;
-    int n = epnp_front<true>(sample_size, rows_idx, obj, img, K4, F, lds, nullptr, part);
-    if (n) n = epnp_back<false>(sample_size, rows_idx, obj, img, K4, F, lds.ev, lds.L, 1, lds.red, out);
-    if (threadIdx.x == 0) {
+    if (wave == 0) {
+        PnpFrame F;
+        const int n = epnp_front<true>(sample_size, rows_idx, obj, img, K4, F, lds, nullptr, part);
+        if (lane == 0) frame = F, front_ok = n;
+    }
+    __syncthreads();
+    if (front_ok) {   // (workgroup-uniform)
+        const PnpFrame F = frame;
+        double cand[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = n ? out[k] : 0.0;
-        n_models[s] = n;
+        for (int k = 0; k < 12; ++k) cand[k] = 0.0;
+        double err;
+        if (wave == 0) err = epnp_back_variant<false, 0>(sample_size, rows_idx, obj, img, K4, F, lds.ev, lds.L, 1, red[0], cand);
+        else if (wave == 1) err = epnp_back_variant<false, 1>(sample_size, rows_idx, obj, img, K4, F, lds.ev, lds.L, 1, red[1], cand);
+        else err = epnp_back_variant<false, 2>(sample_size, rows_idx, obj, img, K4, F, lds.ev, lds.L, 1, red[2], cand);
+        if (lane == 0) {
+            result[wave][0] = err;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) result[wave][1 + k] = cand[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double best = -1.0;
+        int which = -1;
+        if (front_ok)
+            for (int v = 0; v < 3; ++v)
+                if (result[v][0] >= 0.0 && (best < 0.0 || result[v][0] < best)) best = result[v][0], which = v;
+        for (int k = 0; k < 12; ++k) models[12 * (size_t)s + k] = which >= 0 ? result[which][1 + k] : 0.0;
+        n_models[s] = which >= 0 ? 1 : 0;
     }
 }
 
@@ -1421,17 +1438,12 @@ extern "C" int eacham_solve_pnp(eacham_ctx* ctx, int n_points, const double* obj
                 (const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), sample_size, n_samples,
                 (const int*)(base + o_i), (double*)(base + o_f));
             const unsigned gb = (unsigned)((n_samples + 63) / 64);
-#define EACHAM_PNP_BACK(V)                                                                                                          \
-    solve_pnp_back_kernel<V><<<gb, 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K), \
-                                                sample_size, n_samples, (const int*)(base + o_i), (const double*)(base + o_f), (double*)(base + o_t))
-            EACHAM_PNP_BACK(0);
-            EACHAM_PNP_BACK(1);
-            EACHAM_PNP_BACK(2);
-#undef EACHAM_PNP_BACK
+            solve_pnp_back_kernel<<<dim3(gb, 3), 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
+                                                              sample_size, n_samples, (const int*)(base + o_i), (const double*)(base + o_f), (double*)(base + o_t));
             solve_pnp_select_kernel<<<(unsigned)((n_samples + 255) / 256), 256, 0, st>>>(n_samples, (const double*)(base + o_t), (double*)(base + o_m), (int*)(base + o_n));
         }
         else
-            solve_pnp_big_kernel<<<(unsigned)n_samples, 64, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
+            solve_pnp_big_kernel<<<(unsigned)n_samples, 192, 0, st>>>((const double*)(base + o_a), (const double*)(base + o_b), (const double*)(base + o_K),
                                                                      sample_size, (const int*)(base + o_i), (double*)(base + o_m), (int*)(base + o_n));
     }
     EACHAM_HIP_TRY(ctx, hipGetLastError());
