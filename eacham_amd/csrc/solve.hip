@@ -602,18 +602,23 @@ __device__ __forceinline__ int lsq6(const double* A, const double* b, double* x)
 // The N x N eigenproblem (N = 9, 12) by ONE WAVE on one shared copy of A and V, in the ROUND-ROBIN ordering of
 // the CPU restatement (solve_oracle.c)'s jacobi_eig_rr: a sweep is N' - 1 rounds of N' / 2 disjoint rotations (N' = N rounded up to even; position 0
 // holds index 0, position j >= 1 holds 1 + ((j - 1 - round) mod (N' - 1)), pair i = positions i and N' - 1 - i, index N is a bye).
-// Lane i forms rotation i of the round from the matrix the round starts with; then the three stages — columns, rows, eigenvector
-// columns of every pair — run with one (pair, k) per lane: no element is written twice inside a stage, and element by element the
-// arithmetic is the restatement's, so the result is the same bits. A wave's LDS operations execute in program order: the barriers
-// only pin the compiler. 11 rounds of three stages per sweep of a 12 x 12 system, where the cyclic order is 66 dependent rotations
-// (1.9 of the 3.9 ms of a 10 000-sample EPnP batch, measured with a one-sweep build).
-struct JacRound {
+// The unit of work is an ITEM (pair i, k): a lane owns item `lane` and, for N = 12, item 64 + lane (72 items). The lane forms the rotation of
+// its items' pairs ITSELF from the matrix the round starts with (the same operations on the same values in every lane that
+// needs them: the same bits, and no trip through LDS and no barrier to hand six rotations round), then the two stages —
+// columns p, q of row k; rows p, q at column k together with the eigenvector columns — run with every read of a stage issued before
+// its first write: no element is written twice inside a stage and none is read by another item after it was written, and element by
+// element the arithmetic is the restatement's, so the result is the same bits. A wave's LDS operations execute in program order:
+// the barriers only pin the compiler. (Until round 5 lanes 0..5 formed the rotations and handed them over through LDS, and a
+// stage made two dependent passes over its 72 items: ~3.7 k cycles per round, 133 us for the front half of a five-point EPnP sample.)
+struct JacRound {   // (kept for the callers' LDS layouts; the rotations no longer pass through it)
     double c[8], s[8];
     int p[8], q[8], on[8];
 };
 template <int N>
 __device__ __forceinline__ void jacobi_wave(double* A, double* V, double* w, JacRound& R) {
+    (void)R;
     constexpr int n = N, np = N + (N & 1), half = np / 2;
+    constexpr int ITEMS = half * n, PASSES = (ITEMS + 63) / 64;
     const int lane = threadIdx.x & 63;
     for (int e = lane; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     wave_sync_lds();
@@ -628,48 +633,59 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* V, double* w, Jac
         }
         if (off <= 1e-60 || off <= 1e-32 * diag) break;
         for (int round = 0; round < np - 1; ++round) {
-            if (lane < half) {
-                const int i = lane, j1 = i, j2 = np - 1 - i;
+            int ip[PASSES], iq[PASSES], ik[PASSES];
+            bool on[PASSES];
+            double rc[PASSES], rs[PASSES];
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int e = lane + 64 * ps, i = e / n, j1 = i, j2 = np - 1 - i;
+                ik[ps] = e % n;
                 const int a = j1 == 0 ? 0 : 1 + ((j1 - 1 - round) % (np - 1) + (np - 1)) % (np - 1);
                 const int b = 1 + ((j2 - 1 - round) % (np - 1) + (np - 1)) % (np - 1);
                 const int p = a < b ? a : b, q = a < b ? b : a;
-                int on = 0;
-                double c = 1.0, s = 0.0;
-                if (q < n) {
+                ip[ps] = p, iq[ps] = q;
+                on[ps] = false, rc[ps] = 1.0, rs[ps] = 0.0;
+                if (e < ITEMS && q < n) {
                     const double apq = A[p * n + q];
                     if (apq != 0.0) {
                         const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
                         const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                        on = 1;
+                        rc[ps] = 1.0 / sqrt(t * t + 1.0), rs[ps] = t * rc[ps];
+                        on[ps] = true;
                     }
                 }
-                R.p[i] = p, R.q[i] = q, R.on[i] = on, R.c[i] = c, R.s[i] = s;
+            }
+            {   /* columns p, q of every pair: row k of the item */
+                double akp[PASSES], akq[PASSES];
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps)
+                    if (on[ps]) akp[ps] = A[ik[ps] * n + ip[ps]], akq[ps] = A[ik[ps] * n + iq[ps]];
+                wave_sync_lds();   // (every lane's reads of the round's start, the pivots above included, before the first write)
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps)
+                    if (on[ps]) {
+                        A[ik[ps] * n + ip[ps]] = rc[ps] * akp[ps] - rs[ps] * akq[ps];
+                        A[ik[ps] * n + iq[ps]] = rs[ps] * akp[ps] + rc[ps] * akq[ps];
+                    }
             }
             wave_sync_lds();
-            for (int e = lane; e < half * n; e += 64) {  /* columns p, q of every pair */
-                const int i = e / n, k = e % n;
-                if (R.on[i]) {
-                    const int p = R.p[i], q = R.q[i];
-                    const double c = R.c[i], s = R.s[i];
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
-                }
-            }
-            wave_sync_lds();
-            for (int e = lane; e < half * n; e += 64) {  /* rows p, q of every pair; the eigenvector columns */
-                const int i = e / n, k = e % n;
-                if (R.on[i]) {
-                    const int p = R.p[i], q = R.q[i];
-                    const double c = R.c[i], s = R.s[i];
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
-                }
+            {   /* rows p, q of every pair at column k; the eigenvector columns */
+                double apk[PASSES], aqk[PASSES], vkp[PASSES], vkq[PASSES];
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps)
+                    if (on[ps]) {
+                        apk[ps] = A[ip[ps] * n + ik[ps]], aqk[ps] = A[iq[ps] * n + ik[ps]];
+                        vkp[ps] = V[ik[ps] * n + ip[ps]], vkq[ps] = V[ik[ps] * n + iq[ps]];
+                    }
+                wave_sync_lds();
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps)
+                    if (on[ps]) {
+                        A[ip[ps] * n + ik[ps]] = rc[ps] * apk[ps] - rs[ps] * aqk[ps];
+                        A[iq[ps] * n + ik[ps]] = rs[ps] * apk[ps] + rc[ps] * aqk[ps];
+                        V[ik[ps] * n + ip[ps]] = rc[ps] * vkp[ps] - rs[ps] * vkq[ps];
+                        V[ik[ps] * n + iq[ps]] = rs[ps] * vkp[ps] + rc[ps] * vkq[ps];
+                    }
             }
             wave_sync_lds();
         }
