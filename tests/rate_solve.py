@@ -31,11 +31,15 @@ def kept(m, c):
 
 
 def timed(fn, reps):
+    """Median over `reps` calls after one untimed call (a mean carries a single hiccup of a fresh box — a pinned buffer growing, a page
+    fault storm — into the figure: 4.2 against 1.55 ms was seen once for the 10 000-sample EPnP batch)."""
     fn()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         r = fn()
-    return (time.perf_counter() - t0) / reps, r
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), r
 
 
 def main():
