@@ -250,6 +250,7 @@ int eacham_ctx_create(int device_id, eacham_ctx** out_ctx) {
     ctx->match_full_columns = getenv("EACHAM_MATCH_FULL_COLUMNS") != nullptr;
     ctx->exp_all_candidates = getenv("EACHAM_EXP_ALL_CANDIDATES") != nullptr;
     ctx->match_tile_sweep = getenv("EACHAM_MATCH_TILE_SWEEP") != nullptr;
+    if (const char* v = getenv("EACHAM_MATCH_SWEEP_FORM")) ctx->match_sweep_form = !strcmp(v, "exact") ? 1 : !strcmp(v, "bound") ? 2 : 0;
     if (const char* v = getenv("EACHAM_EXP_SWEEP_PRIO")) ctx->exp_sweep_prio = std::max(0, std::min(3, atoi(v)));
     if (const char* v = getenv("EACHAM_EXP_STREAM2_CUS")) ctx->exp_stream2_cus = std::max(0, std::min(256, atoi(v)));
     if (const char* b = getenv("EACHAM_MATCH_BUDGET_MB")) {

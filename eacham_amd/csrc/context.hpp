@@ -129,6 +129,8 @@ struct eacham_ctx {
     bool exp_all_candidates = false;  // EACHAM_EXP_ALL_CANDIDATES (diagnostic, timing only: every row is a candidate of the column pass)
     int exp_sweep_prio = 0;           // EACHAM_EXP_SWEEP_PRIO=1..3 (diagnostic A/B): s_setprio of the sweep's waves (the candidate pass beside it stays at 0)
     int exp_stream2_cus = 0;          // EACHAM_EXP_STREAM2_CUS=<n> (diagnostic A/B): the second stream may use n of the 256 CUs only (hipExtStreamCreateWithCUMask)
+    int match_sweep_form = 0;         // EACHAM_MATCH_SWEEP_FORM=exact|bound (diagnostic A/B, tests): the lean form's row sweep keeps every row's exact top-2 (1), or
+                                      // runs its bound form + the exact pass over the rows left open (2); 0 = by descriptor dimension (bound up to 128-D)
     bool match_tile_sweep = false;    // EACHAM_MATCH_TILE_SWEEP (diagnostic A/B: the lean form's sweep by match_tile_kernel, the first round-4 form)
     bool match_full_columns = false;  // EACHAM_MATCH_FULL_COLUMNS (diagnostic A/B: every column's top-2 from the sweep, the round-1..3 form)
     int match_budget_mb = 1024;     // EACHAM_MATCH_BUDGET_MB (diagnostic: workspace budget of one batch of pairs), read at create

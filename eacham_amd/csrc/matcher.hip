@@ -548,7 +548,18 @@ __device__ __forceinline__ void top2_merge(int& m1, int& m2, int s1, int s2) {
     m1 = imin(m1, s1);
 }
 
-template <int KS>
+//
+// BOUND = true (round 5, the default of the lean form): the sweep keeps NO second-smallest value and no tile. Per sub-tile a lane
+// runs FOUR minima, one per four of its sixteen accumulators (two v_min3 per group and tile: 8 VALU operations per 16 distances
+// instead of 31), over the train rows of four disjoint subsets; with the partner lane and the two parity classes a query row ends
+// with 16 partial minima over 16 DISJOINT subsets of the train frame. Their smallest is the row's minimum v1, and their second
+// smallest u is an UPPER BOUND of the row's true second-smallest value (the runner-up is either the minimum of another subset, or
+// hides behind v1 in v1's own subset and is then even smaller). The ratio test is monotone in the second value, so a row that
+// fails it against u fails it against the truth: such rows are finished. The others — the rows that pass (a few per cent) and the
+// few whose runner-up shared the minimum's subset — are candidates: match_rowpick_kernel lists them and match_colverify_kernel<KS, true>
+// computes their exact {v1, tile, v2} against the whole train frame (the candidate-only pass of the columns with the frames' roles
+// swapped), overwriting their rowres entries before match_rows2_kernel reads them. out: rowres[p][j] = {v1, 0, u, 0}.
+template <int KS, bool BOUND = false>
 __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kernel(const FrameDev* __restrict__ frames, const int2* __restrict__ pairs,
                                                                    int wgs_per_pair, uint4* __restrict__ rowres, int row_stride, int prio) {
     if (prio == 1) __builtin_amdgcn_s_setprio(1);  // (A/B switch EACHAM_EXP_SWEEP_PRIO: workgroup-uniform, off by default)
@@ -584,10 +595,17 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
         for (int ks = 0; ks < KS; ++ks) a[s][ks] = ~Afrag[((size_t)(NSUB * wbc + s) * KS + ks) * 64 + lane];
     // running top-2 values and the tile of the minimum, per sub-tile; the even class is set aside at the parity boundary
     // (set aside in LDS, each lane its own words: six registers less through the sweep)
-    __shared__ int sEven[3 * NSUB][WG_THREADS];
+    constexpr int NG = 4;                    // BOUND: running minima per sub-tile (eight: 14 registers spilled at 256-D)
+    constexpr int NSTATE = BOUND ? NG : 3;   // words of running state per sub-tile
+    __shared__ int sEven[NSTATE * NSUB][WG_THREADS];
     int x1[NSUB], x2[NSUB], xt[NSUB];
+    int xm[NSUB][NG];  // BOUND: the minimum over accumulators 4 g .. 4 g + 3 of every tile of the class
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) x1[s] = x2[s] = BIG, xt[s] = 0;
+    for (int s = 0; s < NSUB; ++s) {
+        x1[s] = x2[s] = BIG, xt[s] = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xm[s][g] = BIG;
+    }
 
     static_assert(TILE_V4 % 64 == 0, "a tile is a whole number of 1 KiB pieces");
     constexpr int PIECES = TILE_V4 / 64;
@@ -664,6 +682,14 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
     // merge, the sixteenth key alone; the tile is recorded when the sub-tile has improved the class minimum strictly
     auto consume = [&](const v16i(&cur)[NSUB], const int idx, const int t, int(&pend)[3], int& before) {
         const int ph = idx / 16, eg = idx % 16;
+        if constexpr (BOUND) {
+            if (eg & 1) {   // accumulators 4 g .. 4 g + 3 -> xm[g], two at a time
+                int d;
+                asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(xm[ph][eg >> 2]), "v"(cur[ph][eg - 1]), "v"(cur[ph][eg]));
+                xm[ph][eg >> 2] = d;
+            }
+            return;
+        }
         const int key = cur[ph][eg];
         if (eg == 0) before = x1[ph];  // the class minimum this sub-tile meets
         pend[eg % 3] = key;
@@ -680,8 +706,13 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
     auto set_aside_even = [&]() {
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            sEven[3 * s][tid] = x1[s], sEven[3 * s + 1][tid] = x2[s], sEven[3 * s + 2][tid] = xt[s];
-            x1[s] = x2[s] = BIG;
+            if constexpr (BOUND) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) sEven[NG * s + g][tid] = xm[s][g], xm[s][g] = BIG;
+            } else {
+                sEven[3 * s][tid] = x1[s], sEven[3 * s + 1][tid] = x2[s], sEven[3 * s + 2][tid] = xt[s];
+                x1[s] = x2[s] = BIG;
+            }
         }
     };
     auto tile = [&](auto PHc, auto SLc, auto PARc, const int t) {
@@ -767,6 +798,28 @@ __global__ __launch_bounds__(WG_THREADS, KS >= 4 ? 3 : 4) void match_sweep_kerne
         else last(std::integral_constant<int, 0>{}, TM);
     }
     if (!active) return;
+    if constexpr (BOUND) {
+        uint4* rr = rowres + (size_t)p * row_stride + ROWS_WAVE * wb;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int ca = Aca[ROWS_WAVE * wb + 32 * s + cl];
+            unsigned v1 = 0xffffffffu, v2 = 0xffffffffu;   // the two smallest of the 16 partial minima (4 groups x 2 lanes x 2 classes)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    // a frame without odd rows never met the boundary: what ran is the even class
+                    const int mine = c == 0 ? (B_even >= T ? xm[s][g] : sEven[NG * s + g][tid]) : (B_even >= T ? BIG : xm[s][g]);
+                    const int other = __shfl_xor(mine, 32);
+                    const unsigned w0 = mine == BIG ? 0xffffffffu : (unsigned)(2 * (mine + ca) + c);
+                    const unsigned w1 = other == BIG ? 0xffffffffu : (unsigned)(2 * (other + ca) + c);
+                    v2 = umin(v2, umax(v1, w0)), v1 = umin(v1, w0);
+                    v2 = umin(v2, umax(v1, w1)), v1 = umin(v1, w1);
+                }
+            if (h == 0) rr[32 * s + cl] = make_uint4(v1, 0u, v2, 0u);
+        }
+        return;
+    }
     int e1[NSUB], e2[NSUB], et[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -1014,6 +1067,46 @@ __global__ __launch_bounds__(FIN_THREADS) void match_rows_kernel(
     }
 }
 
+// Behind the BOUND form of the sweep (match_sweep_kernel<KS, true>): rowres[p][j] = {v1, 0, u, 0} with u an upper bound of the row's
+// second-smallest value. A row that fails the ratio test against u fails it against the truth and stays as it is (match_rows2_kernel
+// will fail it on the same two numbers); every other row with a real minimum is a candidate of the exact pass — also a row whose bound
+// is a padding value (its runner-up, if it has one, shares the minimum's subset: a train frame of two adjacent rows). Lists the
+// candidates of the pair (candlist, state[p].x = their number) and appends one item per 64 of them for match_colverify_kernel<KS, true>.
+__global__ __launch_bounds__(FIN_THREADS) void match_rowpick_kernel(
+    const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint4* __restrict__ rowres, int row_stride, double ratio,
+    int* __restrict__ candlist, int4* __restrict__ state, int2* __restrict__ items, int* __restrict__ n_items) {
+    __shared__ int s_wave[FIN_THREADS / 64];
+    __shared__ int s_item0;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const int2 pr = pairs[p];
+    const FrameDev A = frames[pr.x];
+    const int A_even = A.meta[0], A_tiles = A.meta[1];
+    constexpr unsigned PAD_V = 2u * PADH;
+    int* cl = candlist + (size_t)p * row_stride;
+    int base = 0;
+    for (int j0 = 0; j0 < 32 * A_tiles; j0 += FIN_THREADS) {
+        const int j = j0 + tid;
+        bool ok = false;
+        if (j < 32 * A_tiles && A.orig[j] >= 0) {
+            const uint4 e = rowres[(size_t)p * row_stride + j];
+            const unsigned pa = (j >> 5) >= A_even ? 1u : 0u;
+            ok = e.x < PAD_V && (e.z >= PAD_V || ratio_pass((int)(e.x + pa) - 2, (int)(e.z + pa) - 2, ratio));
+        }
+        int total;
+        const int rank = block_rank(ok, tid, s_wave, total);
+        if (ok) cl[base + rank] = j;
+        base += total;
+    }
+    const int groups = (base + VER_CANDS - 1) / VER_CANDS;
+    if (tid == 0) {
+        state[p] = make_int4(base, 0, 0, 0);
+        s_item0 = groups ? atomicAdd(n_items, groups) : 0;
+    }
+    __syncthreads();
+    for (int g = tid; g < groups; g += FIN_THREADS) items[s_item0 + g] = make_int2(p, g);
+}
+
 // The rows kernel of the operand-swapped sweep (match_sweep_kernel): rowres carries the TILE of a row's minimum, not its column.
 // Besides what match_rows_kernel does, the passing rows of a pair that goes on are grouped by that tile (bytile[p][..], a counting
 // sort in LDS) and one argmin item is appended per (tile, <= 32 rows) — match_argmin_kernel turns the tile into the column.
@@ -1159,12 +1252,18 @@ __global__ __launch_bounds__(64) void match_argmin_kernel(const FrameDev* __rest
 // time: 27 VALU operations per 16 distances (the sweep needs 48) under 8 MFMAs — the kernel is bound by the matrix pipe,
 // which the sweep (bound by the VALU port) leaves idle more than half of the time. Rows of the two parity classes are kept
 // apart (a tile has one parity) and joined when 2H + pa is formed.
-template <int KS>
+// ROWS = true: the same pass with the frames' roles swapped — the candidates are stored ROWS of the query frame (candlist holds them
+// directly), the train frame's tiles stream — for the rows the bound form of the sweep (match_sweep_kernel<KS, true>) could not
+// finish: their exact {v1 = 2H + pb minimum, first tile holding it, v2} go to rowres[p][j], what match_rows2_kernel reads. A wave
+// meets its tiles in ascending order and takes a tile only on a STRICT improvement; equal minima of two waves / the two lanes of
+// a candidate keep the lower tile: the first tile of the minimum, as the exact sweep records it.
+template <int KS, bool ROWS = false>
 __global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
     const FrameDev* __restrict__ frames, const int2* __restrict__ pairs, const uint2* __restrict__ rowcand,
     const int* __restrict__ candlist, const int4* __restrict__ state, const int2* __restrict__ items,
-    const int* __restrict__ n_items, int row_stride, uint2* __restrict__ colres) {
+    const int* __restrict__ n_items, int row_stride, uint2* __restrict__ colres, uint4* __restrict__ rowres_out = nullptr) {
     __shared__ int4 sM[WAVES][VER_GROUPS][32];  // per wave, group, column: {m1 even, m2 even, m1 odd, m2 odd}
+    __shared__ int2 sT[WAVES][VER_GROUPS][32];  // ROWS: {tile of m1 even, tile of m1 odd}
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1175,7 +1274,7 @@ __global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
         const int2 it = items[w];
         const int p = it.x;
         const int2 pr = pairs[p];
-        const FrameDev A = frames[pr.x], B = frames[pr.y];
+        const FrameDev A = frames[ROWS ? pr.y : pr.x], B = frames[ROWS ? pr.x : pr.y];   // A: the frame whose tiles stream, B: the candidates'
         const int A_even = ((gint_t)A.meta)[0], A_tiles = ((gint_t)A.meta)[1];
         const int ncand = state[p].x;
         const gfrag_t Afrag = (gfrag_t)A.frag, Bfrag = (gfrag_t)B.frag;
@@ -1189,13 +1288,14 @@ __global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
             const int i = VER_CANDS * it.y + 32 * g + cl;
             const int j = cand[i < ncand ? i : VER_CANDS * it.y];  // (an item has at least one candidate)
             jg[g] = i < ncand ? j : -1;
-            const unsigned col = rc[j].x;
+            const unsigned col = ROWS ? (unsigned)j : rc[j].x;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bfrag[((size_t)(col >> 5) * KS + ks) * 64 + 32 * h + (col & 31)];
         }
         int m1[VER_GROUPS][2], m2[VER_GROUPS][2];  // [group][row parity]
+        int mt[VER_GROUPS][2];                      // ROWS: the tile of m1
 #pragma unroll
-        for (int g = 0; g < VER_GROUPS; ++g) m1[g][0] = m1[g][1] = m2[g][0] = m2[g][1] = BIG;
+        for (int g = 0; g < VER_GROUPS; ++g) m1[g][0] = m1[g][1] = m2[g][0] = m2[g][1] = BIG, mt[g][0] = mt[g][1] = 0;
         // this wave's tiles: wave, wave + 4, ...; the next tile's fragments and C-init are in flight under the current chains
         v4i a_nxt[KS];
         v4i c_nxt[4];
@@ -1234,6 +1334,11 @@ __global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
                 }
                 x2 = imed3(x1, x2, acc[g][15]);
                 x1 = imin(x1, acc[g][15]);
+                if constexpr (ROWS) {
+                    const int before = odd ? m1[g][1] : m1[g][0];
+                    if (odd) mt[g][1] = x1 < before ? t : mt[g][1];
+                    else mt[g][0] = x1 < before ? t : mt[g][0];
+                }
                 if (odd) m1[g][1] = x1, m2[g][1] = x2;
                 else m1[g][0] = x1, m2[g][0] = x2;
             }
@@ -1243,17 +1348,28 @@ __global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int o1 = __shfl_xor(m1[g][e], 32), o2 = __shfl_xor(m2[g][e], 32);
+                if constexpr (ROWS) {
+                    const int ot = __shfl_xor(mt[g][e], 32);
+                    mt[g][e] = o1 < m1[g][e] ? ot : (o1 == m1[g][e] ? imin(ot, mt[g][e]) : mt[g][e]);
+                }
                 top2_merge(m1[g][e], m2[g][e], o1, o2);
             }
             if (h == 0) sM[wave][g][cl] = make_int4(m1[g][0], m2[g][0], m1[g][1], m2[g][1]);
+            if (ROWS && h == 0) sT[wave][g][cl] = make_int2(mt[g][0], mt[g][1]);
         }
         __syncthreads();
         if (tid < 32 * VER_GROUPS) {
             const int g = tid >> 5, c = tid & 31;
             int4 m = sM[0][g][c];
+            int2 mtile = ROWS ? sT[0][g][c] : make_int2(0, 0);
 #pragma unroll
             for (int k = 1; k < WAVES; ++k) {
                 const int4 e = sM[k][g][c];
+                if constexpr (ROWS) {
+                    const int2 et = sT[k][g][c];
+                    mtile.x = e.x < m.x ? et.x : (e.x == m.x ? imin(et.x, mtile.x) : mtile.x);
+                    mtile.y = e.z < m.z ? et.y : (e.z == m.z ? imin(et.y, mtile.y) : mtile.y);
+                }
                 top2_merge(m.x, m.y, e.x, e.y);
                 top2_merge(m.z, m.w, e.z, e.w);
             }
@@ -1261,13 +1377,14 @@ __global__ __launch_bounds__(WG_THREADS) void match_colverify_kernel(
             const int i = VER_CANDS * it.y + tid;
             if (i < ncand) {
                 const int j = cand[i];
-                const long long hb2 = 2ll * ((gint_t)B.normb)[rc[j].x];
+                const long long hb2 = 2ll * ((gint_t)B.normb)[ROWS ? (unsigned)j : rc[j].x];
                 auto val = [&](int m, int pa) { return m == BIG ? 0xffffffffull : (unsigned long long)(2ll * m + hb2 + pa); };
                 unsigned long long e1 = val(m.x, 0), e2 = val(m.y, 0), o1 = val(m.z, 1), o2 = val(m.w, 1);
                 const unsigned long long v1 = e1 < o1 ? e1 : o1;
                 const unsigned long long hi = e1 < o1 ? o1 : e1, lo2 = e2 < o2 ? e2 : o2;
                 const unsigned long long v2 = hi < lo2 ? hi : lo2;
-                colres[(size_t)p * row_stride + j] = make_uint2((unsigned)v1, (unsigned)v2);
+                if constexpr (ROWS) rowres_out[(size_t)p * row_stride + j] = make_uint4((unsigned)v1, (unsigned)(e1 < o1 ? mtile.x : mtile.y), (unsigned)v2, 0u);
+                else colres[(size_t)p * row_stride + j] = make_uint2((unsigned)v1, (unsigned)v2);
             }
         }
         __syncthreads();
@@ -1572,14 +1689,21 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
         const int2* pb = pairs_dev + first;
         if (b >= pl.slots) EACHAM_HIP_TRY(ctx, hipStreamWaitEvent(st1, ctx->ev_fin[slot], 0));  // slot free again
         const bool row_sweep = !full_cols && !ctx->match_tile_sweep;   // the operand-swapped row sweep (match_sweep_kernel): the default of the lean form
+        // its BOUND form + the exact pass over the rows it could not finish: up to 128-D, where the sweep is bound by its epilogue's
+        // VALU work (S200 at 128-D +5 %, the 1000-frame KITTI stand-in +12 %); at 256-D the sweep is bound by the matrix pipe and gains
+        // 4 % while the exact pass (one more stream of the train frame per pair beside the next sweep) costs the step 4-8 %
+        // (profiles/r05_match_bound_sweep_ab.txt)
+        const bool bound_sweep = row_sweep && (ctx->match_sweep_form == 2 || (ctx->match_sweep_form == 0 && ctx->ks_common <= 4));
         {
             ProfileScope ps(ctx, EACHAM_KERNEL_MATCH_TILE, st1);
             const bool col = full_cols && !ctx->exp_no_coltop2;
             if (row_sweep) {
                 switch (ctx->ks_common) {
-                    case 2: match_sweep_kernel<2><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio); break;
-                    case 4: match_sweep_kernel<4><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio); break;
-                    default: match_sweep_kernel<8><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio); break;
+#define EACHAM_SWEEP(KS_, BOUND_) match_sweep_kernel<KS_, BOUND_><<<nb * pl.wgs_per_pair, WG_THREADS, 0, st1>>>(ctx->frame_table_dev, pb, pl.wgs_per_pair, (uint4*)(ws + pl.off_rowres), pl.row_stride, ctx->exp_sweep_prio)
+                    case 2: if (bound_sweep) EACHAM_SWEEP(2, true); else EACHAM_SWEEP(2, false); break;
+                    case 4: if (bound_sweep) EACHAM_SWEEP(4, true); else EACHAM_SWEEP(4, false); break;
+                    default: if (bound_sweep) EACHAM_SWEEP(8, true); else EACHAM_SWEEP(8, false); break;
+#undef EACHAM_SWEEP
                 }
             } else {
                 switch (ctx->ks_common) {
@@ -1610,6 +1734,17 @@ static int run_match(eacham_ctx* ctx, const int2* pairs_dev, int npairs, double 
                 int* n_items = (int*)(ws + pl.off_nitems);
                 int* n_aitems = n_items + 16;
                 EACHAM_HIP_TRY(ctx, hipMemsetAsync(n_items, 0, 32 * sizeof(int), st2));
+                if (bound_sweep) {   // the rows the bound form left open: exact {v1, tile, v2} into rowres, before the rows kernel reads it
+                    int* n_pre = n_items + 8;
+                    match_rowpick_kernel<<<nb, FIN_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, (const uint4*)(ws + pl.off_rowres), pl.row_stride, ratio,
+                                                                      candlist, state, items, n_pre);
+                    const int vgrid = std::min(std::max(nb * pl.wgs_per_pair, 1), 512);
+                    switch (ctx->ks_common) {
+                        case 2: match_colverify_kernel<2, true><<<vgrid, WG_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, nullptr, candlist, state, items, n_pre, pl.row_stride, nullptr, (uint4*)(ws + pl.off_rowres)); break;
+                        case 4: match_colverify_kernel<4, true><<<vgrid, WG_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, nullptr, candlist, state, items, n_pre, pl.row_stride, nullptr, (uint4*)(ws + pl.off_rowres)); break;
+                        default: match_colverify_kernel<8, true><<<vgrid, WG_THREADS, 0, st2>>>(ctx->frame_table_dev, pb, nullptr, candlist, state, items, n_pre, pl.row_stride, nullptr, (uint4*)(ws + pl.off_rowres)); break;
+                    }
+                }
                 if (row_sweep) {
                     int* bytile = (int*)(ws + pl.off_bytile);
                     int4* aitems = (int4*)(ws + pl.off_aitems);

@@ -225,6 +225,66 @@ def test_row_sweep_every_tile_count_and_parity_boundary(hip_ctx, dim):
     hip_ctx.clear_descriptors()
 
 
+def _ctx_with_env(**env):
+    """A context of its own created under the given environment switches (they are read once, at eacham_ctx_create)."""
+    from eacham_amd import HipContext
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        return HipContext(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("form", ["exact", "bound"])
+@pytest.mark.parametrize("dim", [64, 128, 256])
+def test_both_forms_of_the_row_sweep_at_every_dimension(form, dim):
+    """The lean form's row sweep either keeps every row's exact top-2 or — its bound form, the default up to 128-D — sixteen partial
+    minima per row whose second smallest bounds the row's runner-up from above; the rows that do not fail the ratio test against
+    the bound get their exact {minimum, tile, runner-up} from a pass of their own (match_rowpick_kernel +
+    match_colverify_kernel<KS, true>). Both forms forced at 64 / 128 / 256-D (EACHAM_MATCH_SWEEP_FORM) against the oracle on: the
+    ragged tile-count frames with every position of the parity boundary; train frames whose only two rows are ADJACENT (one subset
+    of the bound form: the bound is a padding value, the row must go to the exact pass) with and without a passing ratio; a
+    duplicated train row (the runner-up equals the minimum: ratio 1) and a row whose runner-up sits in the minimum's own subset."""
+    ctx = _ctx_with_env(EACHAM_MATCH_SWEEP_FORM=form)
+    try:
+        sizes = [1, 2, 33, 64, 97, 160, 257, 350, 480]
+        base = synth.random_u8_descriptors(max(sizes) + 8, dim, 321, 0)
+        descs = []
+        for k, n in enumerate(sizes):
+            D = np.clip(base[:n] + np.rint(6 * synth.rng_normal(321, 20 + k, (n, dim))), 0, 255).astype(np.float32)
+            mode = k % 4
+            par = [None] * n if mode == 0 else [0] * n if mode == 1 else [1] * n if mode == 2 else [0] * (n - 1) + [1]
+            descs.append(_with_norm_parity(D, par))
+        # two-row train frames: the rows are neighbours in the stored order, one subset of the bound form
+        near = np.clip(base[5:6] + np.rint(2 * synth.rng_normal(321, 90, (1, dim))), 0, 255).astype(np.float32)
+        far = np.clip(255 - base[5:6], 0, 255).astype(np.float32)
+        descs.append(_with_norm_parity(np.vstack([near, far]), [0, 0]))                  # row 5 of the others matches `near`: passes
+        descs.append(_with_norm_parity(np.vstack([near, near.copy()]), [0, 0]))         # a duplicate: runner-up == minimum, ratio 1
+        # the runner-up in the minimum's own subset: rows 0..3 of a tile go to one lane's accumulators 0..3 (one group of four)
+        D = descs[4].copy()
+        D[1] = np.clip(D[0] + np.rint(1.5 * synth.rng_normal(321, 91, (dim,))), 0, 255)
+        descs.append(D)
+        _upload(ctx, descs)
+        nf = len(descs)
+        pairs = np.array([[a, b] for a in range(nf) for b in range(nf) if a != b], dtype=np.int32)
+        for md, mm in ((1, 0), (2, 1), (30, 30)):
+            got = ctx.match_all_pairs(pairs, min_dir=md, min_mutual=mm)
+            want = O.match_all_pairs(descs, pairs, min_dir=md, min_mutual=mm)
+            _assert_csr_equal(got, want)
+        assert got[0].sum() > 0
+        for a, b in ((0, 9), (4, 9), (5, 10), (11, 4), (4, 11), (9, 3)):                  # directed lists through the same sweep
+            q, t = ctx.match_pair(a, b)
+            wq, wt = O.match_directed(descs[a], descs[b])
+            assert np.array_equal(q, wq) and np.array_equal(t, wt), (a, b)
+    finally:
+        ctx.close()
+
+
 def test_ratio_range(hip_ctx):
     """The mutual entry points take 0 < ratio <= 1; the directed one takes any ratio
     and must agree with the oracle also when ties pass (ratio > 1: the lower index wins)."""
