@@ -350,7 +350,10 @@ def sweep_kernel(dim: int) -> str:
     ks = 2 if dim <= 64 else 4 if dim <= 128 else 8
     if os.environ.get("EACHAM_MATCH_TILE_SWEEP", "0") not in ("", "0"):
         return f"match_tile_kernel<{ks}, 2, false>"
-    return f"match_sweep_kernel<{ks}>"
+    # the bound form of the sweep (+ an exact pass over the rows it leaves open) up to 128-D, the exact form at 256-D (matcher.hip: run_match)
+    form = os.environ.get("EACHAM_MATCH_SWEEP_FORM", "")
+    bound = form == "bound" or (form != "exact" and ks <= 4)
+    return f"match_sweep_kernel<{ks}, {'true' if bound else 'false'}>"
 
 
 def matching_line(D: Dist, descs, kind: str, dim: int, steps: int, warmup: int, workload: str, kernel: str, gather_at_one: bool = False,
