@@ -256,7 +256,7 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
                                                const std::shared_ptr<MapT>& map, const MatT& K, const unsigned minObservers,
                                                const float maxReprError, const float minTriAngle) {
 #ifdef EACHAM_GLUE_TIMING
-    struct Tm { double conv = 0, call = 0, back = 0; long n = 0; ~Tm() { std::fprintf(stderr, "TriangulateFrame glue: %ld calls, gate %.3f ms, tracks %.3f ms, bookkeeping %.3f ms per call\n", n, conv / n, call / n, back / n); } };
+    struct Tm { double conv = 0, call = 0, back = 0, g_nbs = 0, g_p1 = 0, g_dev = 0; long n = 0, cands = 0, matches = 0; ~Tm() { std::fprintf(stderr, "TriangulateFrame glue: %ld calls, gate %.3f ms (neighbours %.3f, pass one %.3f, reprojection call %.3f; %.0f matches, %.0f candidates per call), tracks %.3f ms, bookkeeping %.3f ms per call\n", n, conv / n, g_nbs / n, g_p1 / n, g_dev / n, (double)matches / n, (double)cands / n, call / n, back / n); } };
     static Tm tm;
     const auto t_a = std::chrono::steady_clock::now();
 #endif
@@ -277,32 +277,52 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
         NodeT* node;
         std::vector<std::pair<unsigned, unsigned>> matches;
     };
-    std::vector<Nb> nbs;
+    // (the neighbour records and the two keypoint-indexed tables belong to the thread and keep their storage from call to call:
+    // ten neighbours' match lists are ten allocations per call otherwise; a table entry is current when its stamp is the neighbour's)
+    static thread_local std::vector<Nb> nbsStore;
+    static thread_local std::vector<unsigned> partnerOf, stampOf;
+    static thread_local unsigned stamp = 0;
     const size_t n_cur = current->GetFeatures().size();
-    std::vector<unsigned> partnerOf(n_cur);   // a factor's matches laid out by the current frame's keypoint: ascending order without a sort
-    std::vector<char> matched(n_cur);
+    if (partnerOf.size() < n_cur) partnerOf.resize(n_cur), stampOf.resize(n_cur, 0u);
+    size_t n_nbs = 0;
     for (const auto& f : current->GetFactors()) {
         auto* other = graph->Get(f.first);
         if (!other) throw std::runtime_error("Node is null");
         if (!other->IsValid()) continue;                 // :208-211
-        Nb nb{f.first, other, {}};
+        if (nbsStore.size() <= n_nbs) nbsStore.emplace_back();
+        Nb& nb = nbsStore[n_nbs++];
+        nb.id = f.first, nb.node = other;
+        nb.matches.clear();
         nb.matches.reserve(f.second.matches.size());
-        std::fill(matched.begin(), matched.end(), 0);
+        if (++stamp == 0) {                              // (the stamp wrapped: no entry is current)
+            std::fill(stampOf.begin(), stampOf.end(), 0u);
+            stamp = 1;
+        }
         bool in_range = true;
+        unsigned lo = 0xffffffffu, hi = 0;               // a factor's matches laid out by the current frame's keypoint: ascending order without a sort
         for (const auto& mm : f.second.matches) {
-            if ((size_t)mm.first < n_cur) partnerOf[mm.first] = mm.second, matched[mm.first] = 1;
-            else in_range = false;
+            if ((size_t)mm.first < n_cur) {
+                partnerOf[mm.first] = mm.second, stampOf[mm.first] = stamp;
+                lo = std::min(lo, mm.first), hi = std::max(hi, mm.first);
+            } else {
+                in_range = false;
+            }
         }
         if (in_range) {
-            for (size_t k = 0; k < n_cur; ++k)
-                if (matched[k]) nb.matches.emplace_back((unsigned)k, partnerOf[k]);
+            for (size_t k = lo; k <= hi && lo != 0xffffffffu; ++k)
+                if (stampOf[k] == stamp) nb.matches.emplace_back((unsigned)k, partnerOf[k]);
         } else {                                         // (a match past the frame's keypoints: kept in order; it is an error further down if it is used)
             for (const auto& mm : f.second.matches) nb.matches.emplace_back(mm.first, mm.second);
             std::sort(nb.matches.begin(), nb.matches.end());
         }
-        nbs.push_back(std::move(nb));
     }
-    std::sort(nbs.begin(), nbs.end(), [](const Nb& a, const Nb& b) { return a.id < b.id; });
+    // ascending neighbour id: an index list over the thread's records (the records themselves stay where their storage is)
+    std::vector<const Nb*> nbs(n_nbs);
+    for (size_t i = 0; i < n_nbs; ++i) nbs[i] = &nbsStore[i];
+    std::sort(nbs.begin(), nbs.end(), [](const Nb* a, const Nb* b) { return a->id < b->id; });
+#ifdef EACHAM_GLUE_TIMING
+    const auto t_g1 = std::chrono::steady_clock::now();
+#endif
     // ---- the re-observation gate (:213-240): errors of all candidates in one call, then the walk ----
     // Pass one looks every match up ONCE (the partner's keypoint -> landmark map, the landmark in the map) and keeps what it found:
     // pass two used to repeat both hash lookups per match. A landmark's record is held by address: the gate adds observers to
@@ -316,12 +336,14 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
     std::vector<char> isCand;         // per match, walk order
     size_t n_matches = 0;
     unsigned max_kp = 0;
-    for (const Nb& nb : nbs) {
+    for (const Nb* nbp : nbs) {
+        const Nb& nb = *nbp;
         n_matches += nb.matches.size();
         if (!nb.matches.empty()) max_kp = std::max(max_kp, nb.matches.back().first);   // (sorted by the current frame's keypoint)
     }
     isCand.reserve(n_matches);
-    for (const Nb& nb : nbs) {
+    for (const Nb* nbp : nbs) {
+        const Nb& nb = *nbp;
         const auto& p3 = nb.node->GetPoints3d();
         for (const auto& mm : nb.matches) {
             const auto has = p3.find(mm.second);
@@ -344,7 +366,20 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
     std::vector<float> cerr(cand3d.size() + 1);
     double Tcur[16];
     matrix_to_rows(current->GetTransform(), Tcur);
+#ifdef EACHAM_GLUE_TIMING
+    const auto t_g2 = std::chrono::steady_clock::now();
+#endif
     ctx.check(eacham_reprojection_errors(ctx.get(), Tcur, 1, (int)cand3d.size(), cframe.data(), cpts.data(), cuv.data(), K4, cerr.data()));
+#ifdef EACHAM_GLUE_TIMING
+    {
+        const auto t_g3 = std::chrono::steady_clock::now();
+        tm.g_nbs += std::chrono::duration<double, std::milli>(t_g1 - t_a).count();
+        tm.g_p1 += std::chrono::duration<double, std::milli>(t_g2 - t_g1).count();
+        tm.g_dev += std::chrono::duration<double, std::milli>(t_g3 - t_g2).count();
+        tm.cands += (long)cand3d.size();
+        tm.matches += (long)n_matches;
+    }
+#endif
     // the observers of every keypoint of the current frame that goes on to triangulation, by keypoint index (ascending = the order
     // of the std::map this used to be); the table is the thread's own and only the entries a call touched are cleared again
     static thread_local std::vector<FlatMap> observersFull;
@@ -357,7 +392,8 @@ inline TriangulateFrameReport TriangulateFrame(const unsigned frameId, const std
     } clearTouched{observersFull, touched};
     {
         size_t ci = 0, mi = 0;
-        for (const Nb& nb : nbs) {
+        for (const Nb* nbp : nbs) {
+        const Nb& nb = *nbp;
             for (const auto& mm : nb.matches) {
                 if (isCand[mi++]) {   // (the gate only writes the CURRENT frame's points3d: a neighbour's is what pass one saw)
                     const unsigned id3d = cand3d[ci];
