@@ -1053,45 +1053,45 @@ __device__ static double epnp_back_variant(int m, const int* idx, const double* 
             }
         } else {
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+            for (int p = 0; p < 6; ++p)
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
-                if (j < ncol[variant]) A[p * ncol[variant] + j] = L[(size_t)(10 * p + cols[variant][j]) * es];
-        const int solved = variant == 0 ? lsq6<4>(A, rho, x) : (variant == 1 ? lsq6<3>(A, rho, x) : lsq6<5>(A, rho, x));
-        if (!solved) return -1.0;
-        if (variant == 0) {  /* x = b00 b01 b02 b03 */
-            const double s = x[0] < 0.0 ? -1.0 : 1.0;
-            beta[0] = sqrt(s * x[0]);
-            if (!(beta[0] > 0.0)) return -1.0;
+                for (int j = 0; j < 5; ++j)
+                    if (j < ncol[variant]) A[p * ncol[variant] + j] = L[(size_t)(10 * p + cols[variant][j]) * es];
+            const int solved = variant == 0 ? lsq6<4>(A, rho, x) : (variant == 1 ? lsq6<3>(A, rho, x) : lsq6<5>(A, rho, x));
+            if (!solved) return -1.0;
+            if (variant == 0) {  /* x = b00 b01 b02 b03 */
+                const double s = x[0] < 0.0 ? -1.0 : 1.0;
+                beta[0] = sqrt(s * x[0]);
+                if (!(beta[0] > 0.0)) return -1.0;
 #pragma unroll
-            for (int k = 1; k < 4; ++k) beta[k] = s * x[k] / beta[0];
-        } else {             /* x = b00 b01 b11 (b02 b12) */
-            const double s = x[0] < 0.0 ? -1.0 : 1.0;
-            beta[0] = sqrt(s * x[0]);
-            beta[1] = s * x[2] > 0.0 ? sqrt(s * x[2]) : 0.0;
-            if (x[1] < 0.0) beta[0] = -beta[0];
-            if (!(beta[0] != 0.0)) return -1.0;
-            if (variant == 2) beta[2] = x[3] / beta[0];
-        }
-        for (int it = 0; it < 5; ++it) {  /* Gauss-Newton on the six distance equations */
-            double J[24], r[6], dx[4];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) {
-                double l[10];
-#pragma unroll
-                for (int q = 0; q < 10; ++q) l[q] = L[(size_t)(10 * p + q) * es];
-                J[4 * p + 0] = 2.0 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
-                J[4 * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1] + l[4] * beta[2] + l[7] * beta[3];
-                J[4 * p + 2] = l[3] * beta[0] + l[4] * beta[1] + 2.0 * l[5] * beta[2] + l[8] * beta[3];
-                J[4 * p + 3] = l[6] * beta[0] + l[7] * beta[1] + l[8] * beta[2] + 2.0 * l[9] * beta[3];
-                r[p] = rho[p] - (l[0] * beta[0] * beta[0] + l[1] * beta[0] * beta[1] + l[2] * beta[1] * beta[1] + l[3] * beta[0] * beta[2] +
-                                 l[4] * beta[1] * beta[2] + l[5] * beta[2] * beta[2] + l[6] * beta[0] * beta[3] + l[7] * beta[1] * beta[3] +
-                                 l[8] * beta[2] * beta[3] + l[9] * beta[3] * beta[3]);
+                for (int k = 1; k < 4; ++k) beta[k] = s * x[k] / beta[0];
+            } else {             /* x = b00 b01 b11 (b02 b12) */
+                const double s = x[0] < 0.0 ? -1.0 : 1.0;
+                beta[0] = sqrt(s * x[0]);
+                beta[1] = s * x[2] > 0.0 ? sqrt(s * x[2]) : 0.0;
+                if (x[1] < 0.0) beta[0] = -beta[0];
+                if (!(beta[0] != 0.0)) return -1.0;
+                if (variant == 2) beta[2] = x[3] / beta[0];
             }
-            if (!lsq6<4>(J, r, dx)) break;
+            for (int it = 0; it < 5; ++it) {  /* Gauss-Newton on the six distance equations */
+                double J[24], r[6], dx[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) beta[k] += dx[k];
-        }
+                for (int p = 0; p < 6; ++p) {
+                    double l[10];
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) l[q] = L[(size_t)(10 * p + q) * es];
+                    J[4 * p + 0] = 2.0 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
+                    J[4 * p + 1] = l[1] * beta[0] + 2.0 * l[2] * beta[1] + l[4] * beta[2] + l[7] * beta[3];
+                    J[4 * p + 2] = l[3] * beta[0] + l[4] * beta[1] + 2.0 * l[5] * beta[2] + l[8] * beta[3];
+                    J[4 * p + 3] = l[6] * beta[0] + l[7] * beta[1] + l[8] * beta[2] + 2.0 * l[9] * beta[3];
+                    r[p] = rho[p] - (l[0] * beta[0] * beta[0] + l[1] * beta[0] * beta[1] + l[2] * beta[1] * beta[1] + l[3] * beta[0] * beta[2] +
+                                     l[4] * beta[1] * beta[2] + l[5] * beta[2] * beta[2] + l[6] * beta[0] * beta[3] + l[7] * beta[1] * beta[3] +
+                                     l[8] * beta[2] * beta[3] + l[9] * beta[3] * beta[3]);
+                }
+                if (!lsq6<4>(J, r, dx)) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) beta[k] += dx[k];
+            }
         }
         /* control points in the camera frame, sign from the first point's depth */
         double cc[4][3];
