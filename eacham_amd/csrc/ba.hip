@@ -3908,32 +3908,46 @@ __device__ __forceinline__ void fill_ptr(int* __restrict__ ptr, int pos, int pre
     for (int k = prev_key + 1; k <= cur_key; ++k) ptr[k] = pos;
 }
 
+constexpr int GATHER_CHUNKS = 4;   // chunks of TPB positions per workgroup of prep_gather_lm
 __global__ __launch_bounds__(TPB) void prep_gather_lm(int no, int nl, int nc, const uint32_t* __restrict__ lm_sorted,
                                                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ in_cam,
                                                       const double* __restrict__ in_uv, unsigned* __restrict__ obs_cam,
                                                       unsigned* __restrict__ obs_lm, double* __restrict__ obs_uv, int* __restrict__ lm_ptr,
                                                       uint32_t* __restrict__ cam_keys, uint32_t* __restrict__ cam_vals,
                                                       PrepCounters* __restrict__ cnt) {
-    const int p = blockIdx.x * TPB + threadIdx.x;
-    bool first = false;
-    if (p < no) {
-        const uint32_t o = order[p];
-        const int lm = (int)lm_sorted[p];
-        uint32_t c = in_cam[o];
-        if (c >= (uint32_t)nc) c = 0;  // (flagged by prep_keys_lm: the call fails, the kernels stay in range)
-        obs_cam[p] = c;
-        obs_lm[p] = (unsigned)lm;
-        obs_uv[2 * (size_t)p] = in_uv[2 * (size_t)o];
-        obs_uv[2 * (size_t)p + 1] = in_uv[2 * (size_t)o + 1];
-        cam_keys[p] = c;
-        cam_vals[p] = (uint32_t)p;
-        const int prev = p > 0 ? (int)lm_sorted[p - 1] : -1;
-        first = lm != prev;
-        if (first) fill_ptr(lm_ptr, p, prev, lm);
-        if (p == no - 1) fill_ptr(lm_ptr, no, lm, nl);
+    // A workgroup takes GATHER_CHUNKS consecutive chunks of TPB positions and adds its count of first positions to n_used ONCE: as one
+    // atomic per wave (7 800 of them on S200, all to one address: ~12 ns each at the L2) the counter alone was 94 us of this kernel.
+    __shared__ int s_first[TPB / 64];
+    int mine = 0;   // first positions seen by this wave (lane 0 carries the count)
+#pragma unroll 1
+    for (int i = 0; i < GATHER_CHUNKS; ++i) {
+        const int p = (blockIdx.x * GATHER_CHUNKS + i) * TPB + threadIdx.x;
+        bool first = false;
+        if (p < no) {
+            const uint32_t o = order[p];
+            const int lm = (int)lm_sorted[p];
+            uint32_t c = in_cam[o];
+            if (c >= (uint32_t)nc) c = 0;  // (flagged by prep_keys_lm: the call fails, the kernels stay in range)
+            obs_cam[p] = c;
+            obs_lm[p] = (unsigned)lm;
+            obs_uv[2 * (size_t)p] = in_uv[2 * (size_t)o];
+            obs_uv[2 * (size_t)p + 1] = in_uv[2 * (size_t)o + 1];
+            cam_keys[p] = c;
+            cam_vals[p] = (uint32_t)p;
+            const int prev = p > 0 ? (int)lm_sorted[p - 1] : -1;
+            first = lm != prev;
+            if (first) fill_ptr(lm_ptr, p, prev, lm);
+            if (p == no - 1) fill_ptr(lm_ptr, no, lm, nl);
+        }
+        mine += __popcll(__ballot(first));
     }
-    const unsigned long long b = __ballot(first);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt->n_used, __popcll(b));
+    if ((threadIdx.x & 63) == 0) s_first[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < TPB / 64; ++w) total += s_first[w];
+        if (total) atomicAdd(&cnt->n_used, total);
+    }
 }
 
 __global__ __launch_bounds__(TPB) void prep_gather_cam(int no, int nc, const uint32_t* __restrict__ cam_sorted,
@@ -4098,29 +4112,40 @@ struct GrpCounters {
 __global__ __launch_bounds__(TPB) void prep_grp_keys(int nl, const int* __restrict__ lm_ptr, const unsigned* __restrict__ obs_cam,
                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* __restrict__ cost,
                                                      GrpCounters* __restrict__ gc) {
+    // (the two maxima leave the workgroup as ONE atomic each: per thread they were 100 000 atomics to two addresses on S200)
+    __shared__ int s_cmax, s_emax;
+    if (threadIdx.x == 0) s_cmax = 0, s_emax = 0;
+    __syncthreads();
     const int j = blockIdx.x * TPB + threadIdx.x;
-    if (j >= nl) return;
-    const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1], m = a1 - a0;
-    vals[j] = (uint32_t)j;
-    if (m == 0) {
-        keys[j] = 0xffffffffu;
-        cost[j] = 0;
-        return;
+    int c = 0, ec = 0;
+    if (j < nl) {
+        const int a0 = lm_ptr[j], a1 = lm_ptr[j + 1], m = a1 - a0;
+        vals[j] = (uint32_t)j;
+        if (m == 0) {
+            keys[j] = 0xffffffffu;
+            cost[j] = 0;
+        } else {
+            unsigned mn = obs_cam[a0], mx = mn;
+            long long e = (long long)(m + 1) * (m + 2) / 2;
+            for (int a = a0; a < a1; ++a) {
+                const unsigned ca = obs_cam[a];
+                mn = min(mn, ca), mx = max(mx, ca);
+                for (int b = a + 1; b < a1; ++b) e += obs_cam[b] == ca ? 1 : 0;
+            }
+            if (e != (long long)(m + 1) * (m + 2) / 2) gc->any_dup = 1;  // (benign race: every writer stores 1)
+            keys[j] = grp_morton(mn, mx);
+            ec = e > 0x3fffffffLL ? 0x3fffffff : (int)e;
+            c = max(max(m + 1, 4), (ec + GRP_ENT_PER_ROW - 1) / GRP_ENT_PER_ROW);  // ceil(e rows / ent_max), ent_max = 16 rows
+            cost[j] = c;
+        }
     }
-    unsigned mn = obs_cam[a0], mx = mn;
-    long long e = (long long)(m + 1) * (m + 2) / 2;
-    for (int a = a0; a < a1; ++a) {
-        const unsigned ca = obs_cam[a];
-        mn = min(mn, ca), mx = max(mx, ca);
-        for (int b = a + 1; b < a1; ++b) e += obs_cam[b] == ca ? 1 : 0;
+    if (c > 0) atomicMax(&s_cmax, c);      // (LDS: order-free maxima; counters start at 0 and every real value is positive)
+    if (ec > 0) atomicMax(&s_emax, ec);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_cmax > 0) atomicMax(&gc->cmax, s_cmax);
+        if (s_emax > 0) atomicMax(&gc->emax, s_emax);
     }
-    if (e != (long long)(m + 1) * (m + 2) / 2) gc->any_dup = 1;  // (benign race: every writer stores 1)
-    keys[j] = grp_morton(mn, mx);
-    const int ec = e > 0x3fffffffLL ? 0x3fffffff : (int)e;
-    const int c = max(max(m + 1, 4), (ec + GRP_ENT_PER_ROW - 1) / GRP_ENT_PER_ROW);  // ceil(e rows / ent_max), ent_max = 16 rows
-    cost[j] = c;
-    atomicMax(&gc->cmax, c);
-    atomicMax(&gc->emax, ec);
 }
 // in sorted order: rows and cost of rank k (zero beyond the used landmarks, which the key puts last)
 __global__ __launch_bounds__(TPB) void prep_grp_sorted(int nl, const uint32_t* __restrict__ lm_sorted, const int* __restrict__ lm_ptr,
@@ -4807,7 +4832,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     prep_values<<<(unsigned)((nc + nl + TPB) / TPB), TPB, 0, st>>>(nc, nl, raw_T, raw_obs, D.pose0, lmprior, D.K0, P->K[0], P->K[1], P->K[2], P->K[3]);
     uint32_t *lm_sorted = w_lm ? kB : kA, *lm_order = w_lm ? vB : vA, *ck = w_lm ? kA : kB, *cv = w_lm ? vA : vB;  // the other pair of buffers feeds the camera sort
     if (no > 0) {
-        prep_gather_lm<<<gobs, TPB, 0, st>>>(no, nl, nc, lm_sorted, lm_order, raw_cam, raw_uv, obs_cam, obs_lm, obs_uv, lm_ptr, ck, cv, cnt);
+        prep_gather_lm<<<(gobs + GATHER_CHUNKS - 1) / GATHER_CHUNKS, TPB, 0, st>>>(no, nl, nc, lm_sorted, lm_order, raw_cam, raw_uv, obs_cam, obs_lm, obs_uv, lm_ptr, ck, cv, cnt);
     } else {
         HIPQ(hipMemsetAsync(lm_ptr, 0, sizeof(int) * ((size_t)nl + 1), st));
         HIPQ(hipMemsetAsync(cam_ptr, 0, sizeof(int) * ((size_t)nc + 1), st));
