@@ -5013,6 +5013,64 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         D.g_rows = R; D.g_ngroups = hg.ng; D.g_nchunks = hg.totals.a; D.g_nent4 = hg.totals.b; D.g_nparts = hg.totals.c;
         n_items = 2 * nc + 1 + hg.totals.c;
     }
+    // ---- second half of the landmark-major structure: the writing pass over the groups, the slots, the block table. It needs the
+    // group counters only, not the plan: it runs HERE, beside the host's analysis (which has become the longer of the two: 0.65 ms
+    // against 0.45 ms of device work from the camera graph's read-back on S200, 1.5 against 0.9 ms on config 4), into staging buffers;
+    // what it produced is copied into the arena once the plan has sized it (the 17 MB of entries: ~10 us device to device). Until the
+    // second half of round 5 it waited for the join: 0.3 ms of every S200 call with the device idle. ----
+    BaChunk* sg_chunks = nullptr;
+    uint32_t *sg_ent = nullptr, *sg_laneinfo = nullptr;
+    int4* sg_blk = nullptr;
+    int* sg_longblk = nullptr;
+    if (use_groups) {
+        const int ngf = D.g_ngroups;
+        void* s3 = nullptr;
+        auto carve3 = [&](void* base) {
+            Bump b(base);
+            sg_chunks = b.take<BaChunk>(D.g_nchunks); sg_ent = b.take<uint32_t>(256 * (size_t)D.g_nent4); sg_laneinfo = b.take<uint32_t>(64 * (size_t)D.g_nchunks);
+            sg_blk = b.take<int4>(n_items); sg_longblk = b.take<int>((size_t)D.g_nparts / GRP_LONG + 1);
+            return b.off;
+        };
+        rc = ba_scratch(ctx, 3, carve3(nullptr), &s3);
+        if (rc) return fail(rc);
+        (void)carve3(s3);
+        void* s1 = nullptr;
+        uint32_t *ikA, *ikB, *iwA, *iwB;
+        int *isort_ws, *blk_first, *longflag, *longpos, *long_ws;
+        prim::I3 *ifl, *isc, *iws;
+        auto carve1g = [&](void* base) {
+            Bump b(base);
+            ikA = b.take<uint32_t>(n_items); ikB = b.take<uint32_t>(n_items); iwA = b.take<uint32_t>(n_items); iwB = b.take<uint32_t>(n_items);
+            isort_ws = b.take<int>(prim::radix_ws_ints(n_items));
+            ifl = b.take<prim::I3>(n_items); isc = b.take<prim::I3>(n_items); iws = b.take<prim::I3>(prim::scan_ws_elems(n_items));
+            blk_first = b.take<int>(n_items); longflag = b.take<int>(n_items); longpos = b.take<int>(n_items); long_ws = b.take<int>(prim::scan_ws_elems(n_items));
+            return b.off;
+        };
+        rc = ba_scratch(ctx, 1, carve1g(nullptr), &s1);
+        if (rc) return fail(rc);
+        (void)carve1g(s1);
+        const int n_mand = 2 * nc + 1;
+        prep_grp_mandatory<<<(unsigned)((n_mand + TPB - 1) / TPB), TPB, 0, st>>>(nc, ikA, iwA);
+        if (ngf > 0) {
+            if (hg.any_dup)
+                prep_grp_entries<1><<<ngf, GE_THREADS, grp_entries_lds_bytes(g_emax, R), st>>>(g_emax, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, nullptr, tg_bases, sg_chunks, sg_ent, sg_laneinfo, ikA, iwA, n_mand);
+            else
+                prep_grp_entries_fast<1><<<ngf, GE_THREADS, grp_entries_fast_lds_bytes(GRP_ENT_PER_ROW * R, R), st>>>(GRP_ENT_PER_ROW * R, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, nullptr, tg_bases, sg_chunks, sg_ent, sg_laneinfo, ikA, iwA, n_mand);
+        }
+        const int w_i = prim::radix_sort_pairs<uint32_t>(st, ikA, iwA, ikB, iwB, n_items, bits_for((long long)(nc + 1) * (nc + 1)), isort_ws);
+        const uint32_t *skey = w_i ? ikB : ikA, *swhere = w_i ? iwB : iwA;
+        const unsigned git = (unsigned)((n_items + TPB - 1) / TPB);
+        prep_grp_flags<<<git, TPB, 0, st>>>(n_items, skey, swhere, ifl);
+        prim::exclusive_scan<prim::I3>(st, ifl, isc, n_items, iws, &gcnt->item_totals);
+        prep_grp_slots<<<git, TPB, 0, st>>>(n_items, nc, skey, swhere, isc, sg_laneinfo, sg_blk, blk_first);
+        prep_grp_blk_counts<<<git, TPB, 0, st>>>(gcnt, n_items, swhere, blk_first, sg_blk, longflag);
+        prim::exclusive_scan<int>(st, longflag, longpos, n_items, long_ws, &gcnt->n_long);
+        prep_grp_long<<<git, TPB, 0, st>>>(gcnt, longflag, longpos, sg_longblk);
+        // ---- read-back 3: blocks, long blocks ----
+        HIPQ(hipMemcpyAsync(&hg, gcnt, sizeof(hg), hipMemcpyDeviceToHost, st));
+        HIPQ(hipStreamSynchronize(st));
+        D.g_nblk = hg.item_totals.b; D.g_nlong = hg.n_long;
+    }
     h->prep_us[0] = us_since(t_begin);
     if (plan_thread.joinable()) plan_thread.join();  // prep_us[1] = the plan's own time; what of it was not hidden behind the device shows in [2]
     if (plan_failed) return fail(ctx->fail(EACHAM_ERR_HIP, "BA preparation: the analysis of the reduced system ran out of memory or threads"));
@@ -5077,51 +5135,21 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     if (D.n_chunks > 0) HIPQ(hipMemcpyAsync(pair_chunks, chunks_tmp, sizeof(int4) * (size_t)D.n_chunks, hipMemcpyDeviceToDevice, st));
     if (D.n_blocks > 0) HIPQ(hipMemcpyAsync(blocks, blocks_tmp, sizeof(int4) * (size_t)D.n_blocks, hipMemcpyDeviceToDevice, st));
     D.pair_entries = pair_entries; D.pair_chunks = pair_chunks; D.blocks = blocks;
-    if (use_groups) {
-        // ---- second half of the landmark-major structure: the writing pass over the groups, the slots, the block table ----
+    if (use_groups) {   // what the two halves staged -> the arena
         if (ngf > 0) {
             HIPQ(hipMemcpyAsync(fg_lmid, tg_lmid, sizeof(int) * (size_t)ngf * LMAXg, hipMemcpyDeviceToDevice, st));
             HIPQ(hipMemcpyAsync(fg_lmrow, tg_lmrow, sizeof(int) * (size_t)ngf * LMAXg, hipMemcpyDeviceToDevice, st));
             HIPQ(hipMemcpyAsync(fg_rowinfo, tg_rowinfo, sizeof(int2) * (size_t)ngf * R, hipMemcpyDeviceToDevice, st));
             HIPQ(hipMemcpyAsync(fg_uv, tg_uv, sizeof(double) * 2 * (size_t)ngf * R, hipMemcpyDeviceToDevice, st));
-        }
-        void* s1 = nullptr;
-        uint32_t *ikA, *ikB, *iwA, *iwB;
-        int *isort_ws, *blk_first, *longflag, *longpos, *long_ws;
-        prim::I3 *ifl, *isc, *iws;
-        auto carve1g = [&](void* base) {
-            Bump b(base);
-            ikA = b.take<uint32_t>(n_items); ikB = b.take<uint32_t>(n_items); iwA = b.take<uint32_t>(n_items); iwB = b.take<uint32_t>(n_items);
-            isort_ws = b.take<int>(prim::radix_ws_ints(n_items));
-            ifl = b.take<prim::I3>(n_items); isc = b.take<prim::I3>(n_items); iws = b.take<prim::I3>(prim::scan_ws_elems(n_items));
-            blk_first = b.take<int>(n_items); longflag = b.take<int>(n_items); longpos = b.take<int>(n_items); long_ws = b.take<int>(prim::scan_ws_elems(n_items));
-            return b.off;
-        };
-        rc = ba_scratch(ctx, 1, carve1g(nullptr), &s1);
-        if (rc) return fail(rc);
-        (void)carve1g(s1);
-        const int n_mand = 2 * nc + 1;
-        prep_grp_mandatory<<<(unsigned)((n_mand + TPB - 1) / TPB), TPB, 0, st>>>(nc, ikA, iwA);
-        if (ngf > 0) {
-            if (hg.any_dup)
-                prep_grp_entries<1><<<ngf, GE_THREADS, grp_entries_lds_bytes(g_emax, R), st>>>(g_emax, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, nullptr, tg_bases, fg_chunks, fg_ent, fg_laneinfo, ikA, iwA, n_mand);
-            else
-                prep_grp_entries_fast<1><<<ngf, GE_THREADS, grp_entries_fast_lds_bytes(GRP_ENT_PER_ROW * R, R), st>>>(GRP_ENT_PER_ROW * R, nc, R, gcnt, tg_groups, tg_rowinfo, tg_lmrow, nullptr, tg_bases, fg_chunks, fg_ent, fg_laneinfo, ikA, iwA, n_mand);
             HIPQ(hipMemcpyAsync(fg_groups, tg_groups, sizeof(BaGroup) * (size_t)ngf, hipMemcpyDeviceToDevice, st));
         }
-        const int w_i = prim::radix_sort_pairs<uint32_t>(st, ikA, iwA, ikB, iwB, n_items, bits_for((long long)(nc + 1) * (nc + 1)), isort_ws);
-        const uint32_t *skey = w_i ? ikB : ikA, *swhere = w_i ? iwB : iwA;
-        const unsigned git = (unsigned)((n_items + TPB - 1) / TPB);
-        prep_grp_flags<<<git, TPB, 0, st>>>(n_items, skey, swhere, ifl);
-        prim::exclusive_scan<prim::I3>(st, ifl, isc, n_items, iws, &gcnt->item_totals);
-        prep_grp_slots<<<git, TPB, 0, st>>>(n_items, nc, skey, swhere, isc, fg_laneinfo, fg_blk, blk_first);
-        prep_grp_blk_counts<<<git, TPB, 0, st>>>(gcnt, n_items, swhere, blk_first, fg_blk, longflag);
-        prim::exclusive_scan<int>(st, longflag, longpos, n_items, long_ws, &gcnt->n_long);
-        prep_grp_long<<<git, TPB, 0, st>>>(gcnt, longflag, longpos, fg_longblk);
-        // ---- read-back 3: blocks, long blocks ----
-        HIPQ(hipMemcpyAsync(&hg, gcnt, sizeof(hg), hipMemcpyDeviceToHost, st));
-        HIPQ(hipStreamSynchronize(st));
-        D.g_nblk = hg.item_totals.b; D.g_nlong = hg.n_long;
+        if (D.g_nchunks > 0) {
+            HIPQ(hipMemcpyAsync(fg_chunks, sg_chunks, sizeof(BaChunk) * (size_t)D.g_nchunks, hipMemcpyDeviceToDevice, st));
+            HIPQ(hipMemcpyAsync(fg_laneinfo, sg_laneinfo, sizeof(uint32_t) * 64 * (size_t)D.g_nchunks, hipMemcpyDeviceToDevice, st));
+        }
+        if (D.g_nent4 > 0) HIPQ(hipMemcpyAsync(fg_ent, sg_ent, sizeof(uint32_t) * 256 * (size_t)D.g_nent4, hipMemcpyDeviceToDevice, st));
+        if (n_items > 0) HIPQ(hipMemcpyAsync(fg_blk, sg_blk, sizeof(int4) * (size_t)n_items, hipMemcpyDeviceToDevice, st));
+        HIPQ(hipMemcpyAsync(fg_longblk, sg_longblk, sizeof(int) * ((size_t)D.g_nparts / GRP_LONG + 1), hipMemcpyDeviceToDevice, st));
         D.g_groups = fg_groups; D.g_lmid = fg_lmid; D.g_lmrow = fg_lmrow; D.g_rowinfo = fg_rowinfo; D.g_uv = fg_uv; D.g_chunks = fg_chunks;
         D.g_ent = fg_ent; D.g_laneinfo = fg_laneinfo; D.g_blk = fg_blk; D.g_longblk = fg_longblk;
     }

@@ -106,7 +106,7 @@ struct eacham_ctx {
     size_t io_host_bytes = 0;
 
     std::vector<eacham::BaBlock> ba_pool;  // arenas of released BA problems, reused by the next eacham_ba_prepare
-    eacham::BaScratch ba_scratch[3];
+    eacham::BaScratch ba_scratch[4];
     int ba_prepare_mode = 0;  // EACHAM_BA_PREPARE=host|device (diagnostic / tests: force one form of the structure construction;
                               // default: device for >= 65536 observations), read at create
     int stream2_attempt = -1;        // which candidate of the second-stream search was kept (0..4; 4 = the last, kept unprobed; -1 = no search)
