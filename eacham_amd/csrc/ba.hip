@@ -3911,8 +3911,8 @@ __device__ __forceinline__ void fill_ptr(int* __restrict__ ptr, int pos, int pre
 constexpr int GATHER_CHUNKS = 4;   // chunks of TPB positions per workgroup of prep_gather_lm
 __global__ __launch_bounds__(TPB) void prep_gather_lm(int no, int nl, int nc, const uint32_t* __restrict__ lm_sorted,
                                                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ in_cam,
-                                                      const double* __restrict__ in_uv, unsigned* __restrict__ obs_cam,
-                                                      unsigned* __restrict__ obs_lm, double* __restrict__ obs_uv, int* __restrict__ lm_ptr,
+                                                      unsigned* __restrict__ obs_cam,
+                                                      unsigned* __restrict__ obs_lm, int* __restrict__ lm_ptr,
                                                       uint32_t* __restrict__ cam_keys, uint32_t* __restrict__ cam_vals,
                                                       PrepCounters* __restrict__ cnt) {
     // A workgroup takes GATHER_CHUNKS consecutive chunks of TPB positions and adds its count of first positions to n_used ONCE: as one
@@ -3930,8 +3930,6 @@ __global__ __launch_bounds__(TPB) void prep_gather_lm(int no, int nl, int nc, co
             if (c >= (uint32_t)nc) c = 0;  // (flagged by prep_keys_lm: the call fails, the kernels stay in range)
             obs_cam[p] = c;
             obs_lm[p] = (unsigned)lm;
-            obs_uv[2 * (size_t)p] = in_uv[2 * (size_t)o];
-            obs_uv[2 * (size_t)p + 1] = in_uv[2 * (size_t)o + 1];
             cam_keys[p] = c;
             cam_vals[p] = (uint32_t)p;
             const int prev = p > 0 ? (int)lm_sorted[p - 1] : -1;
@@ -3952,9 +3950,9 @@ __global__ __launch_bounds__(TPB) void prep_gather_lm(int no, int nl, int nc, co
 
 __global__ __launch_bounds__(TPB) void prep_gather_cam(int no, int nc, const uint32_t* __restrict__ cam_sorted,
                                                        const uint32_t* __restrict__ cam_obs_u, const unsigned* __restrict__ obs_lm,
-                                                       const double* __restrict__ obs_uv, int* __restrict__ cam_obs,
+                                                       int* __restrict__ cam_obs,
                                                        int* __restrict__ obs_pos, int* __restrict__ pos_cam, int* __restrict__ cam_lm,
-                                                       double* __restrict__ cam_uv, int* __restrict__ cam_ptr) {
+                                                       int* __restrict__ cam_ptr) {
     const int q = blockIdx.x * TPB + threadIdx.x;
     if (q >= no) return;
     const int p = (int)cam_obs_u[q], c = (int)cam_sorted[q];
@@ -3962,11 +3960,22 @@ __global__ __launch_bounds__(TPB) void prep_gather_cam(int no, int nc, const uin
     obs_pos[p] = q;
     pos_cam[q] = c;
     cam_lm[q] = (int)obs_lm[p];
-    cam_uv[2 * (size_t)q] = obs_uv[2 * (size_t)p];
-    cam_uv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)p + 1];
     const int prev = q > 0 ? (int)cam_sorted[q - 1] : -1;
     if (c != prev) fill_ptr(cam_ptr, q, prev, c);
     if (q == no - 1) fill_ptr(cam_ptr, no, c, nc);
+}
+// The measurements in landmark order and in camera order, straight from the caller's array. A kernel of its own, LATE in the first
+// half: the 16 bytes per observation are the largest of the caller's arrays (8 MB on S200, ~0.25 ms of PCIe from pageable memory)
+// and nothing before the group rows needs them — the upload runs on the second stream while the sorts do (it sat between the
+// landmark sort and its gather before, with the device idle for its whole length).
+__global__ __launch_bounds__(TPB) void prep_gather_uv(int no, const uint32_t* __restrict__ order, const int* __restrict__ cam_obs,
+                                                      const double* __restrict__ in_uv, double* __restrict__ obs_uv, double* __restrict__ cam_uv) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= no) return;
+    const double2 a = *reinterpret_cast<const double2*>(&in_uv[2 * (size_t)order[i]]);
+    const double2 b = *reinterpret_cast<const double2*>(&in_uv[2 * (size_t)order[cam_obs[i]]]);
+    *reinterpret_cast<double2*>(&obs_uv[2 * (size_t)i]) = a;
+    *reinterpret_cast<double2*>(&cam_uv[2 * (size_t)i]) = b;
 }
 
 __global__ __launch_bounds__(TPB) void prep_cam_chunk_counts(int nc, const int* __restrict__ cam_ptr, int* __restrict__ nchunk) {
@@ -4784,7 +4793,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     h->pose_init = D.pose0; h->pt_init = D.pt0; h->K_init = D.K0;
     // ---- scratch 0: the caller's arrays as they are + the temporaries of the observation sorts ----
     void* s0 = nullptr;
-    uint32_t *raw_cam, *raw_pt, *kA, *kB, *vA, *vB;
+    uint32_t *raw_cam, *raw_pt, *kA, *kB, *vA, *vB, *kC, *vC;
     double *raw_uv, *raw_T;
     int *raw_obs, *sort_ws, *nchunk, *nchunk_ws;
     long long *pcnt, *poff, *pws;
@@ -4799,6 +4808,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         raw_pt = b.take<uint32_t>(no); raw_cam = b.take<uint32_t>(no); raw_uv = b.take<double>(2 * (size_t)no);
         raw_T = b.take<double>(16 * (size_t)nc); raw_obs = b.take<int>(nl);
         kA = b.take<uint32_t>(no); kB = b.take<uint32_t>(no); vA = b.take<uint32_t>(no); vB = b.take<uint32_t>(no);
+        kC = b.take<uint32_t>(no); vC = b.take<uint32_t>(no);   // the camera sort's second pair (the landmark order stays: the late uv gather reads it)
         sort_ws = b.take<int>(prim::radix_ws_ints(no));
         nchunk = b.take<int>(nc); nchunk_ws = b.take<int>(prim::scan_ws_elems(nc));
         pcnt = b.take<long long>(no); poff = b.take<long long>((size_t)no + 1); pws = b.take<long long>(prim::scan_ws_elems(no));
@@ -4824,7 +4834,6 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     auto bits_for = [](long long n) { int b = 1; while ((1ll << b) < n) ++b; return b; };
     if (no > 0) prep_keys_lm<<<gobs, TPB, 0, st>>>(no, nc, nl, raw_cam, raw_pt, kA, vA, cnt);
     const int w_lm = prim::radix_sort_pairs<uint32_t>(st, kA, vA, kB, vB, no, bits_for(std::max(nl, 2)), sort_ws);
-    HIPQ(hipMemcpyAsync(raw_uv, P->obs_uv, sizeof(double) * 2 * (size_t)no, hipMemcpyHostToDevice, st));
     HIPQ(hipMemcpyAsync(raw_T, P->cam_T_wc, sizeof(double) * 16 * (size_t)nc, hipMemcpyHostToDevice, st));
     HIPQ(hipMemcpyAsync(raw_obs, P->point_observers, sizeof(int) * (size_t)nl, hipMemcpyHostToDevice, st));
     HIPQ(hipMemcpyAsync(D.pt0, P->points, sizeof(double) * 3 * (size_t)nl, hipMemcpyHostToDevice, st));
@@ -4832,7 +4841,7 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     prep_values<<<(unsigned)((nc + nl + TPB) / TPB), TPB, 0, st>>>(nc, nl, raw_T, raw_obs, D.pose0, lmprior, D.K0, P->K[0], P->K[1], P->K[2], P->K[3]);
     uint32_t *lm_sorted = w_lm ? kB : kA, *lm_order = w_lm ? vB : vA, *ck = w_lm ? kA : kB, *cv = w_lm ? vA : vB;  // the other pair of buffers feeds the camera sort
     if (no > 0) {
-        prep_gather_lm<<<(gobs + GATHER_CHUNKS - 1) / GATHER_CHUNKS, TPB, 0, st>>>(no, nl, nc, lm_sorted, lm_order, raw_cam, raw_uv, obs_cam, obs_lm, obs_uv, lm_ptr, ck, cv, cnt);
+        prep_gather_lm<<<(gobs + GATHER_CHUNKS - 1) / GATHER_CHUNKS, TPB, 0, st>>>(no, nl, nc, lm_sorted, lm_order, raw_cam, obs_cam, obs_lm, lm_ptr, ck, cv, cnt);
     } else {
         HIPQ(hipMemsetAsync(lm_ptr, 0, sizeof(int) * ((size_t)nl + 1), st));
         HIPQ(hipMemsetAsync(cam_ptr, 0, sizeof(int) * ((size_t)nc + 1), st));
@@ -4841,11 +4850,10 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
     if (nc > 0) HIPQ(hipMemsetAsync(adj_dev, 0, (size_t)nc * nc, st));
     if (no > 0 && nc > 0) prep_cam_adjacency<<<gobs, TPB, 0, st>>>(no, nc, obs_cam, obs_lm, lm_ptr, adj_dev);
     HIPQ(hipEventRecord(ctx->ev_join, st));
-    // the camera sort reuses the landmark sort's output buffers as its second pair (their content has been gathered)
-    const int w_cam = prim::radix_sort_pairs<uint32_t>(st, ck, cv, lm_sorted, lm_order, no, bits_for(std::max(nc, 2)), sort_ws);
+    const int w_cam = prim::radix_sort_pairs<uint32_t>(st, ck, cv, kC, vC, no, bits_for(std::max(nc, 2)), sort_ws);
     if (no > 0) {
-        const uint32_t *cs = w_cam ? lm_sorted : ck, *co = w_cam ? lm_order : cv;
-        prep_gather_cam<<<gobs, TPB, 0, st>>>(no, nc, cs, co, obs_lm, obs_uv, cam_obs, obs_pos, pos_cam, cam_lm, cam_uv, cam_ptr);
+        const uint32_t *cs = w_cam ? kC : ck, *co = w_cam ? vC : cv;
+        prep_gather_cam<<<gobs, TPB, 0, st>>>(no, nc, cs, co, obs_lm, cam_obs, obs_pos, pos_cam, cam_lm, cam_ptr);
         if (!try_groups) prep_pair_counts<<<gobs, TPB, 0, st>>>(no, obs_cam, obs_lm, lm_ptr, pcnt);
     }
     int w_g = 0;
@@ -4894,6 +4902,13 @@ static int ba_prepare_device(eacham_ctx* ctx, const eacham_ba_problem* P, eacham
         plan_thread = std::thread(plan_body);
     } catch (const std::system_error&) {
         plan_body();  // no thread to be had: the analysis runs here, before the rest of the device work is queued
+    }
+    // ---- the measurements: uploaded on the second stream beside the kernels queued above, gathered behind them ----
+    if (no > 0) {
+        HIPQ(hipMemcpyAsync(raw_uv, P->obs_uv, sizeof(double) * 2 * (size_t)no, hipMemcpyHostToDevice, ctx->stream2));
+        HIPQ(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPQ(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        prep_gather_uv<<<gobs, TPB, 0, st>>>(no, lm_order, cam_obs, raw_uv, obs_uv, cam_uv);
     }
     // ---- read-back 1: the number of pair entries sizes the next stage ----
     PrepCounters hc;
